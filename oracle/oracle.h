@@ -1,0 +1,71 @@
+/* oracle/oracle.h -- TEST INFRASTRUCTURE ONLY.  Not part of the product; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so.
+ *
+ * A clean-room, buffer-to-buffer CPU restatement of the reference's three stream codecs
+ *   lzxd_decompress   (libmspack/mspack/lzxd.c:388-771)
+ *   mszipd_decompress (libmspack/mspack/mszipd.c:377-460, inflate :154-316)
+ *   qtmd_decompress   (libmspack/mspack/qtmd.c:257-479)
+ * including their bit readers (readbits.h:133-214) and the accept/reject behaviour of the
+ * canonical-Huffman table builder (readhuff.h:83-176).
+ *
+ * PARITY PINNING: every function here is checked (tests/test_oracle_vs_ref.py) against the real
+ * reference compiled into oracle/_ref/ by oracle/Makefile, on the reference's own known-answer
+ * cabinets (libmspack/test/cabd_test.c:405-520 vectors) and on synthetic corpora, and against
+ * the committed golden fixtures under tests/golden/.
+ */
+#ifndef MSPACK_AMD_ORACLE_H
+#define MSPACK_AMD_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes: identical values to mspack.h:485-507 */
+#define ORC_OK        0
+#define ORC_ARGS      1
+#define ORC_READ      3
+#define ORC_DECRUNCH 11
+
+/* result flags */
+#define ORC_F_E8_APPLIED      1u  /* at least one frame went through the E8 translation      */
+#define ORC_F_LOOKAHEAD_READ  2u  /* LZX: all requested bytes were produced, but the one-frame
+                                     look-ahead (lzxd.c:419) then ran out of input (ERR_READ)  */
+#define ORC_F_INTEL_HEADER    4u  /* LZX: an interval header carried intel_filesize != 0      */
+
+typedef struct oracle_result {
+  int32_t  err;       /* MSPACK_ERR_* the reference would return from the decompress call      */
+  uint32_t flags;
+  uint64_t out_len;   /* bytes the codec handed to sys->write                                   */
+  uint64_t in_used;   /* the reference's i_ptr position (bytes pulled into the bit buffer)      */
+} oracle_result;
+
+/* LZX: equivalent to lzxd_init(window_bits, reset_frames, bufsize, length, is_delta=0) followed
+ * by one lzxd_decompress(out_bytes).  `e8_base` is the value lzx->offset would have had at the
+ * start of this unit if the reference had been decoding since an earlier point (it only shifts
+ * the E8 `curpos`, lzxd.c:712).  `out` receives what sys->write would have received. */
+int oracle_lzx_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                      uint64_t out_bytes, uint64_t length, int window_bits, int reset_frames,
+                      int32_t e8_base, oracle_result *res);
+
+/* MSZIP: mszipd_init(repair_mode) + one mszipd_decompress(out_bytes) over a whole folder stream
+ * (concatenated CFDATA payloads).  block_lens (optional, cap entries) receives each block's
+ * bytes_output; *n_blocks the number of blocks inflated. */
+int oracle_mszip_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                        uint64_t out_bytes, int repair_mode, uint32_t *block_lens, int cap,
+                        int *n_blocks, oracle_result *res);
+
+/* Quantum: qtmd_init(window_bits) + one qtmd_decompress(out_bytes) over a whole folder stream
+ * (CFDATA payloads, each followed by the 0xFF trailer cabd.c:1330-1332 injects). */
+int oracle_qtm_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                      uint64_t out_bytes, int window_bits, oracle_result *res);
+
+/* make_decode_table accept/reject (readhuff.h:83-176): returns 0 if the reference would accept
+ * this set of code lengths for a table with `tablebits` direct bits, 1 if it would reject. */
+int oracle_huff_accepts(const uint8_t *lens, int nsyms, int tablebits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

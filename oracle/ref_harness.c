@@ -1,0 +1,335 @@
+/* oracle/ref_harness.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin memory-to-memory drivers around the REAL reference codecs.  This file is compiled only
+ * in the development container, against the headers and objects that live under
+ * /root/reference (see oracle/Makefile target `ref`); the result goes to oracle/_ref/ and is
+ * never linked into the product.  It lets tests (a) pin our CPU restatement (liboracle.so)
+ * against the reference, (b) validate every synthetic corpus stream, and (c) time the true
+ * reference CPU path as bench.py's cpu_baseline (kind "reference").
+ *
+ * Interfaces used: lzxd_init/lzxd_decompress/lzxd_free (lzx.h:146-214), mszipd_* (mszip.h:85-120),
+ * qtmd_* (qtm.h:92-122), mspack_create_cab_decompressor / mspack_create_chm_decompressor
+ * (mspack.h:522-558) through an in-memory struct mspack_system (mspack.h:285-455).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <time.h>
+#include <pthread.h>
+
+#include <system.h>   /* reference: mspack.h + macros */
+#include <lzx.h>
+#include <mszip.h>
+#include <qtm.h>
+
+/* ---- in-memory mspack_system ------------------------------------------------------------ */
+#define MEMNAME_MAGIC 0x4d454d21u
+struct memname {            /* what we pass as "filename" */
+  unsigned magic;
+  uint8_t *data;            /* read: source; write: destination (may be NULL = discard) */
+  size_t   len;             /* read: size;   write: capacity */
+  size_t   written;         /* write: bytes written (may exceed capacity; excess dropped) */
+};
+struct memfile {
+  struct memname *mn;
+  size_t pos;
+  int writing;
+};
+
+static struct mspack_file *m_open(struct mspack_system *self, const char *filename, int mode) {
+  struct memname *mn = (struct memname *) filename;
+  struct memfile *f;
+  (void) self;
+  if (!mn || mn->magic != MEMNAME_MAGIC) return NULL;
+  f = (struct memfile *) malloc(sizeof(*f));
+  if (!f) return NULL;
+  f->mn = mn; f->pos = 0; f->writing = (mode != MSPACK_SYS_OPEN_READ);
+  if (f->writing) mn->written = 0;
+  return (struct mspack_file *) f;
+}
+static void m_close(struct mspack_file *file) { free(file); }
+static int m_read(struct mspack_file *file, void *buffer, int bytes) {
+  struct memfile *f = (struct memfile *) file;
+  size_t avail;
+  if (!f || f->writing || bytes < 0) return -1;
+  avail = f->mn->len - f->pos;
+  if ((size_t) bytes > avail) bytes = (int) avail;
+  memcpy(buffer, f->mn->data + f->pos, (size_t) bytes);
+  f->pos += (size_t) bytes;
+  return bytes;
+}
+static int m_write(struct mspack_file *file, void *buffer, int bytes) {
+  struct memfile *f = (struct memfile *) file;
+  if (!f || !f->writing || bytes < 0) return -1;
+  if (f->mn->data && f->mn->written < f->mn->len) {
+    size_t room = f->mn->len - f->mn->written;
+    memcpy(f->mn->data + f->mn->written, buffer, (size_t) bytes < room ? (size_t) bytes : room);
+  }
+  f->mn->written += (size_t) bytes;
+  return bytes;
+}
+static int m_seek(struct mspack_file *file, off_t offset, int mode) {
+  struct memfile *f = (struct memfile *) file;
+  off_t base;
+  if (!f) return -1;
+  switch (mode) {
+  case MSPACK_SYS_SEEK_START: base = 0; break;
+  case MSPACK_SYS_SEEK_CUR:   base = (off_t) f->pos; break;
+  case MSPACK_SYS_SEEK_END:   base = (off_t) f->mn->len; break;
+  default: return -1;
+  }
+  if (base + offset < 0 || (size_t)(base + offset) > f->mn->len) return -1;
+  f->pos = (size_t)(base + offset);
+  return 0;
+}
+static off_t m_tell(struct mspack_file *file) {
+  struct memfile *f = (struct memfile *) file;
+  return f ? (off_t) f->pos : 0;
+}
+static void m_msg(struct mspack_file *file, const char *format, ...) { (void) file; (void) format; }
+static void *m_alloc(struct mspack_system *self, size_t bytes) { (void) self; return malloc(bytes); }
+static void m_free(void *p) { free(p); }
+static void m_copy(void *src, void *dest, size_t bytes) { memcpy(dest, src, bytes); }
+
+static struct mspack_system mem_system = {
+  &m_open, &m_close, &m_read, &m_write, &m_seek, &m_tell, &m_msg, &m_alloc, &m_free, &m_copy, NULL
+};
+
+/* ---- codec-level, memory to memory ------------------------------------------------------- */
+/* All return the reference's MSPACK_ERR_* code; *written = bytes the codec wrote. */
+
+int refh_lzx(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, long long out_bytes,
+             int window_bits, int reset_interval, long long output_length, size_t *written)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) in, in_len, 0 };
+  struct memname dst = { MEMNAME_MAGIC, out, out_cap, 0 };
+  struct mspack_file *fi = m_open(&mem_system, (const char *) &src, MSPACK_SYS_OPEN_READ);
+  struct mspack_file *fo = m_open(&mem_system, (const char *) &dst, MSPACK_SYS_OPEN_WRITE);
+  struct lzxd_stream *lzx = lzxd_init(&mem_system, fi, fo, window_bits, reset_interval, 4096,
+                                      (off_t) output_length, 0);
+  int err = MSPACK_ERR_ARGS;
+  if (lzx) { err = lzxd_decompress(lzx, (off_t) out_bytes); lzxd_free(lzx); }
+  if (written) *written = dst.written;
+  m_close(fi); m_close(fo);
+  return err;
+}
+
+int refh_mszip(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, long long out_bytes,
+               int repair_mode, size_t *written)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) in, in_len, 0 };
+  struct memname dst = { MEMNAME_MAGIC, out, out_cap, 0 };
+  struct mspack_file *fi = m_open(&mem_system, (const char *) &src, MSPACK_SYS_OPEN_READ);
+  struct mspack_file *fo = m_open(&mem_system, (const char *) &dst, MSPACK_SYS_OPEN_WRITE);
+  struct mszipd_stream *zip = mszipd_init(&mem_system, fi, fo, 4096, repair_mode);
+  int err = MSPACK_ERR_ARGS;
+  if (zip) { err = mszipd_decompress(zip, (off_t) out_bytes); mszipd_free(zip); }
+  if (written) *written = dst.written;
+  m_close(fi); m_close(fo);
+  return err;
+}
+
+int refh_qtm(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, long long out_bytes,
+             int window_bits, size_t *written)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) in, in_len, 0 };
+  struct memname dst = { MEMNAME_MAGIC, out, out_cap, 0 };
+  struct mspack_file *fi = m_open(&mem_system, (const char *) &src, MSPACK_SYS_OPEN_READ);
+  struct mspack_file *fo = m_open(&mem_system, (const char *) &dst, MSPACK_SYS_OPEN_WRITE);
+  struct qtmd_stream *qtm = qtmd_init(&mem_system, fi, fo, window_bits, 4096);
+  int err = MSPACK_ERR_ARGS;
+  if (qtm) { err = qtmd_decompress(qtm, (off_t) out_bytes); qtmd_free(qtm); }
+  if (written) *written = dst.written;
+  m_close(fi); m_close(fo);
+  return err;
+}
+
+/* ---- container-level: CAB / CHM held in memory --------------------------------------------- */
+/* Enumerate files: fills arrays (up to cap) and returns the number of files, or -err. */
+int refh_cab_list(const uint8_t *cab, size_t cab_len, int cap,
+                  unsigned *lengths, unsigned *offsets, int *comp_types, int *folder_ids,
+                  char *names, int name_stride)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) cab, cab_len, 0 };
+  struct mscab_decompressor *d = mspack_create_cab_decompressor(&mem_system);
+  struct mscabd_cabinet *c;
+  struct mscabd_file *f;
+  struct mscabd_folder *fol;
+  int n = 0;
+  if (!d) return -MSPACK_ERR_NOMEMORY;
+  c = d->open(d, (const char *) &src);
+  if (!c) { n = -d->last_error(d); mspack_destroy_cab_decompressor(d); return n; }
+  for (f = c->files; f; f = f->next, n++) {
+    if (n < cap) {
+      int fid = 0;
+      for (fol = c->folders; fol && fol != f->folder; fol = fol->next) fid++;
+      if (lengths) lengths[n] = f->length;
+      if (offsets) offsets[n] = f->offset;
+      if (comp_types) comp_types[n] = f->folder ? f->folder->comp_type : -1;
+      if (folder_ids) folder_ids[n] = fid;
+      if (names) { strncpy(names + (size_t) n * name_stride, f->filename, name_stride - 1);
+                   names[(size_t) n * name_stride + name_stride - 1] = 0; }
+    }
+  }
+  d->close(d, c);
+  mspack_destroy_cab_decompressor(d);
+  return n;
+}
+
+/* Extract the files listed in order[0..n_order) (indices into the file list) one after another
+ * with ONE decompressor (so folder-state reuse behaves as in the reference).  errs[i] = code of
+ * extract i; outputs are concatenated into out (each file at out_offs[i]). */
+int refh_cab_extract(const uint8_t *cab, size_t cab_len, const int *order, int n_order,
+                     uint8_t *out, size_t out_cap, size_t *out_offs, size_t *out_lens, int *errs,
+                     int fix_mszip, int salvage)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) cab, cab_len, 0 };
+  struct mscab_decompressor *d = mspack_create_cab_decompressor(&mem_system);
+  struct mscabd_cabinet *c;
+  size_t pos = 0;
+  int i;
+  if (!d) return MSPACK_ERR_NOMEMORY;
+  d->set_param(d, MSCABD_PARAM_FIXMSZIP, fix_mszip);
+  d->set_param(d, MSCABD_PARAM_SALVAGE, salvage);
+  c = d->open(d, (const char *) &src);
+  if (!c) { i = d->last_error(d); mspack_destroy_cab_decompressor(d); return i; }
+  for (i = 0; i < n_order; i++) {
+    struct mscabd_file *f = c->files;
+    struct memname dst = { MEMNAME_MAGIC, out ? out + pos : NULL, out ? out_cap - pos : 0, 0 };
+    int k = order[i];
+    while (f && k-- > 0) f = f->next;
+    if (!f) { errs[i] = MSPACK_ERR_ARGS; out_offs[i] = pos; out_lens[i] = 0; continue; }
+    errs[i] = d->extract(d, f, (const char *) &dst);
+    out_offs[i] = pos;
+    out_lens[i] = dst.written;
+    pos += dst.written < (out_cap - pos) ? dst.written : (out_cap - pos);
+  }
+  d->close(d, c);
+  mspack_destroy_cab_decompressor(d);
+  return MSPACK_ERR_OK;
+}
+
+int refh_chm_list(const uint8_t *chm, size_t chm_len, int cap, long long *lengths,
+                  long long *offsets, int *sections, char *names, int name_stride)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) chm, chm_len, 0 };
+  struct mschm_decompressor *d = mspack_create_chm_decompressor(&mem_system);
+  struct mschmd_header *h;
+  struct mschmd_file *f;
+  int n = 0;
+  if (!d) return -MSPACK_ERR_NOMEMORY;
+  h = d->open(d, (const char *) &src);
+  if (!h) { n = -d->last_error(d); mspack_destroy_chm_decompressor(d); return n; }
+  for (f = h->files; f; f = f->next, n++) {
+    if (n < cap) {
+      if (lengths) lengths[n] = (long long) f->length;
+      if (offsets) offsets[n] = (long long) f->offset;
+      if (sections) sections[n] = (int) f->section->id;
+      if (names) { strncpy(names + (size_t) n * name_stride, f->filename, name_stride - 1);
+                   names[(size_t) n * name_stride + name_stride - 1] = 0; }
+    }
+  }
+  d->close(d, h);
+  mspack_destroy_chm_decompressor(d);
+  return n;
+}
+
+int refh_chm_extract(const uint8_t *chm, size_t chm_len, const int *order, int n_order,
+                     uint8_t *out, size_t out_cap, size_t *out_offs, size_t *out_lens, int *errs)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) chm, chm_len, 0 };
+  struct mschm_decompressor *d = mspack_create_chm_decompressor(&mem_system);
+  struct mschmd_header *h;
+  size_t pos = 0;
+  int i;
+  if (!d) return MSPACK_ERR_NOMEMORY;
+  h = d->open(d, (const char *) &src);
+  if (!h) { i = d->last_error(d); mspack_destroy_chm_decompressor(d); return i; }
+  for (i = 0; i < n_order; i++) {
+    struct mschmd_file *f = h->files;
+    struct memname dst = { MEMNAME_MAGIC, out ? out + pos : NULL, out ? out_cap - pos : 0, 0 };
+    int k = order[i];
+    while (f && k-- > 0) f = f->next;
+    if (!f) { errs[i] = MSPACK_ERR_ARGS; out_offs[i] = pos; out_lens[i] = 0; continue; }
+    errs[i] = d->extract(d, f, (const char *) &dst);
+    out_offs[i] = pos;
+    out_lens[i] = dst.written;
+    pos += dst.written < (out_cap - pos) ? dst.written : (out_cap - pos);
+  }
+  d->close(d, h);
+  mspack_destroy_chm_decompressor(d);
+  return MSPACK_ERR_OK;
+}
+
+/* ---- timing: the reference codec over a batch of independent units, T threads -------------- */
+struct bench_job {
+  int kind;                       /* 0 = LZX, 1 = MSZIP, 2 = Quantum */
+  const uint8_t *in_base;
+  const unsigned long long *in_off;
+  const unsigned *in_len;
+  const unsigned *out_len;
+  int window_bits, reset_frames;
+  int first, last;                /* unit range [first,last) */
+  uint8_t *scratch;               /* >= max out_len */
+  size_t scratch_cap;
+  unsigned long long bytes_out;
+  int errors;
+};
+
+static void *bench_worker(void *arg) {
+  struct bench_job *j = (struct bench_job *) arg;
+  int u;
+  for (u = j->first; u < j->last; u++) {
+    size_t w = 0; int err;
+    const uint8_t *in = j->in_base + j->in_off[u];
+    if (j->kind == 0)
+      err = refh_lzx(in, j->in_len[u], j->scratch, j->scratch_cap, j->out_len[u], j->window_bits,
+                     j->reset_frames, j->out_len[u], &w);
+    else if (j->kind == 1)
+      err = refh_mszip(in, j->in_len[u], j->scratch, j->scratch_cap, j->out_len[u], 0, &w);
+    else
+      err = refh_qtm(in, j->in_len[u], j->scratch, j->scratch_cap, j->out_len[u], j->window_bits, &w);
+    if (err != MSPACK_ERR_OK || w != j->out_len[u]) j->errors++;
+    j->bytes_out += w;
+  }
+  return NULL;
+}
+
+/* Returns wall seconds; *bytes_out = total decoded bytes; *errors = units that failed. */
+double refh_bench(int kind, const uint8_t *in_base, const unsigned long long *in_off,
+                  const unsigned *in_len, const unsigned *out_len, int n_units,
+                  int window_bits, int reset_frames, int n_threads,
+                  unsigned long long *bytes_out, int *errors)
+{
+  pthread_t *th;
+  struct bench_job *jobs;
+  struct timespec t0, t1;
+  size_t cap = 0;
+  int t, u;
+  if (n_threads < 1) n_threads = 1;
+  for (u = 0; u < n_units; u++) if (out_len[u] > cap) cap = out_len[u];
+  th = (pthread_t *) calloc((size_t) n_threads, sizeof(*th));
+  jobs = (struct bench_job *) calloc((size_t) n_threads, sizeof(*jobs));
+  for (t = 0; t < n_threads; t++) {
+    jobs[t].kind = kind; jobs[t].in_base = in_base; jobs[t].in_off = in_off;
+    jobs[t].in_len = in_len; jobs[t].out_len = out_len;
+    jobs[t].window_bits = window_bits; jobs[t].reset_frames = reset_frames;
+    jobs[t].first = (int)((long long) n_units * t / n_threads);
+    jobs[t].last  = (int)((long long) n_units * (t + 1) / n_threads);
+    jobs[t].scratch = (uint8_t *) malloc(cap + 64); jobs[t].scratch_cap = cap;
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
+  for (t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  *bytes_out = 0; *errors = 0;
+  for (t = 0; t < n_threads; t++) {
+    *bytes_out += jobs[t].bytes_out; *errors += jobs[t].errors; free(jobs[t].scratch);
+  }
+  free(th); free(jobs);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+const char *refh_version(void) { return "libmspack reference (oracle/_ref), built from /root/reference"; }

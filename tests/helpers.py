@@ -1,0 +1,235 @@
+"""Shared test helpers: ctypes bindings for the oracle (liboracle.so), the compiled reference
+(oracle/_ref/librefharness.so, optional) and a tiny CAB folder gatherer used only by tests.
+
+Nothing here is on the product path."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_DIR = "/root/reference"
+
+ERR_OK, ERR_ARGS, ERR_OPEN, ERR_READ, ERR_WRITE, ERR_SEEK, ERR_NOMEMORY, ERR_SIGNATURE, \
+    ERR_DATAFORMAT, ERR_CHECKSUM, ERR_CRUNCH, ERR_DECRUNCH = range(12)
+
+F_E8_APPLIED, F_LOOKAHEAD_READ, F_INTEL_HEADER = 1, 2, 4
+
+
+class OracleResult(C.Structure):
+    _fields_ = [("err", C.c_int32), ("flags", C.c_uint32), ("out_len", C.c_uint64),
+                ("in_used", C.c_uint64)]
+
+
+def _build_oracle():
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in
+            ("lzx_oracle.c", "mszip_oracle.c", "qtm_oracle.c", "oracle.h", "oracle_huff.h")]
+    if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        lib = C.CDLL(_build_oracle())
+        lib.oracle_lzx_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
+                                          C.c_uint64, C.c_int, C.c_int, C.c_int32, C.POINTER(OracleResult)]
+        lib.oracle_mszip_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
+                                            C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_int),
+                                            C.POINTER(OracleResult)]
+        lib.oracle_qtm_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
+                                          C.c_int, C.POINTER(OracleResult)]
+        lib.oracle_huff_accepts.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        _oracle = lib
+    return _oracle
+
+
+def oracle_lzx(data, out_bytes, window_bits, reset_frames=0, length=None, e8_base=0):
+    """-> (err, bytes, OracleResult)"""
+    if length is None:
+        length = out_bytes
+    buf = C.create_string_buffer(max(int(out_bytes), 1))
+    res = OracleResult()
+    oracle().oracle_lzx_decode(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), int(length),
+                               window_bits, reset_frames, e8_base, C.byref(res))
+    return res.err, buf.raw[:min(res.out_len, out_bytes)], res
+
+
+def oracle_mszip(data, out_bytes, repair=0):
+    buf = C.create_string_buffer(max(int(out_bytes), 1))
+    res = OracleResult()
+    lens = (C.c_uint32 * 70000)()
+    nb = C.c_int(0)
+    oracle().oracle_mszip_decode(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), repair,
+                                 lens, 70000, C.byref(nb), C.byref(res))
+    return res.err, buf.raw[:min(res.out_len, out_bytes)], res, list(lens[:nb.value])
+
+
+def oracle_qtm(data, out_bytes, window_bits):
+    buf = C.create_string_buffer(max(int(out_bytes), 1))
+    res = OracleResult()
+    oracle().oracle_qtm_decode(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), window_bits,
+                               C.byref(res))
+    return res.err, buf.raw[:min(res.out_len, out_bytes)], res
+
+
+# ---- the compiled reference (only where oracle/_ref exists) ------------------------------------
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "librefharness.so"))
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "librefharness.so"))
+        sz = C.POINTER(C.c_size_t)
+        lib.refh_lzx.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_longlong, C.c_int,
+                                 C.c_int, C.c_longlong, sz]
+        lib.refh_mszip.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_longlong, C.c_int, sz]
+        lib.refh_qtm.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_longlong, C.c_int, sz]
+        lib.refh_cab_list.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint),
+                                      C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.c_char_p, C.c_int]
+        lib.refh_cab_extract.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.c_void_p,
+                                         C.c_size_t, sz, sz, C.POINTER(C.c_int), C.c_int, C.c_int]
+        lib.refh_chm_list.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_longlong),
+                                      C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_char_p, C.c_int]
+        lib.refh_chm_extract.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.c_void_p,
+                                         C.c_size_t, sz, sz, C.POINTER(C.c_int)]
+        lib.refh_bench.restype = C.c_double
+        lib.refh_bench.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
+        _ref = lib
+    return _ref
+
+
+def ref_lzx(data, out_bytes, window_bits, reset_frames=0, length=None):
+    if length is None:
+        length = out_bytes
+    buf = C.create_string_buffer(max(int(out_bytes), 1))
+    w = C.c_size_t(0)
+    err = ref().refh_lzx(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), window_bits,
+                         reset_frames, int(length), C.byref(w))
+    return err, buf.raw[:min(w.value, out_bytes)], w.value
+
+
+def ref_mszip(data, out_bytes, repair=0):
+    buf = C.create_string_buffer(max(int(out_bytes), 1))
+    w = C.c_size_t(0)
+    err = ref().refh_mszip(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), repair, C.byref(w))
+    return err, buf.raw[:min(w.value, out_bytes)], w.value
+
+
+def ref_qtm(data, out_bytes, window_bits):
+    buf = C.create_string_buffer(max(int(out_bytes), 1))
+    w = C.c_size_t(0)
+    err = ref().refh_qtm(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), window_bits, C.byref(w))
+    return err, buf.raw[:min(w.value, out_bytes)], w.value
+
+
+def ref_cab_list(cab):
+    n = 4096
+    lens = (C.c_uint * n)(); offs = (C.c_uint * n)(); cts = (C.c_int * n)(); fids = (C.c_int * n)()
+    names = C.create_string_buffer(n * 64)
+    k = ref().refh_cab_list(cab, len(cab), n, lens, offs, cts, fids, names, 64)
+    if k < 0:
+        return -k, []
+    out = []
+    for i in range(min(k, n)):
+        nm = names.raw[i * 64:(i + 1) * 64].split(b"\0")[0]
+        out.append(dict(name=nm, length=lens[i], offset=offs[i], comp_type=cts[i], folder=fids[i]))
+    return 0, out
+
+
+def ref_cab_extract(cab, order, cap=1 << 26, fix_mszip=0, salvage=0):
+    """-> list of (err, bytes) for the files extracted in `order` with ONE decompressor."""
+    n = len(order)
+    arr = (C.c_int * n)(*order)
+    offs = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); errs = (C.c_int * n)()
+    buf = C.create_string_buffer(cap)
+    rc = ref().refh_cab_extract(cab, len(cab), arr, n, buf, cap, offs, lens, errs, fix_mszip, salvage)
+    if rc:
+        return rc, []
+    return 0, [(errs[i], buf.raw[offs[i]:offs[i] + min(lens[i], cap - offs[i])]) for i in range(n)]
+
+
+def ref_chm_list(chm):
+    n = 8192
+    lens = (C.c_longlong * n)(); offs = (C.c_longlong * n)(); secs = (C.c_int * n)()
+    names = C.create_string_buffer(n * 128)
+    k = ref().refh_chm_list(chm, len(chm), n, lens, offs, secs, names, 128)
+    if k < 0:
+        return -k, []
+    out = []
+    for i in range(min(k, n)):
+        nm = names.raw[i * 128:(i + 1) * 128].split(b"\0")[0]
+        out.append(dict(name=nm, length=lens[i], offset=offs[i], section=secs[i]))
+    return 0, out
+
+
+def ref_chm_extract(chm, order, cap=1 << 26):
+    n = len(order)
+    arr = (C.c_int * n)(*order)
+    offs = (C.c_size_t * n)(); lens = (C.c_size_t * n)(); errs = (C.c_int * n)()
+    buf = C.create_string_buffer(cap)
+    rc = ref().refh_chm_extract(chm, len(chm), arr, n, buf, cap, offs, lens, errs)
+    if rc:
+        return rc, []
+    return 0, [(errs[i], buf.raw[offs[i]:offs[i] + min(lens[i], cap - offs[i])]) for i in range(n)]
+
+
+# ---- minimal CAB folder gatherer (tests only; format: cab.h:16-67, cabd.c:1362-1479) -------------
+def cab_folders(cab):
+    """Return [dict(comp_type, blocks=[(payload, cb_uncomp)], files=[(name, offset, length)])].
+    Single-cabinet files only; no checksum validation."""
+    if cab[:4] != b"MSCF":
+        raise ValueError("not a cabinet")
+    files_off, = struct.unpack_from("<I", cab, 0x10)
+    nfolders, nfiles, flags = struct.unpack_from("<HHH", cab, 0x1A)
+    p = 0x24
+    hres = fres = dres = 0
+    if flags & 4:
+        hres, fres, dres = struct.unpack_from("<HBB", cab, p)
+        p += 4 + hres
+    for bit in (1, 2):
+        if flags & bit:
+            for _ in range(2):
+                p = cab.index(b"\0", p) + 1
+    folders = []
+    for _ in range(nfolders):
+        doff, nblocks, ctype = struct.unpack_from("<IHH", cab, p)
+        p += 8 + fres
+        blocks = []
+        q = doff
+        for _b in range(nblocks):
+            if q + 8 > len(cab):
+                break
+            _csum, cb, cu = struct.unpack_from("<IHH", cab, q)
+            q += 8 + dres
+            blocks.append((cab[q:q + cb], cu))
+            q += cb
+        folders.append(dict(comp_type=ctype, blocks=blocks, files=[]))
+    p = files_off
+    for _ in range(nfiles):
+        size, foff, fidx = struct.unpack_from("<IIH", cab, p)
+        e = cab.index(b"\0", p + 16)
+        if fidx < len(folders):
+            folders[fidx]["files"].append((cab[p + 16:e], foff, size))
+        p = e + 1
+    return folders
+
+
+def folder_stream(folder):
+    """Concatenate a folder's CFDATA payloads the way cabd_sys_read feeds the codec
+    (Quantum: 0xFF appended after every block, cabd.c:1330-1332)."""
+    qtm = (folder["comp_type"] & 0x0F) == 2
+    return b"".join(p + (b"\xff" if qtm else b"") for p, _ in folder["blocks"])
