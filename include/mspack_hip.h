@@ -1,0 +1,116 @@
+/* mspack_hip.h -- C ABI of the MI355X batched LZX / Quantum / MSZIP decoder.
+ *
+ * This is the drop-in boundary for the reference's decompression hot path.  The reference exposes
+ * that path only as pull-streams, one stream at a time:
+ *     lzxd_init / lzxd_decompress / lzxd_free      libmspack/mspack/lzx.h:146-214
+ *     qtmd_init / qtmd_decompress / qtmd_free      libmspack/mspack/qtm.h:92-122
+ *     mszipd_init / mszipd_decompress / mszipd_free libmspack/mspack/mszip.h:85-120
+ * driven by cabd_extract (cabd.c:1075-1214, codec dispatch cabd.c:1226-1269) and chmd_extract
+ * (chmd.c:906-1041, chmd_init_decomp chmd.c:1072-1188).  A GPU decodes many independent streams
+ * per launch, so the replacement ABI is "one batch of units in, one batch of results out":
+ * a unit is exactly one reference stream, i.e. what ONE xxxd_init + xxxd_decompress(out_len)
+ * pair would have decoded --
+ *     LZX     : one CAB folder (reset_frames = 0) or one CHM reset interval (chmd.c:1147-1183)
+ *     Quantum : one CAB folder (payloads + the 0xFF trailer cabd.c:1330-1332 adds per block)
+ *     MSZIP   : one CAB folder (concatenated "CK" blocks; history persists, mszipd.c:267-268)
+ * Results are bit-exact with the reference, including its MSPACK_ERR_* code per unit.
+ *
+ * Plain C: pointers and sizes only; no HIP or torch types appear in any signature (device
+ * pointers and the stream are passed as void*).  The libmspack-compatible object API
+ * (mspack_create_cab_decompressor & co.) that sits on top of this lives in mspack.h.
+ */
+#ifndef MSPACK_HIP_H
+#define MSPACK_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* unit kinds: the CAB compression-method codes (cab.h:52-58, cabd.c:1232-1262) */
+#define MSPACK_HIP_KIND_MSZIP   1
+#define MSPACK_HIP_KIND_QUANTUM 2
+#define MSPACK_HIP_KIND_LZX     3
+
+/* result flags */
+#define MSPACK_HIP_F_E8_APPLIED     1u  /* >=1 frame went through the E8 translation (lzxd.c:706-736) */
+#define MSPACK_HIP_F_LOOKAHEAD_READ 2u  /* all bytes produced; the one-frame look-ahead of
+                                           lzxd.c:419 then hit end of input (err = MSPACK_ERR_READ)  */
+#define MSPACK_HIP_F_INTEL_HEADER   4u  /* an LZX interval header carried intel_filesize != 0        */
+
+/* unit input flags */
+#define MSPACK_HIP_UF_MSZIP_REPAIR  1u  /* mszipd repair mode (MSCABD_PARAM_FIXMSZIP, mszipd.c:420-437) */
+
+typedef struct mspack_hip_unit {
+  uint64_t in_off;       /* byte offset of the unit's compressed bytes in the input arena          */
+  uint64_t out_off;      /* byte offset of the unit's output in the output arena                   */
+  uint32_t in_len;       /* compressed bytes available; reading past them yields the reference's
+                            two fabricated zero bytes, then MSPACK_ERR_READ (readbits.h:192-214)   */
+  uint32_t out_len;      /* bytes to produce == xxxd_decompress(out_bytes) == the stream's length  */
+  uint32_t frame_base;   /* LZX: first slot of this unit in the per-frame scratch (see below)      */
+  int32_t  e8_base;      /* LZX: lzx->offset at the unit's first byte (E8 curpos origin)           */
+  uint8_t  kind;         /* MSPACK_HIP_KIND_*                                                      */
+  uint8_t  window_bits;  /* LZX 15..21, Quantum 10..21, ignored for MSZIP                          */
+  uint16_t reset_frames; /* LZX: lzxd_init reset_interval in 32 KiB frames (0 = never, CAB)        */
+  uint32_t flags;        /* MSPACK_HIP_UF_*                                                        */
+} mspack_hip_unit;
+
+typedef struct mspack_hip_result {
+  int32_t  err;          /* MSPACK_ERR_* exactly as the reference's decompress call returns        */
+  uint32_t flags;        /* MSPACK_HIP_F_*                                                         */
+  uint32_t out_len;      /* bytes produced (handed to sys->write in the reference)                 */
+  uint32_t in_used;      /* compressed bytes the unit pulled (diagnostic)                          */
+} mspack_hip_result;
+
+/* ---- library / device ----------------------------------------------------------------------- */
+/* 0 on success, else a negative hipError_t.  All calls are per calling thread's current device
+ * unless mspack_hip_set_device() is used. */
+int  mspack_hip_device_count(void);
+int  mspack_hip_set_device(int device);
+const char *mspack_hip_version(void);
+const char *mspack_hip_last_error(void);
+
+/* ---- device-resident batch decode (the hot path proper) ---------------------------------------
+ * All pointers are DEVICE pointers valid on the current device.  `stream` is a hipStream_t (NULL =
+ * default stream).  The call is asynchronous with respect to the host.
+ *   d_units    : n_units descriptors
+ *   d_order    : optional launch order (unit indices, e.g. longest first); NULL = identity
+ *   d_in       : input arena, in_bytes long (must be followed by >= 8 readable bytes of slack
+ *                or in_bytes must leave 8 bytes of head-room inside the allocation)
+ *   d_out      : output arena (every unit owns [out_off, out_off + out_len))
+ *   d_results  : n_units results
+ *   d_frame_scratch : >= mspack_hip_frame_scratch_bytes(total LZX frames incl. 1 spare per unit);
+ *                may be NULL if the batch has no LZX units
+ * Returns 0 or a negative hipError_t from the launch. */
+int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_t *d_order,
+                                   size_t n_units, const void *d_in, size_t in_bytes,
+                                   void *d_out, size_t out_bytes, mspack_hip_result *d_results,
+                                   void *d_frame_scratch, size_t n_frames_total, void *stream);
+size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total);
+
+/* ---- host-buffer convenience (what the C drivers in mspack.h use) ------------------------------
+ * Same semantics with HOST pointers: stages the arenas to the current device, decodes, copies the
+ * outputs and results back.  `units[i].frame_base` is filled in by the call.  Synchronous. */
+int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
+                            void *out, size_t out_bytes, mspack_hip_result *results);
+
+/* Shard the same host batch across `n_devices` GPUs (devices 0..n_devices-1), one host thread per
+ * device, no inter-device traffic.  Units are dealt longest-first. */
+int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const void *in,
+                                  size_t in_bytes, void *out, size_t out_bytes,
+                                  mspack_hip_result *results, int n_devices);
+
+/* ---- timing helper for bench.py (HIP events on the launch stream) ------------------------------- */
+/* Runs `iters` back-to-back device-resident decodes and returns the average milliseconds per
+ * decode measured with hipEvents on `stream`; < 0 on error. */
+double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32_t *d_order,
+                                    size_t n_units, const void *d_in, size_t in_bytes,
+                                    void *d_out, size_t out_bytes, mspack_hip_result *d_results,
+                                    void *d_frame_scratch, size_t n_frames_total, void *stream,
+                                    int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

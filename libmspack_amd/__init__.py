@@ -1,0 +1,196 @@
+"""libmspack_amd -- MI355X-native batched LZX / Quantum / MSZIP decompression behind libmspack's API.
+
+This Python package is only a thin ctypes mirror of the C ABI in include/mspack_hip.h (and of the
+corpus generators used by tests and bench.py).  The product is the shared library
+libmspack_hip.so (hand-written HIP kernels + C host drivers); there is no CPU fallback: if the
+library is missing, or a GPU call fails, errors are raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(HERE, "libmspack_hip.so")
+CORPUS_SO = os.path.join(HERE, "libmspack_corpus.so")
+
+KIND_MSZIP, KIND_QUANTUM, KIND_LZX = 1, 2, 3
+F_E8_APPLIED, F_LOOKAHEAD_READ, F_INTEL_HEADER = 1, 2, 4
+UF_MSZIP_REPAIR = 1
+ERR_OK, ERR_ARGS, ERR_OPEN, ERR_READ, ERR_WRITE, ERR_SEEK, ERR_NOMEMORY, ERR_SIGNATURE, \
+    ERR_DATAFORMAT, ERR_CHECKSUM, ERR_CRUNCH, ERR_DECRUNCH = range(12)
+
+# struct mspack_hip_unit / mspack_hip_result (include/mspack_hip.h)
+UNIT_DTYPE = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"),
+                       ("frame_base", "<u4"), ("e8_base", "<i4"), ("kind", "u1"), ("window_bits", "u1"),
+                       ("reset_frames", "<u2"), ("flags", "<u4")], align=False)
+RESULT_DTYPE = np.dtype([("err", "<i4"), ("flags", "<u4"), ("out_len", "<u4"), ("in_used", "<u4")])
+assert UNIT_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 16
+
+
+class MspackHipError(RuntimeError):
+    pass
+
+
+_lib = None
+_corpus = None
+
+
+def lib():
+    """Load libmspack_hip.so; fails loudly when it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_SO):
+            raise MspackHipError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % HIP_SO)
+        L = C.CDLL(HIP_SO)
+        vp, sz = C.c_void_p, C.c_size_t
+        L.mspack_hip_version.restype = C.c_char_p
+        L.mspack_hip_last_error.restype = C.c_char_p
+        L.mspack_hip_device_count.restype = C.c_int
+        L.mspack_hip_set_device.argtypes = [C.c_int]
+        L.mspack_hip_frame_scratch_bytes.restype = sz
+        L.mspack_hip_frame_scratch_bytes.argtypes = [sz]
+        L.mspack_hip_decode_batch_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp, sz, vp]
+        L.mspack_hip_time_batch_device.restype = C.c_double
+        L.mspack_hip_time_batch_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp, sz, vp, C.c_int]
+        L.mspack_hip_decode_batch.argtypes = [vp, sz, vp, sz, vp, sz, vp]
+        L.mspack_hip_decode_batch_multi.argtypes = [vp, sz, vp, sz, vp, sz, vp, C.c_int]
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "mspack_hip_device_count", "mspack_hip_set_device", "mspack_hip_version", "mspack_hip_last_error",
+    "mspack_hip_decode_batch_device", "mspack_hip_frame_scratch_bytes", "mspack_hip_decode_batch",
+    "mspack_hip_decode_batch_multi", "mspack_hip_time_batch_device",
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise MspackHipError("%s failed (%d): %s" % (what, rc, lib().mspack_hip_last_error().decode()))
+
+
+def frames_of(units):
+    """per-unit slots in the LZX per-frame scratch (one spare for the look-ahead frame)"""
+    return np.where(units["kind"] == KIND_LZX, units["out_len"] // 32768 + 1, 0).astype(np.int64)
+
+
+def make_units(kind, in_offs, in_lens, out_lens, window_bits=0, reset_frames=0, e8_base=0, flags=0,
+               out_slack=0):
+    """Build a unit table; output regions are laid out back to back (16-byte aligned, plus
+    `out_slack` bytes each: MSZIP units need 32768 bytes of slack after out_len)."""
+    n = len(in_offs)
+    u = np.zeros(n, dtype=UNIT_DTYPE)
+    u["in_off"] = in_offs
+    u["in_len"] = in_lens
+    u["out_len"] = out_lens
+    u["kind"] = kind
+    u["window_bits"] = window_bits
+    u["reset_frames"] = reset_frames
+    u["e8_base"] = e8_base
+    u["flags"] = flags
+    sizes = (np.asarray(out_lens, dtype=np.int64) + out_slack + 15) & ~15
+    offs = np.zeros(n, dtype=np.int64)
+    if n:
+        offs[1:] = np.cumsum(sizes)[:-1]
+    u["out_off"] = offs
+    fr = frames_of(u)
+    fb = np.zeros(n, dtype=np.int64)
+    if n:
+        fb[1:] = np.cumsum(fr)[:-1]
+    u["frame_base"] = fb
+    return u, int(sizes.sum())
+
+
+def decode_batch(units, in_arena, out_bytes, n_devices=1):
+    """Host-buffer batch decode through mspack_hip_decode_batch[_multi].
+    -> (out uint8 array, results structured array)"""
+    units = np.ascontiguousarray(units, dtype=UNIT_DTYPE)
+    in_arena = np.ascontiguousarray(in_arena, dtype=np.uint8)
+    out = np.zeros(max(int(out_bytes), 1), dtype=np.uint8)
+    res = np.zeros(len(units), dtype=RESULT_DTYPE)
+    L = lib()
+    if n_devices > 1:
+        rc = L.mspack_hip_decode_batch_multi(units.ctypes.data, len(units), in_arena.ctypes.data, in_arena.size,
+                                             out.ctypes.data, out.size, res.ctypes.data, n_devices)
+    else:
+        rc = L.mspack_hip_decode_batch(units.ctypes.data, len(units), in_arena.ctypes.data, in_arena.size,
+                                       out.ctypes.data, out.size, res.ctypes.data)
+    _check(rc, "mspack_hip_decode_batch")
+    return out, res
+
+
+# ---- corpus generators (test / bench infrastructure) ---------------------------------------------
+class LzxOpts(C.Structure):
+    _fields_ = [("block_mode", C.c_int), ("block_size", C.c_int), ("chain_depth", C.c_int),
+                ("use_repeats", C.c_int), ("lazy", C.c_int), ("intel_filesize", C.c_int32),
+                ("e8_base", C.c_int32)]
+
+
+def corpus():
+    global _corpus
+    if _corpus is None:
+        if not os.path.exists(CORPUS_SO):
+            raise MspackHipError("%s not built" % CORPUS_SO)
+        L = C.CDLL(CORPUS_SO)
+        vp, sz = C.c_void_p, C.c_size_t
+        L.mspk_gen_plaintext.argtypes = [C.c_uint64, C.c_int, vp, sz]
+        L.mspk_lzx_encode.restype = sz
+        L.mspk_lzx_encode.argtypes = [vp, sz, C.c_int, C.c_int, C.POINTER(LzxOpts), vp, sz, vp]
+        L.mspk_lzx_bound.restype = sz
+        L.mspk_lzx_bound.argtypes = [sz]
+        L.mspk_corpus_lzx_units.restype = sz
+        L.mspk_corpus_lzx_units.argtypes = [C.c_uint64, C.c_int, C.c_int, sz, C.c_int, C.POINTER(LzxOpts),
+                                            C.c_int, vp, vp, sz, vp, vp]
+        _corpus = L
+    return _corpus
+
+
+TEXT_MIX, TEXT_ENGLISH, TEXT_BINARY, TEXT_RECORDS, TEXT_RANDOM, TEXT_REPETITIVE = range(6)
+
+
+def gen_plaintext(seed, kind, n):
+    buf = np.empty(n, dtype=np.uint8)
+    corpus().mspk_gen_plaintext(seed, kind, buf.ctypes.data, n)
+    return buf
+
+
+def lzx_opts(mode=0, block_size=0, depth=0, repeats=1, lazy=1, intel_filesize=0, e8_base=0):
+    return LzxOpts(mode, block_size, depth, repeats, lazy, intel_filesize, e8_base)
+
+
+def lzx_encode(data, window_bits, reset_frames, opts=None):
+    """-> (compressed bytes (np.uint8), frame_off (np.uint64, n_frames+1))"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    n = data.size
+    L = corpus()
+    cap = L.mspk_lzx_bound(n)
+    dst = np.empty(cap, dtype=np.uint8)
+    nfr = (n + 32767) // 32768
+    fo = np.zeros(nfr + 1, dtype=np.uint64)
+    o = opts if opts is not None else lzx_opts()
+    m = L.mspk_lzx_encode(data.ctypes.data, n, window_bits, reset_frames, C.byref(o), dst.ctypes.data, cap,
+                          fo.ctypes.data)
+    if m == 0:
+        raise MspackHipError("mspk_lzx_encode overflow")
+    return dst[:m].copy(), fo
+
+
+def corpus_lzx_units(base_seed, kind, n_units, unit_bytes, window_bits, opts=None, n_threads=None):
+    """Batch of independent LZX units (one reset interval each).
+    -> (plain [n_units*unit_bytes], comp arena, comp_off u64[n], comp_len u32[n])"""
+    L = corpus()
+    if n_threads is None:
+        n_threads = os.cpu_count() or 1
+    plain = np.empty(n_units * unit_bytes, dtype=np.uint8)
+    cap = n_units * (L.mspk_lzx_bound(unit_bytes) + 16)
+    comp = np.zeros(cap, dtype=np.uint8)
+    off = np.zeros(n_units, dtype=np.uint64)
+    ln = np.zeros(n_units, dtype=np.uint32)
+    o = opts if opts is not None else lzx_opts()
+    total = L.mspk_corpus_lzx_units(base_seed, kind, n_units, unit_bytes, window_bits, C.byref(o), n_threads,
+                                    plain.ctypes.data, comp.ctypes.data, cap, off.ctypes.data, ln.ctypes.data)
+    if total == 0:
+        raise MspackHipError("mspk_corpus_lzx_units failed")
+    return plain, comp[:total + 64].copy(), off, ln

@@ -1,0 +1,508 @@
+// lzx_kernel.hpp -- LZX unit decoder: one wavefront per CAB folder / CHM reset interval.
+//
+// Replaces, for one unit, lzxd_init + lzxd_decompress(out_len) of the reference
+// (libmspack/mspack/lzxd.c:274-346, 388-771) with bit-exact output and error code:
+//   bit reader ........ readbits.h:133-166 + lzxd.c:85-91 -> 64-bit SGPR bit buffer, refilled 32 bits
+//                       at a time by v_readlane from the lane-resident input chunk
+//   READ_HUFFSYM ...... readhuff.h:39-66 -> one LDS lookup (10/8/7/6 direct bits); long codes by a
+//                       wave-wide limit compare + ballot (wave_common.hpp)
+//   make_decode_table . readhuff.h:83-176 -> lane-parallel build, same accept/reject set
+//   lzxd_read_lens .... lzxd.c:138-183 (serial by nature: each length is a delta on the previous
+//                       block's value)
+//   main decode loop .. lzxd.c:538-651 -> literals are gathered 64 at a time into one coalesced
+//                       store; a match is one coalesced 64-lane load/store per 64 bytes, with the
+//                       overlapping case (offset < length) served from the periodic source
+//   frame logic ....... lzxd.c:419-466, 677-697, 749-754
+//   E8 translation .... lzxd.c:706-736 -> NOT done here: the window must keep untranslated bytes
+//                       and our window IS the output, so the decode kernel only records, per frame,
+//                       the intel_filesize to apply; a second, frame-parallel kernel translates.
+// The output buffer doubles as the LZ77 window ("linear window"): src = pos - offset, valid because
+// frames never straddle the window wrap (lzxd.c:655-656); positions modulo window_size are kept
+// only for the reference's error checks (lzxd.c:613-634).
+#pragma once
+#include "wave_common.hpp"
+
+#define LZX_FRAME 32768u
+#define LZX_MAIN_P 10
+#define LZX_LEN_P 8
+#define LZX_ALI_P 7
+#define LZX_PRE_P 6
+#define LZX_MAIN_SYMS 720      /* 256 + 50*8 + 64: every index that can ever be non-zero (w<=21) */
+#define LZX_LEN_SYMS 250
+
+struct __align__(16) LzxShared {
+  u16 main_tab[1 << LZX_MAIN_P];
+  u16 main_sorted[LZX_MAIN_SYMS];
+  u16 len_tab[1 << LZX_LEN_P];
+  u16 len_sorted[256];
+  u16 ali_tab[1 << LZX_ALI_P];
+  u16 pre_tab[1 << LZX_PRE_P];
+  u16 ali_sorted[8];
+  u16 pre_sorted[24];
+  u32 cnt[20];
+  u8  main_len[LZX_MAIN_SYMS + 16];
+  u8  len_len[LZX_LEN_SYMS + 70];
+  u8  pre_len[24];
+  u8  ali_len[8];
+};
+
+struct LzxDec {
+  // ---- input / bit buffer (wave-uniform unless noted) ----
+  InWindow w;
+  u64 bb; int bl;
+  bool near_end, careful; int rbl;   // reference bits_left is simulated only near end of input
+  int err;
+  u32 lane;
+  // ---- output ----
+  u8 *out; u32 P;                    // linear position == bytes decoded since unit start
+  u32 lit_buf; u32 lit_n;            // lit_buf is per-lane
+  LzxShared *sh;
+  HuffRegs hr_main, hr_len, hr_ali, hr_pre;
+
+  __device__ __forceinline__ u32 cons_bits() const { return w.wi * 32u - (u32) bl; }
+  __device__ __forceinline__ void refill() {
+    u32 d = w.next_dword(lane);
+    u32 x = (d << 16) | (d >> 16);               // two LE16 words, first word on top (lzxd.c:85-91)
+    bb |= (u64) x << (32 - bl);
+    bl += 32;
+    u32 fetched = w.origin + w.wi * 4u;
+    if (fetched >= w.in_len || w.in_len - fetched <= 64u) near_end = true;
+  }
+  __device__ __forceinline__ void need(int n) { if (bl < n) refill(); }   // n <= 32
+  __device__ bool ref_ensure(int n) {             // ENSURE_BITS(n) of the reference, EOF-exact
+    while (rbl < n) {
+      u32 i = w.origin + ((cons_bits() + (u32) rbl) >> 3);   // the reference's i_ptr
+      if (i > w.in_len) { err = ERR_READ; return false; }     // 2 fake bytes, then ERR_READ
+      rbl += 16;
+    }
+    return true;
+  }
+  __device__ __forceinline__ bool sym_ensure() {  // ENSURE_BITS(16): bits_left becomes a pure
+    if (careful) return ref_ensure(16);           // function of the bit position
+    if (near_end) { careful = true; rbl = 16 + (int)((0u - cons_bits()) & 15u); }
+    return true;
+  }
+  __device__ __forceinline__ void drop(int n) { bb <<= n; bl -= n; if (careful) rbl -= n; }
+  __device__ __forceinline__ bool read_bits(int n, u32 &v) {    // READ_BITS, 1 <= n <= 17
+    need(n);
+    if (careful && !ref_ensure(n)) return false;
+    v = (u32)(bb >> (64 - n));
+    drop(n);
+    return true;
+  }
+  template <int TP>
+  __device__ __forceinline__ int decode_sym(const u16 *tab, const u16 *sorted, const HuffRegs &hr) {
+    if (!sym_ensure()) return -1;
+    u32 e = rfl((u32) tab[(u32)(bb >> (64 - TP))]);
+    if (e == 0) {
+      e = huff_long(hr, sorted, (u32)(bb >> 48), lane);
+      if (e == 0) { err = ERR_DECRUNCH; return -1; }
+    }
+    drop((int)(e >> 10));
+    return (int)(e & 1023u);
+  }
+  // the reference's i_ptr (bytes) -- exact in careful mode, a lower bound otherwise
+  __device__ __forceinline__ u32 iptr() const {
+    u32 c = cons_bits();
+    return w.origin + (careful ? ((c + (u32) rbl) >> 3) : (((c + 15u) & ~15u) >> 3));
+  }
+
+  __device__ __forceinline__ void flush_lits() {
+    if (lit_n) {
+      if (lane < lit_n) out[P - lit_n + lane] = (u8) lit_buf;
+      lit_n = 0;
+    }
+  }
+};
+
+// lzxd_read_lens (lzxd.c:138-183).  Serial: every length is a delta against lens[x].
+__device__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u32 last)
+{
+  LzxShared *sh = d.sh;
+  u32 v;
+  for (u32 x = 0; x < 20; x++) {
+    if (!d.read_bits(4, v)) return false;
+    sh->pre_len[x] = (u8) v;
+  }
+  if (d.lane < 4u) sh->pre_len[20 + d.lane] = 0;
+  if (huff_build<LZX_PRE_P>(sh->pre_len, 20, 6, sh->pre_tab, sh->pre_sorted, sh->cnt, d.hr_pre, d.lane, false)) {
+    d.err = ERR_DECRUNCH; return false;                       // incl. the all-zero pretree
+  }
+  for (u32 x = first; x < last; ) {
+    d.need(32);
+    int z = d.decode_sym<LZX_PRE_P>(sh->pre_tab, sh->pre_sorted, d.hr_pre);
+    if (z < 0) return false;
+    if (z == 17 || z == 18) {
+      u32 y;
+      if (!d.read_bits(z == 17 ? 4 : 5, y)) return false;
+      y += (z == 17) ? 4u : 20u;
+      for (u32 i = d.lane; i < y; i += WAVE) lens[x + i] = 0;  // runs are NOT clipped (lzxd.c:159)
+      x += y;
+    }
+    else if (z == 19) {
+      u32 y;
+      if (!d.read_bits(1, y)) return false;
+      y += 4u;
+      d.need(16);
+      int z2 = d.decode_sym<LZX_PRE_P>(sh->pre_tab, sh->pre_sorted, d.hr_pre);
+      if (z2 < 0) return false;
+      int nv = (int) rfl((u32) lens[x]) - z2; if (nv < 0) nv += 17;
+      if (d.lane < y) lens[x + d.lane] = (u8) nv;
+      x += y;
+    }
+    else {
+      int nv = (int) rfl((u32) lens[x]) - z; if (nv < 0) nv += 17;
+      lens[x] = (u8) nv;
+      x++;
+    }
+  }
+  return true;
+}
+
+struct LzxState {
+  u32 R0, R1, R2;
+  u32 block_type, block_length, block_remaining;
+  u32 wsize, wpos, frame_posn, frame, reset_frames, num_offsets;
+  u32 offset;            // bytes written (lzx->offset)
+  u32 length;            // lzx->length
+  int32_t intel_filesize;
+  bool header_read, intel_started, length_empty;
+  bool raw_mode; u32 raw_pos;   // inside / right after an uncompressed block: input byte position
+};
+
+__device__ __forceinline__ void lzx_reset_state(LzxDec &d, LzxState &s) {      // lzxd.c:257-270
+  s.R0 = s.R1 = s.R2 = 1;
+  s.header_read = false; s.block_remaining = 0; s.block_type = 0;
+  for (u32 i = d.lane; i < LZX_MAIN_SYMS + 16; i += WAVE) d.sh->main_len[i] = 0;
+  // NB the reference clears exactly MAXSYMBOLS entries; the safety area beyond is never cleared
+  // but also never read back for the length tree (index 249 is inside MAXSYMBOLS = 250)
+  for (u32 i = d.lane; i < LZX_LEN_SYMS; i += WAVE) d.sh->len_len[i] = 0;
+}
+
+// leave raw (uncompressed-block) input mode: bit reading restarts at raw_pos with an empty buffer
+__device__ __forceinline__ void lzx_leave_raw(LzxDec &d, LzxState &s) {
+  if (s.raw_mode) {
+    d.w.seek(s.raw_pos, d.lane);
+    d.bb = 0; d.bl = 0; d.rbl = 0;
+    u32 fetched = s.raw_pos;
+    d.near_end = (fetched >= d.w.in_len || d.w.in_len - fetched <= 64u);
+    if (d.near_end) d.careful = true;      // bits_left == 0 here: a determined point
+    s.raw_mode = false;
+  }
+}
+
+// block header (lzxd.c:467-523); returns false on error (d.err set)
+__device__ bool lzx_block_header(LzxDec &d, LzxState &s)
+{
+  LzxShared *sh = d.sh;
+  u32 v, hi, lo;
+  if (s.block_type == 3u && (s.block_length & 1u)) {            // odd-sized stored block: pad byte
+    // bit buffer is empty here; the byte is skipped at i_ptr (lzxd.c:469-474)
+    if (s.raw_mode) {
+      if (s.raw_pos >= d.w.in_len + 2u) { d.err = ERR_READ; return false; }
+      s.raw_pos++;
+    }
+    else {
+      // stored block ended earlier in raw mode and we already re-seeked: cannot happen, raw_mode
+      // is only left here or at a reset (where block_type is cleared)
+    }
+  }
+  lzx_leave_raw(d, s);
+  if (!d.read_bits(3, v) || !d.read_bits(16, hi) || !d.read_bits(8, lo)) return false;
+  s.block_type = v;
+  s.block_remaining = s.block_length = (hi << 8) | lo;
+  if (v == 2u) {
+    for (u32 i = 0; i < 8; i++) { u32 t; if (!d.read_bits(3, t)) return false; sh->ali_len[i] = (u8) t; }
+    if (huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, d.lane, false)) {
+      d.err = ERR_DECRUNCH; return false;
+    }
+  }
+  if (v == 1u || v == 2u) {
+    if (!lzx_read_lens(d, sh->main_len, 0, 256)) return false;
+    if (!lzx_read_lens(d, sh->main_len, 256, 256 + s.num_offsets)) return false;
+    if (huff_build<LZX_MAIN_P>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+                               sh->cnt, d.hr_main, d.lane, false)) {
+      d.err = ERR_DECRUNCH; return false;
+    }
+    if (rfl((u32) sh->main_len[0xE8]) != 0u) s.intel_started = true;
+    if (!lzx_read_lens(d, sh->len_len, 0, 249)) return false;
+    int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt,
+                                  d.hr_len, d.lane, false);
+    if (r == 1) { d.err = ERR_DECRUNCH; return false; }
+    s.length_empty = (r == 2);                                   // lzxd.c:111-125
+    return true;
+  }
+  if (v == 3u) {
+    s.intel_started = true;
+    // discard 1..16 bits up to the next word boundary (a whole word if already aligned),
+    // lzxd.c:506-507.  After the 27 header bits the reference holds < 16 bits, so the data starts
+    // at the end of the current word, or one word further when exactly aligned.
+    u32 c = d.cons_bits();
+    u32 data = d.w.origin + (((c + 15u) & ~15u) >> 3) + (((c & 15u) == 0u) ? 2u : 0u);
+    if (d.careful) {
+      if (d.rbl == 0 && !d.ref_ensure(16)) return false;
+    }
+    // 12 bytes R0,R1,R2 (LE32), then the raw bytes; bytes up to in_len+1 exist (two fake zeros)
+    if (data + 12u > d.w.in_len + 2u) { d.err = ERR_READ; return false; }
+    u32 b = (d.lane < 12u) ? d.w.byte_at(data + d.lane) : 0u;
+    u32 r[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      r[k] = rdl(b, 4 * k) | (rdl(b, 4 * k + 1) << 8) | (rdl(b, 4 * k + 2) << 16) | (rdl(b, 4 * k + 3) << 24);
+    s.R0 = r[0]; s.R1 = r[1]; s.R2 = r[2];
+    s.raw_mode = true; s.raw_pos = data + 12u;
+    d.bb = 0; d.bl = 0; d.rbl = 0;
+    return true;
+  }
+  d.err = ERR_DECRUNCH;
+  return false;
+}
+
+// copy a match of `len` bytes at distance `off` (1 <= off <= window) to the linear position P
+__device__ __forceinline__ void lzx_copy_match(u8 *out, u32 P, u32 off, u32 len, u32 lane)
+{
+  u8 *dst = out + P;
+  const u8 *src = dst - off;
+  if (off >= len || off >= WAVE) {
+    // every 64-byte step only reads bytes that are already complete (earlier steps/tokens)
+    for (u32 i = lane; i < len; i += WAVE) dst[i] = src[i];
+  }
+  else {
+    // overlapping copy, period `off` < 64: lane i takes pattern byte (i mod off)
+    u32 r = lane, s = off << 5;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { u32 t = r - s; r = t < r ? t : r; s >>= 1; }     // r = lane mod off
+    u32 step = 64u, ss = off << 5;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { u32 t = step - ss; step = t < step ? t : step; ss >>= 1; }  // 64 mod off
+    for (u32 i = lane; i < len; i += WAVE) {
+      dst[i] = src[r];
+      r += step; if (r >= off) r -= off;
+    }
+  }
+}
+
+// reference-exact slow path for offsets no encoder produces (0, or beyond the window: only reachable
+// through R0-R2 loaded from a stored-block header).  Byte-serial ring semantics of lzxd.c:618-646.
+__device__ void lzx_copy_match_odd(u8 *out, u32 P, u32 wpos, u32 wsize, u32 off, u32 len)
+{
+  u32 base = P - wpos;                       // linear position of window index 0 in this pass
+  for (u32 k = 0; k < len; k++) {
+    u32 sidx = (wpos - off + k) & (wsize - 1u);
+    if (off > wpos) { u32 j = off - wpos; sidx = (k < j) ? (wsize - j + k) : (k - j); }
+    u8 b = 0;
+    if (sidx < wpos + k) b = out[base + sidx];
+    else if (base + sidx >= wsize) b = out[base + sidx - wsize];
+    out[P + k] = b;
+  }
+}
+
+// decode one LZX unit.  frame_meta[frame_base + f] receives the intel_filesize to apply to frame f
+// (0 = none).  Returns via *res.
+__device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
+                                int32_t *frame_meta, mspack_hip_result *res, LzxShared *sh)
+{
+  const u32 lane = threadIdx.x;
+  LzxDec d;
+  LzxState s;
+  u32 flags = 0;
+  const u32 out_bytes = u.out_len;
+  u32 remaining = out_bytes;
+
+  d.lane = lane; d.sh = sh; d.err = 0;
+  d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
+  d.w.seek(0, lane);
+  d.bb = 0; d.bl = 0; d.rbl = 0;
+  d.near_end = (u.in_len <= 64u); d.careful = d.near_end;
+  d.out = out_arena + u.out_off; d.P = 0; d.lit_buf = 0; d.lit_n = 0;
+
+  s.wsize = 1u << u.window_bits;
+  s.wpos = 0; s.frame_posn = 0; s.frame = 0; s.reset_frames = u.reset_frames;
+  s.offset = 0; s.length = out_bytes;
+  s.intel_filesize = 0; s.intel_started = false; s.length_empty = false;
+  s.raw_mode = false; s.raw_pos = 0;
+  {
+    static const u8 slots[7] = { 30, 32, 34, 36, 38, 42, 50 };
+    u32 wb = u.window_bits;
+    s.num_offsets = (wb >= 15u && wb <= 21u) ? ((u32) slots[wb - 15u] << 3) : 0u;
+  }
+  if (s.num_offsets == 0u) {
+    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; }
+    return;
+  }
+  lzx_reset_state(d, s);
+
+  if (out_bytes != 0u) {
+    const u32 end_frame = out_bytes / LZX_FRAME + 1u;                      // lzxd.c:419
+    while (s.frame < end_frame) {
+      if (s.reset_frames && (s.frame % s.reset_frames) == 0u) {
+        // a reset in raw mode keeps reading bits from raw_pos (no pad byte: block_type is cleared)
+        lzx_reset_state(d, s);
+      }
+      if (!s.header_read) {
+        u32 v, hi = 0, lo = 0;
+        lzx_leave_raw(d, s);
+        if (!d.read_bits(1, v)) break;
+        if (v) { if (!d.read_bits(16, hi) || !d.read_bits(16, lo)) break; }
+        s.intel_filesize = (int32_t)((hi << 16) | lo);
+        if (s.intel_filesize) flags |= MSPACK_HIP_F_INTEL_HEADER;
+        s.header_read = true;
+      }
+      u32 frame_size = LZX_FRAME;
+      if (s.length && (s.length - s.offset) < frame_size) frame_size = s.length - s.offset;
+
+      int todo = (int)(s.frame_posn + frame_size - s.wpos);
+      bool fail = false;
+      while (todo > 0) {
+        if (s.block_remaining == 0u) { if (!lzx_block_header(d, s)) { fail = true; break; } }
+        int run = (int) s.block_remaining;
+        if (run > todo) run = todo;
+        todo -= run; s.block_remaining -= (u32) run;
+
+        if (s.block_type == 1u || s.block_type == 2u) {
+          // ---------------- the hot loop (lzxd.c:538-651) ----------------
+          const bool aligned = (s.block_type == 2u);
+          const u32 run_end = d.P + (u32) run;
+          const u32 wbase = d.P - s.wpos;          // linear position of window index 0
+          while (d.P < run_end) {
+            if (d.bl <= 32) d.refill();
+            int sym = d.decode_sym<LZX_MAIN_P>(sh->main_tab, sh->main_sorted, d.hr_main);
+            if (sym < 0) { fail = true; break; }
+            if (sym < 256) {
+              d.lit_buf = wrl(d.lit_buf, (u32) sym, d.lit_n);
+              d.lit_n++; d.P++;
+              if (d.lit_n == WAVE) d.flush_lits();
+              continue;
+            }
+            u32 m = (u32) sym - 256u, slot = m >> 3, len = m & 7u, off;
+            if (len == 7u) {
+              if (s.length_empty) { d.err = ERR_DECRUNCH; fail = true; break; }
+              int foot = d.decode_sym<LZX_LEN_P>(sh->len_tab, sh->len_sorted, d.hr_len);
+              if (foot < 0) { fail = true; break; }
+              len += (u32) foot;
+            }
+            len += 2u;
+            if (slot == 0u) off = s.R0;
+            else if (slot == 1u) { off = s.R1; s.R1 = s.R0; s.R0 = off; }
+            else if (slot == 2u) { off = s.R2; s.R2 = s.R0; s.R0 = off; }
+            else {
+              // position_base / extra_bits from their closed form (lzxd.c:202-207)
+              u32 extra = slot < 4u ? 0u : (slot < 36u ? (slot >> 1) - 1u : 17u);
+              u32 base = slot < 4u ? slot : (slot < 36u ? ((2u + (slot & 1u)) << extra) : ((slot - 34u) << 17));
+              off = base - 2u;
+              if (d.bl <= 32) d.refill();
+              if (extra >= 3u && aligned) {
+                if (extra > 3u) { u32 vb; if (!d.read_bits((int) extra - 3, vb)) { fail = true; break; } off += vb << 3; }
+                int a = d.decode_sym<LZX_ALI_P>(sh->ali_tab, sh->ali_sorted, d.hr_ali);
+                if (a < 0) { fail = true; break; }
+                off += (u32) a;
+              }
+              else if (extra) { u32 vb; if (!d.read_bits((int) extra, vb)) { fail = true; break; } off += vb; }
+              s.R2 = s.R1; s.R1 = s.R0; s.R0 = off;
+            }
+            u32 wp = d.P - wbase;
+            // a match running past the run is an error in every case (lzxd.c:678-693); test it
+            // before copying so that nothing is ever written past the unit's output
+            if (d.P + len > run_end) { d.err = ERR_DECRUNCH; fail = true; break; }
+            if (wp + len > s.wsize) { d.err = ERR_DECRUNCH; fail = true; break; }       // lzxd.c:613
+            if (off > wp) {
+              if (off > s.offset || (off - wp) > s.wsize) { d.err = ERR_DECRUNCH; fail = true; break; }
+            }
+            d.flush_lits();
+            if (off != 0u && off <= s.wsize) lzx_copy_match(d.out, d.P, off, len, lane);
+            else { if (lane == 0) lzx_copy_match_odd(d.out, d.P, wp, s.wsize, off, len); }
+            d.P += len;
+          }
+          d.flush_lits();
+          if (fail) break;
+          s.wpos = d.P - wbase;
+          run = (int)(run_end - d.P);              // <= 0: overrun of the last match
+        }
+        else if (s.block_type == 3u) {
+          // stored bytes: coalesced copy input -> output (lzxd.c:654-671)
+          u32 n = (u32) run;
+          if (s.raw_pos + n > d.w.in_len + 2u || s.raw_pos + n < s.raw_pos) { d.err = ERR_READ; fail = true; break; }
+          for (u32 i = lane; i < n; i += WAVE) d.out[d.P + i] = (u8) d.w.byte_at(s.raw_pos + i);
+          s.raw_pos += n; d.P += n; s.wpos += n;
+          run = 0;
+        }
+        else { d.err = ERR_DECRUNCH; fail = true; break; }
+
+        if (run < 0) {                                                          // lzxd.c:678-685
+          if ((u32)(-run) > s.block_remaining) { d.err = ERR_DECRUNCH; fail = true; break; }
+          s.block_remaining -= (u32)(-run);
+        }
+      }
+      if (fail) break;
+      if ((s.wpos - s.frame_posn) != frame_size) { d.err = ERR_DECRUNCH; break; }  // lzxd.c:689
+
+      // re-align the bitstream to 16 bits (lzxd.c:695-697)
+      if (!s.raw_mode) {
+        if (d.careful) { if (d.rbl > 0 && !d.ref_ensure(16)) break; }
+        int n = d.bl & 15;
+        if (d.bl < n) d.refill();
+        if (n) d.drop(n);
+      }
+
+      // E8: record what the translation pass must do for this frame (lzxd.c:707-708)
+      {
+        int32_t fs = 0;
+        if (s.intel_started && s.intel_filesize && s.frame < 32768u && frame_size > 10u) {
+          fs = s.intel_filesize; flags |= MSPACK_HIP_F_E8_APPLIED;
+        }
+        if (lane == 0 && frame_meta) frame_meta[u.frame_base + s.frame] = fs;
+      }
+      {
+        u32 n = remaining < frame_size ? remaining : frame_size;
+        s.offset += n; remaining -= n;
+      }
+      s.frame_posn += frame_size; s.frame++;
+      if (s.wpos == s.wsize) s.wpos = 0;
+      if (s.frame_posn == s.wsize) s.frame_posn = 0;
+    }
+  }
+  int err = d.err;
+  if (err == 0 && remaining) err = ERR_DECRUNCH;                                  // lzxd.c:758-761
+  if (err == ERR_READ && remaining == 0u) flags |= MSPACK_HIP_F_LOOKAHEAD_READ;
+  if (lane == 0) {
+    res->err = err; res->flags = flags; res->out_len = s.offset;
+    res->in_used = s.raw_mode ? s.raw_pos : d.iptr();
+  }
+}
+
+// E8 translation of one 32 KiB frame (lzxd.c:706-736), in place; one wavefront per frame.
+// The scan is sequential in the reference (an E8 consumes the 4 following bytes, which are then not
+// examined); here 64 bytes are examined at a time, candidates are found with a ballot and the
+// skip rule is resolved on the 64-bit mask.
+__device__ void lzx_e8_frame(u8 *frame, u32 frame_size, int32_t curpos0, int32_t filesize, u32 lane)
+{
+  if (frame_size <= 10u) return;
+  const u32 end = frame_size - 10u;
+  u32 skip_until = 0;                      // bytes below this index belong to an earlier operand
+  for (u32 base = 0; base < end; base += WAVE) {
+    u32 i = base + lane;
+    bool cand = (i < end) && (i >= skip_until) && (frame[i] == 0xE8);
+    u64 m = ballot(cand);
+    u64 keep = 0;
+    while (m) {
+      u32 l = (u32) __ffsll((long long) m) - 1u;
+      keep |= 1ull << l;
+      u64 clr = (l + 5u >= 64u) ? ~0ull << l : (((1ull << 5) - 1ull) << l);
+      m &= ~clr;
+      skip_until = base + l + 5u;
+    }
+    // curpos at an accepted E8 at index i equals curpos0 + i (every byte advances it by one:
+    // a skipped operand advances it by 5 for 5 bytes, lzxd.c:721,731)
+    if ((keep >> lane) & 1ull) {
+      int32_t curpos = curpos0 + (int32_t) i;
+      int32_t abs_off = (int32_t)((u32) frame[i + 1] | ((u32) frame[i + 2] << 8) | ((u32) frame[i + 3] << 16) |
+                                  ((u32) frame[i + 4] << 24));
+      if (abs_off >= -curpos && abs_off < filesize) {
+        int32_t rel = (abs_off >= 0) ? abs_off - curpos : abs_off + filesize;
+        frame[i + 1] = (u8) rel; frame[i + 2] = (u8)(rel >> 8);
+        frame[i + 3] = (u8)(rel >> 16); frame[i + 4] = (u8)(rel >> 24);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+}

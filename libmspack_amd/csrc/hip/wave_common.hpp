@@ -1,0 +1,190 @@
+// wave_common.hpp -- device-side building blocks shared by the LZX / MSZIP / Quantum kernels.
+//
+// Execution model: ONE WAVEFRONT (64 lanes, one 64-thread workgroup) decodes ONE unit.  Control
+// flow, the bit buffer, positions and match parameters are wave-uniform and live in SGPRs (we force
+// that with readfirstlane / readlane); the 64 lanes are used for
+//   * the compressed-input window: each lane keeps one dword of the current 256-byte chunk in a
+//     VGPR, the bit buffer is refilled with v_readlane (no memory latency on the symbol chain),
+//     the following chunk is prefetched one chunk ahead;
+//   * building canonical-Huffman decode tables in LDS (histogram, ballot-ranked counting sort,
+//     one table entry per lane);
+//   * LZ77 match copies / literal runs as coalesced byte stores.
+// gfx950 only; no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../../include/mspack_hip.h"
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// MSPACK_ERR_* values (mspack.h:485-507)
+#define ERR_OK        0
+#define ERR_ARGS      1
+#define ERR_READ      3
+#define ERR_DECRUNCH 11
+
+#define WAVE 64
+
+__device__ __forceinline__ u32 rfl(u32 v) { return (u32) __builtin_amdgcn_readfirstlane((int) v); }
+__device__ __forceinline__ u32 rdl(u32 v, u32 l) { return (u32) __builtin_amdgcn_readlane((int) v, (int) l); }
+// write `val` into lane `l` of a per-lane register (this clang has no writelane builtin; the
+// compare+select is two VALU ops and keeps everything visible to the scheduler)
+#define wrl(old, val, l) ((threadIdx.x == (u32)(l)) ? (u32)(val) : (u32)(old))
+__device__ __forceinline__ u64 ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ u32 lanemask_lt_popc(u64 m, u32 lane) {
+  return __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Compressed-input window.  Byte offsets are relative to the unit's first compressed byte.  Reads
+// beyond in_len return zero (the reference fabricates two zero bytes at EOF, readbits.h:196-208;
+// whether a read beyond those is an ERR_READ is decided by the callers' position checks).
+// ---------------------------------------------------------------------------------------------------
+struct InWindow {
+  const u8 *unit;     // arena + in_off (uniform); the arena has >= 8 bytes of readable slack
+  u32 in_len;
+  u32 origin;         // byte offset of dword index 0
+  u32 wi;             // next dword index (relative to origin) to hand out
+  u32 cur, nxt;       // per-lane: dword `lane` of the current / next 256-byte chunk
+
+  __device__ __forceinline__ u32 load_chunk(u32 c, u32 lane) const {
+    u32 o = origin + c * 256u + lane * 4u;
+    u32 v = 0;
+    if (o < in_len) {
+      const u8 *p = unit + o;
+      u64 a = (u64) p;
+      u32 sh = (u32)(a & 3u);
+      const u32 *q = (const u32 *)(a & ~3ull);
+      u32 lo = q[0];
+      u32 hi = q[1];
+      v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+      u32 rem = in_len - o;
+      if (rem < 4u) v &= (1u << (8u * rem)) - 1u;
+    }
+    return v;
+  }
+  __device__ __forceinline__ void seek(u32 byte_pos, u32 lane) {
+    origin = byte_pos; wi = 0;
+    cur = load_chunk(0, lane);
+    nxt = load_chunk(1, lane);
+  }
+  __device__ __forceinline__ u32 next_dword(u32 lane) {
+    u32 d = rdl(cur, wi & 63u);
+    wi++;
+    if ((wi & 63u) == 0u) { cur = nxt; nxt = load_chunk((wi >> 6) + 1u, lane); }
+    return d;
+  }
+  // single byte at absolute unit offset (zero beyond in_len); per-lane
+  __device__ __forceinline__ u32 byte_at(u32 pos) const { return pos < in_len ? unit[pos] : 0u; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Canonical Huffman tables in LDS.
+//   tab[1<<P]  : direct lookup on the next P bits (MSB-first codes): sym | len<<10, 0 = "long code"
+//   sorted[]   : symbols ordered by (length, symbol) -- the canonical order (readhuff.h:97-117)
+//   limv / fov : per-lane registers; lane l (1..16) holds the exclusive upper bound of left-aligned
+//                16-bit codes of length <= l, and first_code(l) | offs(l)<<16.  Long codes are
+//                resolved by ONE wave-wide compare + ballot (which lane's limit is the first one
+//                above the 16-bit peek) instead of a bit-by-bit tree walk (readhuff.h:58-65).
+// Acceptance follows make_decode_table exactly: lengths <= ref_tablebits that fill the code space
+// make longer codes unreachable and are accepted (readhuff.h:121-122); otherwise the code must be
+// exactly complete (readhuff.h:108,147,175).
+// ---------------------------------------------------------------------------------------------------
+struct HuffRegs { u32 limv; u32 fov; };
+
+// returns 0 accepted, 1 rejected, 2 accepted-but-empty (no symbol has a length)
+template <int P>
+__device__ int huff_build(const u8 *lens, int nsyms, int ref_tablebits, u16 *tab, u16 *sorted,
+                          u32 *cnt_scratch /* >= 20 u32 in LDS */, HuffRegs &hr, u32 lane, bool lsb)
+{
+  // 1. histogram of code lengths
+  if (lane < 20u) cnt_scratch[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  for (int s = (int) lane; s < nsyms; s += WAVE) {
+    u32 l = lens[s];
+    if (l >= 1u && l <= 16u) atomicAdd(&cnt_scratch[l], 1u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  u32 mycnt = (lane >= 1u && lane <= 16u) ? cnt_scratch[lane] : 0u;
+
+  // 2. Kraft sums, canonical first codes / offsets / limits (wave-uniform scalar work)
+  u32 kshort = 0, kall = 0;
+  for (int l = 1; l <= 16; l++) {
+    u32 c = rdl(mycnt, (u32) l);
+    kall += c << (16 - l);
+    if (l <= ref_tablebits) kshort = kall;
+  }
+  if (kall == 0) return 2;
+  int maxl = 16;
+  if (kshort > 65536u) return 1;
+  if (kshort == 65536u) maxl = ref_tablebits;
+  else if (kall != 65536u) return 1;
+
+  u32 code = 0, n = 0, limv = 0, fov = 0, curv = 0;
+  for (int l = 1; l <= 16; l++) {
+    u32 c = (l <= maxl) ? rdl(mycnt, (u32) l) : 0u;
+    fov  = wrl(fov, code | (n << 16), (u32) l);
+    curv = wrl(curv, n, (u32) l);
+    code += c; n += c;
+    limv = wrl(limv, (l <= maxl) ? (code << (16 - l)) : 0u, (u32) l);
+    code <<= 1;
+  }
+  hr.limv = limv; hr.fov = fov;
+
+  // 3. counting sort by (length, symbol): ballot-ranked, 64 symbols per step
+  for (int base = 0; base < nsyms; base += WAVE) {
+    int s = base + (int) lane;
+    u32 l = (s < nsyms) ? lens[s] : 0u;
+    if (l > (u32) maxl) l = 0;
+    u64 todo = ballot(l != 0u);
+    while (todo) {
+      u32 leader = (u32) __ffsll((long long) todo) - 1u;
+      u32 L = rdl(l, leader);
+      u64 m = ballot(l == L);
+      u32 c = rdl(curv, L);
+      if (l == L) sorted[c + lanemask_lt_popc(m, lane)] = (u16) s;
+      curv = wrl(curv, c + (u32) __popcll(m), L);
+      todo &= ~m;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // 4. direct table, one entry per lane per step
+  u32 lim[P + 1];
+#pragma unroll
+  for (int l = 1; l <= P; l++) lim[l] = rdl(limv, (u32) l);
+  for (u32 e = lane; e < (1u << P); e += WAVE) {
+    u32 peek16 = e << (16 - P);
+    u32 len = 1;
+#pragma unroll
+    for (int l = 1; l <= P; l++) len += (peek16 >= lim[l]) ? 1u : 0u;
+    // first/offs for this lane's length: fetch from the owning lane (all lanes active here)
+    u32 lq = (len <= (u32) P) ? len : 0u;
+    u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) fov);
+    u32 idx = (fo >> 16) + ((peek16 >> (16 - lq)) - (fo & 0xFFFFu));
+    u32 ent = 0;
+    if (lq) ent = (u32) sorted[idx] | (lq << 10);
+    u32 slot = e;
+    if (lsb) slot = __brev(e) >> (32 - P);     // LSB-first streams index by the reversed code
+    tab[slot] = (u16) ent;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return 0;
+}
+
+// Resolve a code longer than the direct table: one compare per lane + ballot.
+// peek16 = next 16 bits, MSB-first, left-aligned in 16 bits.  Returns sym | len<<10 (0 if none).
+__device__ __forceinline__ u32 huff_long(const HuffRegs &hr, const u16 *sorted, u32 peek16, u32 lane)
+{
+  u64 m = ballot(lane >= 1u && lane <= 16u && peek16 < hr.limv);
+  if (m == 0) return 0;
+  u32 len = (u32) __ffsll((long long) m) - 1u;
+  u32 fo = rdl(hr.fov, len);
+  u32 idx = (fo >> 16) + ((peek16 >> (16 - len)) - (fo & 0xFFFFu));
+  return rfl((u32) sorted[idx]) | (len << 10);
+}
