@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(HERE, "libmspack_hip.so")
+HIP_SO = os.environ.get("MSPACK_HIP_SO", os.path.join(HERE, "libmspack_hip.so"))   # env override: kernel experiments only
 CORPUS_SO = os.path.join(HERE, "libmspack_corpus.so")
 
 KIND_MSZIP, KIND_QUANTUM, KIND_LZX = 1, 2, 3

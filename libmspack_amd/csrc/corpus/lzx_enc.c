@@ -62,6 +62,9 @@ static void bw_byte(bw_t *w, unsigned v) {          /* only while word-aligned *
 
 typedef struct { uint32_t off; uint16_t len; uint8_t rslot; uint8_t lit; } tok_t;
 
+/* encoder statistics (diagnostics for DESIGN.md / bench): totals since process start */
+unsigned long long mspk_lzx_stat_tokens = 0, mspk_lzx_stat_literals = 0, mspk_lzx_stat_match_bytes = 0;
+
 typedef struct {
   const uint8_t *src;            /* (possibly E8-pretranslated) plaintext                      */
   size_t istart, iend;           /* current interval                                            */
@@ -399,7 +402,12 @@ size_t mspk_lzx_encode(const uint8_t *src_in, size_t n, int window_bits, int res
         pending_pad = (int)(bbytes & 1);
       }
       else {
-        size_t nt = parse_block(&m, p, bend, toks);
+        size_t nt = parse_block(&m, p, bend, toks), ti;
+        for (ti = 0; ti < nt; ti++) {
+          if (toks[ti].len) __sync_fetch_and_add(&mspk_lzx_stat_match_bytes, toks[ti].len);
+          else __sync_fetch_and_add(&mspk_lzx_stat_literals, 1);
+        }
+        __sync_fetch_and_add(&mspk_lzx_stat_tokens, nt);
         emit_compressed_block(&w, ls, toks, nt, bbytes, num_main, mode, p, frame_off);
       }
       p = bend;

@@ -116,7 +116,7 @@ struct LzxDec {
 };
 
 // lzxd_read_lens (lzxd.c:138-183).  Serial: every length is a delta against lens[x].
-__device__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u32 last)
+__device__ __forceinline__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u32 last)
 {
   LzxShared *sh = d.sh;
   u32 v;
@@ -192,7 +192,7 @@ __device__ __forceinline__ void lzx_leave_raw(LzxDec &d, LzxState &s) {
 }
 
 // block header (lzxd.c:467-523); returns false on error (d.err set)
-__device__ bool lzx_block_header(LzxDec &d, LzxState &s)
+__device__ __forceinline__ bool lzx_block_header(LzxDec &d, LzxState &s)
 {
   LzxShared *sh = d.sh;
   u32 v, hi, lo;
@@ -218,16 +218,23 @@ __device__ bool lzx_block_header(LzxDec &d, LzxState &s)
     }
   }
   if (v == 1u || v == 2u) {
-    if (!lzx_read_lens(d, sh->main_len, 0, 256)) return false;
-    if (!lzx_read_lens(d, sh->main_len, 256, 256 + s.num_offsets)) return false;
-    if (huff_build<LZX_MAIN_P>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
-                               sh->cnt, d.hr_main, d.lane, false)) {
-      d.err = ERR_DECRUNCH; return false;
+    // three pretree-coded runs (lzxd.c:491-497); one inlined call site keeps the code small
+    int r = 0;
+    for (int part = 0; part < 3; part++) {
+      u8 *lens = (part == 2) ? sh->len_len : sh->main_len;
+      u32 first = (part == 1) ? 256u : 0u;
+      u32 last = (part == 0) ? 256u : (part == 1 ? 256u + s.num_offsets : 249u);
+      if (!lzx_read_lens(d, lens, first, last)) return false;
+      if (part == 1) {
+        if (huff_build<LZX_MAIN_P>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+                                   sh->cnt, d.hr_main, d.lane, false)) {
+          d.err = ERR_DECRUNCH; return false;
+        }
+        if (rfl((u32) sh->main_len[0xE8]) != 0u) s.intel_started = true;
+      }
     }
-    if (rfl((u32) sh->main_len[0xE8]) != 0u) s.intel_started = true;
-    if (!lzx_read_lens(d, sh->len_len, 0, 249)) return false;
-    int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt,
-                                  d.hr_len, d.lane, false);
+    r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt,
+                              d.hr_len, d.lane, false);
     if (r == 1) { d.err = ERR_DECRUNCH; return false; }
     s.length_empty = (r == 2);                                   // lzxd.c:111-125
     return true;
@@ -297,6 +304,122 @@ __device__ void lzx_copy_match_odd(u8 *out, u32 P, u32 wpos, u32 wsize, u32 off,
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The steady-state token loop (lzxd.c:538-651), far from the end of the input: no EOF bookkeeping
+// at all.  Everything hot is held in locals for the duration of the run; the loop hands over to
+// the generic (EOF-exact) loop in lzx_decode_unit as soon as the input window gets within 64 bytes
+// of in_len -- always at a token boundary, where the reference's bits_left is a pure function of
+// the bit position (see LzxDec::sym_ensure).
+// ---------------------------------------------------------------------------------------------------
+enum { LZX_RUN_DONE = 0, LZX_RUN_SWITCH = 1, LZX_RUN_FAIL = 2 };
+
+template <bool ALIGNED>
+__device__ __forceinline__ int lzx_run_fast(LzxDec &d, LzxState &s, const u32 run_end, const u32 wbase)
+{
+  const LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  u8 *const out = d.out;
+  u64 bb = d.bb; int bl = d.bl;
+  u32 wi = d.w.wi, cur = d.w.cur, nxt = d.w.nxt;
+  u32 P = d.P, lit_n = d.lit_n, lit_buf = d.lit_buf;
+  u32 R0 = s.R0, R1 = s.R1, R2 = s.R2;
+  const u32 wsize = s.wsize, offset_written = s.offset;
+  // first dword index at which the window is within 64 bytes of the end of the input
+  const u32 room = (d.w.in_len > d.w.origin + 64u) ? (d.w.in_len - d.w.origin - 64u) : 0u;
+  const u32 wi_limit = room >> 2;
+  int rc = LZX_RUN_DONE;
+
+#define FAST_REFILL()                                                              \
+  do {                                                                             \
+    u32 dw_ = rdl(cur, wi & 63u);                                                  \
+    wi++;                                                                          \
+    bb |= (u64)((dw_ << 16) | (dw_ >> 16)) << (32 - bl);                           \
+    bl += 32;                                                                      \
+    if ((wi & 63u) == 0u) { cur = nxt; d.w.wi = wi; nxt = d.w.load_chunk((wi >> 6) + 1u, lane); } \
+  } while (0)
+#define FAST_FLUSH()                                                               \
+  do { if (lit_n) { if (lane < lit_n) out[P - lit_n + lane] = (u8) lit_buf; lit_n = 0; } } while (0)
+#define FAST_FAIL(code) do { d.err = (code); rc = LZX_RUN_FAIL; goto out; } while (0)
+
+  while (P < run_end) {
+    if (bl <= 32) {
+      if (wi >= wi_limit) { rc = LZX_RUN_SWITCH; break; }
+      FAST_REFILL();
+    }
+    u32 e = rfl((u32) sh->main_tab[(u32)(bb >> (64 - LZX_MAIN_P))]);
+    if (e == 0) {
+      e = huff_long(d.hr_main, sh->main_sorted, (u32)(bb >> 48), lane);
+      if (e == 0) FAST_FAIL(ERR_DECRUNCH);
+    }
+    { u32 l = e >> 10; bb <<= l; bl -= (int) l; }
+    u32 sym = e & 1023u;
+    if (sym < 256u) {
+      lit_buf = wrl(lit_buf, sym, lit_n);
+      lit_n++; P++;
+      if (lit_n == WAVE) { if (true) out[P - WAVE + lane] = (u8) lit_buf; lit_n = 0; }
+      continue;
+    }
+    u32 m = sym - 256u, slot = m >> 3, len = (m & 7u) + 2u, off;
+    if ((m & 7u) == 7u) {
+      if (s.length_empty) FAST_FAIL(ERR_DECRUNCH);
+      u32 f = rfl((u32) sh->len_tab[(u32)(bb >> (64 - LZX_LEN_P))]);
+      if (f == 0) {
+        f = huff_long(d.hr_len, sh->len_sorted, (u32)(bb >> 48), lane);
+        if (f == 0) FAST_FAIL(ERR_DECRUNCH);
+      }
+      { u32 l = f >> 10; bb <<= l; bl -= (int) l; }
+      len += f & 1023u;
+    }
+    if (slot < 3u) {
+      if (slot == 0u) off = R0;
+      else if (slot == 1u) { off = R1; R1 = R0; R0 = off; }
+      else { off = R2; R2 = R0; R0 = off; }
+    }
+    else {
+      u32 extra = slot < 4u ? 0u : (slot < 36u ? (slot >> 1) - 1u : 17u);
+      u32 base = slot < 4u ? slot : (slot < 36u ? ((2u + (slot & 1u)) << extra) : ((slot - 34u) << 17));
+      off = base - 2u;
+      if (bl <= 32) {
+        // mid-token refill: if it enters the last 64 bytes, finish this token and hand over
+        if (wi >= wi_limit) rc = LZX_RUN_SWITCH;
+        FAST_REFILL();
+      }
+      if (ALIGNED && extra >= 3u) {
+        if (extra > 3u) { u32 nb = extra - 3u; off += (u32)(bb >> (64 - nb)) << 3; bb <<= nb; bl -= (int) nb; }
+        u32 a = rfl((u32) sh->ali_tab[(u32)(bb >> (64 - LZX_ALI_P))]);
+        if (a == 0) FAST_FAIL(ERR_DECRUNCH);                 // aligned codes are <= 7 bits: never long
+        { u32 l = a >> 10; bb <<= l; bl -= (int) l; }
+        off += a & 1023u;
+      }
+      else if (extra) { off += (u32)(bb >> (64 - extra)); bb <<= extra; bl -= (int) extra; }
+      R2 = R1; R1 = R0; R0 = off;
+    }
+    u32 wp = P - wbase;
+    if (P + len > run_end) FAST_FAIL(ERR_DECRUNCH);          // lzxd.c:678-693
+    if (wp + len > wsize) FAST_FAIL(ERR_DECRUNCH);           // lzxd.c:613
+    if (off > wp) { if (off > offset_written || (off - wp) > wsize) FAST_FAIL(ERR_DECRUNCH); }
+#ifndef LZX_EXP_NOCOPY
+    FAST_FLUSH();
+    if (off != 0u && off <= wsize) lzx_copy_match(out, P, off, len, lane);
+    else { if (lane == 0) lzx_copy_match_odd(out, P, wp, wsize, off, len); }
+#else
+    lit_n = 0;
+#endif
+    P += len;
+    if (rc != LZX_RUN_DONE) break;
+  }
+out:
+  d.bb = bb; d.bl = bl; d.w.wi = wi; d.w.cur = cur; d.w.nxt = nxt;
+  d.P = P; d.lit_n = lit_n; d.lit_buf = lit_buf;
+  s.R0 = R0; s.R1 = R1; s.R2 = R2;
+  if (wi >= wi_limit) d.near_end = true;
+  return rc;
+#undef FAST_REFILL
+#undef FAST_FLUSH
+#undef FAST_FAIL
+}
+
 // decode one LZX unit.  frame_meta[frame_base + f] receives the intel_filesize to apply to frame f
 // (0 = none).  Returns via *res.
 __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
@@ -364,6 +487,10 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
           const bool aligned = (s.block_type == 2u);
           const u32 run_end = d.P + (u32) run;
           const u32 wbase = d.P - s.wpos;          // linear position of window index 0
+          if (!d.careful && !d.near_end) {
+            int rc = aligned ? lzx_run_fast<true>(d, s, run_end, wbase) : lzx_run_fast<false>(d, s, run_end, wbase);
+            if (rc == LZX_RUN_FAIL) { d.flush_lits(); fail = true; break; }
+          }
           while (d.P < run_end) {
             if (d.bl <= 32) d.refill();
             int sym = d.decode_sym<LZX_MAIN_P>(sh->main_tab, sh->main_sorted, d.hr_main);
@@ -408,9 +535,13 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
             if (off > wp) {
               if (off > s.offset || (off - wp) > s.wsize) { d.err = ERR_DECRUNCH; fail = true; break; }
             }
+#ifndef LZX_EXP_NOCOPY
             d.flush_lits();
             if (off != 0u && off <= s.wsize) lzx_copy_match(d.out, d.P, off, len, lane);
             else { if (lane == 0) lzx_copy_match_odd(d.out, d.P, wp, s.wsize, off, len); }
+#else
+            d.lit_n = 0;
+#endif
             d.P += len;
           }
           d.flush_lits();
