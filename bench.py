@@ -113,7 +113,7 @@ def main():
     def step():
         rc = L.mspack_hip_decode_batch_device(d_units.data_ptr(), d_order.data_ptr(), n, d_in.data_ptr(), comp.size,
                                               d_out.data_ptr(), out_bytes, d_res.data_ptr(), d_fm.data_ptr(),
-                                              n_frames, stream)
+                                              n_frames, 1 << M.KIND_LZX, stream)
         if rc:
             raise RuntimeError(L.mspack_hip_last_error().decode())
 
@@ -138,7 +138,7 @@ def main():
     # ---- kernel-only duration with HIP events on the launch stream (roofline numerator) ----
     ms_kernel = L.mspack_hip_time_batch_device(d_units.data_ptr(), d_order.data_ptr(), n, d_in.data_ptr(), comp.size,
                                                d_out.data_ptr(), out_bytes, d_res.data_ptr(), d_fm.data_ptr(),
-                                               n_frames, stream, max(3, min(args.steps, 10)))
+                                               n_frames, 1 << M.KIND_LZX, stream, max(3, min(args.steps, 10)))
     torch.cuda.synchronize()
 
     # ---- parity: every unit, every byte, outside the timed region ----
@@ -167,7 +167,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (ms_kernel * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(algo_bytes / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic": None, "kernel": "mspack_decode_units", "kernel_ms": round(ms_kernel, 4),
+                         "traffic": None, "kernel": "mspack_decode_lzx", "kernel_ms": round(ms_kernel, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }
         if world == 1 and not args.no_cpu and not args.exp:

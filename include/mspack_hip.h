@@ -82,11 +82,15 @@ const char *mspack_hip_last_error(void);
  *   d_results  : n_units results
  *   d_frame_scratch : >= mspack_hip_frame_scratch_bytes(total LZX frames incl. 1 spare per unit);
  *                may be NULL if the batch has no LZX units
+ *   kind_mask  : bit k set = units of kind k may be present (one kernel per codec is launched;
+ *                units of other kinds are skipped); 0 = all three codecs
+ * MSZIP units need 32768 bytes of slack after out_len in their output region.
  * Returns 0 or a negative hipError_t from the launch. */
 int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_t *d_order,
                                    size_t n_units, const void *d_in, size_t in_bytes,
                                    void *d_out, size_t out_bytes, mspack_hip_result *d_results,
-                                   void *d_frame_scratch, size_t n_frames_total, void *stream);
+                                   void *d_frame_scratch, size_t n_frames_total, unsigned kind_mask,
+                                   void *stream);
 size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total);
 
 /* ---- host-buffer convenience (what the C drivers in mspack.h use) ------------------------------
@@ -107,8 +111,8 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
 double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32_t *d_order,
                                     size_t n_units, const void *d_in, size_t in_bytes,
                                     void *d_out, size_t out_bytes, mspack_hip_result *d_results,
-                                    void *d_frame_scratch, size_t n_frames_total, void *stream,
-                                    int iters);
+                                    void *d_frame_scratch, size_t n_frames_total, unsigned kind_mask,
+                                    void *stream, int iters);
 
 #ifdef __cplusplus
 }

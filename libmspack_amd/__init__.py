@@ -50,9 +50,9 @@ def lib():
         L.mspack_hip_set_device.argtypes = [C.c_int]
         L.mspack_hip_frame_scratch_bytes.restype = sz
         L.mspack_hip_frame_scratch_bytes.argtypes = [sz]
-        L.mspack_hip_decode_batch_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp, sz, vp]
+        L.mspack_hip_decode_batch_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp, sz, C.c_uint, vp]
         L.mspack_hip_time_batch_device.restype = C.c_double
-        L.mspack_hip_time_batch_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp, sz, vp, C.c_int]
+        L.mspack_hip_time_batch_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp, sz, C.c_uint, vp, C.c_int]
         L.mspack_hip_decode_batch.argtypes = [vp, sz, vp, sz, vp, sz, vp]
         L.mspack_hip_decode_batch_multi.argtypes = [vp, sz, vp, sz, vp, sz, vp, C.c_int]
         _lib = L

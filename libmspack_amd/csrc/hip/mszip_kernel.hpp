@@ -1,8 +1,368 @@
-// placeholder until the MSZIP kernel lands (next commit)
+// mszip_kernel.hpp -- MSZIP unit decoder: one wavefront per CAB folder stream.
+//
+// Replaces, for one unit, mszipd_init + mszipd_decompress(out_len) of the reference
+// (libmspack/mspack/mszipd.c:335-460) including inflate (mszipd.c:154-316), the dynamic-header
+// reader (mszipd.c:91-151), the "CK" scan (mszipd.c:406-414) and the 32 KiB history that is NOT
+// cleared between blocks (mszipd.c:267-268).
+//   bit reader ...... readbits.h:133-180 + mszipd.c:19-27 (LSB first, bytewise) -> 64-bit SGPR
+//                     buffer refilled 32 bits at a time from the lane-resident input chunk
+//   READ_HUFFSYM .... one LDS lookup (10 / 7 direct bits, index = bit-reversed code); longer codes
+//                     by wave-wide limit compare + ballot
+//   window .......... the reference's window[32768] restarts at index 0 for every block and keeps
+//                     older blocks' bytes above the current position.  Here block b decodes straight
+//                     into out[B_b + idx]; an index the current block has not written yet is
+//                     served from the most recent earlier block that was long enough (a short
+//                     monotonic stack of (B, length) pairs) -- bit-identical to the ring.
+// Output regions of MSZIP units need 32768 bytes of slack after out_len (a block is decoded in
+// full even when only part of it is requested, mszipd.c:442-446).
 #pragma once
 #include "wave_common.hpp"
-struct MszipShared { u32 pad[4]; };
+
+#define ZIP_FRAME 32768u
+#define ZIP_LIT_P 10
+#define ZIP_DIST_P 7
+#define ZIP_BL_P 7
+#define ZIP_HIST 8
+
+struct __align__(16) MszipShared {
+  u16 lit_tab[1 << ZIP_LIT_P];
+  u16 lit_sorted[288];
+  u16 dist_tab[1 << ZIP_DIST_P];
+  u16 dist_sorted[32];
+  u16 bl_tab[1 << ZIP_BL_P];
+  u16 bl_sorted[20];
+  u32 cnt[20];
+  u32 hist_B[ZIP_HIST], hist_len[ZIP_HIST];
+  u8  lit_len[288];
+  u8  dist_len[32];
+  u8  bl_len[20];
+  u8  lens[324];
+};
+
+// inflate() failure classes: <0 = format error (-> MSPACK_ERR_DECRUNCH), >0 = MSPACK_ERR_READ
+#define ZIP_E_FORMAT (-1)
+
+struct ZipDec {
+  InWindow w;
+  u64 bb; int bl;
+  bool near_end, careful; int rbl;
+  u32 lane;
+  MszipShared *sh;
+  HuffRegs hr_lit, hr_dist, hr_bl;
+  // output / window
+  u8 *out;
+  u32 B, wpos; bool flushed;
+  u32 hist_n;                    // entries in the (B, length) stack, most recent first
+  u32 lit_buf, lit_n;
+
+  __device__ __forceinline__ u32 cons_bits() const { return w.wi * 32u - (u32) bl; }
+  __device__ __forceinline__ void refill() {
+    u32 d = w.next_dword(lane);
+    bb |= (u64) d << bl;
+    bl += 32;
+    u32 fetched = w.origin + w.wi * 4u;
+    if (fetched >= w.in_len || w.in_len - fetched <= 64u) near_end = true;
+  }
+  __device__ __forceinline__ void need(int n) { if (bl < n) refill(); }
+  __device__ bool ref_ensure(int n) {             // bytewise ENSURE_BITS, EOF-exact
+    while (rbl < n) {
+      u32 i = w.origin + ((cons_bits() + (u32) rbl) >> 3);
+      if (i >= w.in_len + 2u) return false;        // two fabricated zero bytes, then ERR_READ
+      rbl += 8;
+    }
+    return true;
+  }
+  __device__ __forceinline__ bool sym_ensure() {  // ENSURE_BITS(16)
+    if (careful) return ref_ensure(16);
+    if (near_end) { careful = true; rbl = 16 + (int)((0u - cons_bits()) & 7u); }
+    return true;
+  }
+  __device__ __forceinline__ void drop(int n) { bb >>= n; bl -= n; if (careful) rbl -= n; }
+  // READ_BITS(n), 0 <= n <= 16; returns false on ERR_READ
+  __device__ __forceinline__ bool read_bits(int n, u32 &v) {
+    need(n);
+    if (careful && !ref_ensure(n)) return false;
+    v = (u32) bb & ((1u << n) - 1u);
+    drop(n);
+    return true;
+  }
+  // returns symbol, -1 = format error, -2 = ERR_READ
+  template <int TP>
+  __device__ __forceinline__ int decode_sym(const u16 *tab, const u16 *sorted, const HuffRegs &hr, bool ens16) {
+    if (ens16) { if (!sym_ensure()) return -2; }
+    u32 e = rfl((u32) tab[(u32) bb & ((1u << TP) - 1u)]);
+    if (e == 0) {
+      e = huff_long(hr, sorted, __brev((u32) bb) >> 16, lane);
+      if (e == 0) return -1;
+    }
+    drop((int)(e >> 10));
+    return (int)(e & 1023u);
+  }
+  // byte-align the stream (drop bits_left & 7, mszipd.c:173,407)
+  __device__ __forceinline__ void byte_align() { int n = (int)((0u - cons_bits()) & 7u); if (n) drop(n); }
+  // stream byte position of the next unread bit (must be byte aligned)
+  __device__ __forceinline__ u32 byte_pos() const { return w.origin + (cons_bits() >> 3); }
+  // restart bit reading at an absolute byte position with an empty buffer (bits_left = 0)
+  __device__ __forceinline__ void restart(u32 pos) {
+    w.seek(pos, lane); bb = 0; bl = 0; rbl = 0;
+    near_end = (pos >= w.in_len || w.in_len - pos <= 64u);
+    if (near_end) careful = true;
+  }
+
+  // ---- window --------------------------------------------------------------------------------
+  // byte at window index x (< 32768) given that the current block has `hw` valid bytes from 0
+  __device__ __forceinline__ u32 win_byte(u32 x, u32 hw) const {
+    if (x < hw) return out[B + x];
+    for (u32 k = 0; k < hist_n; k++) {
+      u32 hl = sh->hist_len[k];
+      if (x < hl) return out[sh->hist_B[k] + x];
+    }
+    return 0u;                                     // never written: the reference reads junk here
+  }
+  __device__ __forceinline__ void flush_lits() {
+    if (lit_n) {
+      if (lane < lit_n) out[B + wpos - lit_n + lane] = (u8) lit_buf;
+      lit_n = 0;
+    }
+  }
+  // FLUSH_IF_NEEDED (mszipd.c:37-44): returns false on overflow
+  __device__ __forceinline__ bool wrap_if_needed() {
+    if (wpos == ZIP_FRAME) {
+      flush_lits();
+      if (flushed) return false;
+      flushed = true; wpos = 0;
+    }
+    return true;
+  }
+  // copy `n` bytes (no destination wrap inside) from window index mpos, distance `dist`
+  __device__ __forceinline__ void copy_part(u32 mpos, u32 dist, u32 n) {
+    const u32 hw0 = flushed ? ZIP_FRAME : wpos;
+    if (dist >= n || dist >= WAVE) {
+      for (u32 c = 0; c < n; c += WAVE) {
+        u32 k = c + lane;
+        u32 hw = flushed ? ZIP_FRAME : (wpos + c);
+        if (k < n) out[B + wpos + k] = (u8) win_byte((mpos + k) & (ZIP_FRAME - 1u), hw);
+      }
+    }
+    else {
+      u32 r = lane, s = dist << 5, step = 64u, ss = dist << 5;
+#pragma unroll
+      for (int q = 0; q < 6; q++) { u32 t = r - s; r = t < r ? t : r; s >>= 1; }
+#pragma unroll
+      for (int q = 0; q < 6; q++) { u32 t = step - ss; step = t < step ? t : step; ss >>= 1; }
+      for (u32 k = lane; k < n; k += WAVE) {
+        out[B + wpos + k] = (u8) win_byte((mpos + r) & (ZIP_FRAME - 1u), hw0);
+        r += step; if (r >= dist) r -= dist;
+      }
+    }
+  }
+};
+
+// RFC 1951 3.2.5 tables in closed form (mszipd.c:46-68)
+__device__ __forceinline__ void zip_len_code(u32 code, u32 &base, u32 &extra) {
+  if (code < 8u) { base = 3u + code; extra = 0; }
+  else if (code == 28u) { base = 258u; extra = 0; }
+  else { extra = (code - 4u) >> 2; base = 3u + ((4u + (code & 3u)) << extra); }
+}
+__device__ __forceinline__ void zip_dist_code(u32 code, u32 &base, u32 &extra) {
+  if (code < 4u) { base = 1u + code; extra = 0; }
+  else { extra = (code - 2u) >> 1; base = 1u + ((2u + (code & 1u)) << extra); }
+}
+
+// zip_read_lens (mszipd.c:91-151): 0 ok, <0 format error, >0 ERR_READ
+__device__ __forceinline__ int zip_read_dynamic(ZipDec &d)
+{
+  MszipShared *sh = d.sh;
+  static const u8 order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+  u32 nlit, ndist, nbl, v;
+  if (!d.read_bits(5, nlit) || !d.read_bits(5, ndist) || !d.read_bits(4, nbl)) return ERR_READ;
+  nlit += 257u; ndist += 1u; nbl += 4u;
+  if (nlit > 288u || ndist > 32u) return ZIP_E_FORMAT;
+  if (d.lane < 20u) sh->bl_len[d.lane] = 0;
+  for (u32 i = 0; i < nbl; i++) { if (!d.read_bits(3, v)) return ERR_READ; sh->bl_len[order[i]] = (u8) v; }
+  if (huff_build<ZIP_BL_P>(sh->bl_len, 19, 7, sh->bl_tab, sh->bl_sorted, sh->cnt, d.hr_bl, d.lane, true)) return ZIP_E_FORMAT;
+  u32 last = 0, total = nlit + ndist;
+  for (u32 i = 0; i < total; i++) {
+    d.need(16);
+    if (d.careful && !d.ref_ensure(7)) return ERR_READ;          // ENSURE_BITS(7), mszipd.c:122
+    int code = d.decode_sym<ZIP_BL_P>(sh->bl_tab, sh->bl_sorted, d.hr_bl, false);
+    if (code < 0) return code == -2 ? ERR_READ : ZIP_E_FORMAT;
+    if (code < 16) { sh->lens[i] = (u8) code; last = (u32) code; continue; }
+    u32 run, val;
+    if (code == 16) { if (!d.read_bits(2, run)) return ERR_READ; run += 3u; val = last; }
+    else if (code == 17) { if (!d.read_bits(3, run)) return ERR_READ; run += 3u; val = 0; }
+    else if (code == 18) { if (!d.read_bits(7, run)) return ERR_READ; run += 11u; val = 0; }
+    else return ZIP_E_FORMAT;
+    if (i + run > total) return ZIP_E_FORMAT;
+    for (u32 k = d.lane; k < run; k += WAVE) sh->lens[i + k] = (u8) val;
+    i += run - 1u;
+  }
+  for (u32 k = d.lane; k < 288u; k += WAVE) sh->lit_len[k] = (k < nlit) ? sh->lens[k] : (u8) 0;
+  if (d.lane < 32u) sh->dist_len[d.lane] = (d.lane < ndist) ? sh->lens[nlit + d.lane] : (u8) 0;
+  return 0;
+}
+
+// inflate (mszipd.c:154-316): 0 ok, <0 format error, >0 ERR_READ.  *bytes_output as the reference.
+__device__ int zip_inflate(ZipDec &d, u32 &bytes_output)
+{
+  MszipShared *sh = d.sh;
+  const u32 lane = d.lane;
+  u32 last_block, type;
+  do {
+    if (!d.read_bits(1, last_block) || !d.read_bits(2, type)) return ERR_READ;
+    if (type == 0u) {
+      // stored: byte-align, LEN/NLEN, raw bytes (mszipd.c:168-207)
+      d.byte_align();
+      u32 pos = d.byte_pos();
+      if (pos + 4u > d.w.in_len + 2u) return ERR_READ;
+      u32 hb = (lane < 4u) ? d.w.byte_at(pos + lane) : 0u;
+      u32 length = rdl(hb, 0) | (rdl(hb, 1) << 8), ncomp = rdl(hb, 2) | (rdl(hb, 3) << 8);
+      if (length != (~ncomp & 0xFFFFu)) return ZIP_E_FORMAT;
+      pos += 4u;
+      d.flush_lits();
+      while (length > 0u) {
+        u32 n = length, room = ZIP_FRAME - d.wpos;
+        if (n > room) n = room;
+        // the reference copies what the input buffer holds, including the two fabricated bytes
+        u32 avail = (pos < d.w.in_len + 2u) ? (d.w.in_len + 2u - pos) : 0u;
+        if (avail == 0u) return ERR_READ;
+        if (n > avail) n = avail;
+        for (u32 k = lane; k < n; k += WAVE) d.out[d.B + d.wpos + k] = (u8) d.w.byte_at(pos + k);
+        pos += n; d.wpos += n; length -= n;
+        if (!d.wrap_if_needed()) return ZIP_E_FORMAT;
+      }
+      d.restart(pos);
+    }
+    else if (type == 1u || type == 2u) {
+      if (type == 1u) {
+        for (u32 k = lane; k < 288u; k += WAVE) sh->lit_len[k] = (u8)(k < 144u ? 8 : (k < 256u ? 9 : (k < 280u ? 7 : 8)));
+        if (lane < 32u) sh->dist_len[lane] = 5;
+      }
+      else { int r = zip_read_dynamic(d); if (r) return r; }
+      if (huff_build<ZIP_LIT_P>(sh->lit_len, 288, 9, sh->lit_tab, sh->lit_sorted, sh->cnt, d.hr_lit, lane, true)) return ZIP_E_FORMAT;
+      if (huff_build<ZIP_DIST_P>(sh->dist_len, 32, 6, sh->dist_tab, sh->dist_sorted, sh->cnt, d.hr_dist, lane, true)) return ZIP_E_FORMAT;
+      for (;;) {
+        if (d.bl <= 32) d.refill();
+        int sym = d.decode_sym<ZIP_LIT_P>(sh->lit_tab, sh->lit_sorted, d.hr_lit, true);
+        if (sym < 0) return sym == -2 ? ERR_READ : ZIP_E_FORMAT;
+        if (sym < 256) {
+          d.lit_buf = wrl(d.lit_buf, (u32) sym, d.lit_n);
+          d.lit_n++; d.wpos++;
+          if (d.lit_n == WAVE) d.flush_lits();
+          if (!d.wrap_if_needed()) return ZIP_E_FORMAT;
+          continue;
+        }
+        if (sym == 256) break;
+        u32 code = (u32) sym - 257u, lbase, lextra, dbase, dextra, ev;
+        if (code >= 29u) return ZIP_E_FORMAT;
+        zip_len_code(code, lbase, lextra);
+        if (!d.read_bits((int) lextra, ev)) return ERR_READ;
+        u32 length = lbase + ev;
+        if (d.bl <= 32) d.refill();
+        int ds = d.decode_sym<ZIP_DIST_P>(sh->dist_tab, sh->dist_sorted, d.hr_dist, true);
+        if (ds < 0) return ds == -2 ? ERR_READ : ZIP_E_FORMAT;
+        if (ds >= 30) return ZIP_E_FORMAT;
+        zip_dist_code((u32) ds, dbase, dextra);
+        if (!d.read_bits((int) dextra, ev)) return ERR_READ;
+        u32 dist = dbase + ev;
+        u32 mpos = ((dist > d.wpos) ? ZIP_FRAME : 0u) + d.wpos - dist;          // mszipd.c:267-268
+        d.flush_lits();
+        // the destination may cross the 32 KiB mark once: split there (FLUSH_IF_NEEDED semantics)
+        while (length > 0u) {
+          u32 n = length, room = ZIP_FRAME - d.wpos;
+          if (n > room) n = room;
+          d.copy_part(mpos, dist, n);
+          d.wpos += n; length -= n; mpos = (mpos + n) & (ZIP_FRAME - 1u);
+          if (!d.wrap_if_needed()) return ZIP_E_FORMAT;
+        }
+      }
+    }
+    else return ZIP_E_FORMAT;
+  } while (!last_block);
+  d.flush_lits();
+  bytes_output = (d.flushed ? ZIP_FRAME : 0u) + d.wpos;
+  if (d.flushed && d.wpos) return ZIP_E_FORMAT;                                   // mszipd.c:309-311,326-331
+  return 0;
+}
+
 __device__ void mszip_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
-                                  mspack_hip_result *res, MszipShared *sh) {
-  if (threadIdx.x == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; }
+                                  mspack_hip_result *res, MszipShared *sh)
+{
+  const u32 lane = threadIdx.x;
+  ZipDec d;
+  d.lane = lane; d.sh = sh;
+  d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
+  d.w.seek(0, lane);
+  d.bb = 0; d.bl = 0; d.rbl = 0;
+  // MSZIP has long stretches without an ENSURE_BITS(16) (dynamic headers, the CK scan), so the
+  // reference's bits_left is simply tracked from the first bit on (a few scalar ops per event)
+  d.near_end = true; d.careful = true;
+  d.out = out_arena + u.out_off; d.B = 0; d.wpos = 0; d.flushed = false; d.hist_n = 0;
+  d.lit_buf = 0; d.lit_n = 0;
+  const bool repair = (u.flags & MSPACK_HIP_UF_MSZIP_REPAIR) != 0u;
+  u32 remaining = u.out_len, written = 0;
+  int err = ERR_OK;
+
+  while (remaining > 0u) {
+    // skip to the next 'C','K' (mszipd.c:406-414)
+    d.byte_align();
+    u32 state = 0, v;
+    bool rd_ok = true;
+    do {
+      if (!d.read_bits(8, v)) { rd_ok = false; break; }
+      if (v == 'C') state = 1;
+      else if (state == 1u && v == 'K') state = 2;
+      else state = 0;
+    } while (state != 2u);
+    if (!rd_ok) { err = ERR_READ; break; }
+
+    d.wpos = 0; d.flushed = false;
+    u32 bytes_output = 0;
+    int r = zip_inflate(d, bytes_output);
+    if (r) {
+      d.flush_lits();
+      if (repair) {                                                              // mszipd.c:422-433
+        u32 bo = d.flushed ? ZIP_FRAME : 0u;
+        if (bo == 0u && d.wpos > 0u) bo = d.wpos;
+        for (u32 k = bo + lane; k < ZIP_FRAME; k += WAVE) d.out[d.B + k] = 0;
+        bytes_output = ZIP_FRAME;
+      }
+      else { err = (r > 0) ? r : ERR_DECRUNCH; break; }
+    }
+    u32 n = remaining < bytes_output ? remaining : bytes_output;
+    written += n;
+    if (r > 0 && repair) { err = r; break; }                                     // mszipd.c:449
+    remaining -= n;
+    // remember this block for later blocks' history reads; entries it shadows (not longer than
+    // it) are dropped, so the stack stays strictly increasing in length towards older blocks
+    if (bytes_output) {
+      u32 nh = 0, tl[ZIP_HIST - 1], tb[ZIP_HIST - 1];
+#pragma unroll
+      for (u32 k = 0; k < ZIP_HIST - 1u; k++) { tl[k] = 0; tb[k] = 0; }
+#pragma unroll
+      for (u32 k = 0; k < ZIP_HIST; k++) {
+        if (k < d.hist_n) {
+          u32 hl = rfl(sh->hist_len[k]), hb = rfl(sh->hist_B[k]);
+          if (hl > bytes_output && nh < ZIP_HIST - 1u) {
+#pragma unroll
+            for (u32 q = 0; q < ZIP_HIST - 1u; q++) if (q == nh) { tl[q] = hl; tb[q] = hb; }
+            nh++;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if (lane == 0) {
+        sh->hist_len[0] = bytes_output; sh->hist_B[0] = d.B;
+#pragma unroll
+        for (u32 k = 0; k < ZIP_HIST - 1u; k++) { sh->hist_len[k + 1u] = tl[k]; sh->hist_B[k + 1u] = tb[k]; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      d.hist_n = 1u + nh;
+    }
+    d.B += n;
+  }
+  if (lane == 0) {
+    res->err = err; res->flags = 0; res->out_len = written;
+    res->in_used = d.w.origin + ((d.cons_bits() + (d.careful ? (u32) d.rbl : 0u)) >> 3);
+  }
 }

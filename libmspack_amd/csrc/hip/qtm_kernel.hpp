@@ -1,8 +1,352 @@
-// placeholder until the Quantum kernel lands (next commit)
+// qtm_kernel.hpp -- Quantum unit decoder: one wavefront per CAB folder stream.
+//
+// Replaces, for one unit, qtmd_init + qtmd_decompress(out_len) of the reference
+// (libmspack/mspack/qtmd.c:187-479).
+//   models ........... the nine adaptive models (qtm.h:49-77, qtmd.c:169-182,242-251) live in NINE
+//                      VGPRs: lane i of a model register holds entry i as sym<<16 | cumfreq.
+//   GET_SYMBOL ....... qtmd.c:92-123.  The linear scan "first i with cumfreq[i] <= symf" becomes one
+//                      per-lane multiply/compare + ballot (cumfreq[i]*range <= X  <=>  cumfreq[i] <=
+//                      X/range, no division); the "+8 to every entry before i" is one masked VALU add;
+//                      the two divisions by the model total share one per-lane division (numerators
+//                      in lanes 0 and 1).  Integer widths follow the C promotions of the reference.
+//   qtmd_update_model  qtmd.c:125-166.  Halving keeps strict monotonicity with a suffix-max scan;
+//                      the every-50th re-sort reproduces the reference's exchange pattern exactly:
+//                      per outer step the strict prefix maxima ("records") rotate one place
+//                      (prefix-max scan + ballot + bpermute) -- no serial O(n^2) loop.
+//   window ........... output buffer is the window (offsets never exceed window_size); bytes the
+//                      reference would read from never-written window memory read as zero.
+//   bit reader ....... readbits.h:133-166,143-153 + qtmd.c:27-36 (BE16 words, MSB first); the
+//                      reference's bits_left is tracked exactly at all times (it is cheap next to the
+//                      arithmetic decoder), so ERR_READ fires exactly where the reference's does.
 #pragma once
 #include "wave_common.hpp"
+
+#define QTM_FRAME 32768u
+
 struct QtmShared { u32 pad[4]; };
+
+struct QtmDec {
+  InWindow w;
+  u64 bb; int bl;     // my bit buffer (MSB aligned)
+  int rbl;            // the reference's bits_left
+  u32 lane;
+  u32 H, L, C;        // 16-bit registers kept in 32-bit scalars
+
+  __device__ __forceinline__ u32 cons_bits() const { return w.wi * 32u - (u32) bl; }
+  __device__ __forceinline__ void refill() {
+    u32 d = w.next_dword(lane);
+    bb |= (u64) __builtin_bswap32(d) << (32 - bl);      // two BE16 words in stream order (qtmd.c:30-35)
+    bl += 32;
+  }
+  __device__ __forceinline__ void need(int n) { if (bl < n) refill(); }
+  // one READ_BYTES of the reference (16 bits); false = ERR_READ
+  __device__ __forceinline__ bool ref_fill() {
+    u32 i = w.origin + ((cons_bits() + (u32) rbl) >> 3);
+    if (i > w.in_len) return false;
+    rbl += 16;
+    return true;
+  }
+  __device__ __forceinline__ bool read_bits(int n, u32 &v) {      // READ_BITS, n <= 16
+    need(n);
+    while (rbl < n) { if (!ref_fill()) return false; }
+    v = (u32)(bb >> (64 - n));
+    bb <<= n; bl -= n; rbl -= n;
+    return true;
+  }
+  __device__ __forceinline__ bool read_many(int n, u32 &v) {      // READ_MANY_BITS (readbits.h:143-153)
+    u32 val = 0;
+    while (n > 0) {
+      if (rbl <= 16) { if (!ref_fill()) return false; }
+      int run = rbl < n ? rbl : n;
+      need(run);
+      val = (val << run) | (u32)(bb >> (64 - run));
+      bb <<= run; bl -= run; rbl -= run;
+      n -= run;
+    }
+    v = val;
+    return true;
+  }
+};
+
+// ---- model maintenance (qtmd.c:125-166); `m` is the per-lane model register ---------------------
+__device__ __forceinline__ u32 qtm_shfl_down(u32 v, u32 delta, u32 lane) {
+  // value of lane+delta (0 beyond the wave)
+  u32 r = (u32) __builtin_amdgcn_ds_bpermute((int)((lane + delta) << 2), (int) v);
+  return (lane + delta < WAVE) ? r : 0u;
+}
+__device__ __forceinline__ u32 qtm_shfl_up(u32 v, u32 delta, u32 lane, u32 fill) {
+  u32 r = (u32) __builtin_amdgcn_ds_bpermute((int)((lane - delta) << 2), (int) v);
+  return (lane >= delta) ? r : fill;
+}
+
+__device__ void qtm_update_model(u32 &m, u32 entries, int &shiftsleft, u32 lane)
+{
+  u32 sym = m >> 16, cf = m & 0xFFFFu;
+  const bool act = lane < entries;
+  if (--shiftsleft) {
+    // c'[i] = max(h[i], c'[i+1] + 1), c'[entries] = 0  ==>  c'[i] = max_{j>=i}(h[j] + j) - i
+    u32 g = act ? ((cf >> 1) + lane) : 0u;
+#pragma unroll
+    for (u32 dlt = 1; dlt < WAVE; dlt <<= 1) { u32 o = qtm_shfl_down(g, dlt, lane); g = o > g ? o : g; }
+    if (g < entries) g = entries;                       // the sentinel term (0 + entries)
+    cf = (g - lane) & 0xFFFFu;
+  }
+  else {
+    shiftsleft = 50;
+    // cumulative -> frequency, +1, halve (unsigned short arithmetic)
+    u32 nextcf = qtm_shfl_down(cf, 1, lane);
+    if (lane + 1u >= entries) nextcf = 0;
+    u32 f = act ? ((((cf - nextcf) & 0xFFFFu) + 1u) & 0xFFFFu) >> 1 : 0u;
+    u32 pair = act ? ((sym << 16) | f) : 0u;            // the element that moves: (sym, freq)
+    // for i in 0..n-2: for j in i+1..n-1: if (a[i] < a[j]) swap.  Within one i the strict prefix
+    // maxima over positions i..n-1 ("records") each take over the previous record's element and
+    // position i receives the last record's.
+    for (u32 i = 0; i + 1u < entries; i++) {
+      u32 key = (lane >= i && lane < entries) ? (pair & 0xFFFFu) : 0u;
+      // exclusive prefix max over lanes >= i  (lanes < i contribute nothing)
+      u32 pm = key;
+#pragma unroll
+      for (u32 dlt = 1; dlt < WAVE; dlt <<= 1) { u32 o = qtm_shfl_up(pm, dlt, lane, 0u); pm = o > pm ? o : pm; }
+      u32 excl = qtm_shfl_up(pm, 1, lane, 0u);          // max over lanes < this one
+      bool rec = (lane == i) || (lane > i && lane < entries && key > excl);
+      u64 rm = ballot(rec);
+      // previous record below this lane / the last record of all
+      u64 below = rm & ((1ull << lane) - 1ull);
+      u32 prev = below ? (63u - (u32) __clzll((long long) below)) : 0u;
+      u32 lastrec = 63u - (u32) __clzll((long long) rm);
+      u32 src = (lane == i) ? lastrec : prev;
+      u32 moved = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) pair);
+      if (rec) pair = moved;
+    }
+    // frequency -> cumulative: suffix sum
+    u32 c = act ? (pair & 0xFFFFu) : 0u;
+#pragma unroll
+    for (u32 dlt = 1; dlt < WAVE; dlt <<= 1) c += qtm_shfl_down(c, dlt, lane);
+    sym = pair >> 16; cf = c & 0xFFFFu;
+  }
+  if (act) m = (sym << 16) | cf;
+}
+
+// GET_SYMBOL (qtmd.c:92-123).  Returns the symbol, or -1 on ERR_READ.
+__device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, int &shiftsleft)
+{
+  const u32 lane = d.lane;
+  u32 H = d.H, L = d.L, C = d.C;
+  const u32 cf = m & 0xFFFFu;
+  const u32 tot = rdl(cf, 0);
+  u32 range = ((H - L) & 0xFFFFu) + 1u;
+  u32 X = (u32)((int)(C - L + 1u) * (int) tot - 1);      // int arithmetic, then unsigned (qtmd.c:94)
+  bool hit;
+  if (range < 65536u && X >= (range << 16)) {            // quotient would not fit 16 bits: do as C does
+    u32 symf = (X / range) & 0xFFFFu;
+    hit = cf <= symf;
+  }
+  else hit = cf * range <= X;                            // cf <= floor(X / range), division-free
+  u64 hm = ballot(hit && lane >= 1u && lane < entries);
+  u32 i = hm ? ((u32) __ffsll((long long) hm) - 1u) : entries;
+  u32 e_im1 = rdl(m, i - 1u);
+  u32 cf_i = (i < entries) ? (rdl(m, i & 63u) & 0xFFFFu) : 0u;
+  int sym = (int)(e_im1 >> 16);
+  u32 range2 = (u32)((int) H - (int) L + 1);
+  // H = L + (cf[i-1]*range)/tot - 1 ; L = L + (cf[i]*range)/tot : both quotients from ONE division
+  u32 num = (lane == 0u) ? (e_im1 & 0xFFFFu) * range2 : cf_i * range2;
+  u32 quo = num / tot;
+  H = (L + rdl(quo, 0) - 1u) & 0xFFFFu;
+  L = (L + rdl(quo, 1)) & 0xFFFFu;
+  // cumfreq[0..i-1] += 8; rescale when the total passes 3800
+  if (lane < i) m += 8u;
+  if (tot + 8u > 3800u) qtm_update_model(m, entries, shiftsleft, lane);
+  for (;;) {
+    if ((L & 0x8000u) != (H & 0x8000u)) {
+      if ((L & 0x4000u) && !(H & 0x4000u)) { C ^= 0x4000u; L &= 0x3FFFu; H |= 0x4000u; }
+      else break;
+    }
+    L = (L << 1) & 0xFFFFu; H = ((H << 1) | 1u) & 0xFFFFu;
+    d.need(1);
+    if (d.rbl < 1) { if (!d.ref_fill()) { d.H = H; d.L = L; d.C = C; return -1; } }
+    C = ((C << 1) | (u32)(d.bb >> 63)) & 0xFFFFu;
+    d.bb <<= 1; d.bl -= 1; d.rbl -= 1;
+  }
+  d.H = H; d.L = L; d.C = C;
+  return sym;
+}
+
+__device__ __forceinline__ u32 qtm_model_init(u32 lane, u32 start, u32 len) {   // qtmd.c:169-182
+  return (lane <= len) ? (((start + lane) << 16) | (len - lane)) : 0u;
+}
+
+// static tables in closed form (qtmd.c:52-64)
+__device__ __forceinline__ void qtm_pos_slot(u32 s, u32 &base, u32 &extra) {
+  extra = (s < 2u) ? 0u : ((s - 2u) >> 1);
+  base = (s < 2u) ? s : ((2u + (s & 1u)) << extra);
+}
+__device__ __forceinline__ void qtm_len_slot(u32 s, u32 &base, u32 &extra) {
+  if (s < 6u) { base = s; extra = 0; }
+  else if (s == 26u) { base = 254u; extra = 0; }
+  else { extra = (s - 2u) >> 2; base = ((4u + ((s - 2u) & 3u)) << extra) - 2u; }
+}
+
+// byte-serial window copy semantics (qtmd.c:393-414) on the linear buffer; bytes before the start
+// of the stream read as zero; stores are clipped to the unit's output
+__device__ __forceinline__ void qtm_copy(u8 *out, u32 P, u32 off, u32 len, u32 out_len, u32 lane)
+{
+  if (off > P) {
+    // part of the source lies before the first decoded byte: zeros, then (byte-serial) the rest
+    for (u32 k = lane; k < len; k += WAVE) {
+      // source byte index relative to stream start: P - off + k (negative => 0, or a byte this very
+      // match produced earlier, which then is itself defined by the same rule)
+      u32 kk = k;
+      u32 b = 0;
+      // walk back through the period until the source is outside this match
+      while (kk >= off) kk -= off;                    // now source = P - off + kk, kk < off
+      if (P + kk >= off) b = out[P + kk - off];
+      if (P + k < out_len) out[P + k] = (u8) b;
+    }
+    return;
+  }
+  const u8 *src = out + P - off;
+  if (off >= len || off >= WAVE) {
+    for (u32 k = lane; k < len; k += WAVE) { u32 b = src[k]; if (P + k < out_len) out[P + k] = (u8) b; }
+  }
+  else {
+    u32 r = lane, s = off << 5, step = 64u, ss = off << 5;
+#pragma unroll
+    for (int q = 0; q < 6; q++) { u32 t = r - s; r = t < r ? t : r; s >>= 1; }
+#pragma unroll
+    for (int q = 0; q < 6; q++) { u32 t = step - ss; step = t < step ? t : step; ss >>= 1; }
+    for (u32 k = lane; k < len; k += WAVE) {
+      u32 b = src[r];
+      if (P + k < out_len) out[P + k] = (u8) b;
+      r += step; if (r >= off) r -= off;
+    }
+  }
+}
+
 __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
-                                mspack_hip_result *res, QtmShared *sh) {
-  if (threadIdx.x == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; }
+                                mspack_hip_result *res, QtmShared *sh)
+{
+  (void) sh;
+  const u32 lane = threadIdx.x;
+  const u32 wb = u.window_bits;
+  if (wb < 10u || wb > 21u) {
+    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; }
+    return;
+  }
+  QtmDec d;
+  d.lane = lane;
+  d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
+  d.w.seek(0, lane);
+  d.bb = 0; d.bl = 0; d.rbl = 0; d.H = 0; d.L = 0; d.C = 0;
+  u8 *out = out_arena + u.out_off;
+  const u32 wsize = 1u << wb, out_len = u.out_len;
+
+  const u32 n4 = (2u * wb > 24u) ? 24u : 2u * wb, n5 = (2u * wb > 36u) ? 36u : 2u * wb, n6 = 2u * wb;
+  u32 m0 = qtm_model_init(lane, 0, 64), m1 = qtm_model_init(lane, 64, 64), m2 = qtm_model_init(lane, 128, 64),
+      m3 = qtm_model_init(lane, 192, 64), m4 = qtm_model_init(lane, 0, n4), m5 = qtm_model_init(lane, 0, n5),
+      m6 = qtm_model_init(lane, 0, n6), m6l = qtm_model_init(lane, 0, 27), m7 = qtm_model_init(lane, 0, 7);
+  int s0 = 4, s1 = 4, s2 = 4, s3 = 4, s4 = 4, s5 = 4, s6 = 4, s6l = 4, s7 = 4;
+
+  // the reference's loop variables (qtmd.c:257-479): window_posn, frame_todo, o_ptr/o_end as window
+  // indices, out_bytes still wanted.  P is the linear position of window_posn.
+  u32 P = 0, wpos = 0, frame_todo = QTM_FRAME, o_ptr = 0, o_end = 0, written = 0;
+  long long need = (long long) out_len;
+  bool header_read = false;
+  int err = ERR_OK;
+
+  while ((long long)(o_end - o_ptr) < need) {
+    u32 v;
+    if (!header_read) {
+      d.H = 0xFFFFu; d.L = 0;
+      if (!d.read_bits(16, v)) { err = ERR_READ; break; }
+      d.C = v; header_read = true;
+    }
+    u32 frame_end = (u32)((long long) wpos + (need - (long long)(o_end - o_ptr)));
+    if (wpos + frame_todo < frame_end) frame_end = wpos + frame_todo;
+    if (frame_end > wsize) frame_end = wsize;
+    bool stop = false;
+
+    while (wpos < frame_end) {
+      int sel = qtm_get_symbol(d, m7, 7, s7);
+      if (sel < 0) { err = ERR_READ; stop = true; break; }
+      if (sel < 4) {
+        int sym;
+        if (sel == 0) sym = qtm_get_symbol(d, m0, 64, s0);
+        else if (sel == 1) sym = qtm_get_symbol(d, m1, 64, s1);
+        else if (sel == 2) sym = qtm_get_symbol(d, m2, 64, s2);
+        else sym = qtm_get_symbol(d, m3, 64, s3);
+        if (sym < 0) { err = ERR_READ; stop = true; break; }
+        if (lane == 0 && P < out_len) out[P] = (u8) sym;
+        P++; wpos++; frame_todo--;
+        continue;
+      }
+      u32 moff, mlen, base, extra;
+      int sym;
+      if (sel == 4) {
+        sym = qtm_get_symbol(d, m4, n4, s4);
+        if (sym < 0) { err = ERR_READ; stop = true; break; }
+        qtm_pos_slot((u32) sym, base, extra);
+        if (!d.read_many((int) extra, v)) { err = ERR_READ; stop = true; break; }
+        moff = base + v + 1u; mlen = 3;
+      }
+      else if (sel == 5) {
+        sym = qtm_get_symbol(d, m5, n5, s5);
+        if (sym < 0) { err = ERR_READ; stop = true; break; }
+        qtm_pos_slot((u32) sym, base, extra);
+        if (!d.read_many((int) extra, v)) { err = ERR_READ; stop = true; break; }
+        moff = base + v + 1u; mlen = 4;
+      }
+      else if (sel == 6) {
+        sym = qtm_get_symbol(d, m6l, 27, s6l);
+        if (sym < 0) { err = ERR_READ; stop = true; break; }
+        qtm_len_slot((u32) sym, base, extra);
+        if (!d.read_many((int) extra, v)) { err = ERR_READ; stop = true; break; }
+        mlen = base + v + 5u;
+        sym = qtm_get_symbol(d, m6, n6, s6);
+        if (sym < 0) { err = ERR_READ; stop = true; break; }
+        qtm_pos_slot((u32) sym, base, extra);
+        if (!d.read_many((int) extra, v)) { err = ERR_READ; stop = true; break; }
+        moff = base + v + 1u;
+      }
+      else { err = ERR_DECRUNCH; stop = true; break; }
+
+      frame_todo -= mlen;
+      if (wpos + mlen > wsize) {                                      // qtmd.c:358-390
+        u32 i = wsize - o_ptr;
+        // (the copy itself is the same on the linear buffer; only the flush bookkeeping differs)
+        if ((long long) i > need) {
+          // first part was already copied by the reference before it bails out
+          qtm_copy(out, P, moff, wsize - wpos, out_len, lane);
+          err = ERR_DECRUNCH; stop = true; break;
+        }
+        qtm_copy(out, P, moff, mlen, out_len, lane);
+        written += i; need -= i; o_ptr = 0; o_end = 0;
+        P += mlen; wpos = wpos + mlen - wsize;
+        break;
+      }
+      if (moff > wpos && (moff - wpos) > wsize) { err = ERR_DECRUNCH; stop = true; break; }   // qtmd.c:399
+      qtm_copy(out, P, moff, mlen, out_len, lane);
+      P += mlen; wpos += mlen;
+    }
+    if (stop) break;
+    o_end = wpos;
+    if (frame_todo > QTM_FRAME) { err = ERR_DECRUNCH; break; }         // qtmd.c:424
+    if (frame_todo == 0u) {
+      int n = d.rbl & 7;                                               // qtmd.c:432
+      if (n) { d.need(n); d.bb <<= n; d.bl -= n; d.rbl -= n; }
+      bool ok = true;
+      do { if (!d.read_bits(8, v)) { ok = false; break; } } while (v != 0xFFu);
+      if (!ok) { err = ERR_READ; break; }
+      header_read = false; frame_todo = QTM_FRAME;
+    }
+    if (wpos == wsize) {
+      u32 i = o_end - o_ptr;
+      if ((long long) i >= need) break;
+      written += i; need -= i; o_ptr = 0; o_end = 0; wpos = 0;
+    }
+  }
+  if (err == ERR_OK && need) { written += (u32) need; }
+  if (lane == 0) {
+    res->err = err; res->flags = 0; res->out_len = written;
+    res->in_used = d.w.origin + ((d.cons_bits() + (u32) d.rbl) >> 3);
+  }
 }

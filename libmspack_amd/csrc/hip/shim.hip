@@ -11,54 +11,66 @@
 #include "mszip_kernel.hpp"
 #include "qtm_kernel.hpp"
 
-union __align__(16) UnitShared {
-  LzxShared lzx;
-  MszipShared zip;
-  QtmShared qtm;
-};
-
 // One wavefront == one workgroup == one unit.  blockIdx -> unit through the optional launch order
-// (longest unit first keeps the tail of the batch short).
-__global__ __launch_bounds__(64)
-void mspack_decode_units(const mspack_hip_unit *units, const u32 *order, u32 n_units,
-                         const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
-                         int32_t *frame_meta)
+// (longest unit first keeps the tail of the batch short).  One kernel per codec (their register
+// budgets differ a lot); a block whose unit belongs to another codec exits at once.
+__device__ __forceinline__ bool pick_unit(const mspack_hip_unit *units, const u32 *order, u32 n_units,
+                                          u32 kind, u32 &ui)
 {
-  __shared__ UnitShared sh;
   u32 b = blockIdx.x;
-  if (b >= n_units) return;
-  u32 ui = order ? order[b] : b;
-  ui = rfl(ui);
+  if (b >= n_units) return false;
+  ui = rfl(order ? order[b] : b);
+  return units[ui].kind == kind;
+}
+
+__global__ __launch_bounds__(64)
+void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_units,
+                       const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
+                       int32_t *frame_meta)
+{
+  __shared__ LzxShared sh;
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) return;
   const mspack_hip_unit u = units[ui];
   mspack_hip_result *res = &results[ui];
   const u32 lane = threadIdx.x;
-  switch (u.kind) {
-  case MSPACK_HIP_KIND_LZX: {
-    lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, &sh.lzx);
-    // E8 translation, frame by frame, once the unit no longer needs its window (lzxd.c:706-736)
-    if (frame_meta) {
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      u32 produced = rfl(res->out_len);
-      u32 nfr = (produced + LZX_FRAME - 1u) / LZX_FRAME;
-      for (u32 f = 0; f < nfr; f++) {
-        int32_t fs = (int32_t) rfl((u32) frame_meta[u.frame_base + f]);
-        if (fs == 0) continue;
-        // the frame size the decoder saw: full frames except the last one of the stream
-        u32 fsize = u.out_len - f * LZX_FRAME; if (fsize > LZX_FRAME) fsize = LZX_FRAME;
-        lzx_e8_frame(out_arena + u.out_off + (size_t) f * LZX_FRAME, fsize,
-                     (int32_t)((u32) u.e8_base + f * LZX_FRAME), fs, lane);
-      }
+  lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, &sh);
+  // E8 translation, frame by frame, once the unit no longer needs its window (lzxd.c:706-736)
+  if (frame_meta) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    u32 produced = rfl(res->out_len);
+    u32 nfr = (produced + LZX_FRAME - 1u) / LZX_FRAME;
+    for (u32 f = 0; f < nfr; f++) {
+      int32_t fs = (int32_t) rfl((u32) frame_meta[u.frame_base + f]);
+      if (fs == 0) continue;
+      // the frame size the decoder saw: full frames except the last one of the stream
+      u32 fsize = u.out_len - f * LZX_FRAME; if (fsize > LZX_FRAME) fsize = LZX_FRAME;
+      lzx_e8_frame(out_arena + u.out_off + (size_t) f * LZX_FRAME, fsize,
+                   (int32_t)((u32) u.e8_base + f * LZX_FRAME), fs, lane);
     }
-    break; }
-  case MSPACK_HIP_KIND_MSZIP:
-    mszip_decode_unit(u, in_arena, out_arena, res, &sh.zip);
-    break;
-  case MSPACK_HIP_KIND_QUANTUM:
-    qtm_decode_unit(u, in_arena, out_arena, res, &sh.qtm);
-    break;
-  default:
-    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; }
   }
+}
+
+__global__ __launch_bounds__(64)
+void mspack_decode_mszip(const mspack_hip_unit *units, const u32 *order, u32 n_units,
+                         const u8 *in_arena, u8 *out_arena, mspack_hip_result *results)
+{
+  __shared__ MszipShared sh;
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_MSZIP, ui)) return;
+  const mspack_hip_unit u = units[ui];
+  mszip_decode_unit(u, in_arena, out_arena, &results[ui], &sh);
+}
+
+__global__ __launch_bounds__(64)
+void mspack_decode_qtm(const mspack_hip_unit *units, const u32 *order, u32 n_units,
+                       const u8 *in_arena, u8 *out_arena, mspack_hip_result *results)
+{
+  __shared__ QtmShared sh;
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_QUANTUM, ui)) return;
+  const mspack_hip_unit u = units[ui];
+  qtm_decode_unit(u, in_arena, out_arena, &results[ui], &sh);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -87,13 +99,23 @@ size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total) { return (n_frames_
 int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_t *d_order,
                                    size_t n_units, const void *d_in, size_t in_bytes,
                                    void *d_out, size_t out_bytes, mspack_hip_result *d_results,
-                                   void *d_frame_scratch, size_t n_frames_total, void *stream)
+                                   void *d_frame_scratch, size_t n_frames_total, unsigned kind_mask,
+                                   void *stream)
 {
   (void) in_bytes; (void) out_bytes; (void) n_frames_total;
   if (n_units == 0) return 0;
-  hipLaunchKernelGGL(mspack_decode_units, dim3((unsigned) n_units), dim3(64), 0, (hipStream_t) stream,
-                     d_units, d_order, (u32) n_units, (const u8 *) d_in, (u8 *) d_out, d_results,
-                     (int32_t *) d_frame_scratch);
+  if (kind_mask == 0) kind_mask = 0xE;      // bit k = units of kind k may be present
+  const dim3 grid((unsigned) n_units), block(64);
+  hipStream_t st = (hipStream_t) stream;
+  if (kind_mask & (1u << MSPACK_HIP_KIND_LZX))
+    hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n_units,
+                       (const u8 *) d_in, (u8 *) d_out, d_results, (int32_t *) d_frame_scratch);
+  if (kind_mask & (1u << MSPACK_HIP_KIND_MSZIP))
+    hipLaunchKernelGGL(mspack_decode_mszip, grid, block, 0, st, d_units, d_order, (u32) n_units,
+                       (const u8 *) d_in, (u8 *) d_out, d_results);
+  if (kind_mask & (1u << MSPACK_HIP_KIND_QUANTUM))
+    hipLaunchKernelGGL(mspack_decode_qtm, grid, block, 0, st, d_units, d_order, (u32) n_units,
+                       (const u8 *) d_in, (u8 *) d_out, d_results);
   CK(hipGetLastError());
   return 0;
 }
@@ -101,8 +123,8 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
 double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32_t *d_order,
                                     size_t n_units, const void *d_in, size_t in_bytes,
                                     void *d_out, size_t out_bytes, mspack_hip_result *d_results,
-                                    void *d_frame_scratch, size_t n_frames_total, void *stream,
-                                    int iters)
+                                    void *d_frame_scratch, size_t n_frames_total, unsigned kind_mask,
+                                    void *stream, int iters)
 {
   hipEvent_t e0, e1;
   float ms = 0;
@@ -111,7 +133,7 @@ double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32
   hipEventRecord(e0, (hipStream_t) stream);
   for (int i = 0; i < iters; i++) {
     int rc = mspack_hip_decode_batch_device(d_units, d_order, n_units, d_in, in_bytes, d_out, out_bytes,
-                                            d_results, d_frame_scratch, n_frames_total, stream);
+                                            d_results, d_frame_scratch, n_frames_total, kind_mask, stream);
     if (rc) { hipEventDestroy(e0); hipEventDestroy(e1); return -1.0; }
   }
   hipEventRecord(e1, (hipStream_t) stream);
@@ -136,6 +158,7 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
   std::vector<mspack_hip_unit> local(n_sel);
   std::vector<uint32_t> order(n_sel);
   size_t n_frames = 0;
+  unsigned kind_mask = 0;
   uint64_t in_lo = ~0ull, in_hi = 0, out_lo = ~0ull, out_hi = 0;
   for (size_t i = 0; i < n_sel; i++) {
     size_t ui = sel ? sel[i] : i;
@@ -143,10 +166,13 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
     local[i].frame_base = (uint32_t) n_frames;
     units[ui].frame_base = (uint32_t) n_frames;
     n_frames += unit_frames(&local[i]);
+    kind_mask |= 1u << (local[i].kind & 31u);
     in_lo = std::min<uint64_t>(in_lo, local[i].in_off);
     in_hi = std::max<uint64_t>(in_hi, local[i].in_off + local[i].in_len);
     out_lo = std::min<uint64_t>(out_lo, local[i].out_off);
-    out_hi = std::max<uint64_t>(out_hi, local[i].out_off + local[i].out_len);
+    // MSZIP decodes whole blocks: its region carries 32768 bytes of slack (see mszip_kernel.hpp)
+    out_hi = std::max<uint64_t>(out_hi, local[i].out_off + local[i].out_len +
+                                        (local[i].kind == MSPACK_HIP_KIND_MSZIP ? 32768u : 0u));
     order[i] = (uint32_t) i;
   }
   if (in_hi > in_bytes || out_hi > out_bytes) { snprintf(g_err, sizeof(g_err), "unit outside arena"); return -1; }
@@ -173,7 +199,7 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
   TRY(hipMemset(d_fm, 0, mspack_hip_frame_scratch_bytes(n_frames)));
   rc = mspack_hip_decode_batch_device((const mspack_hip_unit *) d_units, (const uint32_t *) d_order, n_sel,
                                       d_in, in_span, d_out, out_span, (mspack_hip_result *) d_res, d_fm,
-                                      n_frames, nullptr);
+                                      n_frames, kind_mask & 0xE, nullptr);
   if (rc) goto done;
   TRY(hipDeviceSynchronize());
   {

@@ -129,7 +129,7 @@ __device__ int huff_build(const u8 *lens, int nsyms, int ref_tablebits, u16 *tab
     fov  = wrl(fov, code | (n << 16), (u32) l);
     curv = wrl(curv, n, (u32) l);
     code += c; n += c;
-    limv = wrl(limv, (l <= maxl) ? (code << (16 - l)) : 0u, (u32) l);
+    limv = wrl(limv, (l <= maxl) ? (code << (16 - l)) : 0x10000u, (u32) l);   // beyond maxl: never below the peek
     code <<= 1;
   }
   hr.limv = limv; hr.fov = fov;
