@@ -143,6 +143,10 @@ def corpus():
         L.mspk_corpus_lzx_units.restype = sz
         L.mspk_corpus_lzx_units.argtypes = [C.c_uint64, C.c_int, C.c_int, sz, C.c_int, C.POINTER(LzxOpts),
                                             C.c_int, vp, vp, sz, vp, vp]
+        L.mspk_qtm_encode.restype = sz
+        L.mspk_qtm_encode.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp]
+        L.mspk_qtm_bound.restype = sz
+        L.mspk_qtm_bound.argtypes = [sz]
         _corpus = L
     return _corpus
 
@@ -194,3 +198,23 @@ def corpus_lzx_units(base_seed, kind, n_units, unit_bytes, window_bits, opts=Non
     if total == 0:
         raise MspackHipError("mspk_corpus_lzx_units failed")
     return plain, comp[:total + 64].copy(), off, ln
+
+
+def qtm_encode(data, window_bits, chain_depth=0):
+    """-> (folder stream as cabd feeds it to qtmd: every frame followed by the 0xFF trailer,
+           frame payload sizes u32[n_frames])"""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    n = data.size
+    L = corpus()
+    cap = L.mspk_qtm_bound(n)
+    dst = np.empty(cap, dtype=np.uint8)
+    nfr = (n + 32767) // 32768
+    fs = np.zeros(max(nfr, 1), dtype=np.uint32)
+    m = L.mspk_qtm_encode(data.ctypes.data, n, window_bits, chain_depth, dst.ctypes.data, cap, fs.ctypes.data)
+    if m == 0 and n:
+        raise MspackHipError("mspk_qtm_encode failed")
+    parts, pos = [], 0
+    for k in range(nfr):
+        parts.append(dst[pos:pos + int(fs[k])].tobytes() + b"\xff")
+        pos += int(fs[k])
+    return b"".join(parts), fs[:nfr]
