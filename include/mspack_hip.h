@@ -41,6 +41,9 @@ extern "C" {
 
 /* unit input flags */
 #define MSPACK_HIP_UF_MSZIP_REPAIR  1u  /* mszipd repair mode (MSCABD_PARAM_FIXMSZIP, mszipd.c:420-437) */
+#define MSPACK_HIP_UF_HARD_EOF      2u  /* the feeder's read FAILED at in_len (sys->read < 0, e.g. a bad
+                                           CFDATA block, cabd.c:1322-1324): ERR_READ at once, without the
+                                           two fabricated zero bytes of a clean EOF (readbits.h:194-208) */
 
 typedef struct mspack_hip_unit {
   uint64_t in_off;       /* byte offset of the unit's compressed bytes in the input arena          */
@@ -61,6 +64,11 @@ typedef struct mspack_hip_result {
   uint32_t flags;        /* MSPACK_HIP_F_*                                                         */
   uint32_t out_len;      /* bytes produced (handed to sys->write in the reference)                 */
   uint32_t in_used;      /* compressed bytes the unit pulled (diagnostic)                          */
+  uint32_t good_len;     /* bytes decoded before the failing point (== out_len when err == 0).  A
+                            request that ends at or before good_len succeeds in the reference too
+                            (it decodes no further than asked): LZX counts whole frames, MSZIP
+                            whole blocks, Quantum the position of the failing symbol              */
+  uint32_t reserved;
 } mspack_hip_result;
 
 /* ---- library / device ----------------------------------------------------------------------- */

@@ -24,8 +24,9 @@ ERR_OK, ERR_ARGS, ERR_OPEN, ERR_READ, ERR_WRITE, ERR_SEEK, ERR_NOMEMORY, ERR_SIG
 UNIT_DTYPE = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"),
                        ("frame_base", "<u4"), ("e8_base", "<i4"), ("kind", "u1"), ("window_bits", "u1"),
                        ("reset_frames", "<u2"), ("flags", "<u4")], align=False)
-RESULT_DTYPE = np.dtype([("err", "<i4"), ("flags", "<u4"), ("out_len", "<u4"), ("in_used", "<u4")])
-assert UNIT_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 16
+RESULT_DTYPE = np.dtype([("err", "<i4"), ("flags", "<u4"), ("out_len", "<u4"), ("in_used", "<u4"),
+                         ("good_len", "<u4"), ("reserved", "<u4")])
+assert UNIT_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 24
 
 
 class MspackHipError(RuntimeError):
@@ -143,6 +144,12 @@ def corpus():
         L.mspk_corpus_lzx_units.restype = sz
         L.mspk_corpus_lzx_units.argtypes = [C.c_uint64, C.c_int, C.c_int, sz, C.c_int, C.POINTER(LzxOpts),
                                             C.c_int, vp, vp, sz, vp, vp]
+        L.mspk_cab_write.restype = sz
+        L.mspk_cab_write.argtypes = [vp, C.c_int, vp, C.c_int, vp, sz]
+        L.mspk_chm_write.restype = sz
+        L.mspk_chm_write.argtypes = [vp, sz, vp, sz, C.c_uint64, C.c_int, C.c_int, vp, C.c_int, vp, sz]
+        L.mspk_chm_bound.restype = sz
+        L.mspk_chm_bound.argtypes = [sz, sz, C.c_int]
         L.mspk_qtm_encode.restype = sz
         L.mspk_qtm_encode.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp]
         L.mspk_qtm_bound.restype = sz
@@ -218,3 +225,57 @@ def qtm_encode(data, window_bits, chain_depth=0):
         parts.append(dst[pos:pos + int(fs[k])].tobytes() + b"\xff")
         pos += int(fs[k])
     return b"".join(parts), fs[:nfr]
+
+
+class _CabFolder(C.Structure):
+    _fields_ = [("comp_type", C.c_int), ("data", C.c_void_p), ("block_comp", C.c_void_p),
+                ("block_uncomp", C.c_void_p), ("n_blocks", C.c_int)]
+
+
+class _CabFile(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("length", C.c_uint32), ("folder_offset", C.c_uint32),
+                ("folder_index", C.c_uint16)]
+
+
+class _ChmFile(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("offset", C.c_uint64), ("length", C.c_uint64)]
+
+
+def cab_write(folders, files):
+    """folders: list of (comp_type, [block payload bytes], [block uncompressed sizes]);
+    files: list of (name bytes, length, folder_offset, folder_index) -> cabinet bytes"""
+    keep = []
+    fa = (_CabFolder * len(folders))()
+    for i, (ct, blocks, usz) in enumerate(folders):
+        data = np.frombuffer(b"".join(blocks), dtype=np.uint8).copy() if blocks else np.zeros(1, np.uint8)
+        bc = np.array([len(b) for b in blocks], dtype=np.uint32)
+        bu = np.array(usz, dtype=np.uint32)
+        keep += [data, bc, bu]
+        fa[i] = _CabFolder(ct, data.ctypes.data, bc.ctypes.data, bu.ctypes.data, len(blocks))
+    fl = (_CabFile * len(files))()
+    for i, (name, length, off, fidx) in enumerate(files):
+        fl[i] = _CabFile(name, length, off, fidx)
+    cap = sum(len(b) + 8 for _ct, bl, _u in folders for b in bl) + 64 * (len(files) + 4) + 4096
+    dst = np.zeros(cap, dtype=np.uint8)
+    n = corpus().mspk_cab_write(fa, len(folders), fl, len(files), dst.ctypes.data, cap)
+    if n == 0:
+        raise MspackHipError("mspk_cab_write failed")
+    return dst[:n].tobytes()
+
+
+def chm_write(lzx, frame_off, uncomp_len, window_bits, reset_frames, files):
+    """files: list of (name bytes starting with '/', offset, length) in the uncompressed stream"""
+    lzx = np.ascontiguousarray(lzx, dtype=np.uint8)
+    fo = np.ascontiguousarray(frame_off, dtype=np.uint64)
+    n_frames = len(fo) - 1
+    fl = (_ChmFile * len(files))()
+    for i, (name, off, ln) in enumerate(files):
+        fl[i] = _ChmFile(name, off, ln)
+    L = corpus()
+    cap = L.mspk_chm_bound(lzx.size, n_frames, len(files))
+    dst = np.zeros(cap, dtype=np.uint8)
+    n = L.mspk_chm_write(lzx.ctypes.data, lzx.size, fo.ctypes.data, n_frames, uncomp_len, window_bits,
+                         reset_frames, fl, len(files), dst.ctypes.data, cap)
+    if n == 0:
+        raise MspackHipError("mspk_chm_write failed")
+    return dst[:n].tobytes()

@@ -1,0 +1,230 @@
+"""ctypes mirror of include/mspack.h (the libmspack-compatible object API served by libmspack_hip.so).
+
+Names and argument meaning follow the reference API (mspack_create_cab_decompressor -> open /
+extract / close, mspack_create_chm_decompressor -> open / fast_open / fast_find / extract / close),
+so tests read like libmspack/test/cabd_test.c.  File I/O goes through the library's default
+stdio mspack_system (sys = NULL)."""
+import ctypes as C
+import os
+import tempfile
+
+from . import lib
+
+off_t = C.c_int64
+
+
+class MscabdFolder(C.Structure):
+    pass
+
+
+class MscabdFile(C.Structure):
+    pass
+
+
+class MscabdCabinet(C.Structure):
+    pass
+
+
+MscabdFolder._fields_ = [("next", C.POINTER(MscabdFolder)), ("comp_type", C.c_int), ("num_blocks", C.c_uint)]
+MscabdFile._fields_ = [("next", C.POINTER(MscabdFile)), ("filename", C.c_char_p), ("length", C.c_uint),
+                       ("attribs", C.c_int), ("time_h", C.c_char), ("time_m", C.c_char), ("time_s", C.c_char),
+                       ("date_d", C.c_char), ("date_m", C.c_char), ("date_y", C.c_int),
+                       ("folder", C.POINTER(MscabdFolder)), ("offset", C.c_uint)]
+MscabdCabinet._fields_ = [("next", C.POINTER(MscabdCabinet)), ("filename", C.c_char_p), ("base_offset", off_t),
+                          ("length", C.c_uint), ("prevcab", C.POINTER(MscabdCabinet)),
+                          ("nextcab", C.POINTER(MscabdCabinet)), ("prevname", C.c_char_p), ("nextname", C.c_char_p),
+                          ("previnfo", C.c_char_p), ("nextinfo", C.c_char_p), ("files", C.POINTER(MscabdFile)),
+                          ("folders", C.POINTER(MscabdFolder)), ("set_id", C.c_ushort), ("set_index", C.c_ushort),
+                          ("header_resv", C.c_ushort), ("flags", C.c_int)]
+
+
+class MscabDecompressor(C.Structure):
+    pass
+
+
+_P = C.POINTER
+MscabDecompressor._fields_ = [
+    ("open", C.CFUNCTYPE(_P(MscabdCabinet), _P(MscabDecompressor), C.c_char_p)),
+    ("close", C.CFUNCTYPE(None, _P(MscabDecompressor), _P(MscabdCabinet))),
+    ("search", C.CFUNCTYPE(_P(MscabdCabinet), _P(MscabDecompressor), C.c_char_p)),
+    ("append", C.CFUNCTYPE(C.c_int, _P(MscabDecompressor), _P(MscabdCabinet), _P(MscabdCabinet))),
+    ("prepend", C.CFUNCTYPE(C.c_int, _P(MscabDecompressor), _P(MscabdCabinet), _P(MscabdCabinet))),
+    ("extract", C.CFUNCTYPE(C.c_int, _P(MscabDecompressor), _P(MscabdFile), C.c_char_p)),
+    ("set_param", C.CFUNCTYPE(C.c_int, _P(MscabDecompressor), C.c_int, C.c_int)),
+    ("last_error", C.CFUNCTYPE(C.c_int, _P(MscabDecompressor))),
+]
+
+
+class MschmdHeader(C.Structure):
+    pass
+
+
+class MschmdFile(C.Structure):
+    pass
+
+
+class MschmdSection(C.Structure):
+    _fields_ = [("chm", _P(MschmdHeader)), ("id", C.c_uint)]
+
+
+class MschmdSecUncompressed(C.Structure):
+    _fields_ = [("base", MschmdSection), ("offset", off_t)]
+
+
+class MschmdSecMscompressed(C.Structure):
+    _fields_ = [("base", MschmdSection), ("content", _P(MschmdFile)), ("control", _P(MschmdFile)),
+                ("rtable", _P(MschmdFile)), ("spaninfo", _P(MschmdFile))]
+
+
+MschmdFile._fields_ = [("next", _P(MschmdFile)), ("section", _P(MschmdSection)), ("offset", off_t),
+                       ("length", off_t), ("filename", C.c_char_p)]
+MschmdHeader._fields_ = [("version", C.c_uint), ("timestamp", C.c_uint), ("language", C.c_uint),
+                         ("filename", C.c_char_p), ("length", off_t), ("files", _P(MschmdFile)),
+                         ("sysfiles", _P(MschmdFile)), ("sec0", MschmdSecUncompressed),
+                         ("sec1", MschmdSecMscompressed), ("dir_offset", off_t), ("num_chunks", C.c_uint),
+                         ("chunk_size", C.c_uint), ("density", C.c_uint), ("depth", C.c_uint),
+                         ("index_root", C.c_uint), ("first_pmgl", C.c_uint), ("last_pmgl", C.c_uint),
+                         ("chunk_cache", C.c_void_p)]
+
+
+class MschmDecompressor(C.Structure):
+    pass
+
+
+MschmDecompressor._fields_ = [
+    ("open", C.CFUNCTYPE(_P(MschmdHeader), _P(MschmDecompressor), C.c_char_p)),
+    ("close", C.CFUNCTYPE(None, _P(MschmDecompressor), _P(MschmdHeader))),
+    ("extract", C.CFUNCTYPE(C.c_int, _P(MschmDecompressor), _P(MschmdFile), C.c_char_p)),
+    ("last_error", C.CFUNCTYPE(C.c_int, _P(MschmDecompressor))),
+    ("fast_open", C.CFUNCTYPE(_P(MschmdHeader), _P(MschmDecompressor), C.c_char_p)),
+    ("fast_find", C.CFUNCTYPE(C.c_int, _P(MschmDecompressor), _P(MschmdHeader), C.c_char_p, _P(MschmdFile), C.c_int)),
+]
+
+MSCABD_PARAM_SEARCHBUF, MSCABD_PARAM_FIXMSZIP, MSCABD_PARAM_DECOMPBUF, MSCABD_PARAM_SALVAGE = 0, 1, 2, 3
+MSCABD_PARAM_HIP_DEVICES, MSCABD_PARAM_HIP_CACHE_MB = 100, 101
+
+
+def _setup():
+    L = lib()
+    L.mspack_create_cab_decompressor.restype = _P(MscabDecompressor)
+    L.mspack_create_cab_decompressor.argtypes = [C.c_void_p]
+    L.mspack_destroy_cab_decompressor.argtypes = [_P(MscabDecompressor)]
+    L.mspack_create_chm_decompressor.restype = _P(MschmDecompressor)
+    L.mspack_create_chm_decompressor.argtypes = [C.c_void_p]
+    L.mspack_destroy_chm_decompressor.argtypes = [_P(MschmDecompressor)]
+    L.mspack_version.argtypes = [C.c_int]
+    L.mspack_sys_selftest_internal.argtypes = [C.c_int]
+    return L
+
+
+def _walk(ptr):
+    while ptr:
+        yield ptr
+        ptr = ptr.contents.next
+
+
+class Cab:
+    """with Cab(path_or_bytes) as cab: cab.files -> [(name, length, offset, comp_type)];
+    cab.extract(i) -> (err, bytes)"""
+
+    def __init__(self, src, fix_mszip=0, salvage=0):
+        self.L = _setup()
+        self._tmp = None
+        if isinstance(src, (bytes, bytearray)):
+            fd, self._tmp = tempfile.mkstemp(suffix=".cab")
+            os.write(fd, src); os.close(fd)
+            src = self._tmp
+        self.path = os.fsencode(src)
+        self.d = self.L.mspack_create_cab_decompressor(None)
+        if not self.d:
+            raise RuntimeError("mspack_create_cab_decompressor failed")
+        self.d.contents.set_param(self.d, MSCABD_PARAM_FIXMSZIP, fix_mszip)
+        self.d.contents.set_param(self.d, MSCABD_PARAM_SALVAGE, salvage)
+        self.cab = self.d.contents.open(self.d, self.path)
+        self.open_error = self.d.contents.last_error(self.d)
+        self._files = list(_walk(self.cab.contents.files)) if self.cab else []
+
+    @property
+    def files(self):
+        return [(f.contents.filename, f.contents.length, f.contents.offset,
+                 f.contents.folder.contents.comp_type if f.contents.folder else -1) for f in self._files]
+
+    def extract(self, i):
+        fd, out = tempfile.mkstemp(suffix=".out")
+        os.close(fd)
+        try:
+            err = self.d.contents.extract(self.d, self._files[i], os.fsencode(out))
+            with open(out, "rb") as fh:
+                return err, fh.read()
+        finally:
+            os.unlink(out)
+
+    def close(self):
+        if self.cab:
+            self.d.contents.close(self.d, self.cab); self.cab = None
+        if self.d:
+            self.L.mspack_destroy_cab_decompressor(self.d); self.d = None
+        if self._tmp:
+            os.unlink(self._tmp); self._tmp = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Chm:
+    def __init__(self, src, fast=False):
+        self.L = _setup()
+        self._tmp = None
+        if isinstance(src, (bytes, bytearray)):
+            fd, self._tmp = tempfile.mkstemp(suffix=".chm")
+            os.write(fd, src); os.close(fd)
+            src = self._tmp
+        self.path = os.fsencode(src)
+        self.d = self.L.mspack_create_chm_decompressor(None)
+        m = self.d.contents
+        self.chm = (m.fast_open if fast else m.open)(self.d, self.path)
+        self.open_error = m.last_error(self.d)
+        self._files = list(_walk(self.chm.contents.files)) if self.chm else []
+
+    @property
+    def files(self):
+        return [(f.contents.filename, f.contents.length, f.contents.offset, f.contents.section.contents.id)
+                for f in self._files]
+
+    def _extract_ptr(self, fptr):
+        fd, out = tempfile.mkstemp(suffix=".out")
+        os.close(fd)
+        try:
+            err = self.d.contents.extract(self.d, fptr, os.fsencode(out))
+            with open(out, "rb") as fh:
+                return err, fh.read()
+        finally:
+            os.unlink(out)
+
+    def extract(self, i):
+        return self._extract_ptr(self._files[i])
+
+    def find(self, name):
+        f = MschmdFile()
+        err = self.d.contents.fast_find(self.d, self.chm, name, C.byref(f), C.sizeof(MschmdFile))
+        return err, (f if f.section else None)
+
+    def extract_found(self, f):
+        return self._extract_ptr(C.pointer(f))
+
+    def close(self):
+        if self.chm:
+            self.d.contents.close(self.d, self.chm); self.chm = None
+        if self.d:
+            self.L.mspack_destroy_chm_decompressor(self.d); self.d = None
+        if self._tmp:
+            os.unlink(self._tmp); self._tmp = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

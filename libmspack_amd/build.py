@@ -53,9 +53,10 @@ def build_hip(force=False):
         o = c[:-2] + ".o"
         _run(["gcc", "-O2", "-fPIC", "-Wall", "-I", os.path.join(ROOT, "include"), "-c", c, "-o", o])
         objs.append(o)
-    _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-          "-I", os.path.join(ROOT, "include"), "-o", HIP_SO, os.path.join(hip_dir, "shim.hip")] + objs +
-         ["-lpthread"])
+    shim_o = os.path.join(hip_dir, "shim.o")
+    _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+          "-I", os.path.join(ROOT, "include"), "-c", os.path.join(hip_dir, "shim.hip"), "-o", shim_o])
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO, shim_o] + objs + ["-lpthread"])
     return HIP_SO
 
 

@@ -72,7 +72,7 @@ struct LzxDec {
   __device__ bool ref_ensure(int n) {             // ENSURE_BITS(n) of the reference, EOF-exact
     while (rbl < n) {
       u32 i = w.origin + ((cons_bits() + (u32) rbl) >> 3);   // the reference's i_ptr
-      if (i > w.in_len) { err = ERR_READ; return false; }     // 2 fake bytes, then ERR_READ
+      if (i + 2u > w.in_len + w.eofs) { err = ERR_READ; return false; }   // fake bytes, then ERR_READ
       rbl += 16;
     }
     return true;
@@ -199,7 +199,7 @@ __device__ __forceinline__ bool lzx_block_header(LzxDec &d, LzxState &s)
   if (s.block_type == 3u && (s.block_length & 1u)) {            // odd-sized stored block: pad byte
     // bit buffer is empty here; the byte is skipped at i_ptr (lzxd.c:469-474)
     if (s.raw_mode) {
-      if (s.raw_pos >= d.w.in_len + 2u) { d.err = ERR_READ; return false; }
+      if (s.raw_pos >= d.w.in_len + d.w.eofs) { d.err = ERR_READ; return false; }
       s.raw_pos++;
     }
     else {
@@ -250,7 +250,7 @@ __device__ __forceinline__ bool lzx_block_header(LzxDec &d, LzxState &s)
       if (d.rbl == 0 && !d.ref_ensure(16)) return false;
     }
     // 12 bytes R0,R1,R2 (LE32), then the raw bytes; bytes up to in_len+1 exist (two fake zeros)
-    if (data + 12u > d.w.in_len + 2u) { d.err = ERR_READ; return false; }
+    if (data + 12u > d.w.in_len + d.w.eofs) { d.err = ERR_READ; return false; }
     u32 b = (d.lane < 12u) ? d.w.byte_at(data + d.lane) : 0u;
     u32 r[3];
 #pragma unroll
@@ -434,6 +434,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
 
   d.lane = lane; d.sh = sh; d.err = 0;
   d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
+  d.w.eofs = (u.flags & MSPACK_HIP_UF_HARD_EOF) ? 0u : 2u;
   d.w.seek(0, lane);
   d.bb = 0; d.bl = 0; d.rbl = 0;
   d.near_end = (u.in_len <= 64u); d.careful = d.near_end;
@@ -450,7 +451,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
     s.num_offsets = (wb >= 15u && wb <= 21u) ? ((u32) slots[wb - 15u] << 3) : 0u;
   }
   if (s.num_offsets == 0u) {
-    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; }
+    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->reserved = 0; }
     return;
   }
   lzx_reset_state(d, s);
@@ -552,7 +553,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
         else if (s.block_type == 3u) {
           // stored bytes: coalesced copy input -> output (lzxd.c:654-671)
           u32 n = (u32) run;
-          if (s.raw_pos + n > d.w.in_len + 2u || s.raw_pos + n < s.raw_pos) { d.err = ERR_READ; fail = true; break; }
+          if (s.raw_pos + n > d.w.in_len + d.w.eofs || s.raw_pos + n < s.raw_pos) { d.err = ERR_READ; fail = true; break; }
           for (u32 i = lane; i < n; i += WAVE) d.out[d.P + i] = (u8) d.w.byte_at(s.raw_pos + i);
           s.raw_pos += n; d.P += n; s.wpos += n;
           run = 0;
@@ -596,7 +597,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   if (err == 0 && remaining) err = ERR_DECRUNCH;                                  // lzxd.c:758-761
   if (err == ERR_READ && remaining == 0u) flags |= MSPACK_HIP_F_LOOKAHEAD_READ;
   if (lane == 0) {
-    res->err = err; res->flags = flags; res->out_len = s.offset;
+    res->err = err; res->flags = flags; res->out_len = s.offset; res->good_len = s.offset; res->reserved = 0;
     res->in_used = s.raw_mode ? s.raw_pos : d.iptr();
   }
 }

@@ -67,7 +67,7 @@ struct ZipDec {
   __device__ bool ref_ensure(int n) {             // bytewise ENSURE_BITS, EOF-exact
     while (rbl < n) {
       u32 i = w.origin + ((cons_bits() + (u32) rbl) >> 3);
-      if (i >= w.in_len + 2u) return false;        // two fabricated zero bytes, then ERR_READ
+      if (i >= w.in_len + w.eofs) return false;     // fabricated zero bytes, then ERR_READ
       rbl += 8;
     }
     return true;
@@ -214,7 +214,7 @@ __device__ int zip_inflate(ZipDec &d, u32 &bytes_output)
       // stored: byte-align, LEN/NLEN, raw bytes (mszipd.c:168-207)
       d.byte_align();
       u32 pos = d.byte_pos();
-      if (pos + 4u > d.w.in_len + 2u) return ERR_READ;
+      if (pos + 4u > d.w.in_len + d.w.eofs) return ERR_READ;
       u32 hb = (lane < 4u) ? d.w.byte_at(pos + lane) : 0u;
       u32 length = rdl(hb, 0) | (rdl(hb, 1) << 8), ncomp = rdl(hb, 2) | (rdl(hb, 3) << 8);
       if (length != (~ncomp & 0xFFFFu)) return ZIP_E_FORMAT;
@@ -224,7 +224,7 @@ __device__ int zip_inflate(ZipDec &d, u32 &bytes_output)
         u32 n = length, room = ZIP_FRAME - d.wpos;
         if (n > room) n = room;
         // the reference copies what the input buffer holds, including the two fabricated bytes
-        u32 avail = (pos < d.w.in_len + 2u) ? (d.w.in_len + 2u - pos) : 0u;
+        u32 avail = (pos < d.w.in_len + d.w.eofs) ? (d.w.in_len + d.w.eofs - pos) : 0u;
         if (avail == 0u) return ERR_READ;
         if (n > avail) n = avail;
         for (u32 k = lane; k < n; k += WAVE) d.out[d.B + d.wpos + k] = (u8) d.w.byte_at(pos + k);
@@ -292,6 +292,7 @@ __device__ void mszip_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, 
   ZipDec d;
   d.lane = lane; d.sh = sh;
   d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
+  d.w.eofs = (u.flags & MSPACK_HIP_UF_HARD_EOF) ? 0u : 2u;
   d.w.seek(0, lane);
   d.bb = 0; d.bl = 0; d.rbl = 0;
   // MSZIP has long stretches without an ENSURE_BITS(16) (dynamic headers, the CK scan), so the
@@ -362,7 +363,7 @@ __device__ void mszip_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, 
     d.B += n;
   }
   if (lane == 0) {
-    res->err = err; res->flags = 0; res->out_len = written;
+    res->err = err; res->flags = 0; res->out_len = written; res->good_len = written; res->reserved = 0;
     res->in_used = d.w.origin + ((d.cons_bits() + (d.careful ? (u32) d.rbl : 0u)) >> 3);
   }
 }

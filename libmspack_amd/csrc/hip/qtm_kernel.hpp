@@ -42,7 +42,7 @@ struct QtmDec {
   // one READ_BYTES of the reference (16 bits); false = ERR_READ
   __device__ __forceinline__ bool ref_fill() {
     u32 i = w.origin + ((cons_bits() + (u32) rbl) >> 3);
-    if (i > w.in_len) return false;
+    if (i + 2u > w.in_len + w.eofs) return false;
     rbl += 16;
     return true;
   }
@@ -229,12 +229,13 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   const u32 lane = threadIdx.x;
   const u32 wb = u.window_bits;
   if (wb < 10u || wb > 21u) {
-    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; }
+    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->reserved = 0; }
     return;
   }
   QtmDec d;
   d.lane = lane;
   d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
+  d.w.eofs = (u.flags & MSPACK_HIP_UF_HARD_EOF) ? 0u : 2u;
   d.w.seek(0, lane);
   d.bb = 0; d.bl = 0; d.rbl = 0; d.H = 0; d.L = 0; d.C = 0;
   u8 *out = out_arena + u.out_off;
@@ -252,6 +253,7 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   long long need = (long long) out_len;
   bool header_read = false;
   int err = ERR_OK;
+  u32 good = 0;                 // position up to which a request would have succeeded
 
   while ((long long)(o_end - o_ptr) < need) {
     u32 v;
@@ -266,6 +268,7 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
     bool stop = false;
 
     while (wpos < frame_end) {
+      good = P;
       int sel = qtm_get_symbol(d, m7, 7, s7);
       if (sel < 0) { err = ERR_READ; stop = true; break; }
       if (sel < 4) {
@@ -329,7 +332,10 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
     }
     if (stop) break;
     o_end = wpos;
+    // a match that overshot the frame fails every request that needed that match: `good` still
+    // holds the position where it started
     if (frame_todo > QTM_FRAME) { err = ERR_DECRUNCH; break; }         // qtmd.c:424
+    good = P ? P - 1u : 0u;       // errors in the frame-end handling hit the request ending here
     if (frame_todo == 0u) {
       int n = d.rbl & 7;                                               // qtmd.c:432
       if (n) { d.need(n); d.bb <<= n; d.bl -= n; d.rbl -= n; }
@@ -338,6 +344,7 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
       if (!ok) { err = ERR_READ; break; }
       header_read = false; frame_todo = QTM_FRAME;
     }
+    good = P;
     if (wpos == wsize) {
       u32 i = o_end - o_ptr;
       if ((long long) i >= need) break;
@@ -345,8 +352,9 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
     }
   }
   if (err == ERR_OK && need) { written += (u32) need; }
+  if (err == ERR_OK) good = written;
   if (lane == 0) {
-    res->err = err; res->flags = 0; res->out_len = written;
+    res->err = err; res->flags = 0; res->out_len = written; res->good_len = good; res->reserved = 0;
     res->in_used = d.w.origin + ((d.cons_bits() + (u32) d.rbl) >> 3);
   }
 }

@@ -46,6 +46,8 @@ __device__ __forceinline__ u32 lanemask_lt_popc(u64 m, u32 lane) {
 struct InWindow {
   const u8 *unit;     // arena + in_off (uniform); the arena has >= 8 bytes of readable slack
   u32 in_len;
+  u32 eofs;           // zero bytes the reference fabricates at EOF before ERR_READ: 2, or 0 for
+                      // a hard end (MSPACK_HIP_UF_HARD_EOF: the feeder's read failed, readbits.h:194)
   u32 origin;         // byte offset of dword index 0
   u32 wi;             // next dword index (relative to origin) to hand out
   u32 cur, nxt;       // per-lane: dword `lane` of the current / next 256-byte chunk

@@ -1,0 +1,37 @@
+/* host_common.h -- shared bits of the plain-C host drivers (cabd.c, chmd.c, system.c).
+ * The drivers never touch HIP: they gather units, call the C ABI of include/mspack_hip.h and
+ * serve slices of the decoded result through the caller's struct mspack_system. */
+#ifndef MSPACK_AMD_HOST_COMMON_H
+#define MSPACK_AMD_HOST_COMMON_H
+#define _FILE_OFFSET_BITS 64
+#include <stdint.h>
+#include <string.h>
+#include "mspack.h"
+#include "mspack_hip.h"
+
+extern struct mspack_system *mspack_default_system;
+int mspack_valid_system(struct mspack_system *sys);
+int mspack_sys_filelen(struct mspack_system *system, struct mspack_file *file, off_t *length);
+
+static inline unsigned int rd_le16(const unsigned char *p) { return (unsigned int) p[0] | ((unsigned int) p[1] << 8); }
+static inline unsigned int rd_le32(const unsigned char *p) {
+  return (unsigned int) p[0] | ((unsigned int) p[1] << 8) | ((unsigned int) p[2] << 16) | ((unsigned int) p[3] << 24);
+}
+static inline unsigned int rd_be32(const unsigned char *p) {
+  return (unsigned int) p[3] | ((unsigned int) p[2] << 8) | ((unsigned int) p[1] << 16) | ((unsigned int) p[0] << 24);
+}
+static inline int64_t rd_le64(const unsigned char *p) {
+  return (int64_t)((uint64_t) rd_le32(p) | ((uint64_t) rd_le32(p + 4) << 32));
+}
+
+/* write `n` bytes through sys->write in pieces of at most 32 KiB (the reference's codecs hand
+ * over one frame at a time); returns MSPACK_ERR_OK / MSPACK_ERR_WRITE */
+static inline int write_slice(struct mspack_system *sys, struct mspack_file *fh, const unsigned char *p, size_t n) {
+  while (n) {
+    int run = n > 32768 ? 32768 : (int) n;
+    if (sys->write(fh, (void *) p, run) != run) return MSPACK_ERR_WRITE;
+    p += run; n -= (size_t) run;
+  }
+  return MSPACK_ERR_OK;
+}
+#endif

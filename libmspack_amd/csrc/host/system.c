@@ -1,0 +1,103 @@
+/* system.c -- default stdio-backed struct mspack_system, version and self-test entry points.
+ * Interface: reference mspack.h:191-262, 285-455; behaviour follows libmspack/mspack/system.c
+ * (open modes, read/write returning -1 on stream error, alloc/free/copy). */
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdarg.h>
+#include "host_common.h"
+
+int mspack_version(int entity) {
+  switch (entity) {
+  case MSPACK_VER_MSCHMD: case MSPACK_VER_MSCABD:
+    return 2;                       /* structure revisions this library is layout-compatible with */
+  case MSPACK_VER_LIBRARY: case MSPACK_VER_SYSTEM:
+    return 1;
+  case MSPACK_VER_MSOABD: case MSPACK_VER_MSSZDDD: case MSPACK_VER_MSKWAJD:
+  case MSPACK_VER_MSCABC: case MSPACK_VER_MSCHMC: case MSPACK_VER_MSLITD: case MSPACK_VER_MSLITC:
+  case MSPACK_VER_MSHLPD: case MSPACK_VER_MSHLPC: case MSPACK_VER_MSSZDDC: case MSPACK_VER_MSKWAJC:
+  case MSPACK_VER_MSOABC:
+    return 0;                       /* not provided by this library */
+  }
+  return -1;
+}
+
+int mspack_sys_selftest_internal(int offt_size) {
+  return (sizeof(off_t) == (size_t) offt_size) ? MSPACK_ERR_OK : MSPACK_ERR_SEEK;
+}
+
+int mspack_valid_system(struct mspack_system *sys) {
+  return sys && sys->open && sys->close && sys->read && sys->write && sys->seek && sys->tell &&
+         sys->message && sys->alloc && sys->free && sys->copy && (sys->null_ptr == NULL);
+}
+
+int mspack_sys_filelen(struct mspack_system *system, struct mspack_file *file, off_t *length) {
+  off_t here;
+  if (!system || !file || !length) return MSPACK_ERR_OPEN;
+  here = system->tell(file);
+  if (system->seek(file, 0, MSPACK_SYS_SEEK_END)) return MSPACK_ERR_SEEK;
+  *length = system->tell(file);
+  if (system->seek(file, here, MSPACK_SYS_SEEK_START)) return MSPACK_ERR_SEEK;
+  return MSPACK_ERR_OK;
+}
+
+struct stdio_file { FILE *fp; const char *name; };
+
+static struct mspack_file *std_open(struct mspack_system *self, const char *filename, int mode) {
+  static const char *modes[4] = { "rb", "wb", "r+b", "ab" };
+  struct stdio_file *f;
+  (void) self;
+  if (mode < 0 || mode > 3 || !filename) return NULL;
+  if (!(f = (struct stdio_file *) malloc(sizeof(*f)))) return NULL;
+  f->name = filename;
+  if (!(f->fp = fopen(filename, modes[mode]))) { free(f); return NULL; }
+  return (struct mspack_file *) f;
+}
+static void std_close(struct mspack_file *file) {
+  struct stdio_file *f = (struct stdio_file *) file;
+  if (f) { fclose(f->fp); free(f); }
+}
+static int std_read(struct mspack_file *file, void *buffer, int bytes) {
+  struct stdio_file *f = (struct stdio_file *) file;
+  if (f && buffer && bytes >= 0) {
+    size_t n = fread(buffer, 1, (size_t) bytes, f->fp);
+    if (!ferror(f->fp)) return (int) n;
+  }
+  return -1;
+}
+static int std_write(struct mspack_file *file, void *buffer, int bytes) {
+  struct stdio_file *f = (struct stdio_file *) file;
+  if (f && buffer && bytes >= 0) {
+    size_t n = fwrite(buffer, 1, (size_t) bytes, f->fp);
+    if (!ferror(f->fp)) return (int) n;
+  }
+  return -1;
+}
+static int std_seek(struct mspack_file *file, off_t offset, int mode) {
+  struct stdio_file *f = (struct stdio_file *) file;
+  int whence;
+  if (!f) return -1;
+  if (mode == MSPACK_SYS_SEEK_START) whence = SEEK_SET;
+  else if (mode == MSPACK_SYS_SEEK_CUR) whence = SEEK_CUR;
+  else if (mode == MSPACK_SYS_SEEK_END) whence = SEEK_END;
+  else return -1;
+  return fseeko(f->fp, offset, whence);
+}
+static off_t std_tell(struct mspack_file *file) {
+  struct stdio_file *f = (struct stdio_file *) file;
+  return f ? (off_t) ftello(f->fp) : 0;
+}
+static void std_message(struct mspack_file *file, const char *format, ...) {
+  va_list ap;
+  if (file) fprintf(stderr, "%s: ", ((struct stdio_file *) file)->name);
+  va_start(ap, format); vfprintf(stderr, format, ap); va_end(ap);
+  fputc('\n', stderr); fflush(stderr);
+}
+static void *std_alloc(struct mspack_system *self, size_t bytes) { (void) self; return malloc(bytes); }
+static void std_free(void *p) { free(p); }
+static void std_copy(void *src, void *dest, size_t bytes) { memcpy(dest, src, bytes); }
+
+static struct mspack_system std_system = {
+  &std_open, &std_close, &std_read, &std_write, &std_seek, &std_tell, &std_message,
+  &std_alloc, &std_free, &std_copy, NULL
+};
+struct mspack_system *mspack_default_system = &std_system;
