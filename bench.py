@@ -78,21 +78,17 @@ def main():
     import torch
     import libmspack_amd as M
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from libmspack_amd import dist as D
+    rank, world, local = D.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dist = D.init("nccl", torch.device("cuda", local))
 
     n, ub = args.units, args.unit_kib * 1024
     # ---- synthetic corpus: every rank its own seeds (weak scaling: fixed work per GPU) ----
     t0 = time.perf_counter()
-    plain, comp, off, ln = M.corpus_lzx_units(0xBA5E11 + (rank << 32), args.text, n, ub, 21)
+    plain, comp, off, ln = M.corpus_lzx_units(D.unit_seed_base(0xBA5E11, rank), args.text, n, ub, 21)
     gen_s = time.perf_counter() - t0
     units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21,
                                     reset_frames=ub // 32768)
@@ -130,10 +126,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, total_out = D.reduce_scalars(dist, dev, elapsed, float(n * ub))
 
     # ---- kernel-only duration with HIP events on the launch stream (roofline numerator) ----
     ms_kernel = L.mspack_hip_time_batch_device(d_units.data_ptr(), d_order.data_ptr(), n, d_in.data_ptr(), comp.size,
@@ -148,7 +141,6 @@ def main():
     if not ok and not args.exp:
         raise SystemExit("rank %d: GPU output is NOT bit-exact; refusing to report a number" % rank)
 
-    total_out = float(n * ub) * world
     comp_bytes = float(ln.sum())
     algo_bytes = comp_bytes + n * ub                      # in + out, per launch
     if rank == 0:

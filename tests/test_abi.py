@@ -1,0 +1,103 @@
+"""CPU: the C-ABI library loads and exports every function that include/*.h declares, its structs
+have the layout the Python mirror assumes, and the product fails loudly without a GPU (no CPU
+fallback path exists).  No compute calls are made here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+import libmspack_amd as M
+from libmspack_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(mspack_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(n for n in names if not n.endswith("_internal") or True))
+
+
+def test_every_declared_symbol_is_exported(built):
+    L = M.lib()
+    for hdr in ("mspack_hip.h", "mspack.h"):
+        for name in declared_functions(hdr):
+            assert hasattr(L, name), "%s (declared in %s) is not exported" % (name, hdr)
+    for name in M.EXPORTED_SYMBOLS:
+        assert hasattr(L, name)
+
+
+def test_struct_layouts_match_the_c_headers(built):
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "mspack_hip.h"
+#include "mspack.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(mspack_hip_unit), sizeof(mspack_hip_result),
+         offsetof(mspack_hip_unit, kind), offsetof(mspack_hip_unit, flags), offsetof(mspack_hip_result, good_len),
+         sizeof(struct mspack_system));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(struct mscabd_cabinet), sizeof(struct mscabd_folder),
+         sizeof(struct mscabd_file), sizeof(struct mschmd_header), sizeof(struct mschmd_file),
+         sizeof(struct mscab_decompressor));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-D_FILE_OFFSET_BITS=64", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        a, b = [list(map(int, ln.split())) for ln in subprocess.check_output([exe]).decode().splitlines()]
+    assert a[0] == M.UNIT_DTYPE.itemsize and a[1] == M.RESULT_DTYPE.itemsize
+    assert a[2] == M.UNIT_DTYPE.fields["kind"][1] and a[3] == M.UNIT_DTYPE.fields["flags"][1]
+    assert a[4] == M.RESULT_DTYPE.fields["good_len"][1]
+    assert a[5] == 11 * 8
+    assert b == [C.sizeof(api.MscabdCabinet), C.sizeof(api.MscabdFolder), C.sizeof(api.MscabdFile),
+                 C.sizeof(api.MschmdHeader), C.sizeof(api.MschmdFile), C.sizeof(api.MscabDecompressor)]
+
+
+def test_reference_layout_compat(built):
+    """When the reference headers are around (dev container), our structs are byte-compatible."""
+    ref = "/root/reference/libmspack/mspack/mspack.h"
+    if not os.path.exists(ref):
+        pytest.skip("reference headers absent")
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include <mspack.h>
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(struct mscabd_cabinet), sizeof(struct mscabd_folder),
+         sizeof(struct mscabd_file), sizeof(struct mschmd_header), sizeof(struct mschmd_file),
+         sizeof(struct mscab_decompressor), sizeof(struct mschm_decompressor),
+         offsetof(struct mschmd_header, sec1), offsetof(struct mscabd_file, folder));
+  return 0;
+}'''
+    outs = []
+    for inc in (os.path.dirname(ref), os.path.join(ROOT, "include")):
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "t.c"); open(src, "w").write(prog)
+            exe = os.path.join(td, "t")
+            subprocess.check_call(["gcc", "-D_FILE_OFFSET_BITS=64", "-I", inc, src, "-o", exe])
+            outs.append(subprocess.check_output([exe]).decode())
+    assert outs[0] == outs[1]
+
+
+def test_versions_and_selftest(built):
+    L = api._setup()
+    assert L.mspack_version(2) == 2 and L.mspack_version(4) == 2      # MSCABD, MSCHMD (system.c:16-51)
+    assert L.mspack_version(0) == 1 and L.mspack_version(99) == -1
+    assert L.mspack_sys_selftest_internal(8) == 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback(built):
+    """On a machine without a GPU the batch call must FAIL (negative hip error), never decode."""
+    import numpy as np
+    if M.lib().mspack_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    units, out_bytes = M.make_units(M.KIND_LZX, [0], [16], [32768], window_bits=15)
+    with pytest.raises(M.MspackHipError):
+        M.decode_batch(units, np.zeros(64, dtype=np.uint8), out_bytes)
