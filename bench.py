@@ -142,6 +142,16 @@ def main():
         raise SystemExit("rank %d: GPU output is NOT bit-exact; refusing to report a number" % rank)
 
     comp_bytes = float(ln.sum())
+    # HBM traffic per launch: PMC counters cannot be collected from inside this process; the latest
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload are kept in profiles/
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        w = tj["workload"]
+        if (w["units_per_gpu"], w["unit_bytes"], w["text"]) == (n, ub, args.text):
+            traffic = int((tj["fetch_kib_per_launch"] + tj["write_kib_per_launch"]) * 1024)
+    except Exception:
+        traffic = None
     algo_bytes = comp_bytes + n * ub                      # in + out, per launch
     if rank == 0:
         line = {
@@ -159,7 +169,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (ms_kernel * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(algo_bytes / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic": None, "kernel": "mspack_decode_lzx", "kernel_ms": round(ms_kernel, 4),
+                         "traffic": traffic, "kernel": "mspack_decode_lzx", "kernel_ms": round(ms_kernel, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }
         if world == 1 and not args.no_cpu and not args.exp:
