@@ -40,6 +40,7 @@ struct __align__(16) LzxShared {
   u16 ali_sorted[8];
   u16 pre_sorted[24];
   u32 cnt[20];
+  u32 inbuf[128 + 4];            /* speculative path: two 256-byte input chunks, words pre-swapped */
   u8  main_len[LZX_MAIN_SYMS + 16];
   u8  len_len[LZX_LEN_SYMS + 70];
   u8  pre_len[24];
@@ -420,6 +421,241 @@ out:
 #undef FAST_FAIL
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Speculative window decode: the steady-state path.
+//
+// A Huffman/LZ bitstream is serial only because a symbol's start is known once the previous symbol's
+// length is.  So all 64 lanes decode a COMPLETE token (main symbol, length footer, offset bits,
+// aligned symbol) each starting at a different bit -- lane l at bit (pos + l) -- with gathered LDS
+// table lookups, and publish "bits consumed / kind / length / offset" in two registers.  The true
+// symbol boundaries are then followed through those registers with v_readlane: a token costs two
+// readlanes and a handful of scalar ops instead of a chain of dependent LDS round trips, and the
+// lookups of ~6 consecutive tokens (64 bits / ~10 bits per token) overlap.  Tokens with a code
+// longer than the direct table are decoded by the scalar routine from the same 64 bits.
+// Input: the two current 256-byte chunks live in LDS with each dword's 16-bit halves swapped, so the
+// stream is a plain MSB-first bit string; the next chunk is prefetched in a register.
+// ---------------------------------------------------------------------------------------------------
+template <bool ALIGNED>
+__device__ __forceinline__ u32 lzx_scalar_token(const LzxDec &d, bool length_empty, u64 r,
+                                                u32 &kind, u32 &val, u32 &off)
+{
+  const LzxShared *sh = d.sh;
+  u32 tot = 0;
+  u32 e = rfl((u32) sh->main_tab[(u32)(r >> (64 - LZX_MAIN_P))]);
+  if (e == 0) { e = huff_long(d.hr_main, sh->main_sorted, (u32)(r >> 48), d.lane); if (e == 0) return 0; }
+  { u32 l = e >> 10; r <<= l; tot += l; }
+  u32 sym = e & 1023u;
+  if (sym < 256u) { kind = 0; val = sym; off = 0; return tot; }
+  u32 m = sym - 256u, slot = m >> 3, len = (m & 7u) + 2u;
+  if ((m & 7u) == 7u) {
+    if (length_empty) return 0;
+    u32 f = rfl((u32) sh->len_tab[(u32)(r >> (64 - LZX_LEN_P))]);
+    if (f == 0) { f = huff_long(d.hr_len, sh->len_sorted, (u32)(r >> 48), d.lane); if (f == 0) return 0; }
+    { u32 l = f >> 10; r <<= l; tot += l; }
+    len += f & 1023u;
+  }
+  val = len;
+  if (slot < 3u) { kind = 2u + slot; off = 0; return tot; }
+  u32 extra = slot < 4u ? 0u : (slot < 36u ? (slot >> 1) - 1u : 17u);
+  u32 base = slot < 4u ? slot : (slot < 36u ? ((2u + (slot & 1u)) << extra) : ((slot - 34u) << 17));
+  off = base - 2u;
+  if (ALIGNED && extra >= 3u) {
+    u32 nb = extra - 3u;
+    if (nb) { off += (u32)(r >> (64 - nb)) << 3; r <<= nb; tot += nb; }
+    u32 a = rfl((u32) sh->ali_tab[(u32)(r >> (64 - LZX_ALI_P))]);
+    if (a == 0) return 0;
+    tot += a >> 10; off += a & 1023u;
+  }
+  else if (extra) { off += (u32)(r >> (64 - extra)); tot += extra; }
+  kind = 1;
+  return tot;
+}
+
+// inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic)
+__device__ __forceinline__ u32 wave_incl_scan(u32 x)
+{
+  u32 v = x;
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 run_end, const u32 wbase)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  u8 *const out = d.out;
+  u32 P = d.P;
+  u32 R0 = s.R0, R1 = s.R1, R2 = s.R2;
+  const u32 wsize = s.wsize, offset_written = s.offset;
+  const bool length_empty = s.length_empty;
+  int rc = LZX_RUN_DONE;
+
+  // bit position of the next unread bit, relative to d.w.origin; chunk cb = dwords [64cb, 64cb+64)
+  u32 bitpos = d.cons_bits();
+  u32 cb = bitpos >> 11;
+  // last bit position from which a whole window (64 starts + 64 bits of look-ahead) stays 64 bytes
+  // clear of the end of the input
+  const u32 room_bytes = (d.w.in_len > d.w.origin + 96u) ? (d.w.in_len - d.w.origin - 96u) : 0u;
+  const u32 bit_limit = room_bytes * 8u;
+  if (bitpos >= bit_limit) return LZX_RUN_SWITCH;
+  // pending literals of the scalar path go out first: this path stores literals directly
+  d.flush_lits();
+
+#define SWAP16(x) (((x) << 16) | ((x) >> 16))
+  {
+    u32 lo = d.w.load_chunk(cb, lane), hi = d.w.load_chunk(cb + 1u, lane);
+    sh->inbuf[lane] = SWAP16(lo); sh->inbuf[64u + lane] = SWAP16(hi);
+    if (lane < 4u) sh->inbuf[128u + lane] = 0;
+  }
+  u32 pf = d.w.load_chunk(cb + 2u, lane);
+
+  // one match of the walk: LRU update, the reference's checks, copy.  false = DECRUNCH
+#define SPEC_MATCH(pos_, len_, kind_, off_)                                                  \
+  do {                                                                                       \
+    u32 moff_;                                                                               \
+    if ((kind_) == 1u) { moff_ = (off_); R2 = R1; R1 = R0; R0 = moff_; }                     \
+    else if ((kind_) == 2u) moff_ = R0;                                                      \
+    else if ((kind_) == 3u) { moff_ = R1; R1 = R0; R0 = moff_; }                             \
+    else { moff_ = R2; R2 = R0; R0 = moff_; }                                                \
+    u32 wp_ = (pos_) - wbase;                                                                \
+    if ((pos_) + (len_) > run_end || wp_ + (len_) > wsize ||                                 \
+        (moff_ > wp_ && (moff_ > offset_written || (moff_ - wp_) > wsize))) {                \
+      d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL;                                               \
+    }                                                                                        \
+    else if (moff_ != 0u && moff_ <= wsize) lzx_copy_match(out, (pos_), moff_, (len_), lane); \
+    else { if (lane == 0) lzx_copy_match_odd(out, (pos_), wp_, wsize, moff_, (len_)); }      \
+  } while (0)
+
+  while (P < run_end) {
+    if (bitpos >= bit_limit) { rc = LZX_RUN_SWITCH; break; }
+    if ((bitpos >> 11) != cb) {                       // slide the LDS window by one chunk
+      u32 up = sh->inbuf[64u + lane];
+      sh->inbuf[lane] = up; sh->inbuf[64u + lane] = SWAP16(pf);
+      cb++;
+      pf = d.w.load_chunk(cb + 2u, lane);
+    }
+    // ---- every lane decodes the token that would start at bit (bitpos + lane) ----
+    u32 rel = bitpos - (cb << 11) + lane;
+    u32 k = rel >> 5, sft = rel & 31u;
+    u32 a = sh->inbuf[k], b = sh->inbuf[k + 1u], c = sh->inbuf[k + 2u];
+    u32 w0 = (u32)(((((u64) a << 32) | b) << sft) >> 32);
+    u32 w1 = (u32)(((((u64) b << 32) | c) << sft) >> 32);
+    u64 r = ((u64) w0 << 32) | w1;
+    u32 e = sh->main_tab[w0 >> (32 - LZX_MAIN_P)];
+    bool unk = (e == 0u);
+    u32 tot = e >> 10, sym = e & 1023u;
+    r <<= tot;
+    bool is_match = sym >= 256u;
+    u32 m = sym - 256u, slot = m >> 3, lh = m & 7u;
+    u32 e2 = sh->len_tab[(u32)(r >> (64 - LZX_LEN_P))];
+    bool need_len = is_match && lh == 7u;
+    if (need_len) { unk = unk || e2 == 0u || length_empty; u32 l2 = e2 >> 10; r <<= l2; tot += l2; }
+    u32 mlen = lh + 2u + (need_len ? (e2 & 1023u) : 0u);
+    u32 extra = slot < 4u ? 0u : (slot < 36u ? (slot >> 1) - 1u : 17u);
+    u32 base = slot < 4u ? slot : (slot < 36u ? ((2u + (slot & 1u)) << extra) : ((slot - 34u) << 17));
+    u32 off = base - 2u;
+    bool expl = is_match && slot >= 3u;
+    if (ALIGNED) {
+      bool ali = extra >= 3u;
+      u32 nb = ali ? extra - 3u : extra;
+      u32 vb = nb ? (u32)(r >> (64u - nb)) : 0u;
+      u64 r2 = r << nb;
+      u32 e3 = sh->ali_tab[(u32)(r2 >> (64 - LZX_ALI_P))];
+      if (expl) {
+        tot += nb;
+        if (ali) { off += (vb << 3) + (e3 & 1023u); tot += e3 >> 10; unk = unk || e3 == 0u; }
+        else off += vb;
+      }
+    }
+    else {
+      u32 vb = extra ? (u32)(r >> (64u - extra)) : 0u;
+      if (expl) { off += vb; tot += extra; }
+    }
+    const u32 kind = !is_match ? 0u : (expl ? 1u : 2u + slot);
+    const u32 olen = is_match ? mlen : 1u;
+    const u32 vnext = unk ? 255u : (lane + tot);       // 255 = "needs the scalar decoder"
+
+    // ---- follow the real token boundaries: which lanes start a token? ----
+    u64 chain = 0;
+    u32 q = 0;
+    bool hit_unknown = false;
+    while (q < WAVE) {
+      u32 nx = rdl(vnext, q);
+      if (nx == 255u) { hit_unknown = true; break; }
+      chain |= 1ull << q;
+      q = nx;
+    }
+    // q = where the next round starts (or the token the scalar decoder has to take)
+    bool on = (chain >> lane) & 1ull;
+    u32 incl = wave_incl_scan(on ? olen : 0u);
+    u32 opos = P + incl - (on ? olen : 0u);             // output position of this lane's token
+    // tokens are decoded only while the run lasts (lzxd.c:538): cut the chain at the first token
+    // that starts at or after run_end
+    u64 late = ballot(on && opos >= run_end);
+    if (late) {
+      u32 j = (u32) __ffsll((long long) late) - 1u;
+      chain &= (1ull << j) - 1ull;
+      on = (chain >> lane) & 1ull;
+      q = j; hit_unknown = false;
+    }
+    // literals: one store for all of them
+    if (on && kind == 0u) out[opos] = (u8) sym;
+    // matches, in order
+    u64 mm = ballot(on && kind != 0u);
+    u32 newP = P + rdl(incl, 63u);
+    if (late) {                                        // total output of the tokens that remain
+      u32 j = (u32) __ffsll((long long) late) - 1u;
+      newP = rdl(opos, j);
+    }
+    while (mm) {
+      u32 j = (u32) __ffsll((long long) mm) - 1u;
+      mm &= mm - 1ull;
+      u32 len_j = rdl(olen, j), kind_j = rdl(kind, j), off_j = rdl(off, j), pos_j = rdl(opos, j);
+      SPEC_MATCH(pos_j, len_j, kind_j, off_j);
+      if (rc != LZX_RUN_DONE) break;
+    }
+    if (rc != LZX_RUN_DONE) break;
+    P = newP;
+    bitpos += q;
+    if (hit_unknown && P < run_end) {
+      // a code longer than the direct table (or an invalid one): decode this one token on the
+      // scalar side from the 64 bits lane q extracted
+      u32 tk_kind, tk_val, tk_off;
+      u64 rq = ((u64) rdl(w0, q) << 32) | rdl(w1, q);
+      u32 tk_tot = lzx_scalar_token<ALIGNED>(d, length_empty, rq, tk_kind, tk_val, tk_off);
+      if (tk_tot == 0u) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; break; }
+      if (tk_kind == 0u) { if (lane == 0) out[P] = (u8) tk_val; P++; }
+      else { SPEC_MATCH(P, tk_val, tk_kind, tk_off); if (rc != LZX_RUN_DONE) break; P += tk_val; }
+      bitpos += tk_tot;
+    }
+  }
+#undef SWAP16
+#undef SPEC_MATCH
+  // hand the exact bit position back to the scalar reader
+  d.P = P;
+  s.R0 = R0; s.R1 = R1; s.R2 = R2;
+  {
+    u32 wi = bitpos >> 5, ch = wi >> 6;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    u32 lo = sh->inbuf[lane], hi = sh->inbuf[64u + lane];
+    lo = (lo << 16) | (lo >> 16); hi = (hi << 16) | (hi >> 16);
+    if (ch == cb) { d.w.cur = lo; d.w.nxt = hi; }
+    else { d.w.cur = hi; d.w.nxt = pf; }                 // ch == cb + 1
+    d.w.wi = wi; d.bb = 0; d.bl = 0;
+    d.refill(); d.refill();
+    u32 sk = bitpos & 31u;
+    if (sk) { d.bb <<= sk; d.bl -= (int) sk; }
+  }
+  return rc;
+}
+
 // decode one LZX unit.  frame_meta[frame_base + f] receives the intel_filesize to apply to frame f
 // (0 = none).  Returns via *res.
 __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
@@ -489,7 +725,11 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
           const u32 run_end = d.P + (u32) run;
           const u32 wbase = d.P - s.wpos;          // linear position of window index 0
           if (!d.careful && !d.near_end) {
+#ifndef LZX_NO_SPEC
+            int rc = aligned ? lzx_run_spec<true>(d, s, run_end, wbase) : lzx_run_spec<false>(d, s, run_end, wbase);
+#else
             int rc = aligned ? lzx_run_fast<true>(d, s, run_end, wbase) : lzx_run_fast<false>(d, s, run_end, wbase);
+#endif
             if (rc == LZX_RUN_FAIL) { d.flush_lits(); fail = true; break; }
           }
           while (d.P < run_end) {
