@@ -57,6 +57,7 @@ struct LzxDec {
   // ---- output ----
   u8 *out; u32 P;                    // linear position == bytes decoded since unit start
   u32 lit_buf; u32 lit_n;            // lit_buf is per-lane
+  u32 st_rounds, st_unknown;         // statistics (LZX_EXP_STATS builds only)
   LzxShared *sh;
   HuffRegs hr_main, hr_len, hr_ali, hr_pre;
 
@@ -516,6 +517,13 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   }
   u32 pf = d.w.load_chunk(cb + 2u, lane);
 
+#ifndef LZX_EXP_NOCOPY
+#define SPEC_COPY(pos_, len_, moff_, wp_)                                                    \
+  do { if ((moff_) != 0u && (moff_) <= wsize) lzx_copy_match(out, (pos_), (moff_), (len_), lane); \
+       else { if (lane == 0) lzx_copy_match_odd(out, (pos_), (wp_), wsize, (moff_), (len_)); } } while (0)
+#else
+#define SPEC_COPY(pos_, len_, moff_, wp_) do { } while (0)
+#endif
   // one match of the walk: LRU update, the reference's checks, copy.  false = DECRUNCH
 #define SPEC_MATCH(pos_, len_, kind_, off_)                                                  \
   do {                                                                                       \
@@ -529,8 +537,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
         (moff_ > wp_ && (moff_ > offset_written || (moff_ - wp_) > wsize))) {                \
       d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL;                                               \
     }                                                                                        \
-    else if (moff_ != 0u && moff_ <= wsize) lzx_copy_match(out, (pos_), moff_, (len_), lane); \
-    else { if (lane == 0) lzx_copy_match_odd(out, (pos_), wp_, wsize, moff_, (len_)); }      \
+    else SPEC_COPY(pos_, len_, moff_, wp_);                                                  \
   } while (0)
 
   while (P < run_end) {
@@ -606,7 +613,9 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       q = j; hit_unknown = false;
     }
     // literals: one store for all of them
+#ifndef LZX_EXP_NOLIT
     if (on && kind == 0u) out[opos] = (u8) sym;
+#endif
     // matches, in order
     u64 mm = ballot(on && kind != 0u);
     u32 newP = P + rdl(incl, 63u);
@@ -614,6 +623,9 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       u32 j = (u32) __ffsll((long long) late) - 1u;
       newP = rdl(opos, j);
     }
+#ifdef LZX_EXP_NOMATCH
+    mm = 0;
+#endif
     while (mm) {
       u32 j = (u32) __ffsll((long long) mm) - 1u;
       mm &= mm - 1ull;
@@ -624,7 +636,9 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     if (rc != LZX_RUN_DONE) break;
     P = newP;
     bitpos += q;
+    d.st_rounds++;
     if (hit_unknown && P < run_end) {
+      d.st_unknown++;
       // a code longer than the direct table (or an invalid one): decode this one token on the
       // scalar side from the 64 bits lane q extracted
       u32 tk_kind, tk_val, tk_off;
@@ -638,6 +652,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   }
 #undef SWAP16
 #undef SPEC_MATCH
+#undef SPEC_COPY
   // hand the exact bit position back to the scalar reader
   d.P = P;
   s.R0 = R0; s.R1 = R1; s.R2 = R2;
@@ -675,6 +690,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   d.bb = 0; d.bl = 0; d.rbl = 0;
   d.near_end = (u.in_len <= 64u); d.careful = d.near_end;
   d.out = out_arena + u.out_off; d.P = 0; d.lit_buf = 0; d.lit_n = 0;
+  d.st_rounds = 0; d.st_unknown = 0;
 
   s.wsize = 1u << u.window_bits;
   s.wpos = 0; s.frame_posn = 0; s.frame = 0; s.reset_frames = u.reset_frames;
@@ -839,6 +855,9 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   if (lane == 0) {
     res->err = err; res->flags = flags; res->out_len = s.offset; res->good_len = s.offset; res->reserved = 0;
     res->in_used = s.raw_mode ? s.raw_pos : d.iptr();
+#ifdef LZX_EXP_STATS
+    res->in_used = d.st_rounds; res->reserved = d.st_unknown;
+#endif
   }
 }
 

@@ -1,5 +1,5 @@
 import sys, json, base64, hashlib
-sys.path.insert(0, 'tests')
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import libmspack_amd as M
 from libmspack_amd import api
 VECS = json.load(open('tests/golden/driver_cabs.json'))

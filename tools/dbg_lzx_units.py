@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, 'tests')
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import libmspack_amd as M
 n, ub = int(sys.argv[1]) if len(sys.argv) > 1 else 512, 65536
 plain, comp, off, ln = M.corpus_lzx_units(0xC0FFEE, M.TEXT_MIX, n, ub, 21)
