@@ -24,7 +24,7 @@
 
 #define LZX_FRAME 32768u
 #define LZX_MAIN_P 10
-#define LZX_LEN_P 8
+#define LZX_LEN_P 10
 #define LZX_ALI_P 7
 #define LZX_PRE_P 6
 #define LZX_MAIN_SYMS 720      /* 256 + 50*8 + 64: every index that can ever be non-zero (w<=21) */
@@ -516,6 +516,9 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     if (lane < 4u) sh->inbuf[128u + lane] = 0;
   }
   u32 pf = d.w.load_chunk(cb + 2u, lane);
+  u32 mlim[16 - LZX_MAIN_P];                            // limits of the code lengths beyond the table
+#pragma unroll
+  for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
 
 #ifndef LZX_EXP_NOCOPY
 #define SPEC_COPY(pos_, len_, moff_, wp_)                                                    \
@@ -556,6 +559,19 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     u32 w1 = (u32)(((((u64) b << 32) | c) << sft) >> 32);
     u64 r = ((u64) w0 << 32) | w1;
     u32 e = sh->main_tab[w0 >> (32 - LZX_MAIN_P)];
+    {
+      // codes longer than the direct table, for all lanes at once: canonical length = number of
+      // per-length limits the 16-bit peek is not below; symbol via the sorted list (readhuff.h:144-172)
+      u32 peek16 = w0 >> 16, ln = LZX_MAIN_P + 1u;
+#pragma unroll
+      for (int l = LZX_MAIN_P + 1; l <= 16; l++) ln += (peek16 >= mlim[l - LZX_MAIN_P - 1]) ? 1u : 0u;
+      u32 lq = ln <= 16u ? ln : 0u;
+      u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) d.hr_main.fov);
+      u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
+      if (idx >= LZX_MAIN_SYMS) idx = 0;
+      u32 ls = sh->main_sorted[idx];
+      if (e == 0u && lq != 0u) e = ls | (lq << 10);
+    }
     bool unk = (e == 0u);
     u32 tot = e >> 10, sym = e & 1023u;
     r <<= tot;
@@ -587,18 +603,15 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     }
     const u32 kind = !is_match ? 0u : (expl ? 1u : 2u + slot);
     const u32 olen = is_match ? mlen : 1u;
-    const u32 vnext = unk ? 255u : (lane + tot);       // 255 = "needs the scalar decoder"
+    // next token start for every lane; >= 128 marks "needs the scalar decoder" and ends the walk
+    const u32 vnext = unk ? (128u + lane) : (lane + tot);
 
     // ---- follow the real token boundaries: which lanes start a token? ----
     u64 chain = 0;
     u32 q = 0;
+    do { chain |= 1ull << q; q = rdl(vnext, q); } while (q < WAVE);
     bool hit_unknown = false;
-    while (q < WAVE) {
-      u32 nx = rdl(vnext, q);
-      if (nx == 255u) { hit_unknown = true; break; }
-      chain |= 1ull << q;
-      q = nx;
-    }
+    if (q >= 128u) { q -= 128u; chain &= ~(1ull << q); hit_unknown = true; }
     // q = where the next round starts (or the token the scalar decoder has to take)
     bool on = (chain >> lane) & 1ull;
     u32 incl = wave_incl_scan(on ? olen : 0u);
