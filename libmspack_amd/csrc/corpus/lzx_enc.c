@@ -64,6 +64,8 @@ typedef struct { uint32_t off; uint16_t len; uint8_t rslot; uint8_t lit; } tok_t
 
 /* encoder statistics (diagnostics for DESIGN.md / bench): totals since process start */
 unsigned long long mspk_lzx_stat_tokens = 0, mspk_lzx_stat_literals = 0, mspk_lzx_stat_match_bytes = 0;
+unsigned long long mspk_lzx_stat_offhist[24];   /* matches by floor(log2(offset)) */
+unsigned long long mspk_lzx_stat_lenhist[10];   /* matches by length: 2,3,4,5-8,9-16,17-32,33-64,65-128,129+ */
 
 typedef struct {
   const uint8_t *src;            /* (possibly E8-pretranslated) plaintext                      */
@@ -404,7 +406,15 @@ size_t mspk_lzx_encode(const uint8_t *src_in, size_t n, int window_bits, int res
       else {
         size_t nt = parse_block(&m, p, bend, toks), ti;
         for (ti = 0; ti < nt; ti++) {
-          if (toks[ti].len) __sync_fetch_and_add(&mspk_lzx_stat_match_bytes, toks[ti].len);
+          if (toks[ti].len) {
+            unsigned o_ = toks[ti].off, lg_ = 0, l_ = toks[ti].len, lb_;
+            while (o_ > 1) { o_ >>= 1; lg_++; }
+            lb_ = l_ <= 4 ? l_ - 2 : l_ <= 8 ? 3 : l_ <= 16 ? 4 : l_ <= 32 ? 5 : l_ <= 64 ? 6 : l_ <= 128 ? 7 : 8;
+            if (toks[ti].rslot == 3) __sync_fetch_and_add(&mspk_lzx_stat_offhist[lg_ < 23 ? lg_ : 23], 1);
+            else __sync_fetch_and_add(&mspk_lzx_stat_offhist[23], 1);
+            __sync_fetch_and_add(&mspk_lzx_stat_lenhist[lb_], 1);
+            __sync_fetch_and_add(&mspk_lzx_stat_match_bytes, toks[ti].len);
+          }
           else __sync_fetch_and_add(&mspk_lzx_stat_literals, 1);
         }
         __sync_fetch_and_add(&mspk_lzx_stat_tokens, nt);

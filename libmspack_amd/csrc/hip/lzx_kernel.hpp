@@ -58,6 +58,7 @@ struct LzxDec {
   u8 *out; u32 P;                    // linear position == bytes decoded since unit start
   u32 lit_buf; u32 lit_n;            // lit_buf is per-lane
   u32 st_rounds, st_unknown;         // statistics (LZX_EXP_STATS builds only)
+  u32 st_t[6];
   LzxShared *sh;
   HuffRegs hr_main, hr_len, hr_ali, hr_pre;
 
@@ -543,6 +544,12 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     else SPEC_COPY(pos_, len_, moff_, wp_);                                                  \
   } while (0)
 
+  // the last copy group of a round is only LOADED in that round; its store is issued at the start of
+  // the next round's output phase, so the load latency hides behind the next window decode
+  bool pend = false;
+  u32 pend_dst = 0, pend_val = 0;
+  bool pend_act = false;
+
   while (P < run_end) {
     if (bitpos >= bit_limit) { rc = LZX_RUN_SWITCH; break; }
     if ((bitpos >> 11) != cb) {                       // slide the LDS window by one chunk
@@ -551,6 +558,12 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       cb++;
       pf = d.w.load_chunk(cb + 2u, lane);
     }
+#ifdef LZX_EXP_STATS
+#define TICK(k) do { u64 n_ = __builtin_amdgcn_s_memtime(); d.st_t[k] += (u32)(n_ - tk_); tk_ = n_; } while (0)
+    u64 tk_ = __builtin_amdgcn_s_memtime();
+#else
+#define TICK(k) do { } while (0)
+#endif
     // ---- every lane decodes the token that would start at bit (bitpos + lane) ----
     u32 rel = bitpos - (cb << 11) + lane;
     u32 k = rel >> 5, sft = rel & 31u;
@@ -606,6 +619,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     // next token start for every lane; >= 128 marks "needs the scalar decoder" and ends the walk
     const u32 vnext = unk ? (128u + lane) : (lane + tot);
 
+    TICK(0);
     // ---- follow the real token boundaries: which lanes start a token? ----
     u64 chain = 0;
     u32 q = 0;
@@ -613,6 +627,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     bool hit_unknown = false;
     if (q >= 128u) { q -= 128u; chain &= ~(1ull << q); hit_unknown = true; }
     // q = where the next round starts (or the token the scalar decoder has to take)
+    TICK(1);
     bool on = (chain >> lane) & 1ull;
     u32 incl = wave_incl_scan(on ? olen : 0u);
     u32 opos = P + incl - (on ? olen : 0u);             // output position of this lane's token
@@ -625,11 +640,13 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       on = (chain >> lane) & 1ull;
       q = j; hit_unknown = false;
     }
+    if (pend) { if (pend_act) out[pend_dst] = (u8) pend_val; pend = false; }
     // literals: one store for all of them
 #ifndef LZX_EXP_NOLIT
     if (on && kind == 0u) out[opos] = (u8) sym;
 #endif
-    // matches, in order
+    TICK(2);
+    // ---- matches ----
     u64 mm = ballot(on && kind != 0u);
     u32 newP = P + rdl(incl, 63u);
     if (late) {                                        // total output of the tokens that remain
@@ -639,19 +656,81 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
 #ifdef LZX_EXP_NOMATCH
     mm = 0;
 #endif
-    while (mm) {
-      u32 j = (u32) __ffsll((long long) mm) - 1u;
-      mm &= mm - 1ull;
-      u32 len_j = rdl(olen, j), kind_j = rdl(kind, j), off_j = rdl(off, j), pos_j = rdl(opos, j);
-      SPEC_MATCH(pos_j, len_j, kind_j, off_j);
-      if (rc != LZX_RUN_DONE) break;
+    // (1) resolve every match's offset through the R0-R2 LRU (lzxd.c:565-586): sequential by
+    //     nature, but branch-free, and the result goes back into the match's own lane
+    u32 vmoff = off;
+    for (u64 m1 = mm; m1; m1 &= m1 - 1ull) {
+      u32 j = (u32) __ffsll((long long) m1) - 1u;
+      u32 kj = rdl(kind, j), oj = rdl(off, j);
+      u32 n0 = kj == 1u ? oj : (kj == 2u ? R0 : (kj == 3u ? R1 : R2));
+      u32 n1 = (kj == 1u || kj == 3u) ? R0 : R1;
+      u32 n2 = kj == 1u ? R1 : (kj == 4u ? R0 : R2);
+      R0 = n0; R1 = n1; R2 = n2;
+      vmoff = wrl(vmoff, n0, j);
     }
-    if (rc != LZX_RUN_DONE) break;
+    TICK(3);
+    // (2) the reference's checks (lzxd.c:613-634, 678-693) for all matches at once
+    bool fail_after = false;
+    {
+      u32 wp_l = opos - wbase;
+      bool bad = ((mm >> lane) & 1ull) &&
+                 (opos + olen > run_end || wp_l + olen > wsize ||
+                  (vmoff > wp_l && (vmoff > offset_written || (vmoff - wp_l) > wsize)));
+      u64 badm = ballot(bad);
+      if (badm) { mm &= (1ull << ((u32) __ffsll((long long) badm) - 1u)) - 1ull; fail_after = true; }
+    }
+    // (3) copies.  Short matches (<= 16 bytes) are collected four at a time -- 16 lanes each, ONE load
+    //     and ONE store for the group -- as long as none of them reads what an earlier member of
+    //     the group writes; long or dependent ones flush the group first.
+    {
+      u32 gn = 0, gfirst = 0, vgp = 0, vgl = 0, vgo = 0;
+#ifndef LZX_EXP_NOCOPY
+#define SPEC_FLUSH(defer_)                                                                    \
+      do { if (gn) {                                                                          \
+        u32 s4_ = lane >> 4, i_ = lane & 15u;                                                  \
+        u32 gp_ = (u32) __builtin_amdgcn_ds_bpermute((int)(s4_ << 2), (int) vgp);             \
+        u32 gl_ = (u32) __builtin_amdgcn_ds_bpermute((int)(s4_ << 2), (int) vgl);             \
+        u32 go_ = (u32) __builtin_amdgcn_ds_bpermute((int)(s4_ << 2), (int) vgo);             \
+        u32 r_ = i_, t_;                                   /* r = i mod offset (i < 16) */     \
+        t_ = r_ - (go_ << 3); r_ = t_ < r_ ? t_ : r_;                                         \
+        t_ = r_ - (go_ << 2); r_ = t_ < r_ ? t_ : r_;                                         \
+        t_ = r_ - (go_ << 1); r_ = t_ < r_ ? t_ : r_;                                         \
+        t_ = r_ - go_;        r_ = t_ < r_ ? t_ : r_;                                         \
+        bool act_ = s4_ < gn && i_ < gl_;                                                      \
+        u32 val_ = 0; if (act_) val_ = (u32) out[gp_ - go_ + r_];                              \
+        if (defer_) { pend = true; pend_act = act_; pend_dst = gp_ + i_; pend_val = val_; }    \
+        else if (act_) out[gp_ + i_] = (u8) val_;                                              \
+        gn = 0; } } while (0)
+#else
+#define SPEC_FLUSH(defer_) do { gn = 0; } while (0)
+#endif
+      for (u64 m3 = mm; m3; m3 &= m3 - 1ull) {
+        u32 j = (u32) __ffsll((long long) m3) - 1u;
+        u32 len_j = rdl(olen, j), moff_j = rdl(vmoff, j), pos_j = rdl(opos, j);
+        bool plain = (moff_j != 0u && moff_j <= wsize);
+        if (plain && len_j <= 16u) {
+          // does it read bytes the pending group is about to write?
+          if (gn == 4u || (gn && pos_j - moff_j + len_j > gfirst)) SPEC_FLUSH(false);
+          if (gn == 0u) gfirst = pos_j;
+          vgp = wrl(vgp, pos_j, gn); vgl = wrl(vgl, len_j, gn); vgo = wrl(vgo, moff_j, gn);
+          gn++;
+        }
+        else {
+          SPEC_FLUSH(false);
+          SPEC_COPY(pos_j, len_j, moff_j, pos_j - wbase);
+        }
+      }
+      SPEC_FLUSH(true);
+#undef SPEC_FLUSH
+    }
+    TICK(4);
+    if (fail_after) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; break; }
     P = newP;
     bitpos += q;
     d.st_rounds++;
     if (hit_unknown && P < run_end) {
-      d.st_unknown++;
+      if (pend) { if (pend_act) out[pend_dst] = (u8) pend_val; pend = false; }
+
       // a code longer than the direct table (or an invalid one): decode this one token on the
       // scalar side from the 64 bits lane q extracted
       u32 tk_kind, tk_val, tk_off;
@@ -663,6 +742,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       bitpos += tk_tot;
     }
   }
+  if (pend) { if (pend_act) out[pend_dst] = (u8) pend_val; pend = false; }
 #undef SWAP16
 #undef SPEC_MATCH
 #undef SPEC_COPY
@@ -704,6 +784,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   d.near_end = (u.in_len <= 64u); d.careful = d.near_end;
   d.out = out_arena + u.out_off; d.P = 0; d.lit_buf = 0; d.lit_n = 0;
   d.st_rounds = 0; d.st_unknown = 0;
+  for (int k_ = 0; k_ < 6; k_++) d.st_t[k_] = 0;
 
   s.wsize = 1u << u.window_bits;
   s.wpos = 0; s.frame_posn = 0; s.frame = 0; s.reset_frames = u.reset_frames;
@@ -720,6 +801,9 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
     return;
   }
   lzx_reset_state(d, s);
+#ifdef LZX_EXP_STATS
+  u64 tstart_ = __builtin_amdgcn_s_memtime();
+#endif
 
   if (out_bytes != 0u) {
     const u32 end_frame = out_bytes / LZX_FRAME + 1u;                      // lzxd.c:419
@@ -743,7 +827,13 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
       int todo = (int)(s.frame_posn + frame_size - s.wpos);
       bool fail = false;
       while (todo > 0) {
+#ifdef LZX_EXP_STATS
+        u64 t0_ = __builtin_amdgcn_s_memtime();
+#endif
         if (s.block_remaining == 0u) { if (!lzx_block_header(d, s)) { fail = true; break; } }
+#ifdef LZX_EXP_STATS
+        d.st_unknown += (u32)((__builtin_amdgcn_s_memtime() - t0_) >> 6);
+#endif
         int run = (int) s.block_remaining;
         if (run > todo) run = todo;
         todo -= run; s.block_remaining -= (u32) run;
@@ -869,7 +959,9 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
     res->err = err; res->flags = flags; res->out_len = s.offset; res->good_len = s.offset; res->reserved = 0;
     res->in_used = s.raw_mode ? s.raw_pos : d.iptr();
 #ifdef LZX_EXP_STATS
-    res->in_used = d.st_rounds; res->reserved = d.st_unknown;
+    res->in_used = (u32)((__builtin_amdgcn_s_memtime() - tstart_) >> 6); res->reserved = d.st_unknown;
+    res->flags = d.st_t[0] >> 6; res->out_len = d.st_t[1] >> 6; res->good_len = d.st_t[2] >> 6;
+    res->err = (int)(d.st_t[3] >> 6); ((u32 *) res)[5] = d.st_t[4] >> 6; ((u32 *) res)[3] = (u32)((__builtin_amdgcn_s_memtime() - tstart_) >> 6);
 #endif
   }
 }
