@@ -682,7 +682,49 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     // (3) copies.  Short matches (<= 16 bytes) are collected four at a time -- 16 lanes each, ONE load
     //     and ONE store for the group -- as long as none of them reads what an earlier member of
     //     the group writes; long or dependent ones flush the group first.
-    {
+    // (3a) the common round: at most four matches, all plain and <= 16 bytes, none reading what an
+    //      earlier one of them writes -> no per-match scalar work at all.  Each match lane sends its
+    //      (position, offset|length) to the leader lane of a 16-lane slot chosen by its rank among the
+    //      match lanes (ds_permute = scatter), every lane fetches its slot's data back (ds_bpermute)
+    //      and the whole group is ONE load, whose store is deferred to the next round.
+    bool vec_done = false;
+#ifndef LZX_EXP_NOCOPY
+    if (mm) {
+      const bool ism = (mm >> lane) & 1ull;
+      const u32 nm = (u32) __popcll(mm);
+      const u32 first_pos = rdl(opos, (u32) __ffsll((long long) mm) - 1u);
+      // a match is "odd" if it is not plain/short, or if it reads bytes that an earlier match of
+      // this round writes (conservatively: anything at or after the first match's position)
+      const bool is_first = ism && opos == first_pos;
+      const bool odd = ism && (vmoff == 0u || vmoff > wsize || olen > 16u ||
+                               (!is_first && opos - vmoff + olen > first_pos));
+      if (nm <= 4u && ballot(odd) == 0ull) {
+        u32 mlo = (u32) mm, mhi = (u32)(mm >> 32);
+        u32 rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        u32 dst = ism ? (rank << 6) : (63u << 2);        // leader lane = rank*16 ; non-matches park on lane 63
+        u32 pk = (vmoff << 5) | (olen - 1u);
+        // lane 63 is a leader of nothing unless it is itself slot 3's last lane: slot data is only
+        // read from lanes 0,16,32,48
+        u32 sp = (u32) __builtin_amdgcn_ds_permute((int) dst, (int)(ism ? opos : 0u));
+        u32 sk = (u32) __builtin_amdgcn_ds_permute((int) dst, (int)(ism ? pk : 0u));
+        u32 s4 = lane >> 4, i4 = lane & 15u;
+        u32 gp = (u32) __builtin_amdgcn_ds_bpermute((int)(s4 << 6), (int) sp);
+        u32 gk = (u32) __builtin_amdgcn_ds_bpermute((int)(s4 << 6), (int) sk);
+        u32 go = gk >> 5, gl = (gk & 31u) + 1u;
+        u32 r4 = i4, t4;
+        t4 = r4 - (go << 3); r4 = t4 < r4 ? t4 : r4;
+        t4 = r4 - (go << 2); r4 = t4 < r4 ? t4 : r4;
+        t4 = r4 - (go << 1); r4 = t4 < r4 ? t4 : r4;
+        t4 = r4 - go;        r4 = t4 < r4 ? t4 : r4;
+        bool act = s4 < nm && i4 < gl;
+        u32 val = 0; if (act) val = (u32) out[gp - go + r4];
+        pend = true; pend_act = act; pend_dst = gp + i4; pend_val = val;
+        vec_done = true;
+        d.st_t[5]++;
+      }
+    }
+#endif
+    if (!vec_done) {
       u32 gn = 0, gfirst = 0, vgp = 0, vgl = 0, vgo = 0;
 #ifndef LZX_EXP_NOCOPY
 #define SPEC_FLUSH(defer_)                                                                    \
@@ -961,7 +1003,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
 #ifdef LZX_EXP_STATS
     res->in_used = (u32)((__builtin_amdgcn_s_memtime() - tstart_) >> 6); res->reserved = d.st_unknown;
     res->flags = d.st_t[0] >> 6; res->out_len = d.st_t[1] >> 6; res->good_len = d.st_t[2] >> 6;
-    res->err = (int)(d.st_t[3] >> 6); ((u32 *) res)[5] = d.st_t[4] >> 6; ((u32 *) res)[3] = (u32)((__builtin_amdgcn_s_memtime() - tstart_) >> 6);
+    res->err = (int)(d.st_t[4] >> 6); ((u32 *) res)[5] = d.st_t[5] | (d.st_rounds << 16); ((u32 *) res)[3] = (u32)((__builtin_amdgcn_s_memtime() - tstart_) >> 6);
 #endif
   }
 }

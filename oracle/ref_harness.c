@@ -272,62 +272,79 @@ struct bench_job {
   const unsigned *out_len;
   int window_bits, reset_frames;
   int first, last;                /* unit range [first,last) */
+  int reps;
   uint8_t *scratch;               /* >= max out_len */
   size_t scratch_cap;
   unsigned long long bytes_out;
   int errors;
+  pthread_barrier_t *start, *stop;
 };
 
 static void *bench_worker(void *arg) {
   struct bench_job *j = (struct bench_job *) arg;
-  int u;
-  for (u = j->first; u < j->last; u++) {
-    size_t w = 0; int err;
-    const uint8_t *in = j->in_base + j->in_off[u];
-    if (j->kind == 0)
-      err = refh_lzx(in, j->in_len[u], j->scratch, j->scratch_cap, j->out_len[u], j->window_bits,
-                     j->reset_frames, j->out_len[u], &w);
-    else if (j->kind == 1)
-      err = refh_mszip(in, j->in_len[u], j->scratch, j->scratch_cap, j->out_len[u], 0, &w);
-    else
-      err = refh_qtm(in, j->in_len[u], j->scratch, j->scratch_cap, j->out_len[u], j->window_bits, &w);
-    if (err != MSPACK_ERR_OK || w != j->out_len[u]) j->errors++;
-    j->bytes_out += w;
+  int u, r;
+  pthread_barrier_wait(j->start);            /* all threads exist and are warm before the clock starts */
+  for (r = 0; r < j->reps; r++) {
+    for (u = j->first; u < j->last; u++) {
+      size_t w = 0; int err;
+      const uint8_t *in = j->in_base + j->in_off[u];
+      if (j->kind == 0)
+        err = refh_lzx(in, j->in_len[u], j->scratch, j->scratch_cap, j->out_len[u], j->window_bits,
+                       j->reset_frames, j->out_len[u], &w);
+      else if (j->kind == 1)
+        err = refh_mszip(in, j->in_len[u], j->scratch, j->scratch_cap, j->out_len[u], 0, &w);
+      else
+        err = refh_qtm(in, j->in_len[u], j->scratch, j->scratch_cap, j->out_len[u], j->window_bits, &w);
+      if (err != MSPACK_ERR_OK || w != j->out_len[u]) j->errors++;
+      j->bytes_out += w;
+    }
   }
+  pthread_barrier_wait(j->stop);
   return NULL;
 }
 
-/* Returns wall seconds; *bytes_out = total decoded bytes; *errors = units that failed. */
+/* Every thread owns one decompressor at a time (libmspack's threading contract, mspack.h:122-156) and
+ * decodes its slice of the units `reps` times.  The clock runs from the moment all threads are
+ * released until all are done.  Returns wall seconds; *bytes_out = total decoded bytes. */
 double refh_bench(int kind, const uint8_t *in_base, const unsigned long long *in_off,
                   const unsigned *in_len, const unsigned *out_len, int n_units,
-                  int window_bits, int reset_frames, int n_threads,
+                  int window_bits, int reset_frames, int n_threads, int reps,
                   unsigned long long *bytes_out, int *errors)
 {
   pthread_t *th;
   struct bench_job *jobs;
+  pthread_barrier_t start, stop;
   struct timespec t0, t1;
   size_t cap = 0;
   int t, u;
   if (n_threads < 1) n_threads = 1;
+  if (n_threads > n_units) n_threads = n_units;
+  if (reps < 1) reps = 1;
   for (u = 0; u < n_units; u++) if (out_len[u] > cap) cap = out_len[u];
   th = (pthread_t *) calloc((size_t) n_threads, sizeof(*th));
   jobs = (struct bench_job *) calloc((size_t) n_threads, sizeof(*jobs));
+  pthread_barrier_init(&start, NULL, (unsigned) n_threads + 1);
+  pthread_barrier_init(&stop, NULL, (unsigned) n_threads + 1);
   for (t = 0; t < n_threads; t++) {
     jobs[t].kind = kind; jobs[t].in_base = in_base; jobs[t].in_off = in_off;
     jobs[t].in_len = in_len; jobs[t].out_len = out_len;
-    jobs[t].window_bits = window_bits; jobs[t].reset_frames = reset_frames;
+    jobs[t].window_bits = window_bits; jobs[t].reset_frames = reset_frames; jobs[t].reps = reps;
     jobs[t].first = (int)((long long) n_units * t / n_threads);
     jobs[t].last  = (int)((long long) n_units * (t + 1) / n_threads);
     jobs[t].scratch = (uint8_t *) malloc(cap + 64); jobs[t].scratch_cap = cap;
+    jobs[t].start = &start; jobs[t].stop = &stop;
+    pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
   }
+  pthread_barrier_wait(&start);
   clock_gettime(CLOCK_MONOTONIC, &t0);
-  for (t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, bench_worker, &jobs[t]);
-  for (t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  pthread_barrier_wait(&stop);
   clock_gettime(CLOCK_MONOTONIC, &t1);
+  for (t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
   *bytes_out = 0; *errors = 0;
   for (t = 0; t < n_threads; t++) {
     *bytes_out += jobs[t].bytes_out; *errors += jobs[t].errors; free(jobs[t].scratch);
   }
+  pthread_barrier_destroy(&start); pthread_barrier_destroy(&stop);
   free(th); free(jobs);
   return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

@@ -107,7 +107,7 @@ def ref():
                                          C.c_size_t, sz, sz, C.POINTER(C.c_int)]
         lib.refh_bench.restype = C.c_double
         lib.refh_bench.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                   C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
         _ref = lib
     return _ref
 
