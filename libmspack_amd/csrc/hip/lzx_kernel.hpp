@@ -682,89 +682,73 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     // (3) copies.  Short matches (<= 16 bytes) are collected four at a time -- 16 lanes each, ONE load
     //     and ONE store for the group -- as long as none of them reads what an earlier member of
     //     the group writes; long or dependent ones flush the group first.
-    // (3a) the common round: at most four matches, all plain and <= 16 bytes, none reading what an
-    //      earlier one of them writes -> no per-match scalar work at all.  Each match lane sends its
-    //      (position, offset|length) to the leader lane of a 16-lane slot chosen by its rank among the
-    //      match lanes (ds_permute = scatter), every lane fetches its slot's data back (ds_bpermute)
-    //      and the whole group is ONE load, whose store is deferred to the next round.
-    bool vec_done = false;
+    // (3) copies, without any per-match scalar decode: matches are taken four at a time in rank
+    //     order.  Each match lane sends (position, offset|length) to the leader lane of a 16-lane
+    //     slot (ds_permute = scatter), every lane fetches its slot's data back (ds_bpermute).  The
+    //     source of byte k of a match is  pos - off + (k mod off): always bytes that existed before
+    //     the match, so a match never depends on its own earlier bytes.  Slots whose source lies
+    //     entirely before the batch's first destination byte are independent: they advance together,
+    //     16 bytes per slot per pass (ONE load + ONE store per pass).  A slot that may read what an
+    //     earlier slot of the batch writes is replayed afterwards as a wave-wide copy.  In the usual
+    //     case (one pass, nothing dependent) the store is deferred to the next round.
 #ifndef LZX_EXP_NOCOPY
     if (mm) {
       const bool ism = (mm >> lane) & 1ull;
       const u32 nm = (u32) __popcll(mm);
-      const u32 first_pos = rdl(opos, (u32) __ffsll((long long) mm) - 1u);
-      // a match is "odd" if it is not plain/short, or if it reads bytes that an earlier match of
-      // this round writes (conservatively: anything at or after the first match's position)
-      const bool is_first = ism && opos == first_pos;
-      const bool odd = ism && (vmoff == 0u || vmoff > wsize || olen > 16u ||
-                               (!is_first && opos - vmoff + olen > first_pos));
-      if (nm <= 4u && ballot(odd) == 0ull) {
-        u32 mlo = (u32) mm, mhi = (u32)(mm >> 32);
-        u32 rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-        u32 dst = ism ? (rank << 6) : (63u << 2);        // leader lane = rank*16 ; non-matches park on lane 63
-        u32 pk = (vmoff << 5) | (olen - 1u);
-        // lane 63 is a leader of nothing unless it is itself slot 3's last lane: slot data is only
-        // read from lanes 0,16,32,48
-        u32 sp = (u32) __builtin_amdgcn_ds_permute((int) dst, (int)(ism ? opos : 0u));
-        u32 sk = (u32) __builtin_amdgcn_ds_permute((int) dst, (int)(ism ? pk : 0u));
-        u32 s4 = lane >> 4, i4 = lane & 15u;
-        u32 gp = (u32) __builtin_amdgcn_ds_bpermute((int)(s4 << 6), (int) sp);
-        u32 gk = (u32) __builtin_amdgcn_ds_bpermute((int)(s4 << 6), (int) sk);
-        u32 go = gk >> 5, gl = (gk & 31u) + 1u;
-        u32 r4 = i4, t4;
-        t4 = r4 - (go << 3); r4 = t4 < r4 ? t4 : r4;
-        t4 = r4 - (go << 2); r4 = t4 < r4 ? t4 : r4;
-        t4 = r4 - (go << 1); r4 = t4 < r4 ? t4 : r4;
-        t4 = r4 - go;        r4 = t4 < r4 ? t4 : r4;
-        bool act = s4 < nm && i4 < gl;
-        u32 val = 0; if (act) val = (u32) out[gp - go + r4];
-        pend = true; pend_act = act; pend_dst = gp + i4; pend_val = val;
-        vec_done = true;
-        d.st_t[5]++;
-      }
-    }
-#endif
-    if (!vec_done) {
-      u32 gn = 0, gfirst = 0, vgp = 0, vgl = 0, vgo = 0;
-#ifndef LZX_EXP_NOCOPY
-#define SPEC_FLUSH(defer_)                                                                    \
-      do { if (gn) {                                                                          \
-        u32 s4_ = lane >> 4, i_ = lane & 15u;                                                  \
-        u32 gp_ = (u32) __builtin_amdgcn_ds_bpermute((int)(s4_ << 2), (int) vgp);             \
-        u32 gl_ = (u32) __builtin_amdgcn_ds_bpermute((int)(s4_ << 2), (int) vgl);             \
-        u32 go_ = (u32) __builtin_amdgcn_ds_bpermute((int)(s4_ << 2), (int) vgo);             \
-        u32 r_ = i_, t_;                                   /* r = i mod offset (i < 16) */     \
-        t_ = r_ - (go_ << 3); r_ = t_ < r_ ? t_ : r_;                                         \
-        t_ = r_ - (go_ << 2); r_ = t_ < r_ ? t_ : r_;                                         \
-        t_ = r_ - (go_ << 1); r_ = t_ < r_ ? t_ : r_;                                         \
-        t_ = r_ - go_;        r_ = t_ < r_ ? t_ : r_;                                         \
-        bool act_ = s4_ < gn && i_ < gl_;                                                      \
-        u32 val_ = 0; if (act_) val_ = (u32) out[gp_ - go_ + r_];                              \
-        if (defer_) { pend = true; pend_act = act_; pend_dst = gp_ + i_; pend_val = val_; }    \
-        else if (act_) out[gp_ + i_] = (u8) val_;                                              \
-        gn = 0; } } while (0)
-#else
-#define SPEC_FLUSH(defer_) do { gn = 0; } while (0)
-#endif
-      for (u64 m3 = mm; m3; m3 &= m3 - 1ull) {
-        u32 j = (u32) __ffsll((long long) m3) - 1u;
-        u32 len_j = rdl(olen, j), moff_j = rdl(vmoff, j), pos_j = rdl(opos, j);
-        bool plain = (moff_j != 0u && moff_j <= wsize);
-        if (plain && len_j <= 16u) {
-          // does it read bytes the pending group is about to write?
-          if (gn == 4u || (gn && pos_j - moff_j + len_j > gfirst)) SPEC_FLUSH(false);
-          if (gn == 0u) gfirst = pos_j;
-          vgp = wrl(vgp, pos_j, gn); vgl = wrl(vgl, len_j, gn); vgo = wrl(vgo, moff_j, gn);
-          gn++;
+      const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32) mm, 0u));
+      const u32 s4 = lane >> 4, i4 = lane & 15u;
+      for (u32 base = 0; base < nm; base += 4u) {
+        const bool in_b = ism && (rank - base) < 4u;
+        const u32 dstl = in_b ? ((rank - base) << 6) : (63u << 2);   // leaders are lanes 0,16,32,48
+        const u32 sp = (u32) __builtin_amdgcn_ds_permute((int) dstl, (int)(in_b ? opos : 0u));
+        const u32 sk = (u32) __builtin_amdgcn_ds_permute((int) dstl, (int)(in_b ? ((vmoff << 9) | olen) : 0u));
+        const u32 gp = (u32) __builtin_amdgcn_ds_bpermute((int)(s4 << 6), (int) sp);
+        const u32 gk = (u32) __builtin_amdgcn_ds_bpermute((int)(s4 << 6), (int) sk);
+        const u32 go = gk >> 9, gl = gk & 511u;
+        const u32 nb = (nm - base) < 4u ? (nm - base) : 4u;
+        const bool valid = s4 < nb;
+        const u32 first_pos = rdl(gp, 0);
+        const bool oddoff = valid && (go == 0u || go > wsize);
+        const u32 src_hi = gp - go + (go < gl ? go : gl);
+        const bool dep = valid && s4 != 0u && src_hi > first_pos;
+        const bool indep = valid && !dep && !oddoff;
+        const u64 later = ballot((dep || oddoff) && i4 == 0u);       // slots to replay one by one
+        const bool single = ballot(indep && gl > 16u) == 0ull;
+        // residue of the running byte index modulo the offset, kept per slot
+        u32 gd = 0, rs = 0;
+        if (single && later == 0ull && base + 4u >= nm) {
+          u32 x = rs + i4, t;
+          t = x - (go << 3); x = t < x ? t : x;  t = x - (go << 2); x = t < x ? t : x;
+          t = x - (go << 1); x = t < x ? t : x;  t = x - go;        x = t < x ? t : x;
+          bool act = indep && i4 < gl;
+          u32 val = 0; if (act) val = (u32) out[gp - go + x];
+          pend = true; pend_act = act; pend_dst = gp + i4; pend_val = val;
         }
         else {
-          SPEC_FLUSH(false);
-          SPEC_COPY(pos_j, len_j, moff_j, pos_j - wbase);
+          while (ballot(indep && gd < gl)) {
+            u32 x = rs + i4, t;
+            t = x - (go << 3); x = t < x ? t : x;  t = x - (go << 2); x = t < x ? t : x;
+            t = x - (go << 1); x = t < x ? t : x;  t = x - go;        x = t < x ? t : x;
+            bool act = indep && (gd + i4) < gl;
+            if (act) out[gp + gd + i4] = out[gp - go + x];
+            gd += 16u;
+            u32 y = rs + 16u;                                          // (rs + 16) mod go, go >= 1
+            if (go != 0u) {
+              t = y - (go << 4); y = t < y ? t : y;  t = y - (go << 3); y = t < y ? t : y;
+              t = y - (go << 2); y = t < y ? t : y;  t = y - (go << 1); y = t < y ? t : y;
+              t = y - go;        y = t < y ? t : y;
+            }
+            rs = y;
+          }
+          for (u64 dm = later; dm; dm &= dm - 1ull) {
+            u32 l = (u32) __ffsll((long long) dm) - 1u;
+            u32 pos_l = rdl(gp, l), len_l = rdl(gl, l), off_l = rdl(go, l);
+            SPEC_COPY(pos_l, len_l, off_l, pos_l - wbase);
+          }
         }
       }
-      SPEC_FLUSH(true);
-#undef SPEC_FLUSH
     }
+#endif
     TICK(4);
     if (fail_after) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; break; }
     P = newP;
