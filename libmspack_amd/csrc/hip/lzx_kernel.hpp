@@ -29,6 +29,18 @@
 #define LZX_PRE_P 6
 #define LZX_MAIN_SYMS 720      /* 256 + 50*8 + 64: every index that can ever be non-zero (w<=21) */
 #define LZX_LEN_SYMS 250
+#define LZX_MLIST_CAP 160
+#ifndef LZX_SPEC_WIDE
+#define LZX_SPEC_WIDE 0          /* 1: every lane decodes two positions (128 per round) */
+#endif
+#ifdef LZX_EXP_CNT
+#define CNT(k) (d.st_t[k]++)
+#else
+#define CNT(k) ((void) 0)
+#endif
+#ifndef LZX_FLUSH_SPAN
+#define LZX_FLUSH_SPAN 128u
+#endif
 
 struct __align__(16) LzxShared {
   u16 main_tab[1 << LZX_MAIN_P];
@@ -45,6 +57,8 @@ struct __align__(16) LzxShared {
   u8  len_len[LZX_LEN_SYMS + 70];
   u8  pre_len[24];
   u8  ali_len[8];
+  uint2 mlist[LZX_MLIST_CAP];    /* speculative path: queued matches (position, offset<<9 | length) */
+  u16 mtmp[64];
 };
 
 struct LzxDec {
@@ -487,25 +501,100 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 x)
   return v;
 }
 
+// one speculative token: everything lane-local, decoded from 64 bits of the stream
+struct SpecTok { u32 tot, sym, kind, olen, off; bool unk; };
+
 template <bool ALIGNED>
-__device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 run_end, const u32 wbase)
+__device__ __forceinline__ SpecTok lzx_spec_token(const LzxShared *sh, const u32 main_fov, const u32 *mlim,
+                                                  const bool length_empty, const u32 w0, const u32 w1)
 {
+  SpecTok t;
+  u64 r = ((u64) w0 << 32) | w1;
+  u32 e = sh->main_tab[w0 >> (32 - LZX_MAIN_P)];
+  {
+    // codes longer than the direct table, for all lanes at once: canonical length = number of
+    // per-length limits the 16-bit peek is not below; symbol via the sorted list (readhuff.h:144-172)
+    u32 peek16 = w0 >> 16, ln = LZX_MAIN_P + 1u;
+#pragma unroll
+    for (int l = LZX_MAIN_P + 1; l <= 16; l++) ln += (peek16 >= mlim[l - LZX_MAIN_P - 1]) ? 1u : 0u;
+    u32 lq = ln <= 16u ? ln : 0u;
+    u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) main_fov);
+    u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
+    if (idx >= LZX_MAIN_SYMS) idx = 0;
+    u32 ls = sh->main_sorted[idx];
+    if (e == 0u && lq != 0u) e = ls | (lq << 10);
+  }
+  bool unk = (e == 0u);
+  u32 tot = e >> 10, sym = e & 1023u;
+  r <<= tot;
+  bool is_match = sym >= 256u;
+  u32 m = sym - 256u, slot = m >> 3, lh = m & 7u;
+  u32 e2 = sh->len_tab[(u32)(r >> (64 - LZX_LEN_P))];
+  bool need_len = is_match && lh == 7u;
+  if (need_len) { unk = unk || e2 == 0u || length_empty; u32 l2 = e2 >> 10; r <<= l2; tot += l2; }
+  u32 mlen = lh + 2u + (need_len ? (e2 & 1023u) : 0u);
+  u32 extra = slot < 4u ? 0u : (slot < 36u ? (slot >> 1) - 1u : 17u);
+  u32 base = slot < 4u ? slot : (slot < 36u ? ((2u + (slot & 1u)) << extra) : ((slot - 34u) << 17));
+  u32 off = base - 2u;
+  bool expl = is_match && slot >= 3u;
+  if (ALIGNED) {
+    bool ali = extra >= 3u;
+    u32 nb = ali ? extra - 3u : extra;
+    u32 vb = nb ? (u32)(r >> (64u - nb)) : 0u;
+    u64 r2 = r << nb;
+    u32 e3 = sh->ali_tab[(u32)(r2 >> (64 - LZX_ALI_P))];
+    if (expl) {
+      tot += nb;
+      if (ali) { off += (vb << 3) + (e3 & 1023u); tot += e3 >> 10; unk = unk || e3 == 0u; }
+      else off += vb;
+    }
+  }
+  else {
+    u32 vb = extra ? (u32)(r >> (64u - extra)) : 0u;
+    if (expl) { off += vb; tot += extra; }
+  }
+  t.tot = tot; t.sym = sym; t.unk = unk; t.off = off;
+  t.kind = !is_match ? 0u : (expl ? 1u : 2u + slot);
+  t.olen = is_match ? mlen : 1u;
+  return t;
+}
+
+// inclusive prefix maximum over the 64 lanes (values are unsigned; 0 is the identity)
+__device__ __forceinline__ u32 wave_incl_max(u32 x)
+{
+  u32 v = x, t;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+  return v;
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 run_end_, const u32 wbase_)
+{
+  constexpr bool WIDE = LZX_SPEC_WIDE != 0;
   LzxShared *sh = d.sh;
   const u32 lane = d.lane;
   u8 *const out = d.out;
-  u32 P = d.P;
-  u32 R0 = s.R0, R1 = s.R1, R2 = s.R2;
-  const u32 wsize = s.wsize, offset_written = s.offset;
-  const bool length_empty = s.length_empty;
+  // everything below is wave-uniform; readfirstlane tells the compiler so (SGPRs, scalar branches)
+  const u32 run_end = rfl(run_end_), wbase = rfl(wbase_);
+  u32 P = rfl(d.P);
+  u32 R0 = rfl(s.R0), R1 = rfl(s.R1), R2 = rfl(s.R2);
+  const u32 wsize = rfl(s.wsize), offset_written = rfl(s.offset);
+  const bool length_empty = rfl((u32) s.length_empty) != 0u;
   int rc = LZX_RUN_DONE;
 
   // bit position of the next unread bit, relative to d.w.origin; chunk cb = dwords [64cb, 64cb+64)
-  u32 bitpos = d.cons_bits();
+  u32 bitpos = rfl(d.cons_bits());
   u32 cb = bitpos >> 11;
   // last bit position from which a whole window (64 starts + 64 bits of look-ahead) stays 64 bytes
   // clear of the end of the input
-  const u32 room_bytes = (d.w.in_len > d.w.origin + 96u) ? (d.w.in_len - d.w.origin - 96u) : 0u;
-  const u32 bit_limit = room_bytes * 8u;
+  const u32 margin = WIDE ? 112u : 96u;
+  const u32 room_bytes = (d.w.in_len > d.w.origin + margin) ? (d.w.in_len - d.w.origin - margin) : 0u;
+  const u32 bit_limit = rfl(room_bytes * 8u);
   if (bitpos >= bit_limit) return LZX_RUN_SWITCH;
   // pending literals of the scalar path go out first: this path stores literals directly
   d.flush_lits();
@@ -544,231 +633,286 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     else SPEC_COPY(pos_, len_, moff_, wp_);                                                  \
   } while (0)
 
-  // the last copy group of a round is only LOADED in that round; its store is issued at the start of
-  // the next round's output phase, so the load latency hides behind the next window decode
-  bool pend = false;
-  u32 pend_dst = 0, pend_val = 0;
-  bool pend_act = false;
+  // ---- deferred match resolution -------------------------------------------------------------
+  // Rounds only QUEUE their matches (position, offset|length) in LDS; literals go straight to the
+  // output.  The queue is resolved in position space, 64 output bytes per pass, one byte per lane:
+  // a lane finds the match covering its byte (scatter of queue indices to start positions + a DPP
+  // max-scan), and copies out[b] = out[b - offset] -- LZ77 byte semantics, so overlapping matches
+  // need no special case.  A source byte inside the current 64-byte chunk that is itself a match
+  // byte is not in memory yet: such lanes follow the source's own pointer (pointer jumping, log
+  // steps).  Everything below the chunk is final because chunks are resolved in address order.
+  // The store of a chunk is issued one chunk late, so its load overlaps the next chunk's work.
+  u32 Pf = P;                                           // everything below Pf is final in memory
+  u32 mcount = 0;                                       // queued matches (sorted by position)
+  bool pst = false, pst_act = false;                    // store of the previous chunk still to issue
+  u32 pst_c = 0, pst_dst = 0, pst_val = 0;
+  bool slow = false;                                    // this round copies its matches one by one
 
-  while (P < run_end) {
-    if (bitpos >= bit_limit) { rc = LZX_RUN_SWITCH; break; }
+#ifdef LZX_EXP_STATS
+#define TICK(k) do { u64 n_ = __builtin_amdgcn_s_memtime(); d.st_t[k] += (u32)(n_ - tk_); tk_ = n_; } while (0)
+#else
+#define TICK(k) do { } while (0)
+#endif
+  for (;;) {
+#ifdef LZX_EXP_STATS
+    u64 tk_ = __builtin_amdgcn_s_memtime();
+#endif
+    bool live = (rc == LZX_RUN_DONE) && P < run_end;
+    if (live && bitpos >= bit_limit) { rc = LZX_RUN_SWITCH; live = false; }
+    const bool fin = !live || slow;
+#ifndef LZX_EXP_NOCOPY
+    if (fin || P - Pf >= LZX_FLUSH_SPAN || mcount > LZX_MLIST_CAP - 64u) {
+      u32 c = Pf & ~63u;
+      CNT(0);
+      u32 ja = 0, jprev = 0; bool have_prev = false;
+      if (mcount) {                                     // entry 0 may have begun below Pf
+        u32 p0 = rfl(sh->mlist[0].x);
+        if (p0 < c) { have_prev = true; ja = 1u; }
+      }
+      while (fin ? (c < P) : (c + 64u <= P)) {
+        const u32 b = c + lane;
+        CNT(1);
+        sh->mtmp[lane] = 0;
+        const u32 jj = ja + lane;
+        uint2 rec = make_uint2(0u, 0u);
+        if (jj < mcount) rec = sh->mlist[jj];
+        const bool st = jj < mcount && (rec.x - c) < 64u;
+        if (st) sh->mtmp[rec.x - c] = (u16)(jj + 1u);
+        __builtin_amdgcn_wave_barrier();
+        u32 jm = sh->mtmp[lane];
+        const u32 nin = (u32) __popcll(ballot(st));
+        jm = wave_incl_max(jm);
+        const bool hasj = jm != 0u || have_prev;
+        const u32 j = jm ? jm - 1u : jprev;
+        const uint2 mr = sh->mlist[hasj ? j : 0u];
+        const u32 mo = mr.y >> 9, ml = mr.y & 511u;
+        const bool inm = hasj && (b - mr.x) < ml && b >= Pf && b < P;
+        u32 ptr = b - mo;
+        const u64 inmask = ballot(inm);
+        for (;;) {
+          u32 tl = (ptr - c) & 63u;
+          u32 tp = (u32) __builtin_amdgcn_ds_bpermute((int)(tl << 2), (int) ptr);
+          bool follow = inm && ptr >= c && ((inmask >> tl) & 1ull);
+          if (!ballot(follow)) break;
+          CNT(2);
+          if (follow) ptr = tp;
+        }
+        // the previous chunk's store may only wait if nothing here reads that chunk
+        if (pst && ballot(inm && ptr >= pst_c)) { CNT(4); if (pst_act) out[pst_dst] = (u8) pst_val; pst = false; }
+#ifdef LZX_EXP_NOLOAD
+        u32 val = ptr;
+#else
+        u32 val = 0; if (inm) val = (u32) out[ptr];
+#endif
+        if (pst) { if (pst_act) out[pst_dst] = (u8) pst_val; }
+        pst = true; pst_act = inm; pst_c = c; pst_dst = b; pst_val = val;
+        if (nin) { jprev = ja + nin - 1u; have_prev = true; ja += nin; }
+        c += 64u;
+      }
+      if (fin) {
+        if (pst) { if (pst_act) out[pst_dst] = (u8) pst_val; pst = false; }
+        Pf = P; mcount = 0;
+      }
+      else if (c > Pf) {
+        // keep the match that straddles the new Pf (if any) and the ones that start above it
+        Pf = c;
+        u32 keep = ja;
+        if (have_prev) {
+          uint2 lr = sh->mlist[jprev];
+          u32 pe = rfl(lr.x) + (rfl(lr.y) & 511u);
+          if (pe > c) keep = jprev;
+        }
+        const u32 nrem = mcount - keep;                 // <= 33: the span left is below 64 bytes
+        uint2 mv = make_uint2(0u, 0u);
+        if (lane < nrem) mv = sh->mlist[keep + lane];
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nrem) sh->mlist[lane] = mv;
+        mcount = nrem;
+      }
+    }
+#endif
+    if (!live) break;
     if ((bitpos >> 11) != cb) {                       // slide the LDS window by one chunk
       u32 up = sh->inbuf[64u + lane];
       sh->inbuf[lane] = up; sh->inbuf[64u + lane] = SWAP16(pf);
       cb++;
       pf = d.w.load_chunk(cb + 2u, lane);
     }
-#ifdef LZX_EXP_STATS
-#define TICK(k) do { u64 n_ = __builtin_amdgcn_s_memtime(); d.st_t[k] += (u32)(n_ - tk_); tk_ = n_; } while (0)
-    u64 tk_ = __builtin_amdgcn_s_memtime();
-#else
-#define TICK(k) do { } while (0)
-#endif
-    // ---- every lane decodes the token that would start at bit (bitpos + lane) ----
+    TICK(5);
+    // ---- every lane decodes the TWO tokens that would start at bits (bitpos + lane) and
+    //      (bitpos + 64 + lane): two independent instruction streams per lane ----
     u32 rel = bitpos - (cb << 11) + lane;
     u32 k = rel >> 5, sft = rel & 31u;
-    u32 a = sh->inbuf[k], b = sh->inbuf[k + 1u], c = sh->inbuf[k + 2u];
-    u32 w0 = (u32)(((((u64) a << 32) | b) << sft) >> 32);
-    u32 w1 = (u32)(((((u64) b << 32) | c) << sft) >> 32);
-    u64 r = ((u64) w0 << 32) | w1;
-    u32 e = sh->main_tab[w0 >> (32 - LZX_MAIN_P)];
-    {
-      // codes longer than the direct table, for all lanes at once: canonical length = number of
-      // per-length limits the 16-bit peek is not below; symbol via the sorted list (readhuff.h:144-172)
-      u32 peek16 = w0 >> 16, ln = LZX_MAIN_P + 1u;
-#pragma unroll
-      for (int l = LZX_MAIN_P + 1; l <= 16; l++) ln += (peek16 >= mlim[l - LZX_MAIN_P - 1]) ? 1u : 0u;
-      u32 lq = ln <= 16u ? ln : 0u;
-      u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) d.hr_main.fov);
-      u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
-      if (idx >= LZX_MAIN_SYMS) idx = 0;
-      u32 ls = sh->main_sorted[idx];
-      if (e == 0u && lq != 0u) e = ls | (lq << 10);
-    }
-    bool unk = (e == 0u);
-    u32 tot = e >> 10, sym = e & 1023u;
-    r <<= tot;
-    bool is_match = sym >= 256u;
-    u32 m = sym - 256u, slot = m >> 3, lh = m & 7u;
-    u32 e2 = sh->len_tab[(u32)(r >> (64 - LZX_LEN_P))];
-    bool need_len = is_match && lh == 7u;
-    if (need_len) { unk = unk || e2 == 0u || length_empty; u32 l2 = e2 >> 10; r <<= l2; tot += l2; }
-    u32 mlen = lh + 2u + (need_len ? (e2 & 1023u) : 0u);
-    u32 extra = slot < 4u ? 0u : (slot < 36u ? (slot >> 1) - 1u : 17u);
-    u32 base = slot < 4u ? slot : (slot < 36u ? ((2u + (slot & 1u)) << extra) : ((slot - 34u) << 17));
-    u32 off = base - 2u;
-    bool expl = is_match && slot >= 3u;
-    if (ALIGNED) {
-      bool ali = extra >= 3u;
-      u32 nb = ali ? extra - 3u : extra;
-      u32 vb = nb ? (u32)(r >> (64u - nb)) : 0u;
-      u64 r2 = r << nb;
-      u32 e3 = sh->ali_tab[(u32)(r2 >> (64 - LZX_ALI_P))];
-      if (expl) {
-        tot += nb;
-        if (ali) { off += (vb << 3) + (e3 & 1023u); tot += e3 >> 10; unk = unk || e3 == 0u; }
-        else off += vb;
-      }
-    }
-    else {
-      u32 vb = extra ? (u32)(r >> (64u - extra)) : 0u;
-      if (expl) { off += vb; tot += extra; }
-    }
-    const u32 kind = !is_match ? 0u : (expl ? 1u : 2u + slot);
-    const u32 olen = is_match ? mlen : 1u;
-    // next token start for every lane; >= 128 marks "needs the scalar decoder" and ends the walk
-    const u32 vnext = unk ? (128u + lane) : (lane + tot);
+    u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u], i3 = 0, i4 = 0;
+    if (WIDE) { i3 = sh->inbuf[k + 3u]; i4 = sh->inbuf[k + 4u]; }
+    const u32 w0A = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+    const u32 w1A = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
+    const u32 w0B = (u32)(((((u64) i2 << 32) | i3) << sft) >> 32);
+    const u32 w1B = (u32)(((((u64) i3 << 32) | i4) << sft) >> 32);
+    const SpecTok tA = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0A, w1A);
+    SpecTok tB; tB.tot = 0; tB.sym = 0; tB.kind = 0; tB.olen = 0; tB.off = 0; tB.unk = false;
+    if (WIDE) tB = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0B, w1B);
+    // next token start (in bits from bitpos) for both positions; >= 256 marks "needs the scalar
+    // decoder" and ends the walk
+    const u32 vnA = tA.unk ? (256u + lane) : (lane + tA.tot);
+    const u32 vnB = tB.unk ? (320u + lane) : (64u + lane + tB.tot);
 
     TICK(0);
-    // ---- follow the real token boundaries: which lanes start a token? ----
-    u64 chain = 0;
+    // ---- follow the real token boundaries: which positions start a token? ----
+    u64 chainA = 0, chainB = 0;
     u32 q = 0;
-    do { chain |= 1ull << q; q = rdl(vnext, q); } while (q < WAVE);
+    do { chainA |= 1ull << q; q = rdl(vnA, q); } while (q < 64u);
+    if (WIDE) while (q < 128u) { chainB |= 1ull << (q - 64u); q = rdl(vnB, q - 64u); }
     bool hit_unknown = false;
-    if (q >= 128u) { q -= 128u; chain &= ~(1ull << q); hit_unknown = true; }
+    if (q >= 256u) {
+      q -= 256u; hit_unknown = true;
+      if (q < 64u) chainA &= ~(1ull << q); else chainB &= ~(1ull << (q - 64u));
+    }
     // q = where the next round starts (or the token the scalar decoder has to take)
     TICK(1);
-    bool on = (chain >> lane) & 1ull;
-    u32 incl = wave_incl_scan(on ? olen : 0u);
-    u32 opos = P + incl - (on ? olen : 0u);             // output position of this lane's token
+    bool onA = (chainA >> lane) & 1ull, onB = WIDE && ((chainB >> lane) & 1ull);
+    const u32 xA = onA ? tA.olen : 0u, xB = onB ? tB.olen : 0u;
+    const u32 inclA = wave_incl_scan(xA), inclB = WIDE ? wave_incl_scan(xB) : 0u;
+    const u32 sumA = rdl(inclA, 63u);
+    const u32 oposA = P + inclA - xA;                    // output position of this lane's tokens
+    const u32 oposB = P + sumA + inclB - xB;
+    u32 newP = P + sumA + (WIDE ? rdl(inclB, 63u) : 0u);
     // tokens are decoded only while the run lasts (lzxd.c:538): cut the chain at the first token
     // that starts at or after run_end
-    u64 late = ballot(on && opos >= run_end);
-    if (late) {
-      u32 j = (u32) __ffsll((long long) late) - 1u;
-      chain &= (1ull << j) - 1ull;
-      on = (chain >> lane) & 1ull;
-      q = j; hit_unknown = false;
+    {
+      const u64 lateA = ballot(onA && oposA >= run_end), lateB = WIDE ? ballot(onB && oposB >= run_end) : 0ull;
+      if (lateA) {
+        u32 j = (u32) __ffsll((long long) lateA) - 1u;
+        chainA &= (1ull << j) - 1ull; chainB = 0;
+        q = j; hit_unknown = false; newP = rdl(oposA, j);
+        onA = (chainA >> lane) & 1ull; onB = false;
+      }
+      else if (lateB) {
+        u32 j = (u32) __ffsll((long long) lateB) - 1u;
+        chainB &= (1ull << j) - 1ull;
+        q = 64u + j; hit_unknown = false; newP = rdl(oposB, j);
+        onB = (chainB >> lane) & 1ull;
+      }
     }
-    if (pend) { if (pend_act) out[pend_dst] = (u8) pend_val; pend = false; }
-    // literals: one store for all of them
+    // literals: one store per position set
 #ifndef LZX_EXP_NOLIT
-    if (on && kind == 0u) out[opos] = (u8) sym;
+    if (onA && tA.kind == 0u) out[oposA] = (u8) tA.sym;
+    if (WIDE && onB && tB.kind == 0u) out[oposB] = (u8) tB.sym;
 #endif
     TICK(2);
     // ---- matches ----
-    u64 mm = ballot(on && kind != 0u);
-    u32 newP = P + rdl(incl, 63u);
-    if (late) {                                        // total output of the tokens that remain
-      u32 j = (u32) __ffsll((long long) late) - 1u;
-      newP = rdl(opos, j);
-    }
+    u64 mmA = ballot(onA && tA.kind != 0u), mmB = WIDE ? ballot(onB && tB.kind != 0u) : 0ull;
 #ifdef LZX_EXP_NOMATCH
-    mm = 0;
+    mmA = 0; mmB = 0;
 #endif
     // (1) resolve every match's offset through the R0-R2 LRU (lzxd.c:565-586): sequential by
     //     nature, but branch-free, and the result goes back into the match's own lane
-    u32 vmoff = off;
-    for (u64 m1 = mm; m1; m1 &= m1 - 1ull) {
-      u32 j = (u32) __ffsll((long long) m1) - 1u;
-      u32 kj = rdl(kind, j), oj = rdl(off, j);
-      u32 n0 = kj == 1u ? oj : (kj == 2u ? R0 : (kj == 3u ? R1 : R2));
-      u32 n1 = (kj == 1u || kj == 3u) ? R0 : R1;
-      u32 n2 = kj == 1u ? R1 : (kj == 4u ? R0 : R2);
-      R0 = n0; R1 = n1; R2 = n2;
-      vmoff = wrl(vmoff, n0, j);
+    const u32 sR0 = R0, sR1 = R1, sR2 = R2;
+    u32 vmoffA = tA.off, vmoffB = tB.off;
+#define SPEC_LRU(mask_, kind_, off_, vm_)                                                     \
+    for (u64 m1 = (mask_); m1; m1 &= m1 - 1ull) {                                             \
+      u32 j = (u32) __ffsll((long long) m1) - 1u;                                             \
+      u32 kj = rdl((kind_), j), oj = rdl((off_), j);                                          \
+      u32 n0 = kj == 1u ? oj : (kj == 2u ? R0 : (kj == 3u ? R1 : R2));                        \
+      u32 n1 = (kj == 1u || kj == 3u) ? R0 : R1;                                              \
+      u32 n2 = kj == 1u ? R1 : (kj == 4u ? R0 : R2);                                          \
+      R0 = n0; R1 = n1; R2 = n2;                                                              \
+      asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vm_) : "s"(n0), "s"(j) : "m0"); \
     }
+    SPEC_LRU(mmA, tA.kind, tA.off, vmoffA)
+    if (WIDE) { SPEC_LRU(mmB, tB.kind, tB.off, vmoffB) }
+#undef SPEC_LRU
     TICK(3);
     // (2) the reference's checks (lzxd.c:613-634, 678-693) for all matches at once
     bool fail_after = false;
     {
-      u32 wp_l = opos - wbase;
-      bool bad = ((mm >> lane) & 1ull) &&
-                 (opos + olen > run_end || wp_l + olen > wsize ||
-                  (vmoff > wp_l && (vmoff > offset_written || (vmoff - wp_l) > wsize)));
-      u64 badm = ballot(bad);
-      if (badm) { mm &= (1ull << ((u32) __ffsll((long long) badm) - 1u)) - 1ull; fail_after = true; }
+      const u32 wpA = oposA - wbase, wpB = oposB - wbase;
+      const bool badA = ((mmA >> lane) & 1ull) &&
+                 (oposA + tA.olen > run_end || wpA + tA.olen > wsize ||
+                  (vmoffA > wpA && (vmoffA > offset_written || (vmoffA - wpA) > wsize)));
+      const bool badB = WIDE && ((mmB >> lane) & 1ull) &&
+                 (oposB + tB.olen > run_end || wpB + tB.olen > wsize ||
+                  (vmoffB > wpB && (vmoffB > offset_written || (vmoffB - wpB) > wsize)));
+      const u64 badmA = ballot(badA), badmB = WIDE ? ballot(badB) : 0ull;
+      if (badmA) { mmA &= (1ull << ((u32) __ffsll((long long) badmA) - 1u)) - 1ull; mmB = 0; fail_after = true; }
+      else if (badmB) { mmB &= (1ull << ((u32) __ffsll((long long) badmB) - 1u)) - 1ull; fail_after = true; }
     }
-    // (3) copies.  Short matches (<= 16 bytes) are collected four at a time -- 16 lanes each, ONE load
-    //     and ONE store for the group -- as long as none of them reads what an earlier member of
-    //     the group writes; long or dependent ones flush the group first.
-    // (3) copies, without any per-match scalar decode: matches are taken four at a time in rank
-    //     order.  Each match lane sends (position, offset|length) to the leader lane of a 16-lane
-    //     slot (ds_permute = scatter), every lane fetches its slot's data back (ds_bpermute).  The
-    //     source of byte k of a match is  pos - off + (k mod off): always bytes that existed before
-    //     the match, so a match never depends on its own earlier bytes.  Slots whose source lies
-    //     entirely before the batch's first destination byte are independent: they advance together,
-    //     16 bytes per slot per pass (ONE load + ONE store per pass).  A slot that may read what an
-    //     earlier slot of the batch writes is replayed afterwards as a wave-wide copy.  In the usual
-    //     case (one pass, nothing dependent) the store is deferred to the next round.
+    // (3) queue the matches.  Offsets no linear copy can serve (0, or beyond the window: only from
+    //     a stored block's R0-R2) take the slow way: resolve the queue, redo the round one match at
+    //     a time with the reference's ring semantics.  A round that would overflow the queue does too.
 #ifndef LZX_EXP_NOCOPY
-    if (mm) {
-      const bool ism = (mm >> lane) & 1ull;
-      const u32 nm = (u32) __popcll(mm);
-      const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32) mm, 0u));
-      const u32 s4 = lane >> 4, i4 = lane & 15u;
-      for (u32 base = 0; base < nm; base += 4u) {
-        const bool in_b = ism && (rank - base) < 4u;
-        const u32 dstl = in_b ? ((rank - base) << 6) : (63u << 2);   // leaders are lanes 0,16,32,48
-        const u32 sp = (u32) __builtin_amdgcn_ds_permute((int) dstl, (int)(in_b ? opos : 0u));
-        const u32 sk = (u32) __builtin_amdgcn_ds_permute((int) dstl, (int)(in_b ? ((vmoff << 9) | olen) : 0u));
-        const u32 gp = (u32) __builtin_amdgcn_ds_bpermute((int)(s4 << 6), (int) sp);
-        const u32 gk = (u32) __builtin_amdgcn_ds_bpermute((int)(s4 << 6), (int) sk);
-        const u32 go = gk >> 9, gl = gk & 511u;
-        const u32 nb = (nm - base) < 4u ? (nm - base) : 4u;
-        const bool valid = s4 < nb;
-        const u32 first_pos = rdl(gp, 0);
-        const bool oddoff = valid && (go == 0u || go > wsize);
-        const u32 src_hi = gp - go + (go < gl ? go : gl);
-        const bool dep = valid && s4 != 0u && src_hi > first_pos;
-        const bool indep = valid && !dep && !oddoff;
-        const u64 later = ballot((dep || oddoff) && i4 == 0u);       // slots to replay one by one
-        const bool single = ballot(indep && gl > 16u) == 0ull;
-        // residue of the running byte index modulo the offset, kept per slot
-        u32 gd = 0, rs = 0;
-        if (single && later == 0ull && base + 4u >= nm) {
-          u32 x = rs + i4, t;
-          t = x - (go << 3); x = t < x ? t : x;  t = x - (go << 2); x = t < x ? t : x;
-          t = x - (go << 1); x = t < x ? t : x;  t = x - go;        x = t < x ? t : x;
-          bool act = indep && i4 < gl;
-          u32 val = 0; if (act) val = (u32) out[gp - go + x];
-          pend = true; pend_act = act; pend_dst = gp + i4; pend_val = val;
+    if (mmA | mmB) {
+      const bool ismA = (mmA >> lane) & 1ull, ismB = WIDE && ((mmB >> lane) & 1ull);
+      const u32 nmA = (u32) __popcll(mmA), nmB = WIDE ? (u32) __popcll(mmB) : 0u;
+      if (!slow) {
+        if (ballot((ismA && (vmoffA == 0u || vmoffA > wsize)) || (ismB && (vmoffB == 0u || vmoffB > wsize))) ||
+            mcount + nmA + nmB > LZX_MLIST_CAP) {
+          slow = true; R0 = sR0; R1 = sR1; R2 = sR2; continue;
         }
-        else {
-          while (ballot(indep && gd < gl)) {
-            u32 x = rs + i4, t;
-            t = x - (go << 3); x = t < x ? t : x;  t = x - (go << 2); x = t < x ? t : x;
-            t = x - (go << 1); x = t < x ? t : x;  t = x - go;        x = t < x ? t : x;
-            bool act = indep && (gd + i4) < gl;
-            if (act) out[gp + gd + i4] = out[gp - go + x];
-            gd += 16u;
-            u32 y = rs + 16u;                                          // (rs + 16) mod go, go >= 1
-            if (go != 0u) {
-              t = y - (go << 4); y = t < y ? t : y;  t = y - (go << 3); y = t < y ? t : y;
-              t = y - (go << 2); y = t < y ? t : y;  t = y - (go << 1); y = t < y ? t : y;
-              t = y - go;        y = t < y ? t : y;
-            }
-            rs = y;
-          }
-          for (u64 dm = later; dm; dm &= dm - 1ull) {
-            u32 l = (u32) __ffsll((long long) dm) - 1u;
-            u32 pos_l = rdl(gp, l), len_l = rdl(gl, l), off_l = rdl(go, l);
-            SPEC_COPY(pos_l, len_l, off_l, pos_l - wbase);
-          }
+        const u32 rankA = __builtin_amdgcn_mbcnt_hi((u32)(mmA >> 32), __builtin_amdgcn_mbcnt_lo((u32) mmA, 0u));
+        const u32 rankB = __builtin_amdgcn_mbcnt_hi((u32)(mmB >> 32), __builtin_amdgcn_mbcnt_lo((u32) mmB, 0u));
+        if (ismA) sh->mlist[mcount + rankA] = make_uint2(oposA, (vmoffA << 9) | tA.olen);
+        if (WIDE && ismB) sh->mlist[mcount + nmA + rankB] = make_uint2(oposB, (vmoffB << 9) | tB.olen);
+        mcount += nmA + nmB;
+      }
+      else {
+        for (u64 dm = mmA; dm; dm &= dm - 1ull) {
+          u32 l = (u32) __ffsll((long long) dm) - 1u;
+          u32 pos_l = rdl(oposA, l), len_l = rdl(tA.olen, l), off_l = rdl(vmoffA, l);
+          SPEC_COPY(pos_l, len_l, off_l, pos_l - wbase);
+        }
+        if (WIDE) for (u64 dm = mmB; dm; dm &= dm - 1ull) {
+          u32 l = (u32) __ffsll((long long) dm) - 1u;
+          u32 pos_l = rdl(oposB, l), len_l = rdl(tB.olen, l), off_l = rdl(vmoffB, l);
+          SPEC_COPY(pos_l, len_l, off_l, pos_l - wbase);
         }
       }
     }
 #endif
     TICK(4);
-    if (fail_after) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; break; }
+    if (fail_after) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; slow = false; continue; }
     P = newP;
     bitpos += q;
     d.st_rounds++;
+    if (slow) Pf = P;
     if (hit_unknown && P < run_end) {
-      if (pend) { if (pend_act) out[pend_dst] = (u8) pend_val; pend = false; }
-
       // a code longer than the direct table (or an invalid one): decode this one token on the
-      // scalar side from the 64 bits lane q extracted
+      // scalar side from the 64 bits its position extracted
       u32 tk_kind, tk_val, tk_off;
-      u64 rq = ((u64) rdl(w0, q) << 32) | rdl(w1, q);
+      u64 rq = q < 64u ? (((u64) rdl(w0A, q) << 32) | rdl(w1A, q))
+                       : (((u64) rdl(w0B, q - 64u) << 32) | rdl(w1B, q - 64u));
       u32 tk_tot = lzx_scalar_token<ALIGNED>(d, length_empty, rq, tk_kind, tk_val, tk_off);
-      if (tk_tot == 0u) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; break; }
-      if (tk_kind == 0u) { if (lane == 0) out[P] = (u8) tk_val; P++; }
-      else { SPEC_MATCH(P, tk_val, tk_kind, tk_off); if (rc != LZX_RUN_DONE) break; P += tk_val; }
+      if (tk_tot == 0u) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; slow = false; continue; }
+      if (tk_kind == 0u) { if (lane == 0) out[P] = (u8) tk_val; P++; if (slow) Pf = P; }
+      else {
+        u32 moff_;
+        u32 t0 = R0, t1 = R1, t2 = R2;
+        if (tk_kind == 1u) { moff_ = tk_off; t2 = t1; t1 = t0; t0 = moff_; }
+        else if (tk_kind == 2u) moff_ = t0;
+        else if (tk_kind == 3u) { moff_ = t1; t1 = t0; t0 = moff_; }
+        else { moff_ = t2; t2 = t0; t0 = moff_; }
+        u32 wp_ = P - wbase;
+        if (P + tk_val > run_end || wp_ + tk_val > wsize ||
+            (moff_ > wp_ && (moff_ > offset_written || (moff_ - wp_) > wsize))) {
+          d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; slow = false; continue;
+        }
+#ifndef LZX_EXP_NOCOPY
+        if (!slow) {
+          // the round is redone after the queue is resolved: nothing of this token is committed
+          if (moff_ == 0u || moff_ > wsize || mcount >= LZX_MLIST_CAP) { slow = true; continue; }
+          if (lane == 0u) sh->mlist[mcount] = make_uint2(P, (moff_ << 9) | tk_val);
+          mcount++;
+        }
+        else { SPEC_COPY(P, tk_val, moff_, wp_); }
+#endif
+        R0 = t0; R1 = t1; R2 = t2;
+        P += tk_val;
+        if (slow) Pf = P;
+      }
       bitpos += tk_tot;
     }
+    slow = false;
   }
-  if (pend) { if (pend_act) out[pend_dst] = (u8) pend_val; pend = false; }
 #undef SWAP16
 #undef SPEC_MATCH
 #undef SPEC_COPY
@@ -984,10 +1128,16 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   if (lane == 0) {
     res->err = err; res->flags = flags; res->out_len = s.offset; res->good_len = s.offset; res->reserved = 0;
     res->in_used = s.raw_mode ? s.raw_pos : d.iptr();
+#ifdef LZX_EXP_CNT
+    res->flags = d.st_t[0]; res->out_len = d.st_t[1]; res->good_len = d.st_t[2]; res->err = (int) d.st_t[4];
+    ((u32 *) res)[5] = d.st_rounds; ((u32 *) res)[3] = d.st_t[5];
+#endif
 #ifdef LZX_EXP_STATS
-    res->in_used = (u32)((__builtin_amdgcn_s_memtime() - tstart_) >> 6); res->reserved = d.st_unknown;
-    res->flags = d.st_t[0] >> 6; res->out_len = d.st_t[1] >> 6; res->good_len = d.st_t[2] >> 6;
-    res->err = (int)(d.st_t[4] >> 6); ((u32 *) res)[5] = d.st_t[5] | (d.st_rounds << 16); ((u32 *) res)[3] = (u32)((__builtin_amdgcn_s_memtime() - tstart_) >> 6);
+    {   // scratch builds only: section timers overwrite the head of the unit's output
+      u32 *so = (u32 *) d.out;
+      for (int k_ = 0; k_ < 6; k_++) so[k_] = d.st_t[k_];
+      so[6] = (u32)(__builtin_amdgcn_s_memtime() - tstart_); so[7] = d.st_rounds; so[8] = d.st_unknown;
+    }
 #endif
   }
 }

@@ -23,7 +23,7 @@ __device__ __forceinline__ bool pick_unit(const mspack_hip_unit *units, const u3
   return units[ui].kind == kind;
 }
 
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_units,
                        const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
                        int32_t *frame_meta)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # scratch experiment runner (not part of the product): time several kernel builds at several batch sizes
 for so in "$@"; do
-  for u in 1024 4096 16384; do
+  for u in ${UNITS:-1024 4096 16384}; do
     MSPACK_HIP_SO=$so timeout 200 python bench.py --steps 5 --warmup 2 --exp --units $u 2>&1 | python -c "
 import sys,json
 try:
