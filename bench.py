@@ -22,11 +22,34 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def usable_cpus():
+    """CPUs this process can actually run on: the affinity mask capped by the cgroup CPU quota (the GPU
+    boxes expose every host thread but grant a fixed quota, and threads beyond it only add contention)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(comp, off, ln, n_units, unit_bytes, budget_s=12.0):
     """Reference CPU path (oracle/_ref = the real libmspack lzxd, built from /root/reference in the
     dev container) over the same units on the host cores; falls back to our CPU restatement."""
     import ctypes as C
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     try:
         import helpers
         if helpers.have_ref():
@@ -42,13 +65,13 @@ def cpu_baseline(comp, off, ln, n_units, unit_bytes, budget_s=12.0):
                     raise RuntimeError("reference failed on %d units" % e.value)
                 return b.value / t / 1e6, t
             one, _t = run(1, 1)                                   # one core, one pass: MB/s per core
-            # all hardware threads; enough passes for ~10-20 s of CPU work in total
-            est_core_s = n_units * unit_bytes / (one * 1e6)
-            reps = max(2, min(64, int(15.0 / max(est_core_s, 1e-3))))
+            # one thread per usable CPU; enough passes for ~15 s of wall time
+            est_pass_s = n_units * unit_bytes / (one * 1e6) / cores
+            reps = max(2, min(256, int(15.0 / max(est_pass_s, 1e-3))))
             allv, tall = run(cores, reps)
             return {"value": round(allv, 1), "unit": "MB/s", "cores": cores, "kind": "reference",
-                    "one_core_MBps": round(one, 1),
-                    "sample": "%d passes over the same %d-unit batch (%.0f MiB decoded per pass) on %d threads in "
+                    "one_core_MBps": round(one, 1), "host_threads": os.cpu_count(),
+                    "sample": "%d passes over the same %d-unit batch (%.0f MiB decoded per pass) on %d threads (= usable CPUs: affinity and cgroup quota) in "
                               "%.2f s, threads released together; libmspack lzxd_decompress memory-to-memory, one "
                               "decompressor per thread" % (reps, n_units, n_units * unit_bytes / 2**20, cores, tall)}
     except Exception as ex:          # pragma: no cover
