@@ -30,6 +30,7 @@
 #define LZX_MAIN_SYMS 720      /* 256 + 50*8 + 64: every index that can ever be non-zero (w<=21) */
 #define LZX_LEN_SYMS 250
 #define LZX_MLIST_CAP 160
+#define LZX_MFLAG_RING 512u
 #ifndef LZX_SPEC_WIDE
 #define LZX_SPEC_WIDE 0          /* 1: every lane decodes two positions (128 per round) */
 #endif
@@ -58,7 +59,7 @@ struct __align__(16) LzxShared {
   u8  pre_len[24];
   u8  ali_len[8];
   uint2 mlist[LZX_MLIST_CAP];    /* speculative path: queued matches (position, offset<<9 | length) */
-  u16 mtmp[64];
+  u8  mflag[LZX_MFLAG_RING];     /* 1 at (position mod ring) where a queued match starts */
 };
 
 struct LzxDec {
@@ -590,9 +591,12 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   // bit position of the next unread bit, relative to d.w.origin; chunk cb = dwords [64cb, 64cb+64)
   u32 bitpos = rfl(d.cons_bits());
   u32 cb = bitpos >> 11;
-  // last bit position from which a whole window (64 starts + 64 bits of look-ahead) stays 64 bytes
-  // clear of the end of the input
-  const u32 margin = WIDE ? 112u : 96u;
+  // The speculative rounds stop `margin` bytes before the end of the input.  A round (64 starts + a
+  // 53-bit token) plus one scalar token consumes at most 22 bytes, a block header read without any
+  // symbol decode 17 more and the first symbol after it 7: with 56 the EOF-exact reader
+  // (LzxDec::sym_ensure) still takes over at a symbol boundary at least 6 bytes before the
+  // reference's read pointer can reach the end of the input.
+  const u32 margin = WIDE ? 72u : 56u;
   const u32 room_bytes = (d.w.in_len > d.w.origin + margin) ? (d.w.in_len - d.w.origin - margin) : 0u;
   const u32 bit_limit = rfl(room_bytes * 8u);
   if (bitpos >= bit_limit) return LZX_RUN_SWITCH;
@@ -604,6 +608,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     u32 lo = d.w.load_chunk(cb, lane), hi = d.w.load_chunk(cb + 1u, lane);
     sh->inbuf[lane] = SWAP16(lo); sh->inbuf[64u + lane] = SWAP16(hi);
     if (lane < 4u) sh->inbuf[128u + lane] = 0;
+    ((u32 *) sh->mflag)[lane] = 0; ((u32 *) sh->mflag)[64u + lane] = 0;   // no match queued yet
   }
   u32 pf = d.w.load_chunk(cb + 2u, lane);
   u32 mlim[16 - LZX_MAIN_P];                            // limits of the code lengths beyond the table
@@ -634,19 +639,50 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   } while (0)
 
   // ---- deferred match resolution -------------------------------------------------------------
-  // Rounds only QUEUE their matches (position, offset|length) in LDS; literals go straight to the
-  // output.  The queue is resolved in position space, 64 output bytes per pass, one byte per lane:
-  // a lane finds the match covering its byte (scatter of queue indices to start positions + a DPP
-  // max-scan), and copies out[b] = out[b - offset] -- LZ77 byte semantics, so overlapping matches
+  // Rounds only QUEUE their matches (position, offset|length) in LDS and raise a flag at the
+  // match's start position in a small ring; literals go straight to the output.  The queue is
+  // resolved in position space, 64 output bytes per pass, one byte per lane: the number of start
+  // flags at or below a lane's byte (ballot + mbcnt) is the index of the match that may cover it,
+  // and the byte is copied as out[b] = out[b - offset] -- LZ77 byte semantics, so overlapping matches
   // need no special case.  A source byte inside the current 64-byte chunk that is itself a match
   // byte is not in memory yet: such lanes follow the source's own pointer (pointer jumping, log
   // steps).  Everything below the chunk is final because chunks are resolved in address order.
-  // The store of a chunk is issued one chunk late, so its load overlaps the next chunk's work.
+  // The passes are software-pipelined: chunk k's load is in flight while chunk k+1 is set up.
   u32 Pf = P;                                           // everything below Pf is final in memory
   u32 mcount = 0;                                       // queued matches (sorted by position)
-  bool pst = false, pst_act = false;                    // store of the previous chunk still to issue
-  u32 pst_c = 0, pst_dst = 0, pst_val = 0;
+  u32 ja = 0;                                           // queue entries that start below Pf (0 or 1)
   bool slow = false;                                    // this round copies its matches one by one
+
+  // which match covers byte c_ + lane, and where does that byte finally come from
+#define SPEC_COVER(c_, inm_, ptr_, ext_)                                                      \
+  do {                                                                                        \
+    CNT(1);                                                                                   \
+    const u32 b_ = (c_) + lane;                                                               \
+    const u32 fi_ = b_ & (LZX_MFLAG_RING - 1u);                                               \
+    const u32 f_ = sh->mflag[fi_];                                                            \
+    sh->mflag[fi_] = 0;                                                                       \
+    const u64 sm_ = ballot(f_ != 0u);                                                         \
+    const u32 cnt_ = __builtin_amdgcn_mbcnt_hi((u32)(sm_ >> 32), __builtin_amdgcn_mbcnt_lo((u32) sm_, 0u)) + \
+                     (f_ != 0u ? 1u : 0u);                                                    \
+    const int j_ = (int)(ja + cnt_) - 1;                                                      \
+    const uint2 mr_ = sh->mlist[j_ < 0 ? 0 : j_];                                             \
+    const u32 ml_ = mr_.y & 511u;                                                             \
+    inm_ = j_ >= 0 && (b_ - mr_.x) < ml_;                                                     \
+    ptr_ = b_ - (mr_.y >> 9);                                                                 \
+    ja += (u32) __popcll(sm_);                                                                \
+    ext_ = (ballot(inm_ && mr_.x + ml_ > (c_) + 64u) >> 63) != 0ull;                          \
+    const u64 inmask_ = ballot(inm_);                                                         \
+    if (ballot(inm_ && ptr_ >= (c_))) {                                                       \
+      for (;;) {                                                                              \
+        u32 tl_ = (ptr_ - (c_)) & 63u;                                                        \
+        u32 tp_ = (u32) __builtin_amdgcn_ds_bpermute((int)(tl_ << 2), (int) ptr_);            \
+        bool follow_ = inm_ && ptr_ >= (c_) && ((inmask_ >> tl_) & 1ull);                     \
+        if (!ballot(follow_)) break;                                                          \
+        CNT(2);                                                                               \
+        if (follow_) ptr_ = tp_;                                                              \
+      }                                                                                       \
+    }                                                                                         \
+  } while (0)
 
 #ifdef LZX_EXP_STATS
 #define TICK(k) do { u64 n_ = __builtin_amdgcn_s_memtime(); d.st_t[k] += (u32)(n_ - tk_); tk_ = n_; } while (0)
@@ -662,73 +698,36 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     const bool fin = !live || slow;
 #ifndef LZX_EXP_NOCOPY
     if (fin || P - Pf >= LZX_FLUSH_SPAN || mcount > LZX_MLIST_CAP - 64u) {
-      u32 c = Pf & ~63u;
       CNT(0);
-      u32 ja = 0, jprev = 0; bool have_prev = false;
-      if (mcount) {                                     // entry 0 may have begun below Pf
-        u32 p0 = rfl(sh->mlist[0].x);
-        if (p0 < c) { have_prev = true; ja = 1u; }
-      }
-      while (fin ? (c < P) : (c + 64u <= P)) {
-        const u32 b = c + lane;
-        CNT(1);
-        sh->mtmp[lane] = 0;
-        const u32 jj = ja + lane;
-        uint2 rec = make_uint2(0u, 0u);
-        if (jj < mcount) rec = sh->mlist[jj];
-        const bool st = jj < mcount && (rec.x - c) < 64u;
-        if (st) sh->mtmp[rec.x - c] = (u16)(jj + 1u);
-        __builtin_amdgcn_wave_barrier();
-        u32 jm = sh->mtmp[lane];
-        const u32 nin = (u32) __popcll(ballot(st));
-        jm = wave_incl_max(jm);
-        const bool hasj = jm != 0u || have_prev;
-        const u32 j = jm ? jm - 1u : jprev;
-        const uint2 mr = sh->mlist[hasj ? j : 0u];
-        const u32 mo = mr.y >> 9, ml = mr.y & 511u;
-        const bool inm = hasj && (b - mr.x) < ml && b >= Pf && b < P;
-        u32 ptr = b - mo;
-        const u64 inmask = ballot(inm);
+      u32 c = Pf & ~63u;
+      const u32 climit = fin ? P : c + ((P - c) & ~63u);   // unless final: whole chunks only
+      if (c < climit) {
+        bool inm, ext; u32 ptr;
+        SPEC_COVER(c, inm, ptr, ext);
         for (;;) {
-          u32 tl = (ptr - c) & 63u;
-          u32 tp = (u32) __builtin_amdgcn_ds_bpermute((int)(tl << 2), (int) ptr);
-          bool follow = inm && ptr >= c && ((inmask >> tl) & 1ull);
-          if (!ballot(follow)) break;
-          CNT(2);
-          if (follow) ptr = tp;
+          u32 val = 0; if (inm) val = (u32) out[ptr];
+          const u32 bcur = c + lane; const bool icur = inm;
+          c += 64u;
+          const bool more = c < climit;
+          if (more) SPEC_COVER(c, inm, ptr, ext);
+          if (icur) out[bcur] = (u8) val;
+          if (!more) break;
         }
-        // the previous chunk's store may only wait if nothing here reads that chunk
-        if (pst && ballot(inm && ptr >= pst_c)) { CNT(4); if (pst_act) out[pst_dst] = (u8) pst_val; pst = false; }
-#ifdef LZX_EXP_NOLOAD
-        u32 val = ptr;
-#else
-        u32 val = 0; if (inm) val = (u32) out[ptr];
-#endif
-        if (pst) { if (pst_act) out[pst_dst] = (u8) pst_val; }
-        pst = true; pst_act = inm; pst_c = c; pst_dst = b; pst_val = val;
-        if (nin) { jprev = ja + nin - 1u; have_prev = true; ja += nin; }
-        c += 64u;
-      }
-      if (fin) {
-        if (pst) { if (pst_act) out[pst_dst] = (u8) pst_val; pst = false; }
-        Pf = P; mcount = 0;
-      }
-      else if (c > Pf) {
-        // keep the match that straddles the new Pf (if any) and the ones that start above it
-        Pf = c;
-        u32 keep = ja;
-        if (have_prev) {
-          uint2 lr = sh->mlist[jprev];
-          u32 pe = rfl(lr.x) + (rfl(lr.y) & 511u);
-          if (pe > c) keep = jprev;
+        if (!fin) {
+          // keep the match that runs on into the next chunk (if any) and the ones that start above
+          Pf = c;
+          const u32 keep = ja - (ext ? 1u : 0u);
+          const u32 nrem = mcount - keep;               // <= 33: the span left is below 64 bytes
+          if (keep) {
+            uint2 mv = make_uint2(0u, 0u);
+            if (lane < nrem) mv = sh->mlist[keep + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nrem) sh->mlist[lane] = mv;
+          }
+          mcount = nrem; ja = ext ? 1u : 0u;
         }
-        const u32 nrem = mcount - keep;                 // <= 33: the span left is below 64 bytes
-        uint2 mv = make_uint2(0u, 0u);
-        if (lane < nrem) mv = sh->mlist[keep + lane];
-        __builtin_amdgcn_wave_barrier();
-        if (lane < nrem) sh->mlist[lane] = mv;
-        mcount = nrem;
       }
+      if (fin) { Pf = P; mcount = 0; ja = 0; }
     }
 #endif
     if (!live) break;
@@ -846,13 +845,19 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       const u32 nmA = (u32) __popcll(mmA), nmB = WIDE ? (u32) __popcll(mmB) : 0u;
       if (!slow) {
         if (ballot((ismA && (vmoffA == 0u || vmoffA > wsize)) || (ismB && (vmoffB == 0u || vmoffB > wsize))) ||
-            mcount + nmA + nmB > LZX_MLIST_CAP) {
+            mcount + nmA + nmB > LZX_MLIST_CAP || newP - (Pf & ~63u) > LZX_MFLAG_RING) {
           slow = true; R0 = sR0; R1 = sR1; R2 = sR2; continue;
         }
         const u32 rankA = __builtin_amdgcn_mbcnt_hi((u32)(mmA >> 32), __builtin_amdgcn_mbcnt_lo((u32) mmA, 0u));
         const u32 rankB = __builtin_amdgcn_mbcnt_hi((u32)(mmB >> 32), __builtin_amdgcn_mbcnt_lo((u32) mmB, 0u));
-        if (ismA) sh->mlist[mcount + rankA] = make_uint2(oposA, (vmoffA << 9) | tA.olen);
-        if (WIDE && ismB) sh->mlist[mcount + nmA + rankB] = make_uint2(oposB, (vmoffB << 9) | tB.olen);
+        if (ismA) {
+          sh->mlist[mcount + rankA] = make_uint2(oposA, (vmoffA << 9) | tA.olen);
+          sh->mflag[oposA & (LZX_MFLAG_RING - 1u)] = 1;
+        }
+        if (WIDE && ismB) {
+          sh->mlist[mcount + nmA + rankB] = make_uint2(oposB, (vmoffB << 9) | tB.olen);
+          sh->mflag[oposB & (LZX_MFLAG_RING - 1u)] = 1;
+        }
         mcount += nmA + nmB;
       }
       else {
@@ -899,8 +904,12 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
 #ifndef LZX_EXP_NOCOPY
         if (!slow) {
           // the round is redone after the queue is resolved: nothing of this token is committed
-          if (moff_ == 0u || moff_ > wsize || mcount >= LZX_MLIST_CAP) { slow = true; continue; }
-          if (lane == 0u) sh->mlist[mcount] = make_uint2(P, (moff_ << 9) | tk_val);
+          if (moff_ == 0u || moff_ > wsize || mcount >= LZX_MLIST_CAP ||
+              P + tk_val - (Pf & ~63u) > LZX_MFLAG_RING) { slow = true; continue; }
+          if (lane == 0u) {
+            sh->mlist[mcount] = make_uint2(P, (moff_ << 9) | tk_val);
+            sh->mflag[P & (LZX_MFLAG_RING - 1u)] = 1;
+          }
           mcount++;
         }
         else { SPEC_COPY(P, tk_val, moff_, wp_); }
@@ -914,6 +923,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     slow = false;
   }
 #undef SWAP16
+#undef SPEC_COVER
 #undef SPEC_MATCH
 #undef SPEC_COPY
   // hand the exact bit position back to the scalar reader
