@@ -34,6 +34,13 @@
 #ifndef LZX_SPEC_WIDE
 #define LZX_SPEC_WIDE 0          /* 1: every lane decodes two positions (128 per round) */
 #endif
+#ifdef LZX_EXP_STATS
+#define HT0() u64 ht_ = __builtin_amdgcn_s_memtime()
+#define HT(k) do { u64 n_ = __builtin_amdgcn_s_memtime(); d.st_h[k] += (u32)(n_ - ht_); ht_ = n_; } while (0)
+#else
+#define HT0() do { } while (0)
+#define HT(k) do { } while (0)
+#endif
 #ifdef LZX_EXP_CNT
 #define CNT(k) (d.st_t[k]++)
 #else
@@ -74,6 +81,7 @@ struct LzxDec {
   u32 lit_buf; u32 lit_n;            // lit_buf is per-lane
   u32 st_rounds, st_unknown;         // statistics (LZX_EXP_STATS builds only)
   u32 st_t[6];
+  u32 st_h[3];                       // header timers: pretree, length symbols, table builds
   LzxShared *sh;
   HuffRegs hr_main, hr_len, hr_ali, hr_pre;
 
@@ -133,11 +141,16 @@ struct LzxDec {
   }
 };
 
-// lzxd_read_lens (lzxd.c:138-183).  Serial: every length is a delta against lens[x].
+__device__ __forceinline__ u32 lzx_read_lens_spec(LzxDec &d, u8 *lens, u32 first, u32 last);
+
+// lzxd_read_lens (lzxd.c:138-183).  Every length is a delta against the previous block's lens[x], but
+// the tokens of one call never depend on each other: far from the end of the input they are decoded
+// 64 bit positions at a time (lzx_read_lens_spec); the scalar loop below is the EOF-exact version.
 __device__ __forceinline__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u32 last)
 {
   LzxShared *sh = d.sh;
   u32 v;
+  HT0();
   for (u32 x = 0; x < 20; x++) {
     if (!d.read_bits(4, v)) return false;
     sh->pre_len[x] = (u8) v;
@@ -146,6 +159,10 @@ __device__ __forceinline__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u3
   if (huff_build<LZX_PRE_P>(sh->pre_len, 20, 6, sh->pre_tab, sh->pre_sorted, sh->cnt, d.hr_pre, d.lane, false)) {
     d.err = ERR_DECRUNCH; return false;                       // incl. the all-zero pretree
   }
+  HT(0);
+#ifndef LZX_NO_SPEC
+  if (!d.careful) first = lzx_read_lens_spec(d, lens, first, last);
+#endif
   for (u32 x = first; x < last; ) {
     d.need(32);
     int z = d.decode_sym<LZX_PRE_P>(sh->pre_tab, sh->pre_sorted, d.hr_pre);
@@ -174,6 +191,7 @@ __device__ __forceinline__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u3
       x++;
     }
   }
+  HT(1);
   return true;
 }
 
@@ -243,16 +261,20 @@ __device__ __forceinline__ bool lzx_block_header(LzxDec &d, LzxState &s)
       u32 first = (part == 1) ? 256u : 0u;
       u32 last = (part == 0) ? 256u : (part == 1 ? 256u + s.num_offsets : 249u);
       if (!lzx_read_lens(d, lens, first, last)) return false;
+      HT0();
       if (part == 1) {
         if (huff_build<LZX_MAIN_P>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
                                    sh->cnt, d.hr_main, d.lane, false)) {
           d.err = ERR_DECRUNCH; return false;
         }
         if (rfl((u32) sh->main_len[0xE8]) != 0u) s.intel_started = true;
+        HT(2);
       }
     }
+    HT0();
     r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt,
                               d.hr_len, d.lane, false);
+    HT(2);
     if (r == 1) { d.err = ERR_DECRUNCH; return false; }
     s.length_empty = (r == 2);                                   // lzxd.c:111-125
     return true;
@@ -573,6 +595,141 @@ __device__ __forceinline__ u32 wave_incl_max(u32 x)
   return v;
 }
 
+// ---- input staging shared by the speculative paths ----------------------------------------------
+// The two current 256-byte input chunks live in LDS with each dword's 16-bit halves swapped (the
+// stream becomes a plain MSB-first bit string); the next chunk is prefetched in a register.
+#define SWAP16(x) (((x) << 16) | ((x) >> 16))
+__device__ __forceinline__ void spec_stage(LzxDec &d, u32 &bitpos, u32 &cb, u32 &pf)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  bitpos = rfl(d.cons_bits());
+  cb = bitpos >> 11;                                    // chunk cb = dwords [64cb, 64cb+64)
+  u32 lo = d.w.load_chunk(cb, lane), hi = d.w.load_chunk(cb + 1u, lane);
+  sh->inbuf[lane] = SWAP16(lo); sh->inbuf[64u + lane] = SWAP16(hi);
+  if (lane < 4u) sh->inbuf[128u + lane] = 0;
+  pf = d.w.load_chunk(cb + 2u, lane);
+}
+__device__ __forceinline__ void spec_slide(LzxDec &d, const u32 bitpos, u32 &cb, u32 &pf)
+{
+  if ((bitpos >> 11) != cb) {                           // slide the LDS window by one chunk
+    LzxShared *sh = d.sh;
+    const u32 lane = d.lane;
+    u32 up = sh->inbuf[64u + lane];
+    sh->inbuf[lane] = up; sh->inbuf[64u + lane] = SWAP16(pf);
+    cb++;
+    pf = d.w.load_chunk(cb + 2u, lane);
+  }
+}
+// hand the exact bit position back to the scalar reader
+__device__ __forceinline__ void spec_resync(LzxDec &d, const u32 bitpos, const u32 cb, const u32 pf)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  u32 wi = bitpos >> 5, ch = wi >> 6;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  u32 lo = sh->inbuf[lane], hi = sh->inbuf[64u + lane];
+  lo = SWAP16(lo); hi = SWAP16(hi);
+  if (ch == cb) { d.w.cur = lo; d.w.nxt = hi; }
+  else { d.w.cur = hi; d.w.nxt = pf; }                  // ch == cb + 1
+  d.w.wi = wi; d.bb = 0; d.bl = 0;
+  d.refill(); d.refill();
+  u32 sk = bitpos & 31u;
+  if (sk) { d.bb <<= sk; d.bl -= (int) sk; }
+}
+// last bit position (relative to the window origin) from which a speculative round may start; see
+// the margin discussion in lzx_run_spec
+__device__ __forceinline__ u32 spec_bit_limit(const LzxDec &d, const u32 margin)
+{
+  const u32 room_bytes = (d.w.in_len > d.w.origin + margin) ? (d.w.in_len - d.w.origin - margin) : 0u;
+  return rfl(room_bytes * 8u);
+}
+
+// lzxd_read_lens, vector form.  Decodes pretree tokens from `first` on and returns the index the
+// scalar loop has to continue from (== last when everything was done here).  A token = pretree
+// symbol z [+ 4 / 5 / 1 extra bits for z = 17 / 18 / 19] [+ a second symbol for z = 19]; it sets
+// y = 1 or a run of y lengths (lzxd.c:150-179).  All 64 lanes decode the token starting at bit
+// (bitpos + lane); the chain of real tokens is followed with v_readlane; a prefix sum of the run
+// lengths gives every token its index x; then every on-chain lane rewrites its own lens[x .. x+y).
+__device__ __forceinline__ u32 lzx_read_lens_spec(LzxDec &d, u8 *lens, u32 first, u32 last_)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  const u32 last = rfl(last_);
+  u32 X = rfl(first);
+  const u32 bit_limit = spec_bit_limit(d, 56u);
+  if (rfl(d.cons_bits()) >= bit_limit) return X;
+  u32 bitpos, cb, pf;
+  spec_stage(d, bitpos, cb, pf);
+  u32 plim[16 - LZX_PRE_P];                             // limits of the code lengths beyond the table
+#pragma unroll
+  for (int l = LZX_PRE_P + 1; l <= 16; l++) plim[l - LZX_PRE_P - 1] = rdl(d.hr_pre.limv, (u32) l);
+
+  while (X < last && bitpos < bit_limit) {
+    spec_slide(d, bitpos, cb, pf);
+    const u32 rel = bitpos - (cb << 11) + lane;
+    const u32 k = rel >> 5, sft = rel & 31u;
+    const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
+    const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+    const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
+    u64 r = ((u64) w0 << 32) | w1;
+    u32 e = sh->pre_tab[w0 >> (32 - LZX_PRE_P)];
+    {
+      u32 peek16 = w0 >> 16, ln = LZX_PRE_P + 1u;
+#pragma unroll
+      for (int l = LZX_PRE_P + 1; l <= 16; l++) ln += (peek16 >= plim[l - LZX_PRE_P - 1]) ? 1u : 0u;
+      u32 lq = ln <= 16u ? ln : 0u;
+      u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) d.hr_pre.fov);
+      u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
+      if (idx >= 20u) idx = 0;
+      u32 ls = sh->pre_sorted[idx];
+      if (e == 0u && lq != 0u) e = ls | (lq << 10);
+    }
+    bool unk = (e == 0u);
+    const u32 z = e & 1023u;
+    u32 tot = e >> 10;
+    r <<= tot;
+    const u32 nb = z == 17u ? 4u : (z == 18u ? 5u : (z == 19u ? 1u : 0u));
+    const u32 xb = nb ? (u32)(r >> (64u - nb)) : 0u;
+    r <<= nb; tot += nb;
+    const u32 y = z == 17u ? 4u + xb : (z == 18u ? 20u + xb : (z == 19u ? 4u + xb : 1u));
+    const u32 e2 = sh->pre_tab[(u32)(r >> (64 - LZX_PRE_P))];       // second symbol of a "same" run
+    if (z == 19u) { unk = unk || e2 == 0u; tot += e2 >> 10; }       // (a long second code: scalar loop)
+    const u32 zz = z == 19u ? (e2 & 1023u) : z;
+    const bool zero = z == 17u || z == 18u;
+    const u32 vnext = unk ? (128u + lane) : (lane + tot);
+
+    u64 chain = 0;
+    u32 q = 0;
+    do { chain |= 1ull << q; q = rdl(vnext, q); } while (q < WAVE);
+    bool hit_unknown = false;
+    if (q >= 128u) { q -= 128u; chain &= ~(1ull << q); hit_unknown = true; }
+    bool on = (chain >> lane) & 1ull;
+    const u32 yy = on ? y : 0u;
+    const u32 incl = wave_incl_scan(yy);
+    const u32 x = X + incl - yy;
+    u32 newX = X + rdl(incl, 63u);
+    // lengths are read only while x < last (lzxd.c:148); a run may overshoot (it is not clipped)
+    const u64 late = ballot(on && x >= last);
+    if (late) {
+      u32 j = (u32) __ffsll((long long) late) - 1u;
+      chain &= (1ull << j) - 1ull;
+      on = (chain >> lane) & 1ull;
+      q = j; hit_unknown = false; newX = rdl(x, j);
+    }
+    if (on) {
+      int nv = 0;
+      if (!zero) { nv = (int)(u32) lens[x] - (int) zz; if (nv < 0) nv += 17; }
+      for (u32 i = 0; i < y; i++) lens[x + i] = (u8) nv;
+    }
+    X = newX;
+    bitpos += q;
+    if (hit_unknown) break;                             // the scalar loop takes (and judges) this token
+  }
+  spec_resync(d, bitpos, cb, pf);
+  return X;
+}
+
 template <bool ALIGNED>
 __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 run_end_, const u32 wbase_)
 {
@@ -588,29 +745,18 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   const bool length_empty = rfl((u32) s.length_empty) != 0u;
   int rc = LZX_RUN_DONE;
 
-  // bit position of the next unread bit, relative to d.w.origin; chunk cb = dwords [64cb, 64cb+64)
-  u32 bitpos = rfl(d.cons_bits());
-  u32 cb = bitpos >> 11;
   // The speculative rounds stop `margin` bytes before the end of the input.  A round (64 starts + a
   // 53-bit token) plus one scalar token consumes at most 22 bytes, a block header read without any
   // symbol decode 17 more and the first symbol after it 7: with 56 the EOF-exact reader
   // (LzxDec::sym_ensure) still takes over at a symbol boundary at least 6 bytes before the
   // reference's read pointer can reach the end of the input.
-  const u32 margin = WIDE ? 72u : 56u;
-  const u32 room_bytes = (d.w.in_len > d.w.origin + margin) ? (d.w.in_len - d.w.origin - margin) : 0u;
-  const u32 bit_limit = rfl(room_bytes * 8u);
-  if (bitpos >= bit_limit) return LZX_RUN_SWITCH;
+  const u32 bit_limit = spec_bit_limit(d, WIDE ? 72u : 56u);
+  if (rfl(d.cons_bits()) >= bit_limit) return LZX_RUN_SWITCH;
   // pending literals of the scalar path go out first: this path stores literals directly
   d.flush_lits();
-
-#define SWAP16(x) (((x) << 16) | ((x) >> 16))
-  {
-    u32 lo = d.w.load_chunk(cb, lane), hi = d.w.load_chunk(cb + 1u, lane);
-    sh->inbuf[lane] = SWAP16(lo); sh->inbuf[64u + lane] = SWAP16(hi);
-    if (lane < 4u) sh->inbuf[128u + lane] = 0;
-    ((u32 *) sh->mflag)[lane] = 0; ((u32 *) sh->mflag)[64u + lane] = 0;   // no match queued yet
-  }
-  u32 pf = d.w.load_chunk(cb + 2u, lane);
+  u32 bitpos, cb, pf;                                   // next unread bit (relative to d.w.origin)
+  spec_stage(d, bitpos, cb, pf);
+  ((u32 *) sh->mflag)[lane] = 0; ((u32 *) sh->mflag)[64u + lane] = 0;   // no match queued yet
   u32 mlim[16 - LZX_MAIN_P];                            // limits of the code lengths beyond the table
 #pragma unroll
   for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
@@ -731,12 +877,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     }
 #endif
     if (!live) break;
-    if ((bitpos >> 11) != cb) {                       // slide the LDS window by one chunk
-      u32 up = sh->inbuf[64u + lane];
-      sh->inbuf[lane] = up; sh->inbuf[64u + lane] = SWAP16(pf);
-      cb++;
-      pf = d.w.load_chunk(cb + 2u, lane);
-    }
+    spec_slide(d, bitpos, cb, pf);
     TICK(5);
     // ---- every lane decodes the TWO tokens that would start at bits (bitpos + lane) and
     //      (bitpos + 64 + lane): two independent instruction streams per lane ----
@@ -922,25 +1063,12 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     }
     slow = false;
   }
-#undef SWAP16
 #undef SPEC_COVER
 #undef SPEC_MATCH
 #undef SPEC_COPY
-  // hand the exact bit position back to the scalar reader
   d.P = P;
   s.R0 = R0; s.R1 = R1; s.R2 = R2;
-  {
-    u32 wi = bitpos >> 5, ch = wi >> 6;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    u32 lo = sh->inbuf[lane], hi = sh->inbuf[64u + lane];
-    lo = (lo << 16) | (lo >> 16); hi = (hi << 16) | (hi >> 16);
-    if (ch == cb) { d.w.cur = lo; d.w.nxt = hi; }
-    else { d.w.cur = hi; d.w.nxt = pf; }                 // ch == cb + 1
-    d.w.wi = wi; d.bb = 0; d.bl = 0;
-    d.refill(); d.refill();
-    u32 sk = bitpos & 31u;
-    if (sk) { d.bb <<= sk; d.bl -= (int) sk; }
-  }
+  spec_resync(d, bitpos, cb, pf);
   return rc;
 }
 
@@ -965,6 +1093,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   d.out = out_arena + u.out_off; d.P = 0; d.lit_buf = 0; d.lit_n = 0;
   d.st_rounds = 0; d.st_unknown = 0;
   for (int k_ = 0; k_ < 6; k_++) d.st_t[k_] = 0;
+  d.st_h[0] = d.st_h[1] = d.st_h[2] = 0;
 
   s.wsize = 1u << u.window_bits;
   s.wpos = 0; s.frame_posn = 0; s.frame = 0; s.reset_frames = u.reset_frames;
@@ -1147,6 +1276,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
       u32 *so = (u32 *) d.out;
       for (int k_ = 0; k_ < 6; k_++) so[k_] = d.st_t[k_];
       so[6] = (u32)(__builtin_amdgcn_s_memtime() - tstart_); so[7] = d.st_rounds; so[8] = d.st_unknown;
+      so[9] = d.st_h[0]; so[10] = d.st_h[1]; so[11] = d.st_h[2];
     }
 #endif
   }
