@@ -174,6 +174,126 @@ class Cab:
         self.close()
 
 
+
+MSCABD_PARAM_SEARCHBUF = 0
+
+
+class CabSet:
+    """Several cabinets on ONE decompressor, joined with append()/prepend() like cabextract does
+    (reference cabd.c:870-1064):  with CabSet([p1, p2, ...]) as s: s.append(0, 1); s.files(0); s.extract(f)"""
+
+    def __init__(self, srcs, fix_mszip=0, salvage=0):
+        self.L = _setup()
+        self._tmps = []
+        self.paths = []
+        for src in srcs:
+            if isinstance(src, (bytes, bytearray)):
+                fd, tmp = tempfile.mkstemp(suffix=".cab")
+                os.write(fd, src); os.close(fd)
+                self._tmps.append(tmp)
+                src = tmp
+            self.paths.append(os.fsencode(src))           # must outlive the cabinets (mspack.h:968-969)
+        self.d = self.L.mspack_create_cab_decompressor(None)
+        if not self.d:
+            raise RuntimeError("mspack_create_cab_decompressor failed")
+        self.d.contents.set_param(self.d, MSCABD_PARAM_FIXMSZIP, fix_mszip)
+        self.d.contents.set_param(self.d, MSCABD_PARAM_SALVAGE, salvage)
+        self.cabs = [self.d.contents.open(self.d, p) for p in self.paths]
+        self.open_errors = [0 if c else self.d.contents.last_error(self.d) for c in self.cabs]
+
+    def _cab(self, i):
+        return self.cabs[i] if i is not None and i >= 0 else None
+
+    def append(self, a, b):
+        return self.d.contents.append(self.d, self._cab(a), self._cab(b))
+
+    def prepend(self, a, b):
+        return self.d.contents.prepend(self.d, self._cab(a), self._cab(b))
+
+    def file_ptrs(self, i):
+        return list(_walk(self.cabs[i].contents.files))
+
+    def files(self, i):
+        """[(name, length, offset, comp_type, folder ordinal, folder num_blocks)] of cabinet i's list"""
+        folders = [C.addressof(f.contents) for f in _walk(self.cabs[i].contents.folders)]
+        out = []
+        for f in self.file_ptrs(i):
+            fo = f.contents.folder
+            out.append((f.contents.filename, f.contents.length, f.contents.offset,
+                        fo.contents.comp_type if fo else -1,
+                        folders.index(C.addressof(fo.contents)) if fo else -1,
+                        fo.contents.num_blocks if fo else 0))
+        return out
+
+    def extract(self, fptr):
+        fd, out = tempfile.mkstemp(suffix=".out")
+        os.close(fd)
+        try:
+            err = self.d.contents.extract(self.d, fptr, os.fsencode(out))
+            with open(out, "rb") as fh:
+                return err, fh.read()
+        finally:
+            os.unlink(out)
+
+    def close(self):
+        if self.d:
+            # joined cabinets are freed with the one they are joined to: close one per chain
+            seen = set()
+            for c in self.cabs:
+                if not c:
+                    continue
+                chain = set()
+                w = c
+                while w:
+                    chain.add(C.addressof(w.contents)); w = w.contents.prevcab
+                w = c
+                while w:
+                    chain.add(C.addressof(w.contents)); w = w.contents.nextcab
+                if chain & seen:
+                    continue
+                seen |= chain
+                self.d.contents.close(self.d, c)
+            self.cabs = []
+            self.L.mspack_destroy_cab_decompressor(self.d); self.d = None
+        for t in self._tmps:
+            os.unlink(t)
+        self._tmps = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def cab_search(src, searchbuf=0):
+    """search(): [(base_offset, n_files, first file name)] of the cabinets found inside a file"""
+    L = _setup()
+    tmp = None
+    if isinstance(src, (bytes, bytearray)):
+        fd, tmp = tempfile.mkstemp(suffix=".bin")
+        os.write(fd, src); os.close(fd)
+        src = tmp
+    path = os.fsencode(src)
+    d = L.mspack_create_cab_decompressor(None)
+    try:
+        if searchbuf:
+            d.contents.set_param(d, MSCABD_PARAM_SEARCHBUF, searchbuf)
+        head = d.contents.search(d, path)
+        err = d.contents.last_error(d)
+        found = []
+        for c in _walk(head):
+            fl = list(_walk(c.contents.files))
+            found.append((c.contents.base_offset, len(fl), fl[0].contents.filename if fl else b""))
+        if head:
+            d.contents.close(d, head)
+        return err, found
+    finally:
+        L.mspack_destroy_cab_decompressor(d)
+        if tmp:
+            os.unlink(tmp)
+
+
 class Chm:
     def __init__(self, src, fast=False):
         self.L = _setup()

@@ -13,7 +13,11 @@
  * and every extract() is then a slice of that result.  A unit's result tells how far it decoded
  * without error; files that end inside that prefix succeed exactly as they do in the reference
  * (which never decodes further than asked), later ones return the unit's error.
- * Not implemented yet: cabinet sets (append/prepend, split blocks).
+ * Cabinet sets: append()/prepend() join cabinets and merge a folder that
+ * continues across them (reference cabd.c:870-1064); a merged folder is a list of (cabinet, offset)
+ * segments, and a CFDATA block with uncompressed size 0 continues as the first block of the next
+ * segment (cabd.c:1432-1455).  search() finds embedded cabinets with the reference's acceptance
+ * rules (cabd.c:656-868).
  */
 #include <stdlib.h>
 #include <stdio.h>
@@ -23,12 +27,17 @@
 #define CAB_INPUTMAX   (CAB_BLOCKMAX + 6144u)
 #define CAB_INPUTMAX_SALVAGE 65535u
 #define CAB_LENGTHMAX  (CAB_BLOCKMAX * 65535u)
+#define CAB_FOLDERMAX  65535u
 
 struct cab_p;
+struct fseg {                         /* where a folder's CFDATA blocks live: one entry per cabinet */
+  struct fseg *next;
+  struct cab_p *cab;
+  off_t offset;                       /* first CFDATA of this folder in that cabinet               */
+};
 struct folder_p {
   struct mscabd_folder base;
-  struct cab_p *cab;
-  off_t data_offset;                  /* first CFDATA of this folder                               */
+  struct fseg data;
   struct mscabd_file *merge_prev, *merge_next;
   /* decoded state */
   int decoded;
@@ -45,13 +54,31 @@ struct cab_p {
   struct mscabd_cabinet base;
   int block_resv;
 };
+/* the CFDATA feeder of one folder (the subset of the reference's mscabd_decompress_state, cab.h:95-110,
+ * that cabd_sys_read_block works on) */
+struct blk_reader {
+  struct folder_p *folder;
+  struct fseg *seg;                   /* cabinet the next block header is read from                */
+  struct mspack_file *fh;
+  unsigned int block;                 /* blocks started                                            */
+  unsigned char *input;               /* one (possibly reassembled) block                          */
+  unsigned int i_ptr, i_end;
+};
 struct cabd_p {
   struct mscab_decompressor base;
   struct mspack_system *system;
   int error, read_error;
   int searchbuf_size, fix_mszip, buf_size, salvage;
   int devices, cache_mb;
+  /* stored (uncompressed) folders need no codec and are streamed exactly like the reference does it,
+   * including what a later extract() sees after a failed one (cabd.c:1283-1345, 1530-1541) */
+  struct blk_reader st;
+  unsigned int st_offset;             /* bytes produced so far from st.folder                      */
+  int st_active;
+  struct folder_p *last_folder;       /* folder of the previous extract()                          */
 };
+
+static void stored_reset(struct cabd_p *self);
 
 /* ---- small helpers -------------------------------------------------------------------------------- */
 static unsigned int cab_checksum(const unsigned char *data, unsigned int bytes, unsigned int cksum) {
@@ -188,8 +215,9 @@ static int read_headers(struct mspack_system *sys, struct mspack_file *fh, struc
     memset(fol, 0, sizeof(*fol));
     fol->base.comp_type = (int) rd_le16(buf + 6);
     fol->base.num_blocks = rd_le16(buf + 4);
-    fol->cab = cab;
-    fol->data_offset = offset + (off_t) rd_le32(buf);
+    fol->data.next = NULL;
+    fol->data.cab = cab;
+    fol->data.offset = offset + (off_t) rd_le32(buf);
     if (tail) tail->base.next = &fol->base; else cab->base.folders = &fol->base;
     tail = fol;
   }
@@ -219,6 +247,12 @@ static int read_headers(struct mspack_system *sys, struct mspack_file *fh, struc
 }
 
 /* ---- public methods ------------------------------------------------------------------------------------ */
+static void free_cab_strings(struct mspack_system *sys, struct mscabd_cabinet *c) {
+  sys->free(c->prevname); sys->free(c->nextname); sys->free(c->previnfo); sys->free(c->nextinfo);
+}
+
+/* frees a cabinet, every cabinet joined to it by append/prepend (they share ONE files/folders list)
+ * and every cabinet linked through ->next (reference cabd.c:240-307) */
 static void cabd_close(struct mscab_decompressor *base, struct mscabd_cabinet *origcab)
 {
   struct cabd_p *self = (struct cabd_p *) base;
@@ -229,15 +263,20 @@ static void cabd_close(struct mscab_decompressor *base, struct mscabd_cabinet *o
   while (origcab) {
     struct mscabd_file *fi, *nfi;
     struct mscabd_folder *fo, *nfo;
-    struct mscabd_cabinet *nextc = origcab->next;
+    struct mscabd_cabinet *c, *nc, *nextc = origcab->next;
     for (fi = origcab->files; fi; fi = nfi) { nfi = fi->next; sys->free(fi->filename); sys->free(fi); }
     for (fo = origcab->folders; fo; fo = nfo) {
+      struct fseg *sg, *nsg;
       nfo = fo->next;
+      if (self->st_active && self->st.folder == (struct folder_p *) fo) stored_reset(self);
+      if (self->last_folder == (struct folder_p *) fo) self->last_folder = NULL;
       free_folder_cache(sys, (struct folder_p *) fo);
+      for (sg = ((struct folder_p *) fo)->data.next; sg; sg = nsg) { nsg = sg->next; sys->free(sg); }
       sys->free(fo);
     }
-    sys->free(origcab->prevname); sys->free(origcab->nextname);
-    sys->free(origcab->previnfo); sys->free(origcab->nextinfo);
+    for (c = origcab->prevcab; c; c = nc) { nc = c->prevcab; free_cab_strings(sys, c); sys->free(c); }
+    for (c = origcab->nextcab; c; c = nc) { nc = c->nextcab; free_cab_strings(sys, c); sys->free(c); }
+    free_cab_strings(sys, origcab);
     sys->free(origcab);
     origcab = nextc;
   }
@@ -265,63 +304,334 @@ static struct mscabd_cabinet *cabd_open(struct mscab_decompressor *base, const c
   return (struct mscabd_cabinet *) cab;
 }
 
-/* search: scan a file for embedded cabinets (reference cabd.c:656-868, simplified: every "MSCF"
- * whose header parses is returned, in file order) */
+/* search: scan a file for embedded cabinets (reference cabd.c:656-868).  A candidate is every "MSCF"
+ * followed by 16 more header bytes; it is tried when its files offset lies inside its claimed length
+ * and both stay within 32 bytes of the end of the file (salvage: the length may be garbage).  A
+ * candidate that parses restarts the scan after its claimed length, one that does not restarts it
+ * right after the signature.  The scan works on searchbuf_size pieces with a byte-wise state machine,
+ * so signatures may straddle pieces. */
+static int cabd_find(struct cabd_p *self, unsigned char *buf, struct mspack_file *fh, const char *filename,
+                     off_t flen, off_t *firstlen, struct mscabd_cabinet **first)
+{
+  struct mspack_system *sys = self->system;
+  struct mscabd_cabinet *link = NULL;
+  off_t offset, length;
+  unsigned int cablen = 0, foffset = 0;
+  int state = 0;
+
+  for (offset = 0; offset < flen; offset += length) {
+    off_t i;
+    length = flen - offset;
+    if (length > (off_t) self->searchbuf_size) length = (off_t) self->searchbuf_size;
+    if (sys->read(fh, buf, (int) length) != (int) length) return MSPACK_ERR_READ;
+    if (offset == 0 && length >= 4 && rd_le32(buf) == 0x28635349u)
+      sys->message(fh, "WARNING; found InstallShield header. Use unshield "
+                       "(https://github.com/twogood/unshield) to unpack this file");
+    for (i = 0; i < length; ) {
+      unsigned char c = buf[i];
+      if (state == 0) {                                   /* hunt for 'M' */
+        while (i < length && buf[i] != 0x4D) i++;
+        if (i < length) { i++; state = 1; }
+        continue;
+      }
+      i++;
+      switch (state) {
+      case 1: state = (c == 0x53) ? 2 : 0; break;
+      case 2: state = (c == 0x43) ? 3 : 0; break;
+      case 3: state = (c == 0x46) ? 4 : 0; break;
+      case 8:  cablen  = c;                       state++; break;
+      case 9:  cablen |= (unsigned int) c << 8;   state++; break;
+      case 10: cablen |= (unsigned int) c << 16;  state++; break;
+      case 11: cablen |= (unsigned int) c << 24;  state++; break;
+      case 16: foffset  = c;                      state++; break;
+      case 17: foffset |= (unsigned int) c << 8;  state++; break;
+      case 18: foffset |= (unsigned int) c << 16; state++; break;
+      case 19: {
+        off_t caboff = offset + i - 20;
+        foffset |= (unsigned int) c << 24;
+        offset = caboff + 4;                              /* where to go on if this is no cabinet */
+        if (caboff == 0) *firstlen = (off_t) cablen;
+        if (foffset < cablen && (caboff + (off_t) foffset) < (flen + 32) &&
+            ((caboff + (off_t) cablen) < (flen + 32) || self->salvage)) {
+          struct cab_p *cab = (struct cab_p *) sys->alloc(sys, sizeof(*cab));
+          if (!cab) return MSPACK_ERR_NOMEMORY;
+          memset(cab, 0, sizeof(*cab));
+          cab->base.filename = filename;
+          if (read_headers(sys, fh, cab, caboff, self->salvage, caboff > 0)) {
+            cabd_close(&self->base, &cab->base);
+          }
+          else {
+            if (!link) *first = &cab->base; else link->next = &cab->base;
+            link = &cab->base;
+            offset = caboff + (off_t) cablen;
+          }
+        }
+        if (offset >= flen) return MSPACK_ERR_OK;
+        if (sys->seek(fh, offset, MSPACK_SYS_SEEK_START)) return MSPACK_ERR_SEEK;
+        length = 0; i = 0;                                /* leaves the piece loop; refill at `offset` */
+        state = 0;
+        break;
+      }
+      default: state++; break;                            /* bytes 4-7 and 12-15 are not looked at */
+      }
+    }
+  }
+  return MSPACK_ERR_OK;
+}
+
 static struct mscabd_cabinet *cabd_search(struct mscab_decompressor *base, const char *filename)
 {
   struct cabd_p *self = (struct cabd_p *) base;
   struct mspack_system *sys;
   struct mspack_file *fh;
-  struct mscabd_cabinet *head = NULL, *tail = NULL;
+  struct mscabd_cabinet *cab = NULL;
   unsigned char *buf;
-  off_t flen = 0, pos = 0;
-  int bufsz;
+  off_t flen = 0, firstlen = 0;
   if (!self) return NULL;
   sys = self->system;
-  bufsz = self->searchbuf_size;
-  if (!(buf = (unsigned char *) sys->alloc(sys, (size_t) bufsz + 4))) { self->error = MSPACK_ERR_NOMEMORY; return NULL; }
-  if (!(fh = sys->open(sys, filename, MSPACK_SYS_OPEN_READ))) { sys->free(buf); self->error = MSPACK_ERR_OPEN; return NULL; }
-  self->error = MSPACK_ERR_OK;
-  if (mspack_sys_filelen(sys, fh, &flen) == MSPACK_ERR_OK) {
-    while (pos < flen) {
-      int n, i;
-      off_t skip_to = -1;
-      if (sys->seek(fh, pos, MSPACK_SYS_SEEK_START)) { self->error = MSPACK_ERR_SEEK; break; }
-      n = sys->read(fh, buf, bufsz);
-      if (n < 4) break;
-      for (i = 0; i + 4 <= n; i++) {
-        if (buf[i] == 'M' && buf[i + 1] == 'S' && buf[i + 2] == 'C' && buf[i + 3] == 'F') {
-          struct cab_p *cab = (struct cab_p *) sys->alloc(sys, sizeof(*cab));
-          if (!cab) { self->error = MSPACK_ERR_NOMEMORY; break; }
-          memset(cab, 0, sizeof(*cab));
-          cab->base.filename = filename;
-          if (read_headers(sys, fh, cab, pos + i, self->salvage, 1) == MSPACK_ERR_OK) {
-            if (tail) tail->next = &cab->base; else head = &cab->base;
-            tail = &cab->base;
-            skip_to = pos + i + (off_t)(cab->base.length ? cab->base.length : 4);
-            break;
-          }
-          cabd_close(base, &cab->base);
-          self->error = MSPACK_ERR_OK;
-        }
+  if (!(buf = (unsigned char *) sys->alloc(sys, (size_t) self->searchbuf_size))) { self->error = MSPACK_ERR_NOMEMORY; return NULL; }
+  if ((fh = sys->open(sys, filename, MSPACK_SYS_OPEN_READ))) {
+    if (!(self->error = mspack_sys_filelen(sys, fh, &flen)))
+      self->error = cabd_find(self, buf, fh, filename, flen, &firstlen, &cab);
+    if (firstlen && firstlen != flen && (!cab || cab->base_offset == 0)) {
+      if (firstlen < flen) sys->message(fh, "WARNING; possible %ld extra bytes at end of file.", (long)(flen - firstlen));
+      else sys->message(fh, "WARNING; file possibly truncated by %ld bytes.", (long)(firstlen - flen));
+    }
+    sys->close(fh);
+  }
+  else self->error = MSPACK_ERR_OPEN;
+  sys->free(buf);
+  return cab;
+}
+
+/* ---- cabinet sets: append / prepend (reference cabd.c:870-1064) ----------------------------------------- */
+/* may the last folder of the left cabinet be continued by the first folder of the right one? */
+static int can_merge_folders(struct mspack_system *sys, struct folder_p *lfol, struct folder_p *rfol)
+{
+  struct mscabd_file *l, *r;
+  int some = 0;
+  if (lfol->base.comp_type != rfol->base.comp_type) return 0;
+  if (lfol->base.num_blocks + rfol->base.num_blocks > CAB_FOLDERMAX) return 0;
+  if (!lfol->merge_next || !rfol->merge_prev) return 0;
+  /* the files continued out of the left folder should open the right folder, same order, same
+   * offsets and lengths */
+  for (l = lfol->merge_next, r = rfol->merge_prev; l; l = l->next, r = r->next)
+    if (!r || l->offset != r->offset || l->length != r->length) break;
+  if (!l) return 1;
+  /* otherwise accept as soon as ONE continued file is listed on both sides, and name the others */
+  for (l = lfol->merge_next; l; l = l->next) {
+    for (r = rfol->merge_prev; r; r = r->next)
+      if (l->offset == r->offset && l->length == r->length) break;
+    if (r) some = 1;
+    else sys->message(NULL, "WARNING; merged file %s not listed in both cabinets", l->filename);
+  }
+  return some;
+}
+
+static int cabd_merge(struct mscab_decompressor *base, struct mscabd_cabinet *lcab, struct mscabd_cabinet *rcab)
+{
+  struct cabd_p *self = (struct cabd_p *) base;
+  struct mspack_system *sys;
+  struct mscabd_cabinet *c;
+  struct folder_p *lfol, *rfol;
+  struct mscabd_file *fi;
+  if (!self) return MSPACK_ERR_ARGS;
+  sys = self->system;
+  if (!lcab || !rcab || lcab == rcab) return self->error = MSPACK_ERR_ARGS;
+  if (lcab->nextcab || rcab->prevcab) return self->error = MSPACK_ERR_ARGS;       /* already joined */
+  for (c = lcab->prevcab; c; c = c->prevcab) if (c == rcab) return self->error = MSPACK_ERR_ARGS;
+  for (c = rcab->nextcab; c; c = c->nextcab) if (c == lcab) return self->error = MSPACK_ERR_ARGS;
+  if (lcab->set_id != rcab->set_id) sys->message(NULL, "WARNING; merged cabinets with differing Set IDs.");
+  if (lcab->set_index > rcab->set_index) sys->message(NULL, "WARNING; merged cabinets with odd order.");
+
+  lfol = (struct folder_p *) lcab->folders;
+  while (lfol->base.next) lfol = (struct folder_p *) lfol->base.next;
+  rfol = (struct folder_p *) rcab->folders;
+
+  if (!lfol->merge_next && !rfol->merge_prev) {
+    /* nothing continues across the join: chain the cabinets, folders and files */
+    lcab->nextcab = rcab; rcab->prevcab = lcab;
+    lfol->base.next = &rfol->base;
+    for (fi = lcab->files; fi->next; fi = fi->next) ;
+    fi->next = rcab->files;
+  }
+  else {
+    struct fseg *seg, *tail;
+    struct mscabd_file *prev, *nfi;
+    struct folder_p *last;
+    if (!can_merge_folders(sys, lfol, rfol)) return self->error = MSPACK_ERR_DATAFORMAT;
+    if (!(seg = (struct fseg *) sys->alloc(sys, sizeof(*seg)))) return self->error = MSPACK_ERR_NOMEMORY;
+    lcab->nextcab = rcab; rcab->prevcab = lcab;
+    /* the right folder's segments continue the left folder; the split block is counted by both */
+    for (tail = &lfol->data; tail->next; tail = tail->next) ;
+    *seg = rfol->data; tail->next = seg; rfol->data.next = NULL;
+    lfol->base.num_blocks += rfol->base.num_blocks - 1;
+    /* the merged folder is continued further only by files of the right cabinet that live in
+     * ANOTHER folder of it (a right folder that is itself both continued-from and continued-to keeps
+     * the left side's list: its own entries are about to be deleted) */
+    if (!rfol->merge_next || rfol->merge_next->folder != &rfol->base) lfol->merge_next = rfol->merge_next;
+    free_folder_cache(sys, lfol);                       /* anything decoded before the join is stale */
+    for (last = lfol; last->base.next; last = (struct folder_p *) last->base.next) ;
+    last->base.next = rfol->base.next;
+    for (fi = lcab->files; fi->next; fi = fi->next) ;
+    fi->next = rcab->files;
+    /* the right cabinet's copies of the continued files go away with its folder */
+    for (prev = NULL, fi = lcab->files; fi; fi = nfi) {
+      nfi = fi->next;
+      if (fi->folder == &rfol->base) {
+        if (prev) prev->next = nfi; else lcab->files = nfi;
+        sys->free(fi->filename); sys->free(fi);
       }
-      if (self->error) break;
-      if (skip_to >= 0) pos = skip_to;
-      else pos += (n >= 4) ? (n - 3) : n;
+      else prev = fi;
+    }
+    free_folder_cache(sys, rfol);
+    if (self->st_active && (self->st.folder == rfol || self->st.folder == lfol)) stored_reset(self);
+    if (self->last_folder == rfol) self->last_folder = NULL;
+    sys->free(rfol);
+  }
+  /* every cabinet of the set shows the same lists */
+  for (c = lcab->prevcab; c; c = c->prevcab) { c->files = lcab->files; c->folders = lcab->folders; }
+  for (c = lcab->nextcab; c; c = c->nextcab) { c->files = lcab->files; c->folders = lcab->folders; }
+  return self->error = MSPACK_ERR_OK;
+}
+
+static int cabd_append(struct mscab_decompressor *base, struct mscabd_cabinet *cab, struct mscabd_cabinet *nextcab) {
+  return cabd_merge(base, cab, nextcab);
+}
+static int cabd_prepend(struct mscab_decompressor *base, struct mscabd_cabinet *cab, struct mscabd_cabinet *prevcab) {
+  return cabd_merge(base, prevcab, cab);
+}
+
+/* ---- the CFDATA block reader (reference cabd.c:1362-1459) ----------------------------------------------- */
+#define CAB_INPUTBUF (CAB_INPUTMAX_SALVAGE + 8u)
+
+static void reader_close(struct cabd_p *self, struct blk_reader *r) {
+  if (r->fh) self->system->close(r->fh);
+  self->system->free(r->input);
+  memset(r, 0, sizeof(*r));
+}
+
+/* start reading a folder's blocks: MSPACK_ERR_OPEN / SEEK / NOMEMORY as extract() reports them */
+static int reader_open(struct cabd_p *self, struct blk_reader *r, struct folder_p *fol) {
+  struct mspack_system *sys = self->system;
+  memset(r, 0, sizeof(*r));
+  r->folder = fol; r->seg = &fol->data;
+  if (!(r->input = (unsigned char *) sys->alloc(sys, CAB_INPUTBUF))) return MSPACK_ERR_NOMEMORY;
+  if (!(r->fh = sys->open(sys, r->seg->cab->base.filename, MSPACK_SYS_OPEN_READ))) { reader_close(self, r); return MSPACK_ERR_OPEN; }
+  if (sys->seek(r->fh, r->seg->offset, MSPACK_SYS_SEEK_START)) { reader_close(self, r); return MSPACK_ERR_SEEK; }
+  return MSPACK_ERR_OK;
+}
+
+/* read one block into r->input[0, i_end), reassembling a block that is split over the cabinets of a set
+ * (a part with uncompressed size 0 continues as the first block of the next cabinet).  On failure the
+ * parts read so far STAY in the buffer, as in the reference. */
+static int reader_block(struct cabd_p *self, struct blk_reader *r, unsigned int *ulen_out,
+                        int ignore_cksum, int ignore_size)
+{
+  struct mspack_system *sys = self->system;
+  r->i_ptr = r->i_end = 0;
+  for (;;) {
+    unsigned char hdr[8];
+    unsigned int len, ulen, cksum, full;
+    if (sys->read(r->fh, hdr, 8) != 8) return MSPACK_ERR_READ;
+    if (r->seg->cab->block_resv && sys->seek(r->fh, (off_t) r->seg->cab->block_resv, MSPACK_SYS_SEEK_CUR)) return MSPACK_ERR_SEEK;
+    len = rd_le16(hdr + 4); ulen = rd_le16(hdr + 6);
+    full = r->i_end + len;
+    if (full > CAB_INPUTMAX && (!ignore_size || full > CAB_INPUTMAX_SALVAGE)) return MSPACK_ERR_DATAFORMAT;
+    if (ulen > CAB_BLOCKMAX && !ignore_size) return MSPACK_ERR_DATAFORMAT;
+    if (sys->read(r->fh, r->input + r->i_end, (int) len) != (int) len) return MSPACK_ERR_READ;
+    if ((cksum = rd_le32(hdr))) {                         /* every part carries its own checksum */
+      unsigned int sum = cab_checksum(r->input + r->i_end, len, 0);
+      if (cab_checksum(hdr + 4, 4, sum) != cksum) {
+        if (!ignore_cksum) return MSPACK_ERR_CHECKSUM;
+        sys->message(r->fh, "WARNING; bad block checksum found");
+      }
+    }
+    r->i_end += len;
+    if (ulen) { *ulen_out = ulen; return MSPACK_ERR_OK; }
+    sys->close(r->fh); r->fh = NULL;
+    if (!(r->seg = r->seg->next)) {
+      sys->message(NULL, "WARNING; ran out of cabinets in set. Are any missing?");
+      return MSPACK_ERR_DATAFORMAT;
+    }
+    if (!(r->fh = sys->open(sys, r->seg->cab->base.filename, MSPACK_SYS_OPEN_READ))) return MSPACK_ERR_OPEN;
+    if (sys->seek(r->fh, r->seg->offset, MSPACK_SYS_SEEK_START)) return MSPACK_ERR_SEEK;
+  }
+}
+
+/* ---- stored folders: streamed (reference cabd.c:1283-1345 + noned_decompress 1530-1541) --------------- */
+static void stored_reset(struct cabd_p *self) {
+  if (self->st_active) reader_close(self, &self->st);
+  self->st_active = 0; self->st_offset = 0;
+}
+
+/* the feeder as the "codec" sees it: returns the bytes delivered, -1 after a block error */
+static int stored_read(struct cabd_p *self, unsigned char *buf, int bytes) {
+  struct blk_reader *r = &self->st;
+  int todo = bytes;
+  while (todo > 0) {
+    unsigned int avail = r->i_end - r->i_ptr;
+    if (avail) {
+      if (avail > (unsigned int) todo) avail = (unsigned int) todo;
+      self->system->copy(r->input + r->i_ptr, buf, avail);
+      r->i_ptr += avail; buf += avail; todo -= (int) avail;
+    }
+    else {
+      unsigned int ulen;
+      if (r->block++ >= r->folder->base.num_blocks) {     /* out of blocks */
+        if (!self->salvage) self->read_error = MSPACK_ERR_DATAFORMAT;
+        break;
+      }
+      if (!r->fh) { self->read_error = MSPACK_ERR_READ; return -1; }   /* the chain already broke */
+      self->read_error = reader_block(self, r, &ulen, self->salvage, self->salvage);
+      if (self->read_error) return -1;
+    }
+  }
+  return bytes - todo;
+}
+
+/* produce `bytes` more bytes of the folder; out == NULL skips (the offset still advances) */
+static int stored_run(struct cabd_p *self, unsigned int bytes, struct mspack_file *out, unsigned char *buf) {
+  while (bytes > 0) {
+    int run = (bytes > (unsigned int) self->buf_size) ? self->buf_size : (int) bytes;
+    if (stored_read(self, buf, run) != run) return MSPACK_ERR_READ;
+    self->st_offset += (unsigned int) run;
+    if (out && self->system->write(out, buf, run) != run) return MSPACK_ERR_WRITE;
+    bytes -= (unsigned int) run;
+  }
+  return MSPACK_ERR_OK;
+}
+
+static int stored_extract(struct cabd_p *self, struct folder_p *fol, struct mscabd_file *file,
+                          unsigned int filelen, const char *filename)
+{
+  struct mspack_system *sys = self->system;
+  struct mspack_file *fh;
+  unsigned char *buf;
+  if (!self->st_active || self->st.folder != fol || self->st_offset > file->offset) {
+    int err;
+    stored_reset(self);
+    if ((err = reader_open(self, &self->st, fol))) return self->error = err;
+    self->st_active = 1; self->st_offset = 0;
+    self->read_error = MSPACK_ERR_OK;                     /* lasts for the lifetime of a decompressor */
+  }
+  if (!(fh = sys->open(sys, filename, MSPACK_SYS_OPEN_WRITE))) return self->error = MSPACK_ERR_OPEN;
+  self->error = MSPACK_ERR_OK;
+  if (filelen) {
+    if (!(buf = (unsigned char *) sys->alloc(sys, (size_t) self->buf_size))) self->error = MSPACK_ERR_NOMEMORY;
+    else {
+      int err = MSPACK_ERR_OK;
+      if (file->offset > self->st_offset) err = stored_run(self, file->offset - self->st_offset, NULL, buf);
+      self->error = (err == MSPACK_ERR_READ) ? self->read_error : err;
+      if (!self->error) {
+        err = stored_run(self, filelen, fh, buf);
+        self->error = (err == MSPACK_ERR_READ) ? self->read_error : err;
+      }
+      sys->free(buf);
     }
   }
   sys->close(fh);
-  sys->free(buf);
-  return head;
-}
-
-static int cabd_merge_unsupported(struct mscab_decompressor *base, struct mscabd_cabinet *a, struct mscabd_cabinet *b)
-{
-  struct cabd_p *self = (struct cabd_p *) base;
-  (void) a; (void) b;
-  if (!self) return MSPACK_ERR_ARGS;
-  self->system->message(NULL, "cabinet sets (append/prepend) are not supported by this build yet");
-  return self->error = MSPACK_ERR_ARGS;
+  return self->error;
 }
 
 /* ---- gather + batch decode ------------------------------------------------------------------------------ */
@@ -332,56 +642,46 @@ struct gathered {
   int read_err; int hard_eof;
 };
 
-/* walk the CFDATA chain of one folder (reference cabd.c:1283-1345 + 1362-1459) */
-static int gather_folder(struct cabd_p *self, struct mspack_file *fh, struct gathered *g)
+/* walk the CFDATA chain of one folder (reference cabd.c:1283-1345 + 1362-1459), following it through
+ * the cabinets of a set.  Returns MSPACK_ERR_OPEN / SEEK / NOMEMORY when nothing could be started;
+ * every later failure ends the chain and is recorded as the feeder's error (g->read_err, g->hard_eof). */
+static int gather_folder(struct cabd_p *self, struct gathered *g)
 {
   struct mspack_system *sys = self->system;
   struct folder_p *fol = g->fol;
+  struct blk_reader r;
   const int method = fol->base.comp_type & 0x0F;
   const int ignore_cksum = self->salvage || (self->fix_mszip && method == MSCAB_COMP_MSZIP);
   const int ignore_size = self->salvage;
-  unsigned int b;
+  int err;
   g->len = 0; g->total = 0; g->read_err = MSPACK_ERR_OK; g->hard_eof = 0;
   g->cap = (size_t) fol->base.num_blocks * 1024 + 65536;
-  if (!(g->stream = (unsigned char *) sys->alloc(sys, g->cap + 64))) return MSPACK_ERR_NOMEMORY;
-  if (sys->seek(fh, fol->data_offset, MSPACK_SYS_SEEK_START)) { g->read_err = MSPACK_ERR_SEEK; g->hard_eof = 1; return MSPACK_ERR_OK; }
-  for (b = 0; b < fol->base.num_blocks; b++) {
-    unsigned char hdr[8];
-    unsigned int len, ulen, cksum;
-    int err = MSPACK_ERR_OK;
-    if (sys->read(fh, hdr, 8) != 8) err = MSPACK_ERR_READ;
-    else if (fol->cab->block_resv && sys->seek(fh, (off_t) fol->cab->block_resv, MSPACK_SYS_SEEK_CUR)) err = MSPACK_ERR_SEEK;
-    if (!err) {
-      len = rd_le16(hdr + 4); ulen = rd_le16(hdr + 6);
-      if (len > CAB_INPUTMAX && (!ignore_size || len > CAB_INPUTMAX_SALVAGE)) err = MSPACK_ERR_DATAFORMAT;
-      else if (ulen > CAB_BLOCKMAX && !ignore_size) err = MSPACK_ERR_DATAFORMAT;
+  g->stream = NULL;
+  if ((err = reader_open(self, &r, fol))) {
+    if (err != MSPACK_ERR_SEEK) return err;
+    /* the reference fails extract() with SEEK before any decoding; keep it as this folder's error */
+    if (!(g->stream = (unsigned char *) sys->alloc(sys, 64))) return MSPACK_ERR_NOMEMORY;
+    memset(g->stream, 0, 64);
+    g->read_err = MSPACK_ERR_SEEK; g->hard_eof = 1;
+    return MSPACK_ERR_OK;
+  }
+  if (!(g->stream = (unsigned char *) sys->alloc(sys, g->cap + 64))) { reader_close(self, &r); return MSPACK_ERR_NOMEMORY; }
+  while (r.block < fol->base.num_blocks) {
+    unsigned int ulen = 0;
+    r.block++;
+    if ((err = reader_block(self, &r, &ulen, ignore_cksum, ignore_size))) { g->read_err = err; g->hard_eof = 1; break; }
+    if (g->len + r.i_end + 1 > g->cap) {
+      size_t ncap = (g->cap + r.i_end + 1) * 2;
+      unsigned char *n = (unsigned char *) sys->alloc(sys, ncap + 64);
+      if (!n) { sys->free(g->stream); g->stream = NULL; reader_close(self, &r); return MSPACK_ERR_NOMEMORY; }
+      sys->copy(g->stream, n, g->len); sys->free(g->stream); g->stream = n; g->cap = ncap;
     }
-    if (!err) {
-      if (g->len + len + 1 > g->cap) {
-        size_t ncap = (g->cap + len + 1) * 2;
-        unsigned char *n = (unsigned char *) sys->alloc(sys, ncap + 64);
-        if (!n) { sys->free(g->stream); g->stream = NULL; return MSPACK_ERR_NOMEMORY; }
-        sys->copy(g->stream, n, g->len); sys->free(g->stream); g->stream = n; g->cap = ncap;
-      }
-      if (sys->read(fh, g->stream + g->len, (int) len) != (int) len) err = MSPACK_ERR_READ;
-    }
-    if (!err && (cksum = rd_le32(hdr))) {
-      unsigned int sum = cab_checksum(g->stream + g->len, len, 0);
-      if (cab_checksum(hdr + 4, 4, sum) != cksum) {
-        if (!ignore_cksum) err = MSPACK_ERR_CHECKSUM;
-        else sys->message(fh, "WARNING; bad block checksum found");
-      }
-    }
-    if (!err && ulen == 0) {
-      /* a block split over the next cabinet of a set: sets are not supported yet */
-      sys->message(fh, "WARNING; ran out of cabinets in set. Are any missing?");
-      err = MSPACK_ERR_DATAFORMAT;
-    }
-    if (err) { g->read_err = err; g->hard_eof = 1; break; }
-    g->len += len;
+    sys->copy(r.input, g->stream + g->len, r.i_end);
+    g->len += r.i_end;
     if (method == MSCAB_COMP_QUANTUM) g->stream[g->len++] = 0xFF;
     g->total += ulen;
   }
+  reader_close(self, &r);
   if (!g->hard_eof) g->read_err = self->salvage ? MSPACK_ERR_OK : MSPACK_ERR_DATAFORMAT;  /* ran out of blocks */
   else {
     /* the codec pulls buf_size bytes per read; a read that reaches the bad block fails as a whole,
@@ -397,7 +697,6 @@ static int gather_folder(struct cabd_p *self, struct mspack_file *fh, struct gat
 static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_p *want)
 {
   struct mspack_system *sys = self->system;
-  struct mspack_file *fh;
   struct mscabd_folder *fo;
   struct gathered *gs;
   mspack_hip_unit *units;
@@ -411,21 +710,20 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   units = (mspack_hip_unit *) sys->alloc(sys, n * sizeof(*units));
   res = (mspack_hip_result *) sys->alloc(sys, n * sizeof(*res));
   if (!gs || !units || !res) { sys->free(gs); sys->free(units); sys->free(res); return MSPACK_ERR_NOMEMORY; }
-  if (!(fh = sys->open(sys, cab->base.filename, MSPACK_SYS_OPEN_READ))) {
-    sys->free(gs); sys->free(units); sys->free(res); return MSPACK_ERR_OPEN;
-  }
   n = 0;
   for (fo = cab->base.folders; fo; fo = fo->next) {
     struct folder_p *fp = (struct folder_p *) fo;
     size_t est = (size_t) fo->num_blocks * CAB_BLOCKMAX;
     if (fp->decoded) continue;
+    if ((fo->comp_type & 0x0F) == MSCAB_COMP_NONE || fp->merge_prev) continue;   /* streamed / not extractable */
     if (fp != want && used + est > budget) continue;
-    used += est;
     gs[n].fol = fp;
-    if ((err = gather_folder(self, fh, &gs[n]))) break;
+    err = gather_folder(self, &gs[n]);
+    if (err == MSPACK_ERR_OPEN && fp != want) { err = MSPACK_ERR_OK; continue; }   /* that folder stays undecoded */
+    if (err) break;
+    used += est;
     n++;
   }
-  sys->close(fh);
   if (err) { for (k = 0; k < n; k++) sys->free(gs[k].stream); sys->free(gs); sys->free(units); sys->free(res); return err; }
 
   /* lay the units out in two arenas */
@@ -451,7 +749,6 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     size_t nhip = 0;
     memset(in_arena, 0, in_bytes + 64);
     for (k = 0; k < n; k++) sys->copy(gs[k].stream, in_arena + units[k].in_off, gs[k].len);
-    /* stored folders need no codec: their payloads ARE the data (cabd.c:1505-1556) */
     for (k = 0; k < n; k++) if (units[k].kind >= 1 && units[k].kind <= 3) nhip++;
     memset(res, 0, n * sizeof(*res));
     if (nhip) {
@@ -471,14 +768,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
       int method = fp->base.comp_type & 0x0F;
       fp->total = gs[k].total; fp->read_err = gs[k].read_err; fp->hard_eof = gs[k].hard_eof;
       if (!(fp->dec = (unsigned char *) sys->alloc(sys, (size_t) gs[k].total + 1))) { err = MSPACK_ERR_NOMEMORY; break; }
-      if (method == MSCAB_COMP_NONE) {
-        size_t m = gs[k].len < gs[k].total ? gs[k].len : gs[k].total;
-        sys->copy(gs[k].stream, fp->dec, m);
-        fp->good_len = (unsigned int) m;
-        fp->dec_err = (m == gs[k].total && !gs[k].hard_eof) ? MSPACK_ERR_OK : MSPACK_ERR_READ;
-        fp->res_flags = 0;
-      }
-      else if (method >= 1 && method <= 3) {
+      if (method >= 1 && method <= 3) {
         unsigned int g = res[k].good_len > gs[k].total ? gs[k].total : res[k].good_len;
         sys->copy(out_arena + units[k].out_off, fp->dec, g);
         fp->good_len = g; fp->dec_err = res[k].err; fp->res_flags = res[k].flags;
@@ -560,8 +850,13 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
       return self->error = MSPACK_ERR_NOMEMORY;
   }
 
+  /* one decompression state per decompressor: another folder ends the stored folder's stream */
+  if (self->last_folder != fol) stored_reset(self);
+  self->last_folder = fol;
+  if ((fol->base.comp_type & 0x0F) == MSCAB_COMP_NONE) return stored_extract(self, fol, file, filelen, filename);
+
   if (!fol->decoded) {
-    int err = decode_cabinet(self, fol->cab, fol);
+    int err = decode_cabinet(self, (struct cab_p *) fol->data.cab, fol);
     if (err) return self->error = err;
   }
   self->read_error = fol->read_err;
@@ -615,19 +910,20 @@ struct mscab_decompressor *mspack_create_cab_decompressor(struct mspack_system *
   self->base.close = &cabd_close;
   self->base.search = &cabd_search;
   self->base.extract = &cabd_extract;
-  self->base.prepend = &cabd_merge_unsupported;
-  self->base.append = &cabd_merge_unsupported;
+  self->base.prepend = &cabd_prepend;
+  self->base.append = &cabd_append;
   self->base.set_param = &cabd_param;
   self->base.last_error = &cabd_error;
   self->system = sys;
   self->error = MSPACK_ERR_OK; self->read_error = MSPACK_ERR_OK;
   self->searchbuf_size = 32768; self->fix_mszip = 0; self->buf_size = 4096; self->salvage = 0;
   self->devices = 1; self->cache_mb = 2048;
+  memset(&self->st, 0, sizeof(self->st)); self->st_offset = 0; self->st_active = 0; self->last_folder = NULL;
   return &self->base;
 }
 
 void mspack_destroy_cab_decompressor(struct mscab_decompressor *base)
 {
   struct cabd_p *self = (struct cabd_p *) base;
-  if (self) self->system->free(self);
+  if (self) { stored_reset(self); self->system->free(self); }
 }

@@ -235,6 +235,94 @@ int refh_cab_extract(const uint8_t *cab, size_t cab_len, const int *order, int n
   return MSPACK_ERR_OK;
 }
 
+/* ---- cabinet sets: open several cabinets, join them, list and extract (cabd.c:870-1064) ----------- */
+/* ops = n_ops triples (op, a, b): op 0 = append(cab[a], cab[b]), 1 = prepend(cab[a], cab[b]); an index
+ * of -1 passes NULL.  op_errs[i] = return code of op i.  Then the file list of cab[list_cab] is
+ * reported (names, lengths, offsets, comp types, folder ordinals) and every listed file is extracted
+ * in order with ONE decompressor.  Returns the number of files, or -err when a cabinet does not open. */
+int refh_cabset(const uint8_t **cabs, const size_t *lens, int n_cabs, const int *ops, int n_ops, int *op_errs,
+                int list_cab, int cap, unsigned *lengths, unsigned *offsets, int *comp_types, int *folder_ids,
+                unsigned *folder_blocks, char *names, int name_stride,
+                uint8_t *out, size_t out_cap, size_t *out_offs, size_t *out_lens, int *errs)
+{
+  struct memname src[16];
+  struct mscabd_cabinet *c[16];
+  struct mscab_decompressor *d = mspack_create_cab_decompressor(&mem_system);
+  struct mscabd_file *f;
+  struct mscabd_folder *fol;
+  size_t pos = 0;
+  int i, n = 0;
+  if (!d || n_cabs > 16) return -MSPACK_ERR_ARGS;
+  for (i = 0; i < n_cabs; i++) {
+    src[i].magic = MEMNAME_MAGIC; src[i].data = (uint8_t *) cabs[i]; src[i].len = lens[i]; src[i].written = 0;
+    c[i] = d->open(d, (const char *) &src[i]);
+    if (!c[i]) { n = -d->last_error(d); mspack_destroy_cab_decompressor(d); return n ? n : -MSPACK_ERR_OPEN; }
+  }
+  for (i = 0; i < n_ops; i++) {
+    struct mscabd_cabinet *a = ops[3 * i + 1] < 0 ? NULL : c[ops[3 * i + 1]];
+    struct mscabd_cabinet *b = ops[3 * i + 2] < 0 ? NULL : c[ops[3 * i + 2]];
+    op_errs[i] = ops[3 * i] ? d->prepend(d, a, b) : d->append(d, a, b);
+  }
+  for (f = c[list_cab]->files; f; f = f->next, n++) {
+    if (n < cap) {
+      int fid = 0;
+      struct memname dst = { MEMNAME_MAGIC, out ? out + pos : NULL, out ? out_cap - pos : 0, 0 };
+      for (fol = c[list_cab]->folders; fol && fol != f->folder; fol = fol->next) fid++;
+      lengths[n] = f->length; offsets[n] = f->offset;
+      comp_types[n] = f->folder ? f->folder->comp_type : -1;
+      folder_ids[n] = fid;
+      folder_blocks[n] = f->folder ? f->folder->num_blocks : 0;
+      strncpy(names + (size_t) n * name_stride, f->filename, name_stride - 1);
+      names[(size_t) n * name_stride + name_stride - 1] = 0;
+      errs[n] = d->extract(d, f, (const char *) &dst);
+      out_offs[n] = pos; out_lens[n] = dst.written;
+      pos += dst.written < (out_cap - pos) ? dst.written : (out_cap - pos);
+    }
+  }
+  /* cabinets that ended up joined are freed with the one they were joined to */
+  for (i = 0; i < n_cabs; i++) {
+    int j, dup = 0;
+    struct mscabd_cabinet *w;
+    if (!c[i]) continue;
+    for (j = 0; j < i && !dup; j++) {
+      if (!c[j]) continue;
+      for (w = c[j]; w && !dup; w = w->prevcab) if (w == c[i]) dup = 1;
+      for (w = c[j]; w && !dup; w = w->nextcab) if (w == c[i]) dup = 1;
+    }
+    if (dup) c[i] = NULL;
+  }
+  for (i = 0; i < n_cabs; i++) if (c[i]) d->close(d, c[i]);
+  mspack_destroy_cab_decompressor(d);
+  return n;
+}
+
+/* search(): base offsets, file counts and first file names of the cabinets found in a blob */
+int refh_cab_search(const uint8_t *blob, size_t blob_len, int searchbuf, int cap, long long *base_offsets,
+                    int *n_files, char *first_names, int name_stride)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) blob, blob_len, 0 };
+  struct mscab_decompressor *d = mspack_create_cab_decompressor(&mem_system);
+  struct mscabd_cabinet *c, *head;
+  int n = 0;
+  if (!d) return -MSPACK_ERR_NOMEMORY;
+  if (searchbuf > 0) d->set_param(d, MSCABD_PARAM_SEARCHBUF, searchbuf);
+  head = d->search(d, (const char *) &src);
+  if (!head && d->last_error(d)) { n = -d->last_error(d); mspack_destroy_cab_decompressor(d); return n; }
+  for (c = head; c; c = c->next, n++) {
+    if (n < cap) {
+      struct mscabd_file *f;
+      int k = 0;
+      for (f = c->files; f; f = f->next) k++;
+      base_offsets[n] = (long long) c->base_offset; n_files[n] = k;
+      strncpy(first_names + (size_t) n * name_stride, c->files ? c->files->filename : "", name_stride - 1);
+      first_names[(size_t) n * name_stride + name_stride - 1] = 0;
+    }
+  }
+  if (head) d->close(d, head);
+  mspack_destroy_cab_decompressor(d);
+  return n;
+}
+
 int refh_chm_list(const uint8_t *chm, size_t chm_len, int cap, long long *lengths,
                   long long *offsets, int *sections, char *names, int name_stride)
 {

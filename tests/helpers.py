@@ -105,6 +105,12 @@ def ref():
                                       C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.c_char_p, C.c_int]
         lib.refh_chm_extract.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.c_void_p,
                                          C.c_size_t, sz, sz, C.POINTER(C.c_int)]
+        lib.refh_cabset.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_int), C.c_int,
+                                    C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint),
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint), C.c_char_p, C.c_int,
+                                    C.c_void_p, C.c_size_t, sz, sz, C.POINTER(C.c_int)]
+        lib.refh_cab_search.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_longlong),
+                                        C.POINTER(C.c_int), C.c_char_p, C.c_int]
         lib.refh_bench.restype = C.c_double
         lib.refh_bench.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
@@ -160,6 +166,37 @@ def ref_cab_extract(cab, order, cap=1 << 26, fix_mszip=0, salvage=0):
     if rc:
         return rc, []
     return 0, [(errs[i], buf.raw[offs[i]:offs[i] + min(lens[i], cap - offs[i])]) for i in range(n)]
+
+
+def ref_cabset(blobs, ops, list_cab, cap=1 << 24, maxfiles=256):
+    """Reference: open the cabinets, run the join ops [(0 append | 1 prepend, a, b)], list cab[list_cab] and
+    extract every file.  -> (n_files or -err, [op return codes], [file dicts incl. err and data])"""
+    n = len(blobs)
+    arr = (C.c_char_p * n)(*blobs)
+    lens = (C.c_size_t * n)(*[len(b) for b in blobs])
+    flat = [x for op in ops for x in op]
+    opa = (C.c_int * max(len(flat), 1))(*flat)
+    operr = (C.c_int * max(len(ops), 1))()
+    ln = (C.c_uint * maxfiles)(); of = (C.c_uint * maxfiles)(); ct = (C.c_int * maxfiles)(); fid = (C.c_int * maxfiles)()
+    fb = (C.c_uint * maxfiles)(); names = C.create_string_buffer(maxfiles * 64)
+    buf = C.create_string_buffer(cap)
+    offs = (C.c_size_t * maxfiles)(); outl = (C.c_size_t * maxfiles)(); errs = (C.c_int * maxfiles)()
+    k = ref().refh_cabset(arr, lens, n, opa, len(ops), operr, list_cab, maxfiles, ln, of, ct, fid, fb, names, 64,
+                          buf, cap, offs, outl, errs)
+    files = []
+    for i in range(max(min(k, maxfiles), 0)):
+        files.append(dict(name=names.raw[i * 64:(i + 1) * 64].split(b"\0")[0], length=ln[i], offset=of[i],
+                          comp_type=ct[i], folder=fid[i], folder_blocks=fb[i], err=errs[i],
+                          data=buf.raw[offs[i]:offs[i] + min(outl[i], cap - offs[i])]))
+    return k, [operr[i] for i in range(len(ops))], files
+
+
+def ref_cab_search(blob, searchbuf=0, cap=64):
+    offs = (C.c_longlong * cap)(); nf = (C.c_int * cap)(); names = C.create_string_buffer(cap * 64)
+    k = ref().refh_cab_search(blob, len(blob), searchbuf, cap, offs, nf, names, 64)
+    if k < 0:
+        return k
+    return [(offs[i], nf[i], names.raw[i * 64:(i + 1) * 64].split(b"\0")[0]) for i in range(min(k, cap))]
 
 
 def ref_chm_list(chm):
