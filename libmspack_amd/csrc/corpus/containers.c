@@ -93,7 +93,7 @@ static const char n_spaninfo[] = "::DataSpace/Storage/MSCompressed/SpanInfo";
 static const char n_rtable[]   = "::DataSpace/Storage/MSCompressed/Transform/{7FC28940-9D31-11D0-9B27-00A0C91E9C7C}/InstanceData/ResetTable";
 
 size_t mspk_chm_bound(size_t lzx_len, size_t n_frames, int n_files) {
-  return lzx_len + n_frames * 8 + (size_t) n_files * 96 + 65536 + ((size_t) n_files / 30 + 4) * 4096;
+  return lzx_len + n_frames * 8 + (size_t) n_files * 96 + 65536 + ((size_t) n_files / 20 + 8) * 4096;
 }
 
 size_t mspk_chm_write(const uint8_t *lzx, size_t lzx_len, const uint64_t *frame_off, size_t n_frames,
@@ -105,7 +105,8 @@ size_t mspk_chm_write(const uint8_t *lzx, size_t lzx_len, const uint64_t *frame_
     0x11, 0xFD, 0x01, 0x7C, 0xAA, 0x7B, 0xD0, 0x11, 0x9E, 0x0C, 0x00, 0xA0, 0xC9, 0x22, 0xE6, 0xEC };
   static const uint8_t itsp_guid[16] = { 0x6A, 0x92, 0x02, 0x5D, 0x2E, 0x21, 0xD0, 0x11, 0x9D, 0xF9, 0x00, 0xA0, 0xC9, 0x22, 0xE6, 0xEC };
   const size_t CHUNK = 4096;
-  int n_ent = n_files + 4, i, n_chunks = 0;
+  int n_ent = n_files + 4, i, n_chunks = 0, n_pmgl = 0, depth = 1;
+  uint32_t index_root = 0xFFFFFFFFu;
   dirent_t *ents = (dirent_t *) calloc((size_t) n_ent, sizeof(*ents));
   uint8_t *chunks = NULL;
   size_t rt_len = 0x28 + n_frames * 8, sec0_len, dir_off = 0x78 + 0x54, sec0_off, pos, total;
@@ -121,7 +122,7 @@ size_t mspk_chm_write(const uint8_t *lzx, size_t lzx_len, const uint64_t *frame_
   qsort(ents, (size_t) n_ent, sizeof(*ents), ci_cmp);
 
   /* PMGL chunks */
-  chunks = (uint8_t *) calloc(((size_t) n_ent / 8 + 2), CHUNK);
+  chunks = (uint8_t *) calloc(((size_t) n_ent / 8 + 2) * 2 + 4, CHUNK);
   {
     int e = 0;
     while (e < n_ent) {
@@ -152,6 +153,43 @@ size_t mspk_chm_write(const uint8_t *lzx, size_t lzx_len, const uint64_t *frame_
       n_chunks++;
     }
   }
+  /* PMGI index levels over more than one PMGL chunk (chmd.c:560-598, 700-840): an entry is
+   * (first name of a child chunk, child chunk number); levels are stacked until one chunk remains */
+  {
+    int lvl_first = 0, lvl_count = n_chunks;
+    n_pmgl = n_chunks;
+    while (lvl_count > 1) {
+      int child = lvl_first, next_first = n_chunks;
+      while (child < lvl_first + lvl_count) {
+        uint8_t *c = chunks + (size_t) n_chunks * CHUNK;
+        size_t p = 8;
+        int cnt = 0;
+        uint16_t qr[1024]; int nqr = 0;
+        memcpy(c, "PMGI", 4);
+        while (child < lvl_first + lvl_count) {
+          /* first name of the child: its first entry (PMGL at 0x14, PMGI at 8) */
+          const uint8_t *cc = chunks + (size_t) child * CHUNK;
+          const uint8_t *q = cc + (cc[3] == 'L' ? 0x14 : 8);
+          size_t nl = 0, k = 0;
+          do { nl = (nl << 7) | (q[k] & 0x7F); } while (q[k++] & 0x80);
+          size_t need = nl + 2 + 5, qr_bytes = 2 + 2 * (size_t)((cnt + 1 + 4) / 5);
+          if (p + need + qr_bytes + 8 > CHUNK) break;
+          if (cnt && (cnt % 5) == 0) qr[nqr++] = (uint16_t)(p - 8);
+          p += put_encint(c + p, nl);
+          memcpy(c + p, q + k, nl); p += nl;
+          p += put_encint(c + p, (uint64_t) child);
+          cnt++; child++;
+        }
+        w16(c + CHUNK - 2, (unsigned) cnt);
+        for (i = 0; i < nqr; i++) w16(c + CHUNK - 2 - 2 * (size_t)(i + 1), qr[i]);
+        w32(c + 4, (uint32_t)(2 + 2 * (size_t) nqr));
+        n_chunks++;
+      }
+      lvl_first = next_first; lvl_count = n_chunks - next_first;
+      depth++;
+    }
+    if (depth > 1) index_root = (uint32_t)(n_chunks - 1);
+  }
   sec0_off = dir_off + (size_t) n_chunks * CHUNK;
   total = sec0_off + sec0_len;
   if (total > cap) { free(ents); free(chunks); return 0; }
@@ -167,8 +205,8 @@ size_t mspk_chm_write(const uint8_t *lzx, size_t lzx_len, const uint64_t *frame_
   /* header section 1 = ITSP + chunks */
   pos = 0x78;
   memcpy(dst + pos, "ITSP", 4); w32(dst + pos + 4, 1); w32(dst + pos + 8, 0x54); w32(dst + pos + 0x0C, 0x0A);
-  w32(dst + pos + 0x10, (uint32_t) CHUNK); w32(dst + pos + 0x14, 2); w32(dst + pos + 0x18, 1);
-  w32(dst + pos + 0x1C, 0xFFFFFFFFu); w32(dst + pos + 0x20, 0); w32(dst + pos + 0x24, (uint32_t)(n_chunks - 1));
+  w32(dst + pos + 0x10, (uint32_t) CHUNK); w32(dst + pos + 0x14, 2); w32(dst + pos + 0x18, (uint32_t) depth);
+  w32(dst + pos + 0x1C, index_root); w32(dst + pos + 0x20, 0); w32(dst + pos + 0x24, (uint32_t)(n_pmgl - 1));
   w32(dst + pos + 0x28, 0xFFFFFFFFu); w32(dst + pos + 0x2C, (uint32_t) n_chunks); w32(dst + pos + 0x30, 0x409);
   memcpy(dst + pos + 0x34, itsp_guid, 16); w32(dst + pos + 0x44, 0x54);
   w32(dst + pos + 0x48, 0xFFFFFFFFu); w32(dst + pos + 0x4C, 0xFFFFFFFFu); w32(dst + pos + 0x50, 0xFFFFFFFFu);

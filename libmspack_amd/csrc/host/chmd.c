@@ -12,8 +12,8 @@
  * (virtual start / position), because it decides (a) which frames' errors a request sees and (b) the
  * origin of the E8 translation (lzxd.c:712 uses bytes since lzxd_init): intervals whose header asks
  * for E8 are re-decoded with the origin the reference would have had.
- * Simplified: fast_find walks the PMGL chain linearly and compares names
- * ASCII-case-insensitively instead of using the PMGI index and the UTF-8 folding of chmd.c:738-898.
+ * fast_find follows the reference: PMGI index descent, quick-reference binary
+ * search inside a chunk, UTF-8 case-folded name order (chmd.c:543-898).
  */
 #include <stdlib.h>
 #include <stdio.h>
@@ -208,8 +208,12 @@ static struct mschmd_header *open_common(struct mschm_decompressor *base, const 
     c->base.filename = filename;
     err = read_headers(sys, fh, &c->base, entire);
     if (err) {
-      /* like the reference: a badly encoded directory still yields what was read (chmd.c:206-214) */
-      if (c->base.files) sys->message(fh, "WARNING; contents are corrupt");
+      /* like the reference: a badly encoded directory that yielded SOME entries is returned with a
+       * warning and no error (chmd.c:166-176) */
+      if (err == MSPACK_ERR_DATAFORMAT && (c->base.files || c->base.sysfiles)) {
+        sys->message(fh, "WARNING; contents are corrupt");
+        err = MSPACK_ERR_OK;
+      }
       else { chmd_close(base, &c->base); c = NULL; }
     }
     self->error = err;
@@ -221,17 +225,126 @@ static struct mschmd_header *open_common(struct mschm_decompressor *base, const 
 static struct mschmd_header *chmd_open(struct mschm_decompressor *b, const char *f) { return open_common(b, f, 1); }
 static struct mschmd_header *chmd_fast_open(struct mschm_decompressor *b, const char *f) { return open_common(b, f, 0); }
 
-/* ---- fast_find: linear walk of the PMGL chain (see file header) ------------------------------------- */
-static int name_equal(const unsigned char *a, unsigned int alen, const char *b) {
-  unsigned int i;
-  if (strlen(b) != alen) return 0;
-  for (i = 0; i < alen; i++) {
-    unsigned char x = a[i], y = (unsigned char) b[i];
-    if (x >= 'A' && x <= 'Z') x += 32;
-    if (y >= 'A' && y <= 'Z') y += 32;
-    if (x != y) return 0;
+/* ---- fast_find (reference chmd.c:543-898) --------------------------------------------------------------
+ * Descends the PMGI index (when the header names an index root) to the PMGL chunk that can hold the
+ * name, or walks the PMGL chain otherwise.  Inside a chunk: binary search over the quick-reference
+ * entries (one per 1 + 2^density directory entries), then a linear scan of that group.  Names compare
+ * as UTF-8 code points, case-insensitively through towlower(), lengths breaking ties -- the same
+ * order the directory is sorted in.  Chunks are cached in chm->chunk_cache. */
+#include <wctype.h>
+
+/* one UTF-8 character; never reads past e, does not check continuation bytes, lets some overlong
+ * forms through (chmd.c:861-880) */
+static int utf8_next(const unsigned char **s, const unsigned char *e) {
+  const unsigned char *p = *s;
+  unsigned int x = *p++;
+  int c;
+  if (x < 0x80) c = (int) x;
+  else if (x >= 0xC2 && x < 0xE0 && p < e) { c = (int)((x & 0x1F) << 6 | (p[0] & 0x3F)); p += 1; }
+  else if (x >= 0xE0 && x < 0xF0 && p + 1 < e) { c = (int)((x & 0x0F) << 12 | (p[0] & 0x3F) << 6 | (p[1] & 0x3F)); p += 2; }
+  else if (x >= 0xF0 && x <= 0xF5 && p + 2 < e) {
+    c = (int)((x & 0x07) << 18 | (p[0] & 0x3F) << 12 | (p[1] & 0x3F) << 6 | (p[2] & 0x3F));
+    if (c > 0x10FFFF) c = 0xFFFD;
+    p += 3;
   }
-  return 1;
+  else c = 0xFFFD;
+  *s = p;
+  return c;
+}
+
+static int name_compare(const char *s1, const char *s2, int l1, int l2) {
+  const unsigned char *p1 = (const unsigned char *) s1, *p2 = (const unsigned char *) s2;
+  const unsigned char *e1 = p1 + l1, *e2 = p2 + l2;
+  while (p1 < e1 && p2 < e2) {
+    int c1 = utf8_next(&p1, e1), c2 = utf8_next(&p2, e2);
+    if (c1 == c2) continue;
+    c1 = (int) towlower((wint_t) c1); c2 = (int) towlower((wint_t) c2);
+    if (c1 != c2) return c1 - c2;
+  }
+  return l1 - l2;
+}
+
+static unsigned char *read_chunk(struct chmd_p *self, struct mschmd_header *chm, struct mspack_file *fh, unsigned int n)
+{
+  struct mspack_system *sys = self->system;
+  unsigned char *buf;
+  if (n >= chm->num_chunks) return NULL;
+  if (!chm->chunk_cache) {
+    size_t size = sizeof(unsigned char *) * chm->num_chunks;
+    if (!(chm->chunk_cache = (unsigned char **) sys->alloc(sys, size))) { self->error = MSPACK_ERR_NOMEMORY; return NULL; }
+    memset(chm->chunk_cache, 0, size);
+  }
+  if (chm->chunk_cache[n]) return chm->chunk_cache[n];
+  if (!(buf = (unsigned char *) sys->alloc(sys, chm->chunk_size))) { self->error = MSPACK_ERR_NOMEMORY; return NULL; }
+  if (sys->seek(fh, chm->dir_offset + (off_t) n * (off_t) chm->chunk_size, MSPACK_SYS_SEEK_START)) {
+    self->error = MSPACK_ERR_SEEK; sys->free(buf); return NULL;
+  }
+  if (sys->read(fh, buf, (int) chm->chunk_size) != (int) chm->chunk_size) {
+    self->error = MSPACK_ERR_READ; sys->free(buf); return NULL;
+  }
+  if (!(buf[0] == 'P' && buf[1] == 'M' && buf[2] == 'G' && (buf[3] == 'L' || buf[3] == 'I'))) {
+    self->error = MSPACK_ERR_SEEK; sys->free(buf); return NULL;      /* the reference's code for it */
+  }
+  return chm->chunk_cache[n] = buf;
+}
+
+static void skip_encint(const unsigned char **p, const unsigned char *end) {
+  while (*p < end && (*(*p)++ & 0x80)) ;
+}
+
+/* -1 = malformed chunk, 0 = the name is not here, 1 = found: *res points at the entry's data (PMGL:
+ * section, offset, length; PMGI: the child chunk number of the last entry not above the name) */
+static int search_chunk(struct mschmd_header *chm, const unsigned char *chunk, const char *filename,
+                        const unsigned char **res, const unsigned char **res_end)
+{
+  const int is_pmgl = (chunk[3] == 'L');
+  const unsigned int entries_off = is_pmgl ? 0x14u : 8u;
+  const unsigned int fname_len = (unsigned int) strlen(filename);
+  const unsigned int qr_size = rd_le32(chunk + 4);
+  const unsigned char *start = chunk + chm->chunk_size - 2;      /* entry count; quick refs grow down from here */
+  const unsigned char *end = chunk + chm->chunk_size - qr_size;
+  unsigned int num_entries = rd_le16(start), qr_density = 1u + (1u << chm->density), qr_entries, name_len;
+  const unsigned char *p;
+  int cmp = 0, err = 0;
+
+  qr_entries = (num_entries + qr_density - 1) / qr_density;
+  if (num_entries == 0) return -1;
+  if (qr_size > chm->chunk_size) return -1;
+  *res_end = end;
+  if ((int) qr_entries * 2 > (int)(start - end)) qr_entries = 0;  /* more quick refs than room: do without */
+
+  if (qr_entries > 0) {
+    unsigned int L = 0, R = qr_entries - 1, M;
+    do {
+      M = (L + R) >> 1;
+      p = chunk + entries_off + (M ? rd_le16(start - (M << 1)) : 0);
+      name_len = (unsigned int) read_encint(&p, end, &err);
+      if (err || name_len > (unsigned int)(end - p)) return -1;
+      cmp = name_compare(filename, (const char *) p, (int) fname_len, (int) name_len);
+      if (cmp == 0) break;
+      else if (cmp < 0) { if (M) R = M - 1; else return 0; }
+      else L = M + 1;
+    } while (L <= R);
+    M = (L + R) >> 1;
+    if (cmp == 0) { *res = p + name_len; return 1; }
+    p = chunk + entries_off + (M ? rd_le16(start - (M << 1)) : 0);
+    num_entries -= M * qr_density;
+    if (num_entries > qr_density) num_entries = qr_density;
+  }
+  else p = chunk + entries_off;
+
+  *res = NULL;
+  while (num_entries-- > 0) {
+    name_len = (unsigned int) read_encint(&p, end, &err);
+    if (err || name_len > (unsigned int)(end - p)) return -1;
+    cmp = name_compare(filename, (const char *) p, (int) fname_len, (int) name_len);
+    p += name_len;
+    if (cmp == 0) { *res = p; return 1; }
+    if (cmp < 0) break;
+    if (is_pmgl) { skip_encint(&p, end); skip_encint(&p, end); skip_encint(&p, end); }
+    else { *res = p; skip_encint(&p, end); }
+  }
+  return is_pmgl ? 0 : (*res ? 1 : 0);
 }
 
 static int chmd_fast_find(struct mschm_decompressor *base, struct mschmd_header *chm, const char *filename,
@@ -240,46 +353,39 @@ static int chmd_fast_find(struct mschm_decompressor *base, struct mschmd_header 
   struct chmd_p *self = (struct chmd_p *) base;
   struct mspack_system *sys;
   struct mspack_file *fh;
-  unsigned char *chunk;
-  unsigned int n, visited = 0;
-  int err = MSPACK_ERR_OK, found = 0;
+  const unsigned char *chunk, *p = NULL, *end = NULL;
+  int err = MSPACK_ERR_OK, result = -1, e = 0;
+  unsigned int n;
   if (!self || !chm || !f_ptr || f_size != (int) sizeof(struct mschmd_file)) return MSPACK_ERR_ARGS;
   sys = self->system;
   memset(f_ptr, 0, sizeof(*f_ptr));
-  if (!(fh = sys->open(sys, chm->filename, MSPACK_SYS_OPEN_READ))) return self->error = MSPACK_ERR_OPEN;
-  if (!(chunk = (unsigned char *) sys->alloc(sys, chm->chunk_size))) { sys->close(fh); return self->error = MSPACK_ERR_NOMEMORY; }
-  for (n = chm->first_pmgl; n <= chm->last_pmgl && n < chm->num_chunks && visited++ <= chm->num_chunks; ) {
-    const unsigned char *p, *end;
-    int entries, e = 0;
-    unsigned int next;
-    if (sys->seek(fh, chm->dir_offset + (off_t) n * chm->chunk_size, MSPACK_SYS_SEEK_START)) { err = MSPACK_ERR_SEEK; break; }
-    if (sys->read(fh, chunk, (int) chm->chunk_size) != (int) chm->chunk_size) { err = MSPACK_ERR_READ; break; }
-    if (rd_le32(chunk) != 0x4C474D50u) { n++; continue; }
-    p = chunk + 0x14; end = chunk + chm->chunk_size - 2;
-    entries = (int) rd_le16(end);
-    while (entries-- > 0) {
-      unsigned int name_len = (unsigned int) read_encint(&p, end, &e), section;
-      const unsigned char *name;
-      off_t offset, length;
-      if (e || name_len > (unsigned int)(end - p)) { err = MSPACK_ERR_DATAFORMAT; break; }
-      name = p; p += name_len;
-      section = (unsigned int) read_encint(&p, end, &e);
-      offset = read_encint(&p, end, &e);
-      length = read_encint(&p, end, &e);
-      if (e) { err = MSPACK_ERR_DATAFORMAT; break; }
-      if (name_equal(name, name_len, filename)) {
-        f_ptr->section = section ? (struct mschmd_section *) &chm->sec1 : (struct mschmd_section *) &chm->sec0;
-        f_ptr->offset = offset; f_ptr->length = length;
-        found = 1;
-        break;
-      }
+  if (!(fh = sys->open(sys, chm->filename, MSPACK_SYS_OPEN_READ))) return MSPACK_ERR_OPEN;
+
+  if (chm->index_root < chm->num_chunks) {
+    n = chm->index_root;
+    for (;;) {
+      if (!(chunk = read_chunk(self, chm, fh, n))) { sys->close(fh); return self->error; }
+      if ((result = search_chunk(chm, chunk, filename, &p, &end)) <= 0) break;
+      if (chunk[3] == 'L') break;
+      n = (unsigned int) read_encint(&p, end, &e);
+      if (e) { sys->close(fh); return self->error = MSPACK_ERR_DATAFORMAT; }
     }
-    if (found || err) break;
-    next = rd_le32(chunk + 0x10);
-    if (next == n || next == 0xFFFFFFFFu) break;
-    n = next;
   }
-  sys->free(chunk);
+  else {
+    for (n = chm->first_pmgl; n <= chm->last_pmgl; n = rd_le32(chunk + 0x10)) {
+      if (!(chunk = read_chunk(self, chm, fh, n))) { err = self->error; break; }
+      if ((result = search_chunk(chm, chunk, filename, &p, &end)) > 0) break;
+      if (n == rd_le32(chunk + 0x10)) break;              /* a chunk that names itself as its successor */
+    }
+  }
+  if (result > 0) {
+    unsigned int sec = (unsigned int) read_encint(&p, end, &e);
+    f_ptr->section = sec == 0 ? (struct mschmd_section *) &chm->sec0 : (struct mschmd_section *) &chm->sec1;
+    f_ptr->offset = read_encint(&p, end, &e);
+    f_ptr->length = read_encint(&p, end, &e);
+    if (e) { sys->close(fh); return self->error = MSPACK_ERR_DATAFORMAT; }
+  }
+  else if (result < 0) err = MSPACK_ERR_DATAFORMAT;
   sys->close(fh);
   return self->error = err;
 }

@@ -375,6 +375,30 @@ int refh_chm_extract(const uint8_t *chm, size_t chm_len, const int *order, int n
   return MSPACK_ERR_OK;
 }
 
+/* fast_open + fast_find for a list of NUL-separated names: errs[i] = return code, and (section id or
+ * -1 when nothing was found, offset, length) as the reference filled them in (chmd.c:543-640) */
+int refh_chm_find(const uint8_t *chm, size_t chm_len, const char *names, int n_names,
+                  int *errs, int *sections, long long *offsets, long long *lengths)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) chm, chm_len, 0 };
+  struct mschm_decompressor *d = mspack_create_chm_decompressor(&mem_system);
+  struct mschmd_header *h;
+  int i;
+  if (!d) return MSPACK_ERR_NOMEMORY;
+  h = d->fast_open(d, (const char *) &src);
+  if (!h) { i = d->last_error(d); mspack_destroy_chm_decompressor(d); return i ? i : MSPACK_ERR_OPEN; }
+  for (i = 0; i < n_names; i++) {
+    struct mschmd_file r;
+    errs[i] = d->fast_find(d, h, names, &r, (int) sizeof(r));
+    sections[i] = r.section ? (int) r.section->id : -1;
+    offsets[i] = (long long) r.offset; lengths[i] = (long long) r.length;
+    names += strlen(names) + 1;
+  }
+  d->close(d, h);
+  mspack_destroy_chm_decompressor(d);
+  return MSPACK_ERR_OK;
+}
+
 /* ---- timing: the reference codec over a batch of independent units, T threads -------------- */
 struct bench_job {
   int kind;                       /* 0 = LZX, 1 = MSZIP, 2 = Quantum */

@@ -111,6 +111,8 @@ def ref():
                                     C.c_void_p, C.c_size_t, sz, sz, C.POINTER(C.c_int)]
         lib.refh_cab_search.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_longlong),
                                         C.POINTER(C.c_int), C.c_char_p, C.c_int]
+        lib.refh_chm_find.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         lib.refh_bench.restype = C.c_double
         lib.refh_bench.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
@@ -200,7 +202,7 @@ def ref_cab_search(blob, searchbuf=0, cap=64):
 
 
 def ref_chm_list(chm):
-    n = 8192
+    n = 16384
     lens = (C.c_longlong * n)(); offs = (C.c_longlong * n)(); secs = (C.c_int * n)()
     names = C.create_string_buffer(n * 128)
     k = ref().refh_chm_list(chm, len(chm), n, lens, offs, secs, names, 128)
@@ -211,6 +213,17 @@ def ref_chm_list(chm):
         nm = names.raw[i * 128:(i + 1) * 128].split(b"\0")[0]
         out.append(dict(name=nm, length=lens[i], offset=offs[i], section=secs[i]))
     return 0, out
+
+
+def ref_chm_find(chm, names):
+    """Reference fast_open + fast_find for every name -> (open err, [(err, section or -1, offset, length)])"""
+    n = len(names)
+    blob = b"".join(nm + b"\0" for nm in names)
+    errs = (C.c_int * n)(); secs = (C.c_int * n)(); offs = (C.c_longlong * n)(); lens = (C.c_longlong * n)()
+    rc = ref().refh_chm_find(chm, len(chm), blob, n, errs, secs, offs, lens)
+    if rc:
+        return rc, []
+    return 0, [(errs[i], secs[i], offs[i], lens[i]) for i in range(n)]
 
 
 def ref_chm_extract(chm, order, cap=1 << 26):

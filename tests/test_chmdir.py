@@ -1,0 +1,58 @@
+"""CHM directory and fast_find against what the REAL reference answered
+(tests/golden/chmdir.json, made by tests/golden/make_chmdir_golden.py): the reference's own directory
+fixtures (chmd_test.c:27-125) and a synthetic CHM whose PMGI index is two levels deep.  Host logic only:
+no GPU needed."""
+import hashlib
+import json
+import os
+import struct
+
+import pytest
+
+from libmspack_amd import api
+import chmdir_recipe as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "chmdir.json")))
+
+
+def _finds(c, queries):
+    out = []
+    for q in queries:
+        err, f = c.find(q)
+        out.append([err, f.section.contents.id if f is not None else -1, f.offset if f is not None else 0,
+                    f.length if f is not None else 0])
+    return out
+
+
+@pytest.mark.parametrize("fx", G["fixtures"], ids=[f["file"] for f in G["fixtures"]])
+def test_reference_fixtures(fx):
+    path = os.path.join(HERE, "golden", "chmdir", fx["file"])
+    with api.Chm(path) as c:
+        assert c.open_error == fx["open_err"]
+        # (the reference-side lister reports at most 127 name bytes)
+        got = [[nm[:127].decode("latin-1"), sec, off, ln] for nm, ln, off, sec in c.files]
+        assert got == fx["files"]
+    with api.Chm(path, fast=True) as c:
+        assert c.open_error == fx["find_open_err"]
+        if fx["find_open_err"]:
+            return
+        queries = [q[0].encode("latin-1") for q in fx["finds"]]
+        assert _finds(c, queries) == [q[1:] for q in fx["finds"]]
+
+
+def test_pmgi_two_levels():
+    chm, queries = R.synthetic_chm()
+    s = G["synthetic"]
+    assert hashlib.md5(chm).hexdigest() == s["chm_md5"]            # same container the reference saw
+    # ITSP header: index depth 3, a valid index root (chm.h:43-60)
+    depth, index_root = struct.unpack_from("<II", chm, 0x78 + 0x18)
+    n_chunks, = struct.unpack_from("<I", chm, 0x78 + 0x2C)
+    assert depth == 3 and index_root < n_chunks
+    with api.Chm(chm) as c:
+        assert c.open_error == 0 and len(c.files) == s["n_files"]
+        lst = [(nm, sec, off, ln) for nm, ln, off, sec in c.files]
+        assert hashlib.md5(repr(lst).encode()).hexdigest() == s["list_md5"]
+    with api.Chm(chm, fast=True) as c:
+        assert [q[0].encode("latin-1") for q in s["finds"]] == queries
+        assert _finds(c, queries) == [q[1:] for q in s["finds"]]
