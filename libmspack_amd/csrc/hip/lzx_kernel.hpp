@@ -21,6 +21,7 @@
 // only for the reference's error checks (lzxd.c:613-634).
 #pragma once
 #include "wave_common.hpp"
+#include "spec_queue.hpp"
 
 #define LZX_FRAME 32768u
 #define LZX_MAIN_P 10
@@ -29,8 +30,6 @@
 #define LZX_PRE_P 6
 #define LZX_MAIN_SYMS 720      /* 256 + 50*8 + 64: every index that can ever be non-zero (w<=21) */
 #define LZX_LEN_SYMS 250
-#define LZX_MLIST_CAP 160
-#define LZX_MFLAG_RING 512u
 #ifndef LZX_SPEC_WIDE
 #define LZX_SPEC_WIDE 0          /* 1: every lane decodes two positions (128 per round) */
 #endif
@@ -45,9 +44,6 @@
 #define CNT(k) (d.st_t[k]++)
 #else
 #define CNT(k) ((void) 0)
-#endif
-#ifndef LZX_FLUSH_SPAN
-#define LZX_FLUSH_SPAN 128u
 #endif
 
 struct __align__(16) LzxShared {
@@ -65,8 +61,7 @@ struct __align__(16) LzxShared {
   u8  len_len[LZX_LEN_SYMS + 70];
   u8  pre_len[24];
   u8  ali_len[8];
-  uint2 mlist[LZX_MLIST_CAP];    /* speculative path: queued matches (position, offset<<9 | length) */
-  u8  mflag[LZX_MFLAG_RING];     /* 1 at (position mod ring) where a queued match starts */
+  SpecQueueLds spq;              /* speculative path: queued matches + start flags (spec_queue.hpp) */
 };
 
 struct LzxDec {
@@ -511,18 +506,6 @@ __device__ __forceinline__ u32 lzx_scalar_token(const LzxDec &d, bool length_emp
   return tot;
 }
 
-// inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic)
-__device__ __forceinline__ u32 wave_incl_scan(u32 x)
-{
-  u32 v = x;
-  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);   // row_shr:1
-  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);   // row_shr:2
-  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);   // row_shr:4
-  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);   // row_shr:8
-  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
-  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
-  return v;
-}
 
 // one speculative token: everything lane-local, decoded from 64 bits of the stream
 struct SpecTok { u32 tot, sym, kind, olen, off; bool unk; };
@@ -582,18 +565,6 @@ __device__ __forceinline__ SpecTok lzx_spec_token(const LzxShared *sh, const u32
   return t;
 }
 
-// inclusive prefix maximum over the 64 lanes (values are unsigned; 0 is the identity)
-__device__ __forceinline__ u32 wave_incl_max(u32 x)
-{
-  u32 v = x, t;
-  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
-  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
-  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
-  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
-  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
-  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
-  return v;
-}
 
 // ---- input staging shared by the speculative paths ----------------------------------------------
 // The two current 256-byte input chunks live in LDS with each dword's 16-bit halves swapped (the
@@ -756,7 +727,6 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   d.flush_lits();
   u32 bitpos, cb, pf;                                   // next unread bit (relative to d.w.origin)
   spec_stage(d, bitpos, cb, pf);
-  ((u32 *) sh->mflag)[lane] = 0; ((u32 *) sh->mflag)[64u + lane] = 0;   // no match queued yet
   u32 mlim[16 - LZX_MAIN_P];                            // limits of the code lengths beyond the table
 #pragma unroll
   for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
@@ -784,51 +754,13 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     else SPEC_COPY(pos_, len_, moff_, wp_);                                                  \
   } while (0)
 
-  // ---- deferred match resolution -------------------------------------------------------------
-  // Rounds only QUEUE their matches (position, offset|length) in LDS and raise a flag at the
-  // match's start position in a small ring; literals go straight to the output.  The queue is
-  // resolved in position space, 64 output bytes per pass, one byte per lane: the number of start
-  // flags at or below a lane's byte (ballot + mbcnt) is the index of the match that may cover it,
-  // and the byte is copied as out[b] = out[b - offset] -- LZ77 byte semantics, so overlapping matches
-  // need no special case.  A source byte inside the current 64-byte chunk that is itself a match
-  // byte is not in memory yet: such lanes follow the source's own pointer (pointer jumping, log
-  // steps).  Everything below the chunk is final because chunks are resolved in address order.
-  // The passes are software-pipelined: chunk k's load is in flight while chunk k+1 is set up.
-  u32 Pf = P;                                           // everything below Pf is final in memory
-  u32 mcount = 0;                                       // queued matches (sorted by position)
-  u32 ja = 0;                                           // queue entries that start below Pf (0 or 1)
+  // ---- deferred match resolution: rounds queue their matches, spec_queue.hpp resolves them ----
+  SpecQueue Q;
+  spq_init(sh->spq, Q, P, lane);
+  u32 &Pf = Q.Pf, &mcount = Q.mcount;
+  uint2 *const mlist = sh->spq.mlist;
+  u8 *const mflag = sh->spq.mflag;
   bool slow = false;                                    // this round copies its matches one by one
-
-  // which match covers byte c_ + lane, and where does that byte finally come from
-#define SPEC_COVER(c_, inm_, ptr_, ext_)                                                      \
-  do {                                                                                        \
-    CNT(1);                                                                                   \
-    const u32 b_ = (c_) + lane;                                                               \
-    const u32 fi_ = b_ & (LZX_MFLAG_RING - 1u);                                               \
-    const u32 f_ = sh->mflag[fi_];                                                            \
-    sh->mflag[fi_] = 0;                                                                       \
-    const u64 sm_ = ballot(f_ != 0u);                                                         \
-    const u32 cnt_ = __builtin_amdgcn_mbcnt_hi((u32)(sm_ >> 32), __builtin_amdgcn_mbcnt_lo((u32) sm_, 0u)) + \
-                     (f_ != 0u ? 1u : 0u);                                                    \
-    const int j_ = (int)(ja + cnt_) - 1;                                                      \
-    const uint2 mr_ = sh->mlist[j_ < 0 ? 0 : j_];                                             \
-    const u32 ml_ = mr_.y & 511u;                                                             \
-    inm_ = j_ >= 0 && (b_ - mr_.x) < ml_;                                                     \
-    ptr_ = b_ - (mr_.y >> 9);                                                                 \
-    ja += (u32) __popcll(sm_);                                                                \
-    ext_ = (ballot(inm_ && mr_.x + ml_ > (c_) + 64u) >> 63) != 0ull;                          \
-    const u64 inmask_ = ballot(inm_);                                                         \
-    if (ballot(inm_ && ptr_ >= (c_))) {                                                       \
-      for (;;) {                                                                              \
-        u32 tl_ = (ptr_ - (c_)) & 63u;                                                        \
-        u32 tp_ = (u32) __builtin_amdgcn_ds_bpermute((int)(tl_ << 2), (int) ptr_);            \
-        bool follow_ = inm_ && ptr_ >= (c_) && ((inmask_ >> tl_) & 1ull);                     \
-        if (!ballot(follow_)) break;                                                          \
-        CNT(2);                                                                               \
-        if (follow_) ptr_ = tp_;                                                              \
-      }                                                                                       \
-    }                                                                                         \
-  } while (0)
 
 #ifdef LZX_EXP_STATS
 #define TICK(k) do { u64 n_ = __builtin_amdgcn_s_memtime(); d.st_t[k] += (u32)(n_ - tk_); tk_ = n_; } while (0)
@@ -843,38 +775,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     if (live && bitpos >= bit_limit) { rc = LZX_RUN_SWITCH; live = false; }
     const bool fin = !live || slow;
 #ifndef LZX_EXP_NOCOPY
-    if (fin || P - Pf >= LZX_FLUSH_SPAN || mcount > LZX_MLIST_CAP - 64u) {
-      CNT(0);
-      u32 c = Pf & ~63u;
-      const u32 climit = fin ? P : c + ((P - c) & ~63u);   // unless final: whole chunks only
-      if (c < climit) {
-        bool inm, ext; u32 ptr;
-        SPEC_COVER(c, inm, ptr, ext);
-        for (;;) {
-          u32 val = 0; if (inm) val = (u32) out[ptr];
-          const u32 bcur = c + lane; const bool icur = inm;
-          c += 64u;
-          const bool more = c < climit;
-          if (more) SPEC_COVER(c, inm, ptr, ext);
-          if (icur) out[bcur] = (u8) val;
-          if (!more) break;
-        }
-        if (!fin) {
-          // keep the match that runs on into the next chunk (if any) and the ones that start above
-          Pf = c;
-          const u32 keep = ja - (ext ? 1u : 0u);
-          const u32 nrem = mcount - keep;               // <= 33: the span left is below 64 bytes
-          if (keep) {
-            uint2 mv = make_uint2(0u, 0u);
-            if (lane < nrem) mv = sh->mlist[keep + lane];
-            __builtin_amdgcn_wave_barrier();
-            if (lane < nrem) sh->mlist[lane] = mv;
-          }
-          mcount = nrem; ja = ext ? 1u : 0u;
-        }
-      }
-      if (fin) { Pf = P; mcount = 0; ja = 0; }
-    }
+    if (fin || spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, fin, lane);
 #endif
     if (!live) break;
     spec_slide(d, bitpos, cb, pf);
@@ -986,18 +887,18 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       const u32 nmA = (u32) __popcll(mmA), nmB = WIDE ? (u32) __popcll(mmB) : 0u;
       if (!slow) {
         if (ballot((ismA && (vmoffA == 0u || vmoffA > wsize)) || (ismB && (vmoffB == 0u || vmoffB > wsize))) ||
-            mcount + nmA + nmB > LZX_MLIST_CAP || newP - (Pf & ~63u) > LZX_MFLAG_RING) {
+            mcount + nmA + nmB > SPQ_CAP || newP - (Pf & ~63u) > SPQ_RING) {
           slow = true; R0 = sR0; R1 = sR1; R2 = sR2; continue;
         }
         const u32 rankA = __builtin_amdgcn_mbcnt_hi((u32)(mmA >> 32), __builtin_amdgcn_mbcnt_lo((u32) mmA, 0u));
         const u32 rankB = __builtin_amdgcn_mbcnt_hi((u32)(mmB >> 32), __builtin_amdgcn_mbcnt_lo((u32) mmB, 0u));
         if (ismA) {
-          sh->mlist[mcount + rankA] = make_uint2(oposA, (vmoffA << 9) | tA.olen);
-          sh->mflag[oposA & (LZX_MFLAG_RING - 1u)] = 1;
+          mlist[mcount + rankA] = make_uint2(oposA, (vmoffA << 9) | tA.olen);
+          mflag[oposA & (SPQ_RING - 1u)] = 1;
         }
         if (WIDE && ismB) {
-          sh->mlist[mcount + nmA + rankB] = make_uint2(oposB, (vmoffB << 9) | tB.olen);
-          sh->mflag[oposB & (LZX_MFLAG_RING - 1u)] = 1;
+          mlist[mcount + nmA + rankB] = make_uint2(oposB, (vmoffB << 9) | tB.olen);
+          mflag[oposB & (SPQ_RING - 1u)] = 1;
         }
         mcount += nmA + nmB;
       }
@@ -1045,11 +946,11 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
 #ifndef LZX_EXP_NOCOPY
         if (!slow) {
           // the round is redone after the queue is resolved: nothing of this token is committed
-          if (moff_ == 0u || moff_ > wsize || mcount >= LZX_MLIST_CAP ||
-              P + tk_val - (Pf & ~63u) > LZX_MFLAG_RING) { slow = true; continue; }
+          if (moff_ == 0u || moff_ > wsize || mcount >= SPQ_CAP ||
+              P + tk_val - (Pf & ~63u) > SPQ_RING) { slow = true; continue; }
           if (lane == 0u) {
-            sh->mlist[mcount] = make_uint2(P, (moff_ << 9) | tk_val);
-            sh->mflag[P & (LZX_MFLAG_RING - 1u)] = 1;
+            mlist[mcount] = make_uint2(P, (moff_ << 9) | tk_val);
+            mflag[P & (SPQ_RING - 1u)] = 1;
           }
           mcount++;
         }
@@ -1063,7 +964,6 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     }
     slow = false;
   }
-#undef SPEC_COVER
 #undef SPEC_MATCH
 #undef SPEC_COPY
   d.P = P;

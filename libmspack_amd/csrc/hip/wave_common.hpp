@@ -190,3 +190,29 @@ __device__ __forceinline__ u32 huff_long(const HuffRegs &hr, const u16 *sorted, 
   u32 idx = (fo >> 16) + ((peek16 >> (16 - len)) - (fo & 0xFFFFu));
   return rfl((u32) sorted[idx]) | (len << 10);
 }
+
+// inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic)
+__device__ __forceinline__ u32 wave_incl_scan(u32 x)
+{
+  u32 v = x;
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+  v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+// inclusive prefix maximum over the 64 lanes (values are unsigned; 0 is the identity)
+__device__ __forceinline__ u32 wave_incl_max(u32 x)
+{
+  u32 v = x, t;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+  t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+  return v;
+}
