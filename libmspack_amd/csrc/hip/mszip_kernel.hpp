@@ -17,10 +17,11 @@
 // full even when only part of it is requested, mszipd.c:442-446).
 #pragma once
 #include "wave_common.hpp"
+#include "spec_queue.hpp"
 
 #define ZIP_FRAME 32768u
 #define ZIP_LIT_P 10
-#define ZIP_DIST_P 7
+#define ZIP_DIST_P 9
 #define ZIP_BL_P 7
 #define ZIP_HIST 8
 
@@ -37,6 +38,8 @@ struct __align__(16) MszipShared {
   u8  dist_len[32];
   u8  bl_len[20];
   u8  lens[324];
+  u32 inbuf[128 + 4];            /* speculative path: two 256-byte input chunks */
+  SpecQueueLds spq;              /* speculative path: queued matches + start flags (spec_queue.hpp) */
 };
 
 // inflate() failure classes: <0 = format error (-> MSPACK_ERR_DECRUNCH), >0 = MSPACK_ERR_READ
@@ -202,6 +205,182 @@ __device__ __forceinline__ int zip_read_dynamic(ZipDec &d)
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Speculative window decode of the literal/length + distance token loop (mszipd.c:228-303), the same
+// scheme as lzx_run_spec: all 64 lanes decode a COMPLETE token (literal/length symbol, length extra
+// bits, distance symbol, distance extra bits) starting at bit (bitpos + lane) of the LSB-first stream;
+// the chain of real tokens is followed with v_readlane; a DPP prefix sum gives every token its output
+// position; literals go out in one store and matches are queued for spec_queue.hpp.
+// The run stops -- always at a token boundary -- at the end-of-block symbol (consumed here), at a
+// token this path does not take (a code longer than the direct tables or an invalid one, a match that
+// reaches into an earlier block's bytes, output reaching the 32 KiB mark) and near the end of the
+// input; the EOF-exact scalar loop of zip_inflate takes over from there.
+// Returns 1 when the end-of-block symbol was consumed, 0 otherwise.
+// ---------------------------------------------------------------------------------------------------
+struct ZipTok { u32 tot, sym, kind, olen, dist; bool unk; };      // kind 0 literal, 1 match, 2 end of block
+
+__device__ __forceinline__ ZipTok zip_spec_token(const MszipShared *sh, const u32 lit_fov, const u32 *llim, u64 r)
+{
+  ZipTok t;
+  const u32 lo = (u32) r;
+  u32 e = sh->lit_tab[lo & ((1u << ZIP_LIT_P) - 1u)];
+  {
+    // codes longer than the direct table: canonical length = number of per-length limits the
+    // (MSB-first) 16-bit peek is not below; symbol via the sorted list (readhuff.h:144-172)
+    u32 peek16 = __brev(lo) >> 16, ln = ZIP_LIT_P + 1u;
+#pragma unroll
+    for (int l = ZIP_LIT_P + 1; l <= 16; l++) ln += (peek16 >= llim[l - ZIP_LIT_P - 1]) ? 1u : 0u;
+    u32 lq = ln <= 16u ? ln : 0u;
+    u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) lit_fov);
+    u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
+    if (idx >= 288u) idx = 0;
+    u32 ls = sh->lit_sorted[idx];
+    if (e == 0u && lq != 0u) e = ls | (lq << 10);
+  }
+  bool unk = (e == 0u);
+  u32 tot = e >> 10;
+  const u32 sym = e & 1023u;
+  r >>= tot;
+  const bool is_match = sym > 256u;
+  const u32 code = sym - 257u;
+  if (is_match && code >= 29u) unk = true;                        // mszipd.c:246
+  u32 lbase, lextra, dbase, dextra;
+  zip_len_code(code < 29u ? code : 0u, lbase, lextra);
+  const u32 lev = (u32) r & ((1u << lextra) - 1u);
+  r >>= lextra;
+  const u32 e2 = sh->dist_tab[(u32) r & ((1u << ZIP_DIST_P) - 1u)];
+  const u32 ds = e2 & 1023u;
+  zip_dist_code(ds < 30u ? ds : 0u, dbase, dextra);
+  r >>= (e2 >> 10);
+  const u32 dev = (u32) r & ((1u << dextra) - 1u);
+  if (is_match) {
+    unk = unk || e2 == 0u || ds >= 30u;                           // long distance codes: scalar loop
+    tot += lextra + (e2 >> 10) + dextra;
+  }
+  t.tot = tot; t.sym = sym; t.unk = unk;
+  t.kind = is_match ? 1u : (sym == 256u ? 2u : 0u);
+  t.olen = is_match ? lbase + lev : (sym == 256u ? 0u : 1u);
+  t.dist = dbase + dev;
+  return t;
+}
+
+__device__ __forceinline__ int zip_run_spec(ZipDec &d)
+{
+  MszipShared *sh = d.sh;
+  const u32 lane = d.lane;
+  u8 *const out = d.out + d.B;                        // positions below are window indices of this block
+  u32 P = rfl(d.wpos);
+  // same margin reasoning as lzx_run_spec: a round consumes at most 64 + 48 bits
+  const u32 room_bytes = (d.w.in_len > d.w.origin + 56u) ? (d.w.in_len - d.w.origin - 56u) : 0u;
+  const u32 bit_limit = rfl(room_bytes * 8u);
+  u32 bitpos = rfl(d.cons_bits());
+  if (bitpos >= bit_limit || P >= ZIP_FRAME - 1u) return 0;
+  d.flush_lits();
+  u32 cb = bitpos >> 11;
+  {
+    u32 lo = d.w.load_chunk(cb, lane), hi = d.w.load_chunk(cb + 1u, lane);
+    sh->inbuf[lane] = lo; sh->inbuf[64u + lane] = hi;
+    if (lane < 4u) sh->inbuf[128u + lane] = 0;
+  }
+  u32 pf = d.w.load_chunk(cb + 2u, lane);
+  u32 llim[16 - ZIP_LIT_P];
+#pragma unroll
+  for (int l = ZIP_LIT_P + 1; l <= 16; l++) llim[l - ZIP_LIT_P - 1] = rdl(d.hr_lit.limv, (u32) l);
+  SpecQueue Q;
+  spq_init(sh->spq, Q, P, lane);
+  int rc = 0;
+  bool stop = false;
+
+  for (;;) {
+    const bool live = !stop && bitpos < bit_limit;
+    if (!live || spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, !live, lane);
+    if (!live) break;
+    if ((bitpos >> 11) != cb) {                       // slide the LDS window by one chunk
+      u32 up = sh->inbuf[64u + lane];
+      sh->inbuf[lane] = up; sh->inbuf[64u + lane] = pf;
+      cb++;
+      pf = d.w.load_chunk(cb + 2u, lane);
+    }
+    // ---- every lane decodes the token that would start at bit (bitpos + lane) ----
+    const u32 rel = bitpos - (cb << 11) + lane;
+    const u32 k = rel >> 5, sft = rel & 31u;
+    const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
+    const u64 q01 = ((u64) i1 << 32) | i0, q12 = ((u64) i2 << 32) | i1;
+    const u64 r = (u64)(u32)(q01 >> sft) | ((u64)(u32)(q12 >> sft) << 32);
+    const ZipTok t = zip_spec_token(sh, d.hr_lit.fov, llim, r);
+    // next token start; >= 128 ends the walk: 128 + lane = not for this path, 192 + lane = end of block
+    const u32 vnext = t.unk ? (128u + lane) : (t.kind == 2u ? (192u + lane) : (lane + t.tot));
+
+    // ---- follow the real token boundaries ----
+    u64 chain = 0;
+    u32 q = 0;
+    do { chain |= 1ull << q; q = rdl(vnext, q); } while (q < WAVE);
+    bool eob = false;
+    if (q >= 192u) { q -= 192u; eob = true; }                      // the end-of-block token stays on the chain
+    else if (q >= 128u) { q -= 128u; chain &= ~(1ull << q); stop = true; }
+    bool on = (chain >> lane) & 1ull;
+    const u32 x = on ? t.olen : 0u;
+    const u32 incl = wave_incl_scan(x);
+    const u32 opos = P + incl - x;
+    u32 newP = P + rdl(incl, 63u);
+    // tokens this path leaves to the scalar loop: output reaching the 32 KiB mark (FLUSH_IF_NEEDED,
+    // mszipd.c:37-44) and matches whose source lies before the start of this block (mszipd.c:267-268)
+    {
+      const u64 cut = ballot(on && (opos + t.olen >= ZIP_FRAME || (t.kind == 1u && t.dist > opos)));
+      if (cut) {
+        u32 j = (u32) __ffsll((long long) cut) - 1u;
+        chain &= (1ull << j) - 1ull;
+        on = (chain >> lane) & 1ull;
+        q = j; eob = false; stop = true; newP = rdl(opos, j);
+      }
+    }
+    if (on && t.kind == 0u) out[opos] = (u8) t.sym;
+    const u64 mm = ballot(on && t.kind == 1u);
+    if (mm) {
+      const u32 nm = (u32) __popcll(mm);
+      if (Q.mcount + nm > SPQ_CAP || newP - (Q.Pf & ~63u) > SPQ_RING) spq_resolve(sh->spq, Q, out, P, true, lane);
+      if (newP - (Q.Pf & ~63u) > SPQ_RING) {
+        // a round that is larger than the flag ring by itself: copy its matches one by one
+        for (u64 dm = mm; dm; dm &= dm - 1ull) {
+          u32 l = (u32) __ffsll((long long) dm) - 1u;
+          u32 pos_l = rdl(opos, l), len_l = rdl(t.olen, l), dist_l = rdl(t.dist, l);
+          const u8 *src = out + pos_l - dist_l;
+          for (u32 i = 0; i < len_l; i += WAVE) {
+            // distance >= 64: a step only reads bytes below it; shorter: the periodic source, i.e. only
+            // the bytes that existed before the match
+            u32 kk = i + lane;
+            if (kk < len_l) out[pos_l + kk] = (dist_l >= WAVE) ? src[kk] : src[kk % dist_l];
+          }
+        }
+        Q.Pf = newP;
+      }
+      else {
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32) mm, 0u));
+        spq_push(sh->spq, Q, (mm >> lane) & 1ull, rank, nm, opos, t.dist, t.olen);
+      }
+    }
+    P = newP;
+    if (eob) { bitpos += q + rdl(t.tot, q); rc = 1; stop = true; }
+    else bitpos += q;
+  }
+  // hand the exact bit position back to the scalar reader; its bits_left restarts from the byte the
+  // position lies in (every later ENSURE_BITS re-derives the reference's value from there)
+  d.wpos = P;
+  {
+    u32 wi = bitpos >> 5, ch = wi >> 6;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    u32 lo = sh->inbuf[lane], hi = sh->inbuf[64u + lane];
+    if (ch == cb) { d.w.cur = lo; d.w.nxt = hi; }
+    else { d.w.cur = hi; d.w.nxt = pf; }
+    d.w.wi = wi; d.bb = 0; d.bl = 0;
+    d.refill(); d.refill();
+    u32 sk = bitpos & 31u;
+    if (sk) { d.bb >>= sk; d.bl -= (int) sk; }
+    d.rbl = (int)((0u - bitpos) & 7u);
+  }
+  return rc;
+}
+
 // inflate (mszipd.c:154-316): 0 ok, <0 format error, >0 ERR_READ.  *bytes_output as the reference.
 __device__ int zip_inflate(ZipDec &d, u32 &bytes_output)
 {
@@ -241,7 +420,15 @@ __device__ int zip_inflate(ZipDec &d, u32 &bytes_output)
       else { int r = zip_read_dynamic(d); if (r) return r; }
       if (huff_build<ZIP_LIT_P>(sh->lit_len, 288, 9, sh->lit_tab, sh->lit_sorted, sh->cnt, d.hr_lit, lane, true)) return ZIP_E_FORMAT;
       if (huff_build<ZIP_DIST_P>(sh->dist_len, 32, 6, sh->dist_tab, sh->dist_sorted, sh->cnt, d.hr_dist, lane, true)) return ZIP_E_FORMAT;
+      u32 cooldown = 0;                                // scalar tokens to take before the next speculative run
       for (;;) {
+#ifndef ZIP_NO_SPEC
+        if (cooldown == 0u && !d.flushed) {
+          if (zip_run_spec(d)) break;                    // consumed the end-of-block symbol
+          cooldown = 8u;
+        }
+        else if (cooldown) cooldown--;
+#endif
         if (d.bl <= 32) d.refill();
         int sym = d.decode_sym<ZIP_LIT_P>(sh->lit_tab, sh->lit_sorted, d.hr_lit, true);
         if (sym < 0) return sym == -2 ? ERR_READ : ZIP_E_FORMAT;
