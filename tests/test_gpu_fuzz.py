@@ -1,0 +1,115 @@
+"""Differential fuzzing on the GPU: several hundred damaged streams per codec (bit flips, byte and word
+overwrites, truncations, spliced-in garbage, cut-and-paste of stream parts) must give the oracle's
+error code, byte count and -- up to that count -- bytes.  The speculative paths (64 tokens per round,
+queued matches, vectorised block headers) have many hand-over points to the EOF-exact scalar loops;
+this is where a damaged stream lands in them at every possible token."""
+import zlib
+
+import numpy as np
+import pytest
+
+import libmspack_amd as M
+from helpers import oracle_lzx, oracle_mszip, oracle_qtm
+from test_gpu_lzx import run_units as run_lzx
+from test_gpu_mszip import run as run_mszip, folder as zip_folder
+from test_gpu_qtm import run as run_qtm
+
+pytestmark = pytest.mark.gpu
+
+
+def mutations(s, rng, n):
+    """n damaged copies of the byte string s"""
+    out = []
+    L = len(s)
+    for i in range(n):
+        b = bytearray(s)
+        m = i % 7
+        if m == 0:                                              # one bit
+            k = int(rng.integers(0, L)); b[k] ^= 1 << int(rng.integers(0, 8))
+        elif m == 1:                                            # a few bits close together
+            k = int(rng.integers(0, L))
+            for _ in range(3):
+                j = min(L - 1, k + int(rng.integers(0, 6))); b[j] ^= 1 << int(rng.integers(0, 8))
+        elif m == 2:                                            # overwrite 1-8 bytes with noise
+            k = int(rng.integers(0, L)); w = int(rng.integers(1, 9))
+            b[k:k + w] = bytes(rng.integers(0, 256, size=min(w, L - k), dtype=np.uint8))
+        elif m == 3:                                            # truncate
+            b = b[:int(rng.integers(0, L))]
+        elif m == 4:                                            # zero or 0xFF run
+            k = int(rng.integers(0, L)); w = int(rng.integers(1, 40))
+            b[k:k + w] = bytes([0 if i & 8 else 255]) * min(w, L - k)
+        elif m == 5:                                            # delete a slice (everything after it shifts)
+            k = int(rng.integers(0, L)); w = int(rng.integers(1, 16))
+            del b[k:k + w]
+        else:                                                   # copy one part of the stream over another
+            k = int(rng.integers(0, L)); j = int(rng.integers(0, L)); w = int(rng.integers(1, 64))
+            seg = bytes(b[j:j + w]); b[k:k + len(seg)] = seg
+        out.append(bytes(b))
+    return out
+
+
+def compare(kind, i, res, units, out, e, o, r):
+    assert res["err"][i] == e, (kind, i, res[i], e)
+    assert res["out_len"][i] == r.out_len, (kind, i, res[i], r.out_len)
+    got = out[units["out_off"][i]:units["out_off"][i] + r.out_len].tobytes()
+    if got != o[:r.out_len]:
+        k = next(j for j in range(len(got)) if got[j] != o[j])
+        raise AssertionError("%s stream %d: byte %d of %d differs (err %d)" % (kind, i, k, r.out_len, e))
+
+
+def test_fuzz_lzx(built):
+    rng = np.random.default_rng(20240926)
+    streams, params = [], []
+    cfgs = [(17, 0, dict(mode=4, block_size=12345)), (21, 2, dict()), (16, 1, dict(mode=2)),
+            (18, 0, dict(mode=1)), (15, 0, dict(mode=3)), (21, 2, dict(intel_filesize=200000)),
+            (19, 4, dict(mode=4, block_size=40001, intel_filesize=5000, e8_base=1000))]
+    for ci, (wb, rf, kw) in enumerate(cfgs):
+        n = 90000 if rf == 0 else 32768 * max(rf, 1) * 2
+        data = M.gen_plaintext(100 + ci, ci % 6, n)
+        comp, _ = M.lzx_encode(data, wb, rf, M.lzx_opts(**kw))
+        comp = comp.tobytes()
+        e8 = kw.get("e8_base", 0)
+        for m in [comp] + mutations(comp, rng, 350):
+            streams.append(m + b"\0" * 4 if rf else m); params.append((n, wb, rf, e8))
+    units, out, res = run_lzx(streams, params)
+    bad = 0
+    for i, (s, p) in enumerate(zip(streams, params)):
+        e, o, r = oracle_lzx(s, p[0], p[1], p[2], length=p[0], e8_base=p[3])
+        compare("lzx", i, res, units, out, e, o, r)
+        assert res["flags"][i] == r.flags, (i, res[i], r.flags)
+        bad += e != 0
+    assert bad > len(streams) // 4                               # the damage does reach the decoder
+
+
+def test_fuzz_mszip(built):
+    rng = np.random.default_rng(777)
+    streams, lens = [], []
+    for ci, (level, strat, hist, bs) in enumerate([(6, zlib.Z_DEFAULT_STRATEGY, False, 32768), (9, zlib.Z_DEFAULT_STRATEGY, True, 32768),
+                                                   (1, zlib.Z_FIXED, True, 32768), (6, zlib.Z_HUFFMAN_ONLY, False, 32768),
+                                                   (6, zlib.Z_DEFAULT_STRATEGY, True, 20000), (0, zlib.Z_DEFAULT_STRATEGY, False, 32768),
+                                                   (6, zlib.Z_RLE, True, 32768)]):
+        data = M.gen_plaintext(300 + ci, ci % 6, 98304 if bs == 32768 else 80000).tobytes()
+        s = zip_folder(data, level, strat, history=hist, bs=bs)
+        for m in [s] + mutations(s, rng, 350):
+            streams.append(m); lens.append(len(data))
+    units, out, res = run_mszip(streams, lens)
+    bad = 0
+    for i, st in enumerate(streams):
+        e, o, r, _ = oracle_mszip(st, lens[i])
+        compare("mszip", i, res, units, out, e, o, r)
+        bad += e != 0
+    assert bad > len(streams) // 4
+
+
+def test_fuzz_qtm(built):
+    rng = np.random.default_rng(4242)
+    streams, lens, wbs = [], [], []
+    for ci, wb in enumerate([16, 21, 10, 13]):
+        data = M.gen_plaintext(500 + ci, ci % 6, 100000)
+        s, _ = M.qtm_encode(data, wb)
+        for m in [s] + mutations(s, rng, 150):
+            streams.append(m); lens.append(data.size); wbs.append(wb)
+    units, out, res = run_qtm(streams, lens, wbs)
+    for i, st in enumerate(streams):
+        e, o, r = oracle_qtm(st, lens[i], wbs[i])
+        compare("qtm", i, res, units, out, e, o, r)

@@ -91,3 +91,59 @@ def test_mszip_oracle_vs_reference(built):
             # window is malloc'ed): contents are only comparable when the result is the plaintext
             if e1 == 0 and o1 == data[:want]:
                 assert o1 == o2
+
+
+def _mutations():
+    from test_gpu_fuzz import mutations
+    return mutations
+
+
+def test_fuzz_oracle_vs_reference_lzx(built):
+    """The damaged-stream corpus of tests/test_gpu_fuzz.py (same generator, same seeds): the oracle's error
+    code and byte count against the REAL reference -- this is what makes the GPU-vs-oracle fuzz a
+    GPU-vs-reference statement."""
+    mutations = _mutations()
+    rng = np.random.default_rng(20240926)
+    cfgs = [(17, 0, dict(mode=4, block_size=12345)), (21, 2, dict()), (16, 1, dict(mode=2)),
+            (18, 0, dict(mode=1)), (15, 0, dict(mode=3)), (21, 2, dict(intel_filesize=200000)),
+            (19, 4, dict(mode=4, block_size=40001, intel_filesize=5000, e8_base=1000))]
+    n_bad = 0
+    for ci, (wb, rf, kw) in enumerate(cfgs):
+        n = 90000 if rf == 0 else 32768 * max(rf, 1) * 2
+        data = M.gen_plaintext(100 + ci, ci % 6, n)
+        comp = M.lzx_encode(data, wb, rf, M.lzx_opts(**kw))[0].tobytes()
+        if kw.get("e8_base"):
+            continue                                   # the memory-to-memory reference driver starts E8 at 0
+        for m in [comp] + mutations(comp, rng, 350):
+            s = m + b"\0" * 4 if rf else m
+            e1, o1, w1 = ref_lzx(s, n, wb, rf)
+            e2, o2, r = oracle_lzx(s, n, wb, rf)
+            assert (e1, w1) == (e2, r.out_len), (ci, len(s), e1, w1, e2, r.out_len)
+            n_bad += e1 != 0
+            if e1 == 0 and o1 == data.tobytes():
+                assert o2 == o1
+    assert n_bad > 300
+
+
+def test_fuzz_oracle_vs_reference_mszip_qtm(built):
+    mutations = _mutations()
+    from test_gpu_mszip import folder as zip_folder
+    rng = np.random.default_rng(777)
+    for ci, (level, strat, hist, bs) in enumerate([(6, zlib.Z_DEFAULT_STRATEGY, False, 32768), (9, zlib.Z_DEFAULT_STRATEGY, True, 32768),
+                                                   (1, zlib.Z_FIXED, True, 32768), (6, zlib.Z_HUFFMAN_ONLY, False, 32768),
+                                                   (6, zlib.Z_DEFAULT_STRATEGY, True, 20000), (0, zlib.Z_DEFAULT_STRATEGY, False, 32768),
+                                                   (6, zlib.Z_RLE, True, 32768)]):
+        data = M.gen_plaintext(300 + ci, ci % 6, 98304 if bs == 32768 else 80000).tobytes()
+        s = zip_folder(data, level, strat, history=hist, bs=bs)
+        for m in [s] + mutations(s, rng, 350):
+            e1, o1, w1 = ref_mszip(m, len(data))
+            e2, o2, r, _ = oracle_mszip(m, len(data))
+            assert (e1, w1) == (e2, r.out_len), ("mszip", ci, e1, w1, e2, r.out_len)
+    rng = np.random.default_rng(4242)
+    for ci, wb in enumerate([16, 21, 10, 13]):
+        data = M.gen_plaintext(500 + ci, ci % 6, 100000)
+        s, _ = M.qtm_encode(data, wb)
+        for m in [s] + mutations(s, rng, 150):
+            e1, o1, w1 = ref_qtm(m, data.size, wb)
+            e2, o2, r = oracle_qtm(m, data.size, wb)
+            assert (e1, w1) == (e2, r.out_len), ("qtm", ci, e1, w1, e2, r.out_len)
