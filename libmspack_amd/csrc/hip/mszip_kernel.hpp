@@ -382,7 +382,7 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
 }
 
 // inflate (mszipd.c:154-316): 0 ok, <0 format error, >0 ERR_READ.  *bytes_output as the reference.
-__device__ int zip_inflate(ZipDec &d, u32 &bytes_output)
+__device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
 {
   MszipShared *sh = d.sh;
   const u32 lane = d.lane;
@@ -472,7 +472,7 @@ __device__ int zip_inflate(ZipDec &d, u32 &bytes_output)
   return 0;
 }
 
-__device__ void mszip_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
+__device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
                                   mspack_hip_result *res, MszipShared *sh)
 {
   const u32 lane = threadIdx.x;
