@@ -20,10 +20,11 @@
 //                      arithmetic decoder), so ERR_READ fires exactly where the reference's does.
 #pragma once
 #include "wave_common.hpp"
+#include "spec_queue.hpp"
 
 #define QTM_FRAME 32768u
 
-struct QtmShared { u32 pad[4]; };
+struct QtmShared { SpecQueueLds spq; };
 
 struct QtmDec {
   InWindow w;
@@ -150,22 +151,58 @@ __device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, in
   u32 range2 = (u32)((int) H - (int) L + 1);
   // H = L + (cf[i-1]*range)/tot - 1 ; L = L + (cf[i]*range)/tot : both quotients from ONE division
   u32 num = (lane == 0u) ? (e_im1 & 0xFFFFu) * range2 : cf_i * range2;
-  u32 quo = num / tot;
+  // exact 32-bit / 16-bit division through one double-precision reciprocal (a generic integer
+  // division is ~25 dependent instructions): the estimate is off by at most one either way
+  u32 quo;
+  {
+    const double td = (double) tot;
+    double rc = __builtin_amdgcn_rcp(td);
+    rc = __builtin_fma(__builtin_fma(-td, rc, 1.0), rc, rc);           // one Newton step: full precision
+    quo = (u32)((double) num * rc);
+    u32 rem = num - quo * tot;
+    if ((int) rem < 0) quo--;
+    else if (rem >= tot) quo++;
+  }
   H = (L + rdl(quo, 0) - 1u) & 0xFFFFu;
   L = (L + rdl(quo, 1)) & 0xFFFFu;
   // cumfreq[0..i-1] += 8; rescale when the total passes 3800
   if (lane < i) m += 8u;
   if (tot + 8u > 3800u) qtm_update_model(m, entries, shiftsleft, lane);
-  for (;;) {
-    if ((L & 0x8000u) != (H & 0x8000u)) {
-      if ((L & 0x4000u) && !(H & 0x4000u)) { C ^= 0x4000u; L &= 0x3FFFu; H |= 0x4000u; }
-      else break;
+  // Renormalisation (qtmd.c:107-122) in closed form.  The reference's bit-at-a-time loop is always
+  // n shifts while the top bits of L and H agree, then m "underflow" steps while L = 01.., H = 10..
+  // (each drops bit 14 and keeps the top bits 0 / 1), then it stops: n = leading equal bits,
+  // m = leading positions below the top where L has 1 and H has 0.
+  {
+    u32 n = (u32) __builtin_clz(((L ^ H) << 16) | 0x8000u);            // 0..16
+    u32 L1 = (L << n) & 0xFFFFu, H1 = ((H << n) | ((1u << n) - 1u)) & 0xFFFFu;
+    u32 t = ((L1 & ~H1) & 0x7FFFu) << 17;
+    u32 mu = (u32) __builtin_clz(~t);                                   // 0..15
+    if (n == 16u) mu = 0;                                               // L == H: 16 shifts, then 0000 / FFFF
+    const u32 k = n + mu;
+    if (k) {
+      // k one-bit reads: the reference refills 16 bits whenever bits_left is 0 at a read
+      u32 have = (u32) d.rbl;
+      while (have < k) {
+        if (!d.ref_fill()) {                                            // ERR_READ at the bit that needed it
+          u32 used = (u32) d.rbl;                                       // bits consumed before the failing read
+          d.need((int) used); if (used) { d.bb <<= used; d.bl -= (int) used; }
+          d.rbl = 0; d.H = H; d.L = L; d.C = C;
+          return -1;
+        }
+        have = (u32) d.rbl;
+      }
+      d.need((int) k);
+      const u32 nb = (u32)(d.bb >> (64u - k));
+      d.bb <<= k; d.bl -= (int) k; d.rbl -= (int) k;
+      u32 C1 = ((C << n) | (nb >> mu)) & 0xFFFFu;
+      if (mu) {
+        u32 top = (~(C1 >> (15u - mu)) & 1u) << 15;
+        C1 = (((C1 << mu) | (nb & ((1u << mu) - 1u))) & 0x7FFFu) | top;
+        L1 = (L1 << mu) & 0x7FFFu;
+        H1 = 0x8000u | (((H1 << mu) | ((1u << mu) - 1u)) & 0x7FFFu);
+      }
+      L = L1; H = H1; C = C1;
     }
-    L = (L << 1) & 0xFFFFu; H = ((H << 1) | 1u) & 0xFFFFu;
-    d.need(1);
-    if (d.rbl < 1) { if (!d.ref_fill()) { d.H = H; d.L = L; d.C = C; return -1; } }
-    C = ((C << 1) | (u32)(d.bb >> 63)) & 0xFFFFu;
-    d.bb <<= 1; d.bl -= 1; d.rbl -= 1;
   }
   d.H = H; d.L = L; d.C = C;
   return sym;
@@ -225,7 +262,6 @@ __device__ __forceinline__ void qtm_copy(u8 *out, u32 P, u32 off, u32 len, u32 o
 __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
                                 mspack_hip_result *res, QtmShared *sh)
 {
-  (void) sh;
   const u32 lane = threadIdx.x;
   const u32 wb = u.window_bits;
   if (wb < 10u || wb > 21u) {
@@ -254,6 +290,21 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   bool header_read = false;
   int err = ERR_OK;
   u32 good = 0;                 // position up to which a request would have succeeded
+  // matches are queued and resolved 64 output bytes at a time (spec_queue.hpp) instead of paying a
+  // dependent load -> store round trip per match; literals are stored directly
+  SpecQueue Q;
+  spq_init(sh->spq, Q, 0u, lane);
+#define QTM_COPY(P_, off_, len_)                                                              \
+  do {                                                                                        \
+    if ((off_) <= (P_) && (P_) + (len_) - (Q.Pf & ~63u) <= SPQ_RING && Q.mcount < SPQ_CAP) {   \
+      spq_push(sh->spq, Q, lane == 0u, 0u, 1u, (P_), (off_), (len_));                         \
+    }                                                                                         \
+    else {                                                                                    \
+      spq_resolve(sh->spq, Q, out, (P_), true, lane, out_len);                                \
+      qtm_copy(out, (P_), (off_), (len_), out_len, lane);                                     \
+      Q.Pf = (P_) + (len_);                                                                   \
+    }                                                                                         \
+  } while (0)
 
   while ((long long)(o_end - o_ptr) < need) {
     u32 v;
@@ -318,17 +369,18 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
         // (the copy itself is the same on the linear buffer; only the flush bookkeeping differs)
         if ((long long) i > need) {
           // first part was already copied by the reference before it bails out
-          qtm_copy(out, P, moff, wsize - wpos, out_len, lane);
+          QTM_COPY(P, moff, wsize - wpos);
           err = ERR_DECRUNCH; stop = true; break;
         }
-        qtm_copy(out, P, moff, mlen, out_len, lane);
+        QTM_COPY(P, moff, mlen);
         written += i; need -= i; o_ptr = 0; o_end = 0;
         P += mlen; wpos = wpos + mlen - wsize;
         break;
       }
       if (moff > wpos && (moff - wpos) > wsize) { err = ERR_DECRUNCH; stop = true; break; }   // qtmd.c:399
-      qtm_copy(out, P, moff, mlen, out_len, lane);
+      QTM_COPY(P, moff, mlen);
       P += mlen; wpos += mlen;
+      if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane, out_len);
     }
     if (stop) break;
     o_end = wpos;
@@ -351,6 +403,14 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
       written += i; need -= i; o_ptr = 0; o_end = 0; wpos = 0;
     }
   }
+  // whatever is still queued lies below the highest position any token reached
+  {
+    u32 top = Q.Pf;
+    if (Q.mcount) { uint2 lr = sh->spq.mlist[Q.mcount - 1u]; top = rfl(lr.x) + (rfl(lr.y) & 511u); }
+    if (P > top) top = P;
+    spq_resolve(sh->spq, Q, out, top, true, lane, out_len);
+  }
+#undef QTM_COPY
   if (err == ERR_OK && need) { written += (u32) need; }
   if (err == ERR_OK) good = written;
   if (lane == 0) {

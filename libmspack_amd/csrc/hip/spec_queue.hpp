@@ -72,8 +72,9 @@ __device__ __forceinline__ void spq_cover(SpecQueueLds &l, SpecQueue &q, const u
 }
 
 // resolve the queue up to position P: whole 64-byte chunks only unless `fin`
+// (stores at or above `clip` are dropped: for callers whose last match may overshoot the output)
 __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *const out, const u32 P,
-                                            const bool fin, const u32 lane)
+                                            const bool fin, const u32 lane, const u32 clip = 0xFFFFFFFFu)
 {
   u32 c = q.Pf & ~63u;
   const u32 climit = fin ? P : c + ((P - c) & ~63u);
@@ -86,7 +87,7 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
       c += 64u;
       const bool more = c < climit;
       if (more) spq_cover(l, q, c, lane, inm, ptr, ext);
-      if (icur) out[bcur] = (u8) val;
+      if (icur && bcur < clip) out[bcur] = (u8) val;
       if (!more) break;
     }
     if (!fin) {
