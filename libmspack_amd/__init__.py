@@ -126,7 +126,7 @@ def decode_batch(units, in_arena, out_bytes, n_devices=1):
 class LzxOpts(C.Structure):
     _fields_ = [("block_mode", C.c_int), ("block_size", C.c_int), ("chain_depth", C.c_int),
                 ("use_repeats", C.c_int), ("lazy", C.c_int), ("intel_filesize", C.c_int32),
-                ("e8_base", C.c_int32)]
+                ("e8_base", C.c_int32), ("delta", C.c_int), ("ref", C.c_void_p), ("ref_len", C.c_size_t)]
 
 
 def corpus():
@@ -168,7 +168,18 @@ def gen_plaintext(seed, kind, n):
 
 
 def lzx_opts(mode=0, block_size=0, depth=0, repeats=1, lazy=1, intel_filesize=0, e8_base=0):
-    return LzxOpts(mode, block_size, depth, repeats, lazy, intel_filesize, e8_base)
+    return LzxOpts(mode, block_size, depth, repeats, lazy, intel_filesize, e8_base, 0, None, 0)
+
+
+def lzxd_encode(data, window_bits, ref=b"", **kw):
+    """LZX DELTA stream (one lzxd_init'ed block as OAB files hold them) -> compressed bytes (np.uint8)"""
+    o = lzx_opts(**kw)
+    refbuf = np.frombuffer(bytes(ref), dtype=np.uint8) if len(ref) else np.zeros(1, dtype=np.uint8)
+    o.delta = 1
+    o.ref = refbuf.ctypes.data if len(ref) else None
+    o.ref_len = len(ref)
+    comp, _fo = lzx_encode(data, window_bits, 0, o)
+    return comp
 
 
 def lzx_encode(data, window_bits, reset_frames, opts=None):

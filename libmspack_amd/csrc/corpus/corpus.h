@@ -37,6 +37,10 @@ typedef struct mspk_lzx_opts {
   int32_t intel_filesize; /* != 0: set the E8 header and pre-translate x86 CALLs (lzxd.c:706-736
                              inverse) so that decode(encode(x)) == x                            */
   int32_t e8_base;     /* value of lzx->offset at the first byte of `src` (curpos origin)       */
+  int delta;           /* 1 = LZX DELTA (lzxd.c:288-293,440-444,588-611): window 2^17..2^25, a 16-bit
+                          chunk size before every frame, match lengths beyond 257; reset_frames 0 */
+  const uint8_t *ref;  /* DELTA reference data the matches may reach into (lzxd.c:348-382)       */
+  size_t ref_len;
 } mspk_lzx_opts;
 
 /* Encode src[0..n) as one LZX stream.  reset_frames > 0: encoder state (match history, Huffman

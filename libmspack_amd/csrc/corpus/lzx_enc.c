@@ -22,10 +22,11 @@
 #define MINM 2
 #define MAXM 257
 #define HBITS 15
-#define MAXSLOTS 50
+#define MAXSLOTS 290
+#define MAXM_DELTA 32768
 #define MAINSYMS (256 + MAXSLOTS * 8)
 
-static const uint16_t slots_for_bits[7] = { 30, 32, 34, 36, 38, 42, 50 };
+static const uint16_t slots_for_bits[11] = { 30, 32, 34, 36, 38, 42, 50, 66, 98, 162, 290 };
 static uint32_t slot_base[MAXSLOTS + 1];
 static uint8_t  slot_extra[MAXSLOTS + 1];
 static void init_slots(void) {
@@ -37,7 +38,7 @@ static void init_slots(void) {
   }
 }
 static int slot_of(uint32_t formatted) {
-  int lo = 0, hi = MAXSLOTS - 1;
+  int lo = 0, hi = MAXSLOTS - 1;      /* (callers never pass offsets beyond their window) */
   while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (slot_base[mid] <= formatted) lo = mid; else hi = mid - 1; }
   return lo;
 }
@@ -74,6 +75,8 @@ typedef struct {
   int32_t *head, *prev;          /* hash chains, positions relative to istart (+1)              */
   uint32_t R[3];
   int depth, lazy, use_rep;
+  int maxm;                      /* longest match: 257, or 32768 in DELTA streams              */
+  size_t bias;                   /* DELTA: bytes of reference data in front of the plaintext    */
 } mf_t;
 
 static inline uint32_t hash3(const uint8_t *p) {
@@ -136,14 +139,14 @@ static void r_update(uint32_t *R, int rslot, uint32_t off) {
 static size_t parse_block(mf_t *m, size_t bstart, size_t bend, tok_t *toks) {
   size_t p = bstart, nt = 0;
   while (p < bend) {
-    size_t fend = (p / FRAME + 1) * FRAME;
+    size_t fend = ((p - m->bias) / FRAME + 1) * FRAME + m->bias;
     size_t lim = bend < fend ? bend : fend;
-    int maxl = (int)((lim - p) < MAXM ? (lim - p) : MAXM);
+    int maxl = (int)((lim - p) < (size_t) m->maxm ? (lim - p) : (size_t) m->maxm);
     uint32_t off = 0; int rs = 3;
     int len = mf_find(m, p, maxl, &off, &rs);
     if (len >= MINM && m->lazy && len < 40 && p + 1 < lim) {
       uint32_t off2; int rs2;
-      int maxl2 = (int)((lim - p - 1) < MAXM ? (lim - p - 1) : MAXM);
+      int maxl2 = (int)((lim - p - 1) < (size_t) m->maxm ? (lim - p - 1) : (size_t) m->maxm);
       int len2;
       mf_insert(m, p);
       len2 = mf_find(m, p + 1, maxl2, &off2, &rs2);
@@ -179,7 +182,7 @@ typedef struct { uint8_t sym, extra_bits, sym2; uint16_t extra; } plsym_t;
 
 static void write_lens(bw_t *w, const uint8_t *prev, const uint8_t *cur, int first, int last)
 {
-  plsym_t seq[800];
+  plsym_t seq[MAINSYMS + 64];
   uint32_t freq[20];
   uint8_t plen[20];
   uint16_t pcode[20];
@@ -221,9 +224,15 @@ typedef struct {
   uint8_t main_len[MAINSYMS + 8], len_len[256];   /* lengths of the previous block (delta base) */
 } lens_state_t;
 
+/* DELTA: the 16-bit chunk size in front of every frame; the decoder skips it (lzxd.c:440-444) */
+static void put_chunk_size(bw_t *w, size_t pos, size_t total) {
+  size_t left = total - pos;
+  bw_put(w, (uint32_t)(left < FRAME ? left : FRAME) & 0xFFFF, 16);
+}
+
 static void emit_compressed_block(bw_t *w, lens_state_t *ls, const tok_t *toks, size_t nt,
                                   uint32_t block_bytes, int num_main, int want_type,
-                                  size_t pos, uint64_t *frame_off)
+                                  size_t pos, uint64_t *frame_off, int delta, size_t total)
 {
   uint32_t fmain[MAINSYMS], flen[256], fali[8];
   uint8_t main_len[MAINSYMS + 8], len_len[256], ali_len[8];
@@ -237,7 +246,7 @@ static void emit_compressed_block(bw_t *w, lens_state_t *ls, const tok_t *toks, 
     const tok_t *t = &toks[i];
     if (t->len == 0) { fmain[t->lit]++; continue; }
     {
-      int lh = t->len - MINM, slot;
+      int lh = (t->len > MAXM ? MAXM : t->len) - MINM, slot;
       if (t->rslot < 3) slot = t->rslot;
       else {
         uint32_t f = t->off + 2;
@@ -277,7 +286,7 @@ static void emit_compressed_block(bw_t *w, lens_state_t *ls, const tok_t *toks, 
     const tok_t *t = &toks[i];
     if (t->len == 0) { bw_put(w, main_code[t->lit], main_len[t->lit]); pos++; }
     else {
-      int lh = t->len - MINM, slot, ms;
+      int lh = (t->len > MAXM ? MAXM : t->len) - MINM, slot, ms;
       uint32_t f = 0;
       if (t->rslot < 3) slot = t->rslot;
       else { f = t->off + 2; slot = slot_of(f); }
@@ -296,11 +305,19 @@ static void emit_compressed_block(bw_t *w, lens_state_t *ls, const tok_t *toks, 
           else bw_put(w, x, e);
         }
       }
+      if (delta && t->len >= MAXM) {     /* length 257 announces an extension (lzxd.c:588-611) */
+        uint32_t x = (uint32_t) t->len - MAXM;
+        if (x < 0x100) { bw_put(w, 0, 1); bw_put(w, x, 8); }
+        else if (x < 0x100 + 0x400) { bw_put(w, 2, 2); bw_put(w, x - 0x100, 10); }
+        else if (x < 0x500 + 0x1000) { bw_put(w, 6, 3); bw_put(w, x - 0x500, 12); }
+        else { bw_put(w, 7, 3); bw_put(w, x, 15); }
+      }
       pos += t->len;
     }
     if ((pos % FRAME) == 0) {            /* frame complete: re-align to 16 bits (lzxd.c:695-697) */
       bw_align(w);
       if (frame_off) frame_off[pos / FRAME] = w->n;
+      if (delta && pos < total) put_chunk_size(w, pos, total);
     }
   }
 }
@@ -335,19 +352,27 @@ size_t mspk_lzx_encode(const uint8_t *src_in, size_t n, int window_bits, int res
   mf_t m;
   lens_state_t *ls;
   tok_t *toks;
-  uint8_t *src;
-  size_t interval_bytes, istart, nframes = (n + FRAME - 1) / FRAME, fi, blk_no = 0;
+  uint8_t *src, *srcbuf;
+  size_t interval_bytes, istart, nframes = (n + FRAME - 1) / FRAME, fi, blk_no = 0, rl;
   int num_main;
 
   memset(&o, 0, sizeof(o));
   if (opts_in) o = *opts_in; else { o.use_repeats = 1; o.lazy = 1; }
   if (o.block_size <= 0) o.block_size = (int) FRAME;
   if (o.chain_depth <= 0) o.chain_depth = 24;
-  if (window_bits < 15 || window_bits > 21) return 0;
+  if (o.delta ? (window_bits < 17 || window_bits > 25 || reset_frames != 0 || o.intel_filesize)
+              : (window_bits < 15 || window_bits > 21 || o.ref_len)) return 0;
+  rl = o.delta ? o.ref_len : 0;
+  if (rl + n > ((size_t) 1 << window_bits)) return 0;        /* reference data + output share the window */
   init_slots();
   num_main = 256 + (slots_for_bits[window_bits - 15] << 3);
 
-  src = (uint8_t *) malloc(n + 16);
+  /* the match finder sees [reference data | plaintext]: a source inside the reference data is an
+   * offset larger than the window position, which is exactly what the decoder resolves against the
+   * end of its window (lzxd.c:618-642) */
+  srcbuf = (uint8_t *) malloc(rl + n + 16);
+  if (rl) memcpy(srcbuf, o.ref, rl);
+  src = srcbuf + rl;
   memcpy(src, src_in, n);
   if (o.intel_filesize) {
     for (fi = 0; fi < nframes && fi < 32768; fi++) {
@@ -358,11 +383,12 @@ size_t mspk_lzx_encode(const uint8_t *src_in, size_t n, int window_bits, int res
   memset(&w, 0, sizeof(w)); w.p = dst; w.cap = dst_cap;
   memset(&m, 0, sizeof(m));
   m.src = src; m.depth = o.chain_depth; m.lazy = o.lazy; m.use_rep = o.use_repeats;
+  m.maxm = o.delta ? MAXM_DELTA : MAXM;
   m.wmax = (1u << window_bits) - 3;
   m.head = (int32_t *) malloc(sizeof(int32_t) << HBITS);
   interval_bytes = reset_frames > 0 ? (size_t) reset_frames * FRAME : n;
   if (interval_bytes == 0) interval_bytes = FRAME;
-  m.prev = (int32_t *) malloc(sizeof(int32_t) * (interval_bytes < n ? interval_bytes : n) + 64);
+  m.prev = (int32_t *) malloc(sizeof(int32_t) * ((interval_bytes < n ? interval_bytes : n) + rl) + 64);
   ls = (lens_state_t *) calloc(1, sizeof(*ls));
   toks = (tok_t *) malloc(sizeof(tok_t) * ((size_t) o.block_size + 8));
 
@@ -373,8 +399,14 @@ size_t mspk_lzx_encode(const uint8_t *src_in, size_t n, int window_bits, int res
     /* interval start: encoder + decoder state restart (lzxd.c:257-270); always word-aligned here */
     memset(m.head, 0, sizeof(int32_t) << HBITS);
     m.istart = istart; m.iend = iend; m.R[0] = m.R[1] = m.R[2] = 1;
+    if (rl) {                    /* DELTA: positions are taken from the start of the reference data */
+      size_t q;
+      m.src = srcbuf; m.istart = 0; m.iend = rl + iend; m.bias = rl;
+      for (q = 0; q < rl; q++) mf_insert(&m, q);
+    }
     memset(ls, 0, sizeof(*ls));
     if (frame_off) frame_off[istart / FRAME] = w.n;
+    if (o.delta && n) put_chunk_size(&w, istart, n);
     if (o.intel_filesize) {
       bw_put(&w, 1, 1);
       bw_put(&w, (uint32_t) o.intel_filesize >> 16, 16);
@@ -397,14 +429,15 @@ size_t mspk_lzx_encode(const uint8_t *src_in, size_t n, int window_bits, int res
           bw_byte(&w, r & 0xFF); bw_byte(&w, (r >> 8) & 0xFF); bw_byte(&w, (r >> 16) & 0xFF); bw_byte(&w, r >> 24);
         }
         for (q = p; q < bend; q++) {
-          bw_byte(&w, src[q]); mf_insert(&m, q);
+          bw_byte(&w, src[q]); mf_insert(&m, q + rl);
           /* a frame end inside a stored block needs no padding: the bit buffer is empty */
           if (((q + 1) % FRAME) == 0 && frame_off) frame_off[(q + 1) / FRAME] = w.n;
+          if (((q + 1) % FRAME) == 0 && o.delta && q + 1 < n) put_chunk_size(&w, q + 1, n);
         }
         pending_pad = (int)(bbytes & 1);
       }
       else {
-        size_t nt = parse_block(&m, p, bend, toks), ti;
+        size_t nt = parse_block(&m, p + rl, bend + rl, toks), ti;
         for (ti = 0; ti < nt; ti++) {
           if (toks[ti].len) {
             unsigned o_ = toks[ti].off, lg_ = 0, l_ = toks[ti].len, lb_;
@@ -418,13 +451,13 @@ size_t mspk_lzx_encode(const uint8_t *src_in, size_t n, int window_bits, int res
           else __sync_fetch_and_add(&mspk_lzx_stat_literals, 1);
         }
         __sync_fetch_and_add(&mspk_lzx_stat_tokens, nt);
-        emit_compressed_block(&w, ls, toks, nt, bbytes, num_main, mode, p, frame_off);
+        emit_compressed_block(&w, ls, toks, nt, bbytes, num_main, mode, p, frame_off, o.delta, n);
       }
       p = bend;
     }
     bw_align(&w);   /* short final frame: the decoder re-aligns after it too */
   }
   if (frame_off) frame_off[nframes] = w.n;
-  free(src); free(m.head); free(m.prev); free(ls); free(toks);
+  free(srcbuf); free(m.head); free(m.prev); free(ls); free(toks);
   return w.overflow ? 0 : w.n;
 }

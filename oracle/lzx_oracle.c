@@ -69,6 +69,7 @@ typedef struct {
   uint32_t R0, R1, R2, block_length, block_remaining;
   int32_t  intel_filesize;
   int block_type, header_read, intel_started, length_empty;
+  int is_delta; uint32_t ref_size;   /* LZX DELTA (lzxd.c:288-293, 348-382) */
   uint8_t pre_len[20 + SAFETY], main_len[MAIN_MAXSYMS + SAFETY], len_len[LEN_MAXSYMS + SAFETY],
           ali_len[8 + SAFETY];
   oh_table pre_t, main_t, len_t, ali_t;
@@ -194,10 +195,20 @@ static int32_t decode_run(lzx_t *z, int32_t run) {
         else if (extra) { if (rd_bits(b, extra, &v)) return INT32_MIN; off += v; }
         z->R2 = z->R1; z->R1 = z->R0; z->R0 = off;
       }
+      if (len == 257 && z->is_delta) {                               /* lzxd.c:588-611 */
+        unsigned p, x = 0;
+        if (ensure(b, 3)) return INT32_MIN;
+        p = PEEK(b, 3);
+        if ((p & 4) == 0)      { DROP(b, 1); if (rd_bits(b, 8, &x)) return INT32_MIN; }
+        else if ((p >> 1) == 2) { DROP(b, 2); if (rd_bits(b, 10, &x)) return INT32_MIN; x += 0x100; }
+        else if (p == 6)        { DROP(b, 3); if (rd_bits(b, 12, &x)) return INT32_MIN; x += 0x500; }
+        else                    { DROP(b, 3); if (rd_bits(b, 15, &x)) return INT32_MIN; }
+        len += (int) x;
+      }
       if (z->wpos + (uint32_t) len > z->wsize) { b->err = ORC_DECRUNCH; return INT32_MIN; }
       dst = &win[z->wpos]; i = (uint32_t) len;
       if (off > z->wpos) {                                           /* lzxd.c:622-642 */
-        if ((uint64_t) off > z->offset) { b->err = ORC_DECRUNCH; return INT32_MIN; }
+        if ((uint64_t) off > z->offset && (off - z->wpos) > z->ref_size) { b->err = ORC_DECRUNCH; return INT32_MIN; }
         j = off - z->wpos;
         if (j > z->wsize) { b->err = ORC_DECRUNCH; return INT32_MIN; }
         src = &win[z->wsize - j];
@@ -215,13 +226,25 @@ int oracle_lzx_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
                       uint64_t out_bytes, uint64_t length, int window_bits, int reset_frames,
                       int32_t e8_base, oracle_result *res)
 {
+  return oracle_lzxd_decode(in, in_len, out, out_cap, out_bytes, length, window_bits, reset_frames, e8_base,
+                            0, NULL, 0, res);
+}
+
+/* is_delta != 0: LZX DELTA (window 2^17..2^25, a 16-bit chunk size in front of every frame, match
+ * lengths extended beyond 257, `ref` = reference data preloaded at the end of the window:
+ * lzxd.c:288-293, 348-382, 440-444, 588-611, 622-634) */
+int oracle_lzxd_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                       uint64_t out_bytes, uint64_t length, int window_bits, int reset_frames,
+                       int32_t e8_base, int is_delta, const uint8_t *ref, size_t ref_len, oracle_result *res)
+{
   lzx_t *z;
   uint64_t written = 0, remaining = out_bytes;
   uint32_t end_frame, flags = 0;
   int err = ORC_OK;
 
   memset(res, 0, sizeof(*res));
-  if (window_bits < 15 || window_bits > 21 || reset_frames < 0) { res->err = ORC_ARGS; return ORC_ARGS; }
+  if (is_delta ? (window_bits < 17 || window_bits > 25) : (window_bits < 15 || window_bits > 21)) { res->err = ORC_ARGS; return ORC_ARGS; }
+  if (reset_frames < 0 || (ref_len && !is_delta) || ref_len > ((size_t) 1 << window_bits)) { res->err = ORC_ARGS; return ORC_ARGS; }
   init_slots();
   z = (lzx_t *) calloc(1, sizeof(*z));
   z->win = (uint8_t *) calloc(1, (size_t) 1 << window_bits);
@@ -230,6 +253,8 @@ int oracle_lzx_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
   z->reset_frames = (uint32_t) reset_frames;
   z->length = length;
   z->num_offsets = (uint32_t) slots_for_bits[window_bits - 15] << 3;
+  z->is_delta = is_delta; z->ref_size = (uint32_t) ref_len;
+  if (ref_len) memcpy(z->win + z->wsize - ref_len, ref, ref_len);
   reset_state(z);
   if (out_bytes == 0) goto done;
 
@@ -242,6 +267,7 @@ int oracle_lzx_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
     uint8_t e8buf[FRAME];
 
     if (z->reset_frames && (z->frame % z->reset_frames) == 0) reset_state(z);
+    if (z->is_delta) { if (ensure(&z->b, 16)) goto fail; DROP(&z->b, 16); }     /* chunk size, lzxd.c:440-444 */
     if (!z->header_read) {
       hi = lo = 0;
       if (rd_bits(&z->b, 1, &v)) goto fail;

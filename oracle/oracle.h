@@ -48,6 +48,11 @@ typedef struct oracle_result {
 int oracle_lzx_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
                       uint64_t out_bytes, uint64_t length, int window_bits, int reset_frames,
                       int32_t e8_base, oracle_result *res);
+/* the same with LZX DELTA (is_delta: window 2^17..2^25, per-frame chunk size, extended match lengths)
+ * and its reference data (lzxd_set_reference_data, lzxd.c:348-382) */
+int oracle_lzxd_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
+                       uint64_t out_bytes, uint64_t length, int window_bits, int reset_frames,
+                       int32_t e8_base, int is_delta, const uint8_t *ref, size_t ref_len, oracle_result *res);
 
 /* MSZIP: mszipd_init(repair_mode) + one mszipd_decompress(out_bytes) over a whole folder stream
  * (concatenated CFDATA payloads).  block_lens (optional, cap entries) receives each block's

@@ -140,6 +140,30 @@ int refh_lzx(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, lon
   return err;
 }
 
+/* LZX DELTA: lzxd_init(is_delta = 1) + lzxd_set_reference_data + lzxd_decompress (lzxd.c:274-382) */
+int refh_lzxd(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, long long out_bytes,
+              int window_bits, int reset_interval, long long output_length,
+              const uint8_t *ref, size_t ref_len, size_t *written)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) in, in_len, 0 };
+  struct memname dst = { MEMNAME_MAGIC, out, out_cap, 0 };
+  struct memname rsrc = { MEMNAME_MAGIC, (uint8_t *) ref, ref_len, 0 };
+  struct mspack_file *fi = m_open(&mem_system, (const char *) &src, MSPACK_SYS_OPEN_READ);
+  struct mspack_file *fo = m_open(&mem_system, (const char *) &dst, MSPACK_SYS_OPEN_WRITE);
+  struct mspack_file *fr = m_open(&mem_system, (const char *) &rsrc, MSPACK_SYS_OPEN_READ);
+  struct lzxd_stream *lzx = lzxd_init(&mem_system, fi, fo, window_bits, reset_interval, 4096,
+                                      (off_t) output_length, 1);
+  int err = MSPACK_ERR_ARGS;
+  if (lzx) {
+    err = ref_len ? lzxd_set_reference_data(lzx, &mem_system, fr, (unsigned int) ref_len) : MSPACK_ERR_OK;
+    if (!err) err = lzxd_decompress(lzx, (off_t) out_bytes);
+    lzxd_free(lzx);
+  }
+  if (written) *written = dst.written;
+  m_close(fi); m_close(fo); m_close(fr);
+  return err;
+}
+
 int refh_mszip(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, long long out_bytes,
                int repair_mode, size_t *written)
 {

@@ -46,6 +46,9 @@ def oracle():
         lib.oracle_qtm_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
                                           C.c_int, C.POINTER(OracleResult)]
         lib.oracle_huff_accepts.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        lib.oracle_lzxd_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
+                                           C.c_uint64, C.c_int, C.c_int, C.c_int32, C.c_int, C.c_char_p, C.c_size_t,
+                                           C.POINTER(OracleResult)]
         _oracle = lib
     return _oracle
 
@@ -58,6 +61,17 @@ def oracle_lzx(data, out_bytes, window_bits, reset_frames=0, length=None, e8_bas
     res = OracleResult()
     oracle().oracle_lzx_decode(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), int(length),
                                window_bits, reset_frames, e8_base, C.byref(res))
+    return res.err, buf.raw[:min(res.out_len, out_bytes)], res
+
+
+def oracle_lzxd(data, out_bytes, window_bits, ref=b"", reset_frames=0, length=None, e8_base=0):
+    """LZX DELTA through the oracle -> (err, bytes, OracleResult)"""
+    if length is None:
+        length = out_bytes
+    buf = C.create_string_buffer(max(int(out_bytes), 1))
+    res = OracleResult()
+    oracle().oracle_lzxd_decode(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), int(length),
+                                window_bits, reset_frames, e8_base, 1, bytes(ref), len(ref), C.byref(res))
     return res.err, buf.raw[:min(res.out_len, out_bytes)], res
 
 
@@ -94,6 +108,8 @@ def ref():
         sz = C.POINTER(C.c_size_t)
         lib.refh_lzx.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_longlong, C.c_int,
                                  C.c_int, C.c_longlong, sz]
+        lib.refh_lzxd.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_longlong, C.c_int, C.c_int,
+                                  C.c_longlong, C.c_char_p, C.c_size_t, sz]
         lib.refh_mszip.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_longlong, C.c_int, sz]
         lib.refh_qtm.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_longlong, C.c_int, sz]
         lib.refh_cab_list.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint),
@@ -127,6 +143,16 @@ def ref_lzx(data, out_bytes, window_bits, reset_frames=0, length=None):
     w = C.c_size_t(0)
     err = ref().refh_lzx(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), window_bits,
                          reset_frames, int(length), C.byref(w))
+    return err, buf.raw[:min(w.value, out_bytes)], w.value
+
+
+def ref_lzxd(data, out_bytes, window_bits, ref=b"", reset_frames=0, length=None):
+    if length is None:
+        length = out_bytes
+    buf = C.create_string_buffer(max(int(out_bytes), 1))
+    w = C.c_size_t(0)
+    err = globals()["ref"]().refh_lzxd(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), window_bits,
+                                       reset_frames, int(length), bytes(ref), len(ref), C.byref(w))
     return err, buf.raw[:min(w.value, out_bytes)], w.value
 
 

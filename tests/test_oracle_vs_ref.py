@@ -147,3 +147,41 @@ def test_fuzz_oracle_vs_reference_mszip_qtm(built):
             e1, o1, w1 = ref_qtm(m, data.size, wb)
             e2, o2, r = oracle_qtm(m, data.size, wb)
             assert (e1, w1) == (e2, r.out_len), ("qtm", ci, e1, w1, e2, r.out_len)
+
+
+DELTA_CASES = [(70000, 17, 0, {}), (200000, 18, 0, dict(mode=4, block_size=20000)), (100000, 19, 50000, {}),
+               (300000, 21, 100000, dict(mode=2)), (5000, 17, 3000, dict(mode=3)),
+               (65536, 17, 65536, dict(mode=4, block_size=9999)), (1 << 20, 22, 1 << 20, {}), (100000, 25, 0, {})]
+
+
+def delta_case(n, wb, refn, kw):
+    """plaintext sharing content with its reference data, with a long run (extended match lengths)"""
+    data = M.gen_plaintext(7 + n, 0, n).copy()
+    ref = b""
+    if refn:
+        r = M.gen_plaintext(99, 0, refn)
+        k = min(n, refn) // 2
+        data[1000:1000 + k // 2] = r[500:500 + k // 2]
+        ref = r.tobytes()
+    data[n // 3:n // 3 + 5000] = 0x41
+    return data, ref, M.lzxd_encode(data, wb, ref, **kw).tobytes()
+
+
+@pytest.mark.parametrize("case", DELTA_CASES, ids=[str(c[:3]) for c in DELTA_CASES])
+def test_lzx_delta_encoder_and_oracle_vs_reference(built, case):
+    """LZX DELTA: our encoder's streams through the real lzxd (is_delta, reference data)
+    and through the oracle; plus damaged copies for error codes and byte counts."""
+    from helpers import ref_lzxd, oracle_lzxd
+    n, wb, refn, kw = case
+    data, ref, comp = delta_case(n, wb, refn, kw)
+    e1, o1, w1 = ref_lzxd(comp + b"\0" * 8, n, wb, ref)
+    e2, o2, r = oracle_lzxd(comp + b"\0" * 8, n, wb, ref)
+    assert e1 == e2 == 0 and o1 == o2 == data.tobytes() and w1 == r.out_len
+    if n > 400000:
+        return
+    mutations = _mutations()
+    rng = np.random.default_rng(n + wb)
+    for m in mutations(comp, rng, 120):
+        e1, o1, w1 = ref_lzxd(m, n, wb, ref)
+        e2, o2, r = oracle_lzxd(m, n, wb, ref)
+        assert (e1, w1) == (e2, r.out_len), (len(m), e1, w1, e2, r.out_len)
