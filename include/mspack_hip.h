@@ -32,6 +32,7 @@ extern "C" {
 #define MSPACK_HIP_KIND_MSZIP   1
 #define MSPACK_HIP_KIND_QUANTUM 2
 #define MSPACK_HIP_KIND_LZX     3
+#define MSPACK_HIP_KIND_LZX_DELTA 4   /* lzxd_init(is_delta = 1): OAB blocks (oabd.c:196, 346; lzxd.c:288-293) */
 
 /* result flags */
 #define MSPACK_HIP_F_E8_APPLIED     1u  /* >=1 frame went through the E8 translation (lzxd.c:706-736) */
@@ -54,9 +55,12 @@ typedef struct mspack_hip_unit {
   uint32_t frame_base;   /* LZX: first slot of this unit in the per-frame scratch (see below)      */
   int32_t  e8_base;      /* LZX: lzx->offset at the unit's first byte (E8 curpos origin)           */
   uint8_t  kind;         /* MSPACK_HIP_KIND_*                                                      */
-  uint8_t  window_bits;  /* LZX 15..21, Quantum 10..21, ignored for MSZIP                          */
+  uint8_t  window_bits;  /* LZX 15..21, LZX DELTA 17..22, Quantum 10..21, ignored for MSZIP         */
   uint16_t reset_frames; /* LZX: lzxd_init reset_interval in 32 KiB frames (0 = never, CAB)        */
   uint32_t flags;        /* MSPACK_HIP_UF_*                                                        */
+  uint32_t ref_len;      /* LZX DELTA: bytes of reference data (lzxd_set_reference_data, lzxd.c:348-382)
+                            that the caller placed in the output arena at [out_off - ref_len, out_off) */
+  uint32_t reserved;     /* 0                                                                      */
 } mspack_hip_unit;
 
 typedef struct mspack_hip_result {

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("MSPACK_HIP_SO", os.path.join(HERE, "libmspack_hip.so"))   # env override: kernel experiments only
 CORPUS_SO = os.path.join(HERE, "libmspack_corpus.so")
 
-KIND_MSZIP, KIND_QUANTUM, KIND_LZX = 1, 2, 3
+KIND_MSZIP, KIND_QUANTUM, KIND_LZX, KIND_LZX_DELTA = 1, 2, 3, 4
 F_E8_APPLIED, F_LOOKAHEAD_READ, F_INTEL_HEADER = 1, 2, 4
 UF_MSZIP_REPAIR = 1
 ERR_OK, ERR_ARGS, ERR_OPEN, ERR_READ, ERR_WRITE, ERR_SEEK, ERR_NOMEMORY, ERR_SIGNATURE, \
@@ -23,10 +23,11 @@ ERR_OK, ERR_ARGS, ERR_OPEN, ERR_READ, ERR_WRITE, ERR_SEEK, ERR_NOMEMORY, ERR_SIG
 # struct mspack_hip_unit / mspack_hip_result (include/mspack_hip.h)
 UNIT_DTYPE = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"),
                        ("frame_base", "<u4"), ("e8_base", "<i4"), ("kind", "u1"), ("window_bits", "u1"),
-                       ("reset_frames", "<u2"), ("flags", "<u4")], align=False)
+                       ("reset_frames", "<u2"), ("flags", "<u4"), ("ref_len", "<u4"), ("reserved", "<u4")],
+                      align=False)
 RESULT_DTYPE = np.dtype([("err", "<i4"), ("flags", "<u4"), ("out_len", "<u4"), ("in_used", "<u4"),
                          ("good_len", "<u4"), ("reserved", "<u4")])
-assert UNIT_DTYPE.itemsize == 40 and RESULT_DTYPE.itemsize == 24
+assert UNIT_DTYPE.itemsize == 48 and RESULT_DTYPE.itemsize == 24
 
 
 class MspackHipError(RuntimeError):
@@ -74,13 +75,15 @@ def _check(rc, what):
 
 def frames_of(units):
     """per-unit slots in the LZX per-frame scratch (one spare for the look-ahead frame)"""
-    return np.where(units["kind"] == KIND_LZX, units["out_len"] // 32768 + 1, 0).astype(np.int64)
+    return np.where((units["kind"] == KIND_LZX) | (units["kind"] == KIND_LZX_DELTA),
+                    units["out_len"] // 32768 + 1, 0).astype(np.int64)
 
 
 def make_units(kind, in_offs, in_lens, out_lens, window_bits=0, reset_frames=0, e8_base=0, flags=0,
-               out_slack=0):
+               out_slack=0, ref_lens=0):
     """Build a unit table; output regions are laid out back to back (16-byte aligned, plus
-    `out_slack` bytes each: MSZIP units need 32768 bytes of slack after out_len)."""
+    `out_slack` bytes each: MSZIP units need 32768 bytes of slack after out_len).  LZX DELTA units
+    get `ref_lens` bytes of room for their reference data right below their output."""
     n = len(in_offs)
     u = np.zeros(n, dtype=UNIT_DTYPE)
     u["in_off"] = in_offs
@@ -91,11 +94,13 @@ def make_units(kind, in_offs, in_lens, out_lens, window_bits=0, reset_frames=0, 
     u["reset_frames"] = reset_frames
     u["e8_base"] = e8_base
     u["flags"] = flags
-    sizes = (np.asarray(out_lens, dtype=np.int64) + out_slack + 15) & ~15
+    u["ref_len"] = ref_lens
+    rl = (u["ref_len"].astype(np.int64) + 15) & ~15
+    sizes = ((np.asarray(out_lens, dtype=np.int64) + out_slack + 15) & ~15) + rl
     offs = np.zeros(n, dtype=np.int64)
     if n:
         offs[1:] = np.cumsum(sizes)[:-1]
-    u["out_off"] = offs
+    u["out_off"] = offs + rl
     fr = frames_of(u)
     fb = np.zeros(n, dtype=np.int64)
     if n:
@@ -104,12 +109,18 @@ def make_units(kind, in_offs, in_lens, out_lens, window_bits=0, reset_frames=0, 
     return u, int(sizes.sum())
 
 
-def decode_batch(units, in_arena, out_bytes, n_devices=1):
+def decode_batch(units, in_arena, out_bytes, n_devices=1, refs=None):
     """Host-buffer batch decode through mspack_hip_decode_batch[_multi].
+    refs: per-unit reference data (bytes) of LZX DELTA units, placed right below each unit's output.
     -> (out uint8 array, results structured array)"""
     units = np.ascontiguousarray(units, dtype=UNIT_DTYPE)
     in_arena = np.ascontiguousarray(in_arena, dtype=np.uint8)
     out = np.zeros(max(int(out_bytes), 1), dtype=np.uint8)
+    if refs is not None:
+        for u, r in zip(units, refs):
+            if len(r):
+                o = int(u["out_off"])
+                out[o - len(r):o] = np.frombuffer(bytes(r), dtype=np.uint8)
     res = np.zeros(len(units), dtype=RESULT_DTYPE)
     L = lib()
     if n_devices > 1:

@@ -363,7 +363,7 @@ size_t mspk_lzx_encode(const uint8_t *src_in, size_t n, int window_bits, int res
   if (o.delta ? (window_bits < 17 || window_bits > 25 || reset_frames != 0 || o.intel_filesize)
               : (window_bits < 15 || window_bits > 21 || o.ref_len)) return 0;
   rl = o.delta ? o.ref_len : 0;
-  if (rl + n > ((size_t) 1 << window_bits)) return 0;        /* reference data + output share the window */
+  if (o.delta && rl + n > ((size_t) 1 << window_bits)) return 0;   /* reference data + output share the window */
   init_slots();
   num_main = 256 + (slots_for_bits[window_bits - 15] << 3);
 

@@ -19,7 +19,14 @@
 // The output buffer doubles as the LZ77 window ("linear window"): src = pos - offset, valid because
 // frames never straddle the window wrap (lzxd.c:655-656); positions modulo window_size are kept
 // only for the reference's error checks (lzxd.c:613-634).
-#pragma once
+//
+// The header is compiled twice by shim.hip, each time inside its own namespace: once as is (LZX of
+// CAB folders and CHM sections) and once with LZX_DELTA defined -- LZX DELTA of OAB files
+// (lzxd.c:288-293, 348-382, 440-444, 588-611): windows 2^17..2^22 here (the 10-bit symbol field of the
+// table entries holds main alphabets up to 1023 symbols, i.e. up to 66 position slots), a 16-bit
+// chunk size in front of every frame, match lengths extended beyond 257, and reference data that
+// sits in the output arena right below the unit's output (positions are then biased by its size,
+// so a source inside the reference data is an ordinary linear copy).
 #include "wave_common.hpp"
 #include "spec_queue.hpp"
 
@@ -28,7 +35,12 @@
 #define LZX_LEN_P 10
 #define LZX_ALI_P 7
 #define LZX_PRE_P 6
+#undef LZX_MAIN_SYMS
+#ifdef LZX_DELTA
+#define LZX_MAIN_SYMS 848      /* 256 + 66*8 + 64 (w<=22) */
+#else
 #define LZX_MAIN_SYMS 720      /* 256 + 50*8 + 64: every index that can ever be non-zero (w<=21) */
+#endif
 #define LZX_LEN_SYMS 250
 #ifndef LZX_SPEC_WIDE
 #define LZX_SPEC_WIDE 0          /* 1: every lane decodes two positions (128 per round) */
@@ -199,7 +211,13 @@ struct LzxState {
   int32_t intel_filesize;
   bool header_read, intel_started, length_empty;
   bool raw_mode; u32 raw_pos;   // inside / right after an uncompressed block: input byte position
+  u32 ref_size;          // LZX DELTA: bytes of reference data below position 0 (0 otherwise)
 };
+
+// a match source before the window position is legal when the stream has produced that much, or
+// (DELTA) when it stays inside the reference data; never beyond the window (lzxd.c:622-634)
+#define LZX_BAD_SOURCE(off_, wp_, written_, ref_, wsize_)                                       \
+  ((off_) > (wp_) && ((((off_) > (written_)) && (((off_) - (wp_)) > (ref_))) || (((off_) - (wp_)) > (wsize_))))
 
 __device__ __forceinline__ void lzx_reset_state(LzxDec &d, LzxState &s) {      // lzxd.c:257-270
   s.R0 = s.R1 = s.R2 = 1;
@@ -433,7 +451,7 @@ __device__ __forceinline__ int lzx_run_fast(LzxDec &d, LzxState &s, const u32 ru
     u32 wp = P - wbase;
     if (P + len > run_end) FAST_FAIL(ERR_DECRUNCH);          // lzxd.c:678-693
     if (wp + len > wsize) FAST_FAIL(ERR_DECRUNCH);           // lzxd.c:613
-    if (off > wp) { if (off > offset_written || (off - wp) > wsize) FAST_FAIL(ERR_DECRUNCH); }
+    if (LZX_BAD_SOURCE(off, wp, offset_written, s.ref_size, wsize)) FAST_FAIL(ERR_DECRUNCH);
 #ifndef LZX_EXP_NOCOPY
     FAST_FLUSH();
     if (off != 0u && off <= wsize) lzx_copy_match(out, P, off, len, lane);
@@ -539,6 +557,9 @@ __device__ __forceinline__ SpecTok lzx_spec_token(const LzxShared *sh, const u32
   bool need_len = is_match && lh == 7u;
   if (need_len) { unk = unk || e2 == 0u || length_empty; u32 l2 = e2 >> 10; r <<= l2; tot += l2; }
   u32 mlen = lh + 2u + (need_len ? (e2 & 1023u) : 0u);
+#ifdef LZX_DELTA
+  if (is_match && mlen == 257u) unk = true;             // announces an extended length (lzxd.c:588-611)
+#endif
   u32 extra = slot < 4u ? 0u : (slot < 36u ? (slot >> 1) - 1u : 17u);
   u32 base = slot < 4u ? slot : (slot < 36u ? ((2u + (slot & 1u)) << extra) : ((slot - 34u) << 17));
   u32 off = base - 2u;
@@ -712,7 +733,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   const u32 run_end = rfl(run_end_), wbase = rfl(wbase_);
   u32 P = rfl(d.P);
   u32 R0 = rfl(s.R0), R1 = rfl(s.R1), R2 = rfl(s.R2);
-  const u32 wsize = rfl(s.wsize), offset_written = rfl(s.offset);
+  const u32 wsize = rfl(s.wsize), offset_written = rfl(s.offset), ref_size = rfl(s.ref_size);
   const bool length_empty = rfl((u32) s.length_empty) != 0u;
   int rc = LZX_RUN_DONE;
 
@@ -748,7 +769,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     else { moff_ = R2; R2 = R0; R0 = moff_; }                                                \
     u32 wp_ = (pos_) - wbase;                                                                \
     if ((pos_) + (len_) > run_end || wp_ + (len_) > wsize ||                                 \
-        (moff_ > wp_ && (moff_ > offset_written || (moff_ - wp_) > wsize))) {                \
+        LZX_BAD_SOURCE(moff_, wp_, offset_written, ref_size, wsize)) {                        \
       d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL;                                               \
     }                                                                                        \
     else SPEC_COPY(pos_, len_, moff_, wp_);                                                  \
@@ -760,7 +781,8 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   u32 &Pf = Q.Pf, &mcount = Q.mcount;
   uint2 *const mlist = sh->spq.mlist;
   u8 *const mflag = sh->spq.mflag;
-  bool slow = false;                                    // this round copies its matches one by one
+  bool slow = false;
+  bool bail = false;                                    // DELTA: leave the token at hand to the scalar loop                                    // this round copies its matches one by one
 
 #ifdef LZX_EXP_STATS
 #define TICK(k) do { u64 n_ = __builtin_amdgcn_s_memtime(); d.st_t[k] += (u32)(n_ - tk_); tk_ = n_; } while (0)
@@ -771,7 +793,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
 #ifdef LZX_EXP_STATS
     u64 tk_ = __builtin_amdgcn_s_memtime();
 #endif
-    bool live = (rc == LZX_RUN_DONE) && P < run_end;
+    bool live = (rc == LZX_RUN_DONE) && P < run_end && !bail;
     if (live && bitpos >= bit_limit) { rc = LZX_RUN_SWITCH; live = false; }
     const bool fin = !live || slow;
 #ifndef LZX_EXP_NOCOPY
@@ -870,10 +892,10 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       const u32 wpA = oposA - wbase, wpB = oposB - wbase;
       const bool badA = ((mmA >> lane) & 1ull) &&
                  (oposA + tA.olen > run_end || wpA + tA.olen > wsize ||
-                  (vmoffA > wpA && (vmoffA > offset_written || (vmoffA - wpA) > wsize)));
+                  LZX_BAD_SOURCE(vmoffA, wpA, offset_written, ref_size, wsize));
       const bool badB = WIDE && ((mmB >> lane) & 1ull) &&
                  (oposB + tB.olen > run_end || wpB + tB.olen > wsize ||
-                  (vmoffB > wpB && (vmoffB > offset_written || (vmoffB - wpB) > wsize)));
+                  LZX_BAD_SOURCE(vmoffB, wpB, offset_written, ref_size, wsize));
       const u64 badmA = ballot(badA), badmB = WIDE ? ballot(badB) : 0ull;
       if (badmA) { mmA &= (1ull << ((u32) __ffsll((long long) badmA) - 1u)) - 1ull; mmB = 0; fail_after = true; }
       else if (badmB) { mmB &= (1ull << ((u32) __ffsll((long long) badmB) - 1u)) - 1ull; fail_after = true; }
@@ -930,6 +952,11 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
                        : (((u64) rdl(w0B, q - 64u) << 32) | rdl(w1B, q - 64u));
       u32 tk_tot = lzx_scalar_token<ALIGNED>(d, length_empty, rq, tk_kind, tk_val, tk_off);
       if (tk_tot == 0u) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; slow = false; continue; }
+#ifdef LZX_DELTA
+      // length 257 announces an extension that follows the offset bits (lzxd.c:588-611): that token
+      // belongs to the scalar loop of lzx_decode_unit, which comes back here afterwards
+      if (tk_kind != 0u && tk_val == 257u) { bail = true; slow = false; continue; }
+#endif
       if (tk_kind == 0u) { if (lane == 0) out[P] = (u8) tk_val; P++; if (slow) Pf = P; }
       else {
         u32 moff_;
@@ -940,7 +967,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
         else { moff_ = t2; t2 = t0; t0 = moff_; }
         u32 wp_ = P - wbase;
         if (P + tk_val > run_end || wp_ + tk_val > wsize ||
-            (moff_ > wp_ && (moff_ > offset_written || (moff_ - wp_) > wsize))) {
+            LZX_BAD_SOURCE(moff_, wp_, offset_written, ref_size, wsize)) {
           d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; slow = false; continue;
         }
 #ifndef LZX_EXP_NOCOPY
@@ -990,7 +1017,13 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   d.w.seek(0, lane);
   d.bb = 0; d.bl = 0; d.rbl = 0;
   d.near_end = (u.in_len <= 64u); d.careful = d.near_end;
-  d.out = out_arena + u.out_off; d.P = 0; d.lit_buf = 0; d.lit_n = 0;
+#ifdef LZX_DELTA
+  // reference data lies right below the unit's output; positions are biased by its size
+  d.out = out_arena + u.out_off - u.ref_len; d.P = u.ref_len;
+#else
+  d.out = out_arena + u.out_off; d.P = 0;
+#endif
+  d.lit_buf = 0; d.lit_n = 0;
   d.st_rounds = 0; d.st_unknown = 0;
   for (int k_ = 0; k_ < 6; k_++) d.st_t[k_] = 0;
   d.st_h[0] = d.st_h[1] = d.st_h[2] = 0;
@@ -1001,9 +1034,15 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   s.intel_filesize = 0; s.intel_started = false; s.length_empty = false;
   s.raw_mode = false; s.raw_pos = 0;
   {
-    static const u8 slots[7] = { 30, 32, 34, 36, 38, 42, 50 };
+    static const u8 slots[8] = { 30, 32, 34, 36, 38, 42, 50, 66 };
     u32 wb = u.window_bits;
+#ifdef LZX_DELTA
+    s.ref_size = u.ref_len;
+    s.num_offsets = (wb >= 17u && wb <= 22u && u.ref_len <= (1u << wb)) ? ((u32) slots[wb - 15u] << 3) : 0u;
+#else
+    s.ref_size = 0;
     s.num_offsets = (wb >= 15u && wb <= 21u) ? ((u32) slots[wb - 15u] << 3) : 0u;
+#endif
   }
   if (s.num_offsets == 0u) {
     if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->reserved = 0; }
@@ -1021,6 +1060,17 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
         // a reset in raw mode keeps reading bits from raw_pos (no pad byte: block_type is cleared)
         lzx_reset_state(d, s);
       }
+#ifdef LZX_DELTA
+      {                                                               // chunk size (lzxd.c:440-444)
+        u32 cs;
+        if (s.raw_mode) {
+          // inside a stored block the bit buffer is empty: ENSURE_BITS(16) reads two bytes, REMOVE drops them
+          if (s.raw_pos + 2u > d.w.in_len + d.w.eofs) { d.err = ERR_READ; break; }
+          s.raw_pos += 2u;
+        }
+        else if (!d.read_bits(16, cs)) break;
+      }
+#endif
       if (!s.header_read) {
         u32 v, hi = 0, lo = 0;
         lzx_leave_raw(d, s);
@@ -1052,15 +1102,22 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
           const bool aligned = (s.block_type == 2u);
           const u32 run_end = d.P + (u32) run;
           const u32 wbase = d.P - s.wpos;          // linear position of window index 0
-          if (!d.careful && !d.near_end) {
-#ifndef LZX_NO_SPEC
-            int rc = aligned ? lzx_run_spec<true>(d, s, run_end, wbase) : lzx_run_spec<false>(d, s, run_end, wbase);
-#else
-            int rc = aligned ? lzx_run_fast<true>(d, s, run_end, wbase) : lzx_run_fast<false>(d, s, run_end, wbase);
-#endif
-            if (rc == LZX_RUN_FAIL) { d.flush_lits(); fail = true; break; }
-          }
+          bool respec = true;                      // try the speculative path (again)
           while (d.P < run_end) {
+            if (respec && !d.careful && !d.near_end) {
+#ifndef LZX_NO_SPEC
+              int rc = aligned ? lzx_run_spec<true>(d, s, run_end, wbase) : lzx_run_spec<false>(d, s, run_end, wbase);
+#else
+              int rc = aligned ? lzx_run_fast<true>(d, s, run_end, wbase) : lzx_run_fast<false>(d, s, run_end, wbase);
+#endif
+              if (rc == LZX_RUN_FAIL) { fail = true; break; }
+              if (d.P >= run_end) break;
+            }
+#ifdef LZX_DELTA
+            respec = true;                           // it hands single tokens over (extended match lengths)
+#else
+            respec = false;
+#endif
             if (d.bl <= 32) d.refill();
             int sym = d.decode_sym<LZX_MAIN_P>(sh->main_tab, sh->main_sorted, d.hr_main);
             if (sym < 0) { fail = true; break; }
@@ -1096,14 +1153,25 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
               else if (extra) { u32 vb; if (!d.read_bits((int) extra, vb)) { fail = true; break; } off += vb; }
               s.R2 = s.R1; s.R1 = s.R0; s.R0 = off;
             }
+#ifdef LZX_DELTA
+            if (len == 257u) {                                          // lzxd.c:588-611
+              u32 p3, x;
+              if (d.bl <= 32) d.refill();
+              if (d.careful && !d.ref_ensure(3)) { fail = true; break; }
+              p3 = (u32)(d.bb >> 61);
+              if ((p3 & 4u) == 0u)      { d.drop(1); if (!d.read_bits(8, x)) { fail = true; break; } }
+              else if ((p3 >> 1) == 2u) { d.drop(2); if (!d.read_bits(10, x)) { fail = true; break; } x += 0x100u; }
+              else if (p3 == 6u)        { d.drop(3); if (!d.read_bits(12, x)) { fail = true; break; } x += 0x500u; }
+              else                      { d.drop(3); if (!d.read_bits(15, x)) { fail = true; break; } }
+              len += x;
+            }
+#endif
             u32 wp = d.P - wbase;
             // a match running past the run is an error in every case (lzxd.c:678-693); test it
             // before copying so that nothing is ever written past the unit's output
             if (d.P + len > run_end) { d.err = ERR_DECRUNCH; fail = true; break; }
             if (wp + len > s.wsize) { d.err = ERR_DECRUNCH; fail = true; break; }       // lzxd.c:613
-            if (off > wp) {
-              if (off > s.offset || (off - wp) > s.wsize) { d.err = ERR_DECRUNCH; fail = true; break; }
-            }
+            if (LZX_BAD_SOURCE(off, wp, s.offset, s.ref_size, s.wsize)) { d.err = ERR_DECRUNCH; fail = true; break; }
 #ifndef LZX_EXP_NOCOPY
             d.flush_lits();
             if (off != 0u && off <= s.wsize) lzx_copy_match(d.out, d.P, off, len, lane);

@@ -7,7 +7,17 @@
 #include <thread>
 #include <vector>
 #include <algorithm>
+#include "wave_common.hpp"
+#include "spec_queue.hpp"
+// lzx_kernel.hpp is compiled twice: plain LZX (CAB, CHM) and LZX DELTA (OAB) -- see its header
+namespace lzxn {
 #include "lzx_kernel.hpp"
+}
+#define LZX_DELTA 1
+namespace lzxd {
+#include "lzx_kernel.hpp"
+}
+#undef LZX_DELTA
 #include "mszip_kernel.hpp"
 #include "qtm_kernel.hpp"
 
@@ -28,13 +38,13 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
                        const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
                        int32_t *frame_meta)
 {
-  __shared__ LzxShared sh;
+  __shared__ lzxn::LzxShared sh;
   u32 ui;
   if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) return;
   const mspack_hip_unit u = units[ui];
   mspack_hip_result *res = &results[ui];
   const u32 lane = threadIdx.x;
-  lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, &sh);
+  lzxn::lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, &sh);
   // E8 translation, frame by frame, once the unit no longer needs its window (lzxd.c:706-736)
   if (frame_meta) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -45,8 +55,35 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
       if (fs == 0) continue;
       // the frame size the decoder saw: full frames except the last one of the stream
       u32 fsize = u.out_len - f * LZX_FRAME; if (fsize > LZX_FRAME) fsize = LZX_FRAME;
-      lzx_e8_frame(out_arena + u.out_off + (size_t) f * LZX_FRAME, fsize,
-                   (int32_t)((u32) u.e8_base + f * LZX_FRAME), fs, lane);
+      lzxn::lzx_e8_frame(out_arena + u.out_off + (size_t) f * LZX_FRAME, fsize,
+                         (int32_t)((u32) u.e8_base + f * LZX_FRAME), fs, lane);
+    }
+  }
+}
+
+// LZX DELTA units (OAB blocks): the same decoder compiled with LZX_DELTA
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void mspack_decode_lzxd(const mspack_hip_unit *units, const u32 *order, u32 n_units,
+                        const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
+                        int32_t *frame_meta)
+{
+  __shared__ lzxd::LzxShared sh;
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX_DELTA, ui)) return;
+  const mspack_hip_unit u = units[ui];
+  mspack_hip_result *res = &results[ui];
+  const u32 lane = threadIdx.x;
+  lzxd::lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, &sh);
+  if (frame_meta) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    u32 produced = rfl(res->out_len);
+    u32 nfr = (produced + LZX_FRAME - 1u) / LZX_FRAME;
+    for (u32 f = 0; f < nfr; f++) {
+      int32_t fs = (int32_t) rfl((u32) frame_meta[u.frame_base + f]);
+      if (fs == 0) continue;
+      u32 fsize = u.out_len - f * LZX_FRAME; if (fsize > LZX_FRAME) fsize = LZX_FRAME;
+      lzxd::lzx_e8_frame(out_arena + u.out_off + (size_t) f * LZX_FRAME, fsize,
+                         (int32_t)((u32) u.e8_base + f * LZX_FRAME), fs, lane);
     }
   }
 }
@@ -83,7 +120,7 @@ static int fail(hipError_t e, const char *what) {
 
 extern "C" {
 
-const char *mspack_hip_version(void) { return "mspack-hip 0.1 (gfx950; LZX/Quantum/MSZIP batch decode)"; }
+const char *mspack_hip_version(void) { return "mspack-hip 0.2 (gfx950; LZX/LZX-DELTA/Quantum/MSZIP batch decode)"; }
 const char *mspack_hip_last_error(void) { return g_err; }
 
 int mspack_hip_device_count(void) {
@@ -104,11 +141,14 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
 {
   (void) in_bytes; (void) out_bytes; (void) n_frames_total;
   if (n_units == 0) return 0;
-  if (kind_mask == 0) kind_mask = 0xE;      // bit k = units of kind k may be present
+  if (kind_mask == 0) kind_mask = 0x1E;     // bit k = units of kind k may be present
   const dim3 grid((unsigned) n_units), block(64);
   hipStream_t st = (hipStream_t) stream;
   if (kind_mask & (1u << MSPACK_HIP_KIND_LZX))
     hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n_units,
+                       (const u8 *) d_in, (u8 *) d_out, d_results, (int32_t *) d_frame_scratch);
+  if (kind_mask & (1u << MSPACK_HIP_KIND_LZX_DELTA))
+    hipLaunchKernelGGL(mspack_decode_lzxd, grid, block, 0, st, d_units, d_order, (u32) n_units,
                        (const u8 *) d_in, (u8 *) d_out, d_results, (int32_t *) d_frame_scratch);
   if (kind_mask & (1u << MSPACK_HIP_KIND_MSZIP))
     hipLaunchKernelGGL(mspack_decode_mszip, grid, block, 0, st, d_units, d_order, (u32) n_units,
@@ -145,7 +185,7 @@ double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32
 
 // frames (incl. the look-ahead slot) a unit needs in the per-frame scratch
 static inline size_t unit_frames(const mspack_hip_unit *u) {
-  return (u->kind == MSPACK_HIP_KIND_LZX) ? (size_t) u->out_len / 32768u + 1u : 0u;
+  return (u->kind == MSPACK_HIP_KIND_LZX || u->kind == MSPACK_HIP_KIND_LZX_DELTA) ? (size_t) u->out_len / 32768u + 1u : 0u;
 }
 
 static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel, size_t n_sel,
@@ -169,7 +209,9 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
     kind_mask |= 1u << (local[i].kind & 31u);
     in_lo = std::min<uint64_t>(in_lo, local[i].in_off);
     in_hi = std::max<uint64_t>(in_hi, local[i].in_off + local[i].in_len);
-    out_lo = std::min<uint64_t>(out_lo, local[i].out_off);
+    if (local[i].kind != MSPACK_HIP_KIND_LZX_DELTA) local[i].ref_len = 0;
+    if (local[i].ref_len > local[i].out_off) { snprintf(g_err, sizeof(g_err), "reference data outside arena"); return -1; }
+    out_lo = std::min<uint64_t>(out_lo, local[i].out_off - local[i].ref_len);
     // MSZIP decodes whole blocks: its region carries 32768 bytes of slack (see mszip_kernel.hpp)
     out_hi = std::max<uint64_t>(out_hi, local[i].out_off + local[i].out_len +
                                         (local[i].kind == MSPACK_HIP_KIND_MSZIP ? 32768u : 0u));
@@ -197,9 +239,14 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
   TRY(hipMemcpy(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice));
   TRY(hipMemcpy(d_order, order.data(), n_sel * sizeof(uint32_t), hipMemcpyHostToDevice));
   TRY(hipMemset(d_fm, 0, mspack_hip_frame_scratch_bytes(n_frames)));
+  for (size_t i = 0; i < n_sel; i++)                  // LZX DELTA reference data sits below the unit's output
+    if (local[i].ref_len)
+      TRY(hipMemcpy((char *) d_out + local[i].out_off - local[i].ref_len,
+                    (const char *) out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
+                    hipMemcpyHostToDevice));
   rc = mspack_hip_decode_batch_device((const mspack_hip_unit *) d_units, (const uint32_t *) d_order, n_sel,
                                       d_in, in_span, d_out, out_span, (mspack_hip_result *) d_res, d_fm,
-                                      n_frames, kind_mask & 0xE, nullptr);
+                                      n_frames, kind_mask & 0x1E, nullptr);
   if (rc) goto done;
   TRY(hipDeviceSynchronize());
   {
