@@ -2,16 +2,17 @@
  *
  * This is the drop-in surface for programs written against the reference's public header
  * (libmspack/mspack/mspack.h): the same type names, member order and constants for the parts of
- * the API that sit on the LZX / Quantum / MSZIP hot path --
+ * the API that sit on the LZX / LZX DELTA / Quantum / MSZIP hot path --
  *     struct mspack_system / mspack_file ............ reference mspack.h:285-480
  *     MSPACK_ERR_* ................................... reference mspack.h:485-507
  *     struct mscabd_cabinet / folder / file ......... reference mspack.h:699-916
  *     struct mscab_decompressor (8 methods) ......... reference mspack.h:957-1180
  *     struct mschmd_* / struct mschm_decompressor ... reference mspack.h:1218-1391, 1577-1724
  *     mspack_create/destroy_{cab,chm}_decompressor .. reference mspack.h:522-558
+ *     struct msoab_decompressor (3 methods) ......... reference mspack.h:2300-2380
  *     mspack_version, MSPACK_SYS_SELFTEST ........... reference mspack.h:191-262
  * Structure layouts are kept identical so that objects can be exchanged with code compiled
- * against the reference header.  Everything else in the reference header (KWAJ, SZDD, OAB, LIT,
+ * against the reference header.  Everything else in the reference header (KWAJ, SZDD, LIT,
  * HLP and all compressors) is outside this library's scope: the creators for those are not
  * provided.  Behavioural difference, by design: extract() decodes a whole folder / compressed
  * section on the GPU in one batch on first use and serves later extract() calls from that
@@ -242,6 +243,19 @@ struct mschm_decompressor {
   int (*fast_find)(struct mschm_decompressor *self, struct mschmd_header *chm, const char *filename,
                    struct mschmd_file *f_ptr, int f_size);
 };
+
+/* ---- OAB (Offline Address Book, LZX DELTA) -------------------------------------------------------------- */
+/* reference mspack.h:663-683, 2300-2380 */
+struct msoab_decompressor {
+  int (*decompress) (struct msoab_decompressor *self, const char *input, const char *output);
+  int (*decompress_incremental) (struct msoab_decompressor *self, const char *input, const char *base,
+                                 const char *output);
+  int (*set_param)(struct msoab_decompressor *self, int param, int value);
+};
+#define MSOABD_PARAM_DECOMPBUF (0)
+
+extern struct msoab_decompressor *mspack_create_oab_decompressor(struct mspack_system *sys);
+extern void mspack_destroy_oab_decompressor(struct msoab_decompressor *self);
 
 #ifdef __cplusplus
 }

@@ -348,3 +348,45 @@ class Chm:
 
     def __exit__(self, *a):
         self.close()
+
+
+class MsoabDecompressor(C.Structure):
+    pass
+
+
+MsoabDecompressor._fields_ = [
+    ("decompress", C.CFUNCTYPE(C.c_int, _P(MsoabDecompressor), C.c_char_p, C.c_char_p)),
+    ("decompress_incremental", C.CFUNCTYPE(C.c_int, _P(MsoabDecompressor), C.c_char_p, C.c_char_p, C.c_char_p)),
+    ("set_param", C.CFUNCTYPE(C.c_int, _P(MsoabDecompressor), C.c_int, C.c_int)),
+]
+
+
+def oab_decompress(blob, base=None, decompbuf=0):
+    """mspack_create_oab_decompressor -> decompress / decompress_incremental over temporary files
+    -> (err, output bytes)"""
+    L = lib()
+    L.mspack_create_oab_decompressor.restype = _P(MsoabDecompressor)
+    L.mspack_create_oab_decompressor.argtypes = [C.c_void_p]
+    L.mspack_destroy_oab_decompressor.argtypes = [_P(MsoabDecompressor)]
+    tmps = []
+
+    def tmp(data):
+        fd, path = tempfile.mkstemp(suffix=".oab")
+        os.write(fd, data); os.close(fd)
+        tmps.append(path)
+        return os.fsencode(path)
+    d = L.mspack_create_oab_decompressor(None)
+    try:
+        if decompbuf:
+            d.contents.set_param(d, 0, decompbuf)
+        pin, pout = tmp(bytes(blob)), tmp(b"")
+        if base is None:
+            err = d.contents.decompress(d, pin, pout)
+        else:
+            err = d.contents.decompress_incremental(d, pin, tmp(bytes(base)), pout)
+        with open(os.fsdecode(pout), "rb") as fh:
+            return err, fh.read()
+    finally:
+        L.mspack_destroy_oab_decompressor(d)
+        for t in tmps:
+            os.unlink(t)

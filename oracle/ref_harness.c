@@ -423,6 +423,24 @@ int refh_chm_find(const uint8_t *chm, size_t chm_len, const char *names, int n_n
   return MSPACK_ERR_OK;
 }
 
+/* OAB files through the reference's msoab_decompressor (oabd.c:103-382); base == NULL: full file */
+int refh_oab(const uint8_t *in, size_t in_len, const uint8_t *base, size_t base_len,
+             uint8_t *out, size_t out_cap, size_t *written, int decompbuf)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) in, in_len, 0 };
+  struct memname bsrc = { MEMNAME_MAGIC, (uint8_t *) base, base_len, 0 };
+  struct memname dst = { MEMNAME_MAGIC, out, out_cap, 0 };
+  struct msoab_decompressor *d = mspack_create_oab_decompressor(&mem_system);
+  int err;
+  if (!d) return MSPACK_ERR_NOMEMORY;
+  if (decompbuf > 0) d->set_param(d, MSOABD_PARAM_DECOMPBUF, decompbuf);
+  err = base ? d->decompress_incremental(d, (const char *) &src, (const char *) &bsrc, (const char *) &dst)
+             : d->decompress(d, (const char *) &src, (const char *) &dst);
+  if (written) *written = dst.written;
+  mspack_destroy_oab_decompressor(d);
+  return err;
+}
+
 /* ---- timing: the reference codec over a batch of independent units, T threads -------------- */
 struct bench_job {
   int kind;                       /* 0 = LZX, 1 = MSZIP, 2 = Quantum */

@@ -129,6 +129,7 @@ def ref():
                                         C.POINTER(C.c_int), C.c_char_p, C.c_int]
         lib.refh_chm_find.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+        lib.refh_oab.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, sz, C.c_int]
         lib.refh_bench.restype = C.c_double
         lib.refh_bench.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
@@ -239,6 +240,14 @@ def ref_chm_list(chm):
         nm = names.raw[i * 128:(i + 1) * 128].split(b"\0")[0]
         out.append(dict(name=nm, length=lens[i], offset=offs[i], section=secs[i]))
     return 0, out
+
+
+def ref_oab(blob, base=None, cap=1 << 26, decompbuf=0):
+    """Reference msoab_decompressor -> (err, bytes written)"""
+    buf = C.create_string_buffer(cap)
+    w = C.c_size_t(0)
+    err = ref().refh_oab(blob, len(blob), base, len(base) if base is not None else 0, buf, cap, C.byref(w), decompbuf)
+    return err, buf.raw[:min(w.value, cap)]
 
 
 def ref_chm_find(chm, names):

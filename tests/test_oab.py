@@ -1,0 +1,58 @@
+"""OAB files through mspack_create_oab_decompressor: full files and incremental patches
+(LZX DELTA blocks with reference data), and damaged copies, against what the REAL reference answered
+(tests/golden/oab.json, made by tests/golden/make_oab_golden.py): error code, bytes written, MD5."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from libmspack_amd import api
+import oab_recipe as R
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = {e["name"]: e for e in json.load(open(os.path.join(HERE, "golden", "oab.json")))}
+CASES = None
+
+
+def _cases():
+    global CASES
+    if CASES is None:
+        CASES = {c[0]: c for c in R.cases()}
+    return CASES
+
+
+def _sig(err, out):
+    return [err, len(out), hashlib.md5(out).hexdigest()]
+
+
+@pytest.mark.parametrize("name", sorted(G))
+def test_oab_file_and_damage(built, name):
+    _n, blob, base, want = _cases()[name]
+    g = G[name]
+    assert hashlib.md5(blob).hexdigest() == g["blob_md5"]            # the very file the reference saw
+    err, out = api.oab_decompress(blob, base)
+    assert err == 0 and out == want
+    rng = np.random.default_rng(len(blob))
+    for i, m in enumerate(R.damaged(blob, rng, len(g["damaged"]))):
+        err, out = api.oab_decompress(m, base)
+        assert _sig(err, out) == g["damaged"][i], (name, i)
+    err, out = api.oab_decompress(blob[:len(blob) * 2 // 3], base, decompbuf=1000)
+    assert _sig(err, out) == g["truncated_buf1000"]
+    if base is not None:
+        err, out = api.oab_decompress(blob, base[:len(base) // 2])
+        assert _sig(err, out) == g["short_base"]
+
+
+def test_oab_arguments(built):
+    L = api.lib()
+    L.mspack_create_oab_decompressor.restype = api._P(api.MsoabDecompressor)
+    L.mspack_create_oab_decompressor.argtypes = [api.C.c_void_p]
+    d = L.mspack_create_oab_decompressor(None)
+    assert d.contents.set_param(d, 0, 15) == 1 and d.contents.set_param(d, 1, 4096) == 1      # oabd.c:405-413
+    assert d.contents.set_param(d, 0, 16) == 0
+    assert d.contents.decompress(d, b"/nonexistent/in.oab", b"/tmp/x.out") == 2              # MSPACK_ERR_OPEN
+    L.mspack_destroy_oab_decompressor(d)
+    assert api.oab_decompress(b"\x03\0\0\0\x02\0\0\0" + b"\0" * 8)[0] == 7                     # a patch is no full file
