@@ -55,7 +55,7 @@ typedef struct mspack_hip_unit {
   uint32_t frame_base;   /* LZX: first slot of this unit in the per-frame scratch (see below)      */
   int32_t  e8_base;      /* LZX: lzx->offset at the unit's first byte (E8 curpos origin)           */
   uint8_t  kind;         /* MSPACK_HIP_KIND_*                                                      */
-  uint8_t  window_bits;  /* LZX 15..21, LZX DELTA 17..22, Quantum 10..21, ignored for MSZIP         */
+  uint8_t  window_bits;  /* LZX 15..21, LZX DELTA 17..25, Quantum 10..21, ignored for MSZIP         */
   uint16_t reset_frames; /* LZX: lzxd_init reset_interval in 32 KiB frames (0 = never, CAB)        */
   uint32_t flags;        /* MSPACK_HIP_UF_*                                                        */
   uint32_t ref_len;      /* LZX DELTA: bytes of reference data (lzxd_set_reference_data, lzxd.c:348-382)

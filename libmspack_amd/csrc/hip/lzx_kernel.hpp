@@ -22,8 +22,8 @@
 //
 // The header is compiled twice by shim.hip, each time inside its own namespace: once as is (LZX of
 // CAB folders and CHM sections) and once with LZX_DELTA defined -- LZX DELTA of OAB files
-// (lzxd.c:288-293, 348-382, 440-444, 588-611): windows 2^17..2^22 here (the 10-bit symbol field of the
-// table entries holds main alphabets up to 1023 symbols, i.e. up to 66 position slots), a 16-bit
+// (lzxd.c:288-293, 348-382, 440-444, 588-611): windows 2^17..2^25 (main alphabets of up to 2576
+// symbols: the main-tree table entries are 32 bits wide with a 12-bit symbol field), a 16-bit
 // chunk size in front of every frame, match lengths extended beyond 257, and reference data that
 // sits in the output arena right below the unit's output (positions are then biased by its size,
 // so a source inside the reference data is an ordinary linear copy).
@@ -36,11 +36,18 @@
 #define LZX_ALI_P 7
 #define LZX_PRE_P 6
 #undef LZX_MAIN_SYMS
+#undef LZX_MSH
+#undef LZX_MTAB_T
 #ifdef LZX_DELTA
-#define LZX_MAIN_SYMS 848      /* 256 + 66*8 + 64 (w<=22) */
+#define LZX_MAIN_SYMS 2640     /* 256 + 290*8 + 64 (w<=25) */
+#define LZX_MSH 12             /* main-tree table entries: symbol | length << 12, in 32 bits */
+#define LZX_MTAB_T u32
 #else
 #define LZX_MAIN_SYMS 720      /* 256 + 50*8 + 64: every index that can ever be non-zero (w<=21) */
+#define LZX_MSH 10             /* symbol | length << 10, in 16 bits */
+#define LZX_MTAB_T u16
 #endif
+#define LZX_MMASK ((1u << LZX_MSH) - 1u)
 #define LZX_LEN_SYMS 250
 #ifndef LZX_SPEC_WIDE
 #define LZX_SPEC_WIDE 0          /* 1: every lane decodes two positions (128 per round) */
@@ -59,7 +66,7 @@
 #endif
 
 struct __align__(16) LzxShared {
-  u16 main_tab[1 << LZX_MAIN_P];
+  LZX_MTAB_T main_tab[1 << LZX_MAIN_P];
   u16 main_sorted[LZX_MAIN_SYMS];
   u16 len_tab[1 << LZX_LEN_P];
   u16 len_sorted[256];
@@ -123,16 +130,16 @@ struct LzxDec {
     drop(n);
     return true;
   }
-  template <int TP>
-  __device__ __forceinline__ int decode_sym(const u16 *tab, const u16 *sorted, const HuffRegs &hr) {
+  template <int TP, int SH = 10, typename TabT = u16>
+  __device__ __forceinline__ int decode_sym(const TabT *tab, const u16 *sorted, const HuffRegs &hr) {
     if (!sym_ensure()) return -1;
     u32 e = rfl((u32) tab[(u32)(bb >> (64 - TP))]);
     if (e == 0) {
-      e = huff_long(hr, sorted, (u32)(bb >> 48), lane);
+      e = huff_long<SH>(hr, sorted, (u32)(bb >> 48), lane);
       if (e == 0) { err = ERR_DECRUNCH; return -1; }
     }
-    drop((int)(e >> 10));
-    return (int)(e & 1023u);
+    drop((int)(e >> SH));
+    return (int)(e & ((1u << SH) - 1u));
   }
   // the reference's i_ptr (bytes) -- exact in careful mode, a lower bound otherwise
   __device__ __forceinline__ u32 iptr() const {
@@ -276,7 +283,7 @@ __device__ __forceinline__ bool lzx_block_header(LzxDec &d, LzxState &s)
       if (!lzx_read_lens(d, lens, first, last)) return false;
       HT0();
       if (part == 1) {
-        if (huff_build<LZX_MAIN_P>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+        if (huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
                                    sh->cnt, d.hr_main, d.lane, false)) {
           d.err = ERR_DECRUNCH; return false;
         }
@@ -402,11 +409,11 @@ __device__ __forceinline__ int lzx_run_fast(LzxDec &d, LzxState &s, const u32 ru
     }
     u32 e = rfl((u32) sh->main_tab[(u32)(bb >> (64 - LZX_MAIN_P))]);
     if (e == 0) {
-      e = huff_long(d.hr_main, sh->main_sorted, (u32)(bb >> 48), lane);
+      e = huff_long<LZX_MSH>(d.hr_main, sh->main_sorted, (u32)(bb >> 48), lane);
       if (e == 0) FAST_FAIL(ERR_DECRUNCH);
     }
-    { u32 l = e >> 10; bb <<= l; bl -= (int) l; }
-    u32 sym = e & 1023u;
+    { u32 l = e >> LZX_MSH; bb <<= l; bl -= (int) l; }
+    u32 sym = e & LZX_MMASK;
     if (sym < 256u) {
       lit_buf = wrl(lit_buf, sym, lit_n);
       lit_n++; P++;
@@ -495,9 +502,9 @@ __device__ __forceinline__ u32 lzx_scalar_token(const LzxDec &d, bool length_emp
   const LzxShared *sh = d.sh;
   u32 tot = 0;
   u32 e = rfl((u32) sh->main_tab[(u32)(r >> (64 - LZX_MAIN_P))]);
-  if (e == 0) { e = huff_long(d.hr_main, sh->main_sorted, (u32)(r >> 48), d.lane); if (e == 0) return 0; }
-  { u32 l = e >> 10; r <<= l; tot += l; }
-  u32 sym = e & 1023u;
+  if (e == 0) { e = huff_long<LZX_MSH>(d.hr_main, sh->main_sorted, (u32)(r >> 48), d.lane); if (e == 0) return 0; }
+  { u32 l = e >> LZX_MSH; r <<= l; tot += l; }
+  u32 sym = e & LZX_MMASK;
   if (sym < 256u) { kind = 0; val = sym; off = 0; return tot; }
   u32 m = sym - 256u, slot = m >> 3, len = (m & 7u) + 2u;
   if ((m & 7u) == 7u) {
@@ -546,10 +553,10 @@ __device__ __forceinline__ SpecTok lzx_spec_token(const LzxShared *sh, const u32
     u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
     if (idx >= LZX_MAIN_SYMS) idx = 0;
     u32 ls = sh->main_sorted[idx];
-    if (e == 0u && lq != 0u) e = ls | (lq << 10);
+    if (e == 0u && lq != 0u) e = ls | (lq << LZX_MSH);
   }
   bool unk = (e == 0u);
-  u32 tot = e >> 10, sym = e & 1023u;
+  u32 tot = e >> LZX_MSH, sym = e & LZX_MMASK;
   r <<= tot;
   bool is_match = sym >= 256u;
   u32 m = sym - 256u, slot = m >> 3, lh = m & 7u;
@@ -1034,11 +1041,11 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   s.intel_filesize = 0; s.intel_started = false; s.length_empty = false;
   s.raw_mode = false; s.raw_pos = 0;
   {
-    static const u8 slots[8] = { 30, 32, 34, 36, 38, 42, 50, 66 };
+    static const u16 slots[11] = { 30, 32, 34, 36, 38, 42, 50, 66, 98, 162, 290 };
     u32 wb = u.window_bits;
 #ifdef LZX_DELTA
     s.ref_size = u.ref_len;
-    s.num_offsets = (wb >= 17u && wb <= 22u && u.ref_len <= (1u << wb)) ? ((u32) slots[wb - 15u] << 3) : 0u;
+    s.num_offsets = (wb >= 17u && wb <= 25u && u.ref_len <= (1u << wb)) ? ((u32) slots[wb - 15u] << 3) : 0u;
 #else
     s.ref_size = 0;
     s.num_offsets = (wb >= 15u && wb <= 21u) ? ((u32) slots[wb - 15u] << 3) : 0u;
@@ -1119,7 +1126,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
             respec = false;
 #endif
             if (d.bl <= 32) d.refill();
-            int sym = d.decode_sym<LZX_MAIN_P>(sh->main_tab, sh->main_sorted, d.hr_main);
+            int sym = d.decode_sym<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_tab, sh->main_sorted, d.hr_main);
             if (sym < 0) { fail = true; break; }
             if (sym < 256) {
               d.lit_buf = wrl(d.lit_buf, (u32) sym, d.lit_n);

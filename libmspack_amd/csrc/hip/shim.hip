@@ -61,8 +61,8 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
   }
 }
 
-// LZX DELTA units (OAB blocks): the same decoder compiled with LZX_DELTA
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+// LZX DELTA units (OAB blocks): the same decoder compiled with LZX_DELTA (17.4 KiB of LDS: 9 units per CU)
+__global__ __launch_bounds__(64)
 void mspack_decode_lzxd(const mspack_hip_unit *units, const u32 *order, u32 n_units,
                         const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
                         int32_t *frame_meta)

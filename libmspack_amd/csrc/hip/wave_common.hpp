@@ -98,8 +98,10 @@ struct InWindow {
 struct HuffRegs { u32 limv; u32 fov; };
 
 // returns 0 accepted, 1 rejected, 2 accepted-but-empty (no symbol has a length)
-template <int P>
-__device__ int huff_build(const u8 *lens, int nsyms, int ref_tablebits, u16 *tab, u16 *sorted,
+// Table entries are symbol | length << SH: 10 bits of symbol in u16 entries everywhere, except alphabets
+// above 1023 symbols (LZX DELTA main tree: 12 bits of symbol in u32 entries).
+template <int P, int SH = 10, typename TabT = u16>
+__device__ int huff_build(const u8 *lens, int nsyms, int ref_tablebits, TabT *tab, u16 *sorted,
                           u32 *cnt_scratch /* >= 20 u32 in LDS */, HuffRegs &hr, u32 lane, bool lsb)
 {
   // 1. histogram of code lengths
@@ -169,10 +171,10 @@ __device__ int huff_build(const u8 *lens, int nsyms, int ref_tablebits, u16 *tab
     u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) fov);
     u32 idx = (fo >> 16) + ((peek16 >> (16 - lq)) - (fo & 0xFFFFu));
     u32 ent = 0;
-    if (lq) ent = (u32) sorted[idx] | (lq << 10);
+    if (lq) ent = (u32) sorted[idx] | (lq << SH);
     u32 slot = e;
     if (lsb) slot = __brev(e) >> (32 - P);     // LSB-first streams index by the reversed code
-    tab[slot] = (u16) ent;
+    tab[slot] = (TabT) ent;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -181,6 +183,7 @@ __device__ int huff_build(const u8 *lens, int nsyms, int ref_tablebits, u16 *tab
 
 // Resolve a code longer than the direct table: one compare per lane + ballot.
 // peek16 = next 16 bits, MSB-first, left-aligned in 16 bits.  Returns sym | len<<10 (0 if none).
+template <int SH = 10>
 __device__ __forceinline__ u32 huff_long(const HuffRegs &hr, const u16 *sorted, u32 peek16, u32 lane)
 {
   u64 m = ballot(lane >= 1u && lane <= 16u && peek16 < hr.limv);
@@ -188,7 +191,7 @@ __device__ __forceinline__ u32 huff_long(const HuffRegs &hr, const u16 *sorted, 
   u32 len = (u32) __ffsll((long long) m) - 1u;
   u32 fo = rdl(hr.fov, len);
   u32 idx = (fo >> 16) + ((peek16 >> (16 - len)) - (fo & 0xFFFFu));
-  return rfl((u32) sorted[idx]) | (len << 10);
+  return rfl((u32) sorted[idx]) | (len << SH);
 }
 
 // inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (no LDS traffic)

@@ -14,8 +14,6 @@
  * independent unit, so ALL blocks of a file are decoded in ONE GPU batch (MSPACK_HIP_KIND_LZX_DELTA) and
  * the file is then replayed in order: each block's bytes are written, its error (if any) returned at the
  * point where the reference would have returned it.
- * Windows beyond 2^22 (blocks or source+target above 4 MiB) are not decoded by this build: such a block
- * returns MSPACK_ERR_NOMEMORY (the reference decodes up to 2^25).
  */
 #include <stdlib.h>
 #include <stdio.h>
@@ -178,8 +176,7 @@ static int oab_run(struct oabd_p *self, const char *input, const char *base, con
       }
     }
     {
-      /* blocks this build cannot decode (window above 2^22), blocks without reference data and empty
-       * blocks are kept out of the batch */
+      /* blocks whose reference data could not be read and empty blocks are kept out of the batch */
       size_t nsel = 0;
       mspack_hip_unit *sel = (mspack_hip_unit *) sys->alloc(sys, n_units * sizeof(*sel));
       mspack_hip_result *rsel = (mspack_hip_result *) sys->alloc(sys, n_units * sizeof(*rsel));
@@ -187,7 +184,7 @@ static int oab_run(struct oabd_p *self, const char *input, const char *base, con
       if (!sel || !rsel || !map) { sys->free(sel); sys->free(rsel); sys->free(map); ret = MSPACK_ERR_NOMEMORY; goto out; }
       for (k = 0; k < n_blks; k++) {
         struct oab_blk *b = &blks[k];
-        if (!b->compressed || b->ref_err || b->window_bits > 22 || b->dsize == 0) continue;
+        if (!b->compressed || b->ref_err || b->dsize == 0) continue;
         map[nsel] = b->unit; sel[nsel++] = units[b->unit];
       }
       if (nsel) {
@@ -215,10 +212,6 @@ static int oab_run(struct oabd_p *self, const char *input, const char *base, con
       continue;
     }
     if (b->ref_err) { ret = b->ref_err; break; }                            /* lzxd_set_reference_data */
-    if (b->window_bits > 22) {
-      sys->message(NULL, "OAB block needs a 2^%d LZX DELTA window; this build decodes up to 2^22", b->window_bits);
-      ret = MSPACK_ERR_NOMEMORY; break;
-    }
     {
       const mspack_hip_unit *u = &units[b->unit];
       const mspack_hip_result *r = &res[b->unit];

@@ -1,6 +1,6 @@
 """GPU parity for LZX DELTA: streams of our DELTA encoder (validated against the real
 lzxd in tests/test_oracle_vs_ref.py) through the C ABI as MSPACK_HIP_KIND_LZX_DELTA units -- reference
-data below the output, per-frame chunk sizes, extended match lengths, windows 2^17..2^22 -- against the
+data below the output, per-frame chunk sizes, extended match lengths, windows 2^17..2^25 -- against the
 oracle: error code, flags, byte count and every byte; plus damaged copies."""
 import numpy as np
 import pytest
@@ -32,8 +32,6 @@ def test_lzx_delta_streams_and_damage(built):
     rng = np.random.default_rng(99)
     streams, params, refs, plains = [], [], [], []
     for (n, wb, refn, kw) in DELTA_CASES:
-        if wb > 22:
-            continue
         data, ref, comp = delta_case(n, wb, refn, kw)
         variants = [comp + b"\0" * 8] + (mutations(comp, rng, 60) if n <= 400000 else [])
         for v in variants:
@@ -54,9 +52,8 @@ def test_lzx_delta_streams_and_damage(built):
 
 
 def test_lzx_delta_window_limits(built):
-    """windows the reference accepts but this build does not decode (2^23..2^25: main alphabets beyond the
-    10-bit symbol field) and windows nobody accepts answer MSPACK_ERR_ARGS without touching the output"""
+    """windows lzxd_init refuses for DELTA streams (lzxd.c:288-293) answer MSPACK_ERR_ARGS"""
     data = M.gen_plaintext(1, 0, 40000)
     comp = M.lzxd_encode(data, 17).tobytes()
-    units, out, res = run_delta([comp] * 4, [(40000, 16), (40000, 23), (40000, 26), (40000, 17)], [b""] * 4)
-    assert list(res["err"][:3]) == [1, 1, 1] and res["err"][3] == 0
+    units, out, res = run_delta([comp] * 3, [(40000, 16), (40000, 26), (40000, 17)], [b""] * 3)
+    assert list(res["err"][:2]) == [1, 1] and res["err"][2] == 0
