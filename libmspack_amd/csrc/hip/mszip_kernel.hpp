@@ -268,13 +268,19 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
 {
   MszipShared *sh = d.sh;
   const u32 lane = d.lane;
-  u8 *const out = d.out + d.B;                        // positions below are window indices of this block
-  u32 P = rfl(d.wpos);
+  // Positions are linear positions in the unit's output: block base + window index.  When the
+  // previous block filled the whole 32 KiB window, the bytes a match finds "above" the current
+  // position in the reference's ring (mszipd.c:267-268) are exactly the previous block's, which lie
+  // right below this block in the output: such a source is an ordinary linear copy.
+  u8 *const out = d.out;
+  const u32 B = rfl(d.B);
+  const bool lin_hist = d.hist_n > 0u && rfl(sh->hist_len[0]) == ZIP_FRAME && rfl(sh->hist_B[0]) + ZIP_FRAME == B;
+  u32 P = B + rfl(d.wpos);
   // same margin reasoning as lzx_run_spec: a round consumes at most 64 + 48 bits
   const u32 room_bytes = (d.w.in_len > d.w.origin + 56u) ? (d.w.in_len - d.w.origin - 56u) : 0u;
   const u32 bit_limit = rfl(room_bytes * 8u);
   u32 bitpos = rfl(d.cons_bits());
-  if (bitpos >= bit_limit || P >= ZIP_FRAME - 1u) return 0;
+  if (bitpos >= bit_limit || P - B >= ZIP_FRAME - 1u) return 0;
   d.flush_lits();
   u32 cb = bitpos >> 11;
   {
@@ -326,7 +332,8 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
     // tokens this path leaves to the scalar loop: output reaching the 32 KiB mark (FLUSH_IF_NEEDED,
     // mszipd.c:37-44) and matches whose source lies before the start of this block (mszipd.c:267-268)
     {
-      const u64 cut = ballot(on && (opos + t.olen >= ZIP_FRAME || (t.kind == 1u && t.dist > opos)));
+      const u64 cut = ballot(on && (opos - B + t.olen >= ZIP_FRAME ||
+                                    (t.kind == 1u && t.dist > opos - B && !lin_hist)));
       if (cut) {
         u32 j = (u32) __ffsll((long long) cut) - 1u;
         chain &= (1ull << j) - 1ull;
@@ -365,7 +372,7 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
   }
   // hand the exact bit position back to the scalar reader; its bits_left restarts from the byte the
   // position lies in (every later ENSURE_BITS re-derives the reference's value from there)
-  d.wpos = P;
+  d.wpos = P - B;
   {
     u32 wi = bitpos >> 5, ch = wi >> 6;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
