@@ -74,10 +74,17 @@ def build_oracle():
         _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
 
 
+def build_reftests():
+    """the reference's own cabd_test / chmd_test programs against our header + library (checker only)"""
+    if os.path.isdir("/root/reference/libmspack/test") and os.path.exists(HIP_SO):
+        _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "reftests"])
+
+
 def build_all(force=False):
     build_corpus(force)
     build_oracle()
     build_hip(force)
+    build_reftests()
 
 
 if __name__ == "__main__":
