@@ -9,11 +9,12 @@
  *     struct mscab_decompressor (8 methods) ......... reference mspack.h:957-1180
  *     struct mschmd_* / struct mschm_decompressor ... reference mspack.h:1218-1391, 1577-1724
  *     mspack_create/destroy_{cab,chm}_decompressor .. reference mspack.h:522-558
+ *     struct msszdd_* / mskwaj_* (5 methods each) ... reference mspack.h:1750-2250
  *     struct msoab_decompressor (3 methods) ......... reference mspack.h:2300-2380
  *     mspack_version, MSPACK_SYS_SELFTEST ........... reference mspack.h:191-262
  * Structure layouts are kept identical so that objects can be exchanged with code compiled
- * against the reference header.  Everything else in the reference header (KWAJ, SZDD, LIT,
- * HLP and all compressors) is outside this library's scope: the creators for those are not
+ * against the reference header.  Everything else in the reference header (LIT, HLP and all
+ * compressors) is outside this library's scope: the creators for those are not
  * provided.  Behavioural difference, by design: extract() decodes a whole folder / compressed
  * section on the GPU in one batch on first use and serves later extract() calls from that
  * result; outputs and error codes are those of the reference.
@@ -243,6 +244,55 @@ struct mschm_decompressor {
   int (*fast_find)(struct mschm_decompressor *self, struct mschmd_header *chm, const char *filename,
                    struct mschmd_file *f_ptr, int f_size);
 };
+
+/* ---- SZDD (reference mspack.h:1750-1790, 1876-1975) ------------------------------------------------------ */
+#define MSSZDD_FMT_NORMAL (0)
+#define MSSZDD_FMT_QBASIC (1)
+struct msszddd_header {
+  int format;
+  off_t length;
+  char missing_char;
+};
+struct msszdd_decompressor {
+  struct msszddd_header *(*open)(struct msszdd_decompressor *self, const char *filename);
+  void (*close)(struct msszdd_decompressor *self, struct msszddd_header *szdd);
+  int (*extract)(struct msszdd_decompressor *self, struct msszddd_header *szdd, const char *filename);
+  int (*decompress)(struct msszdd_decompressor *self, const char *input, const char *output);
+  int (*last_error)(struct msszdd_decompressor *self);
+};
+extern struct msszdd_decompressor *mspack_create_szdd_decompressor(struct mspack_system *sys);
+extern void mspack_destroy_szdd_decompressor(struct msszdd_decompressor *self);
+
+/* ---- KWAJ (reference mspack.h:1978-2036, 2156-2250) ----------------------------------------------------- */
+#define MSKWAJ_COMP_NONE (0)
+#define MSKWAJ_COMP_XOR (1)
+#define MSKWAJ_COMP_SZDD (2)
+#define MSKWAJ_COMP_LZH (3)
+#define MSKWAJ_COMP_MSZIP (4)
+#define MSKWAJ_HDR_HASLENGTH (0x01)
+#define MSKWAJ_HDR_HASUNKNOWN1 (0x02)
+#define MSKWAJ_HDR_HASUNKNOWN2 (0x04)
+#define MSKWAJ_HDR_HASFILENAME (0x08)
+#define MSKWAJ_HDR_HASFILEEXT (0x10)
+#define MSKWAJ_HDR_HASEXTRATEXT (0x20)
+struct mskwajd_header {
+  unsigned short comp_type;
+  off_t data_offset;
+  int headers;
+  off_t length;
+  char *filename;
+  char *extra;
+  unsigned short extra_length;
+};
+struct mskwaj_decompressor {
+  struct mskwajd_header *(*open)(struct mskwaj_decompressor *self, const char *filename);
+  void (*close)(struct mskwaj_decompressor *self, struct mskwajd_header *kwaj);
+  int (*extract)(struct mskwaj_decompressor *self, struct mskwajd_header *kwaj, const char *filename);
+  int (*decompress)(struct mskwaj_decompressor *self, const char *input, const char *output);
+  int (*last_error)(struct mskwaj_decompressor *self);
+};
+extern struct mskwaj_decompressor *mspack_create_kwaj_decompressor(struct mspack_system *sys);
+extern void mspack_destroy_kwaj_decompressor(struct mskwaj_decompressor *self);
 
 /* ---- OAB (Offline Address Book, LZX DELTA) -------------------------------------------------------------- */
 /* reference mspack.h:663-683, 2300-2380 */

@@ -33,15 +33,25 @@ extern "C" {
 #define MSPACK_HIP_KIND_QUANTUM 2
 #define MSPACK_HIP_KIND_LZX     3
 #define MSPACK_HIP_KIND_LZX_DELTA 4   /* lzxd_init(is_delta = 1): OAB blocks (oabd.c:196, 346; lzxd.c:288-293) */
+#define MSPACK_HIP_KIND_LZSS     5   /* lzss_decompress (lzssd.c:36-91): SZDD, KWAJ method 2; window_bits = mode
+                                       (0 EXPAND, 1 MSHELP, 2 QBASIC).  The stream carries no length: out_len is
+                                       the room available, the result's out_len what the stream produced.  The
+                                       4096 bytes below out_off belong to the unit (its window pre-fill).        */
+#define MSPACK_HIP_KIND_KWAJ_LZH 6   /* lzh_decompress (kwajd.c:432-563): KWAJ method 3; same conventions         */
 
 /* result flags */
 #define MSPACK_HIP_F_E8_APPLIED     1u  /* >=1 frame went through the E8 translation (lzxd.c:706-736) */
 #define MSPACK_HIP_F_LOOKAHEAD_READ 2u  /* all bytes produced; the one-frame look-ahead of
                                            lzxd.c:419 then hit end of input (err = MSPACK_ERR_READ)  */
 #define MSPACK_HIP_F_INTEL_HEADER   4u  /* an LZX interval header carried intel_filesize != 0        */
+#define MSPACK_HIP_F_OUT_FULL       8u  /* KWAJ-framed MSZIP: the next block did not fit out_len (give the
+                                           unit more room and decode again)                          */
 
 /* unit input flags */
 #define MSPACK_HIP_UF_MSZIP_REPAIR  1u  /* mszipd repair mode (MSCABD_PARAM_FIXMSZIP, mszipd.c:420-437) */
+#define MSPACK_HIP_UF_MSZIP_KWAJ    4u  /* MSZIP as KWAJ files frame it (mszipd_decompress_kwaj, mszipd.c:462-495):
+                                           16-bit block length (0 ends the stream), 'C','K', one deflate stream;
+                                           out_len is the room available, the result's out_len what was produced */
 #define MSPACK_HIP_UF_HARD_EOF      2u  /* the feeder's read FAILED at in_len (sys->read < 0, e.g. a bad
                                            CFDATA block, cabd.c:1322-1324): ERR_READ at once, without the
                                            two fabricated zero bytes of a clean EOF (readbits.h:194-208) */

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_SO = os.environ.get("MSPACK_HIP_SO", os.path.join(HERE, "libmspack_hip.so"))   # env override: kernel experiments only
 CORPUS_SO = os.path.join(HERE, "libmspack_corpus.so")
 
-KIND_MSZIP, KIND_QUANTUM, KIND_LZX, KIND_LZX_DELTA = 1, 2, 3, 4
+KIND_MSZIP, KIND_QUANTUM, KIND_LZX, KIND_LZX_DELTA, KIND_LZSS, KIND_KWAJ_LZH = 1, 2, 3, 4, 5, 6
 F_E8_APPLIED, F_LOOKAHEAD_READ, F_INTEL_HEADER = 1, 2, 4
 UF_MSZIP_REPAIR = 1
 ERR_OK, ERR_ARGS, ERR_OPEN, ERR_READ, ERR_WRITE, ERR_SEEK, ERR_NOMEMORY, ERR_SIGNATURE, \
@@ -96,6 +96,7 @@ def make_units(kind, in_offs, in_lens, out_lens, window_bits=0, reset_frames=0, 
     u["flags"] = flags
     u["ref_len"] = ref_lens
     rl = (u["ref_len"].astype(np.int64) + 15) & ~15
+    rl = np.where((u["kind"] == KIND_LZSS) | (u["kind"] == KIND_KWAJ_LZH), 4096, rl)   # window pre-fill room
     sizes = ((np.asarray(out_lens, dtype=np.int64) + out_slack + 15) & ~15) + rl
     offs = np.zeros(n, dtype=np.int64)
     if n:

@@ -390,3 +390,67 @@ def oab_decompress(blob, base=None, decompbuf=0):
         L.mspack_destroy_oab_decompressor(d)
         for t in tmps:
             os.unlink(t)
+
+
+class MsszdddHeader(C.Structure):
+    _fields_ = [("format", C.c_int), ("length", off_t), ("missing_char", C.c_char)]
+
+
+class MsszddDecompressor(C.Structure):
+    pass
+
+
+MsszddDecompressor._fields_ = [
+    ("open", C.CFUNCTYPE(_P(MsszdddHeader), _P(MsszddDecompressor), C.c_char_p)),
+    ("close", C.CFUNCTYPE(None, _P(MsszddDecompressor), _P(MsszdddHeader))),
+    ("extract", C.CFUNCTYPE(C.c_int, _P(MsszddDecompressor), _P(MsszdddHeader), C.c_char_p)),
+    ("decompress", C.CFUNCTYPE(C.c_int, _P(MsszddDecompressor), C.c_char_p, C.c_char_p)),
+    ("last_error", C.CFUNCTYPE(C.c_int, _P(MsszddDecompressor))),
+]
+
+
+class MskwajdHeader(C.Structure):
+    _fields_ = [("comp_type", C.c_ushort), ("data_offset", off_t), ("headers", C.c_int), ("length", off_t),
+                ("filename", C.c_char_p), ("extra", C.c_char_p), ("extra_length", C.c_ushort)]
+
+
+class MskwajDecompressor(C.Structure):
+    pass
+
+
+MskwajDecompressor._fields_ = [
+    ("open", C.CFUNCTYPE(_P(MskwajdHeader), _P(MskwajDecompressor), C.c_char_p)),
+    ("close", C.CFUNCTYPE(None, _P(MskwajDecompressor), _P(MskwajdHeader))),
+    ("extract", C.CFUNCTYPE(C.c_int, _P(MskwajDecompressor), _P(MskwajdHeader), C.c_char_p)),
+    ("decompress", C.CFUNCTYPE(C.c_int, _P(MskwajDecompressor), C.c_char_p, C.c_char_p)),
+    ("last_error", C.CFUNCTYPE(C.c_int, _P(MskwajDecompressor))),
+]
+
+
+def szdd_kwaj_extract(kind, blob):
+    """kind 0 = SZDD, 1 = KWAJ: open() + extract() over temporary files
+    -> dict(open_err, err, data, comp_type (SZDD: format), length, filename (SZDD: the missing character))"""
+    L = lib()
+    T = MsszddDecompressor if kind == 0 else MskwajDecompressor
+    create = L.mspack_create_szdd_decompressor if kind == 0 else L.mspack_create_kwaj_decompressor
+    destroy = L.mspack_destroy_szdd_decompressor if kind == 0 else L.mspack_destroy_kwaj_decompressor
+    create.restype = _P(T); create.argtypes = [C.c_void_p]; destroy.argtypes = [_P(T)]
+    fd, pin = tempfile.mkstemp(suffix=".in"); os.write(fd, bytes(blob)); os.close(fd)
+    fd, pout = tempfile.mkstemp(suffix=".out"); os.close(fd)
+    d = create(None)
+    try:
+        h = d.contents.open(d, os.fsencode(pin))
+        if not h:
+            e = d.contents.last_error(d)
+            return dict(open_err=e, err=e, data=b"", comp_type=-1, length=-1, filename=b"")
+        hc = h.contents
+        info = dict(open_err=0, comp_type=hc.format if kind == 0 else hc.comp_type, length=hc.length,
+                    filename=(hc.missing_char.rstrip(b"\0") if kind == 0 else (hc.filename or b"")))
+        info["err"] = d.contents.extract(d, h, os.fsencode(pout))
+        d.contents.close(d, h)
+        with open(pout, "rb") as fh:
+            info["data"] = fh.read()
+        return info
+    finally:
+        destroy(d)
+        os.unlink(pin); os.unlink(pout)

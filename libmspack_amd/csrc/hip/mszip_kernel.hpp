@@ -495,21 +495,36 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
   d.out = out_arena + u.out_off; d.B = 0; d.wpos = 0; d.flushed = false; d.hist_n = 0;
   d.lit_buf = 0; d.lit_n = 0;
   const bool repair = (u.flags & MSPACK_HIP_UF_MSZIP_REPAIR) != 0u;
-  u32 remaining = u.out_len, written = 0;
+  const bool kwaj = (u.flags & MSPACK_HIP_UF_MSZIP_KWAJ) != 0u;
+  u32 remaining = u.out_len, written = 0, rflags = 0;
   int err = ERR_OK;
 
-  while (remaining > 0u) {
-    // skip to the next 'C','K' (mszipd.c:406-414)
+  while (remaining > 0u || kwaj) {
     d.byte_align();
     u32 state = 0, v;
     bool rd_ok = true;
-    do {
-      if (!d.read_bits(8, v)) { rd_ok = false; break; }
-      if (v == 'C') state = 1;
-      else if (state == 1u && v == 'K') state = 2;
-      else state = 0;
-    } while (state != 2u);
-    if (!rd_ok) { err = ERR_READ; break; }
+    if (kwaj) {
+      // mszipd_decompress_kwaj (mszipd.c:462-495): block length (only 0 matters: end of stream), then
+      // exactly 'C','K'
+      u32 lo, hi;
+      if (!d.read_bits(8, lo) || !d.read_bits(8, hi)) { err = ERR_READ; break; }
+      if ((lo | (hi << 8)) == 0u) break;
+      if (!d.read_bits(8, v)) { err = ERR_READ; break; }
+      if (v != 'C') { err = ERR_DATAFORMAT; break; }
+      if (!d.read_bits(8, v)) { err = ERR_READ; break; }
+      if (v != 'K') { err = ERR_DATAFORMAT; break; }
+      if (remaining < ZIP_FRAME) { rflags |= MSPACK_HIP_F_OUT_FULL; break; }   // a block needs 32 KiB of room
+    }
+    else {
+      // skip to the next 'C','K' (mszipd.c:406-414)
+      do {
+        if (!d.read_bits(8, v)) { rd_ok = false; break; }
+        if (v == 'C') state = 1;
+        else if (state == 1u && v == 'K') state = 2;
+        else state = 0;
+      } while (state != 2u);
+      if (!rd_ok) { err = ERR_READ; break; }
+    }
 
     d.wpos = 0; d.flushed = false;
     u32 bytes_output = 0;
@@ -557,7 +572,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
     d.B += n;
   }
   if (lane == 0) {
-    res->err = err; res->flags = 0; res->out_len = written; res->good_len = written; res->reserved = 0;
+    res->err = err; res->flags = rflags; res->out_len = written; res->good_len = written; res->reserved = 0;
     res->in_used = d.w.origin + ((d.cons_bits() + (d.careful ? (u32) d.rbl : 0u)) >> 3);
   }
 }

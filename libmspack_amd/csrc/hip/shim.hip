@@ -20,6 +20,7 @@ namespace lzxd {
 #undef LZX_DELTA
 #include "mszip_kernel.hpp"
 #include "qtm_kernel.hpp"
+#include "lzss_kernel.hpp"
 
 // One wavefront == one workgroup == one unit.  blockIdx -> unit through the optional launch order
 // (longest unit first keeps the tail of the batch short).  One kernel per codec (their register
@@ -110,6 +111,27 @@ void mspack_decode_qtm(const mspack_hip_unit *units, const u32 *order, u32 n_uni
   qtm_decode_unit(u, in_arena, out_arena, &results[ui], &sh);
 }
 
+__global__ __launch_bounds__(64)
+void mspack_decode_lzss(const mspack_hip_unit *units, const u32 *order, u32 n_units,
+                        const u8 *in_arena, u8 *out_arena, mspack_hip_result *results)
+{
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZSS, ui)) return;
+  const mspack_hip_unit u = units[ui];
+  lzss_decode_unit(u, in_arena, out_arena, &results[ui]);
+}
+
+__global__ __launch_bounds__(64)
+void mspack_decode_kwaj_lzh(const mspack_hip_unit *units, const u32 *order, u32 n_units,
+                            const u8 *in_arena, u8 *out_arena, mspack_hip_result *results)
+{
+  __shared__ LzhShared sh;
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_KWAJ_LZH, ui)) return;
+  const mspack_hip_unit u = units[ui];
+  kwaj_lzh_decode_unit(u, in_arena, out_arena, &results[ui], &sh);
+}
+
 // ---------------------------------------------------------------------------------------------------
 static thread_local char g_err[256] = "";
 static int fail(hipError_t e, const char *what) {
@@ -141,7 +163,7 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
 {
   (void) in_bytes; (void) out_bytes; (void) n_frames_total;
   if (n_units == 0) return 0;
-  if (kind_mask == 0) kind_mask = 0x1E;     // bit k = units of kind k may be present
+  if (kind_mask == 0) kind_mask = 0x7E;     // bit k = units of kind k may be present
   const dim3 grid((unsigned) n_units), block(64);
   hipStream_t st = (hipStream_t) stream;
   if (kind_mask & (1u << MSPACK_HIP_KIND_LZX))
@@ -155,6 +177,12 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
                        (const u8 *) d_in, (u8 *) d_out, d_results);
   if (kind_mask & (1u << MSPACK_HIP_KIND_QUANTUM))
     hipLaunchKernelGGL(mspack_decode_qtm, grid, block, 0, st, d_units, d_order, (u32) n_units,
+                       (const u8 *) d_in, (u8 *) d_out, d_results);
+  if (kind_mask & (1u << MSPACK_HIP_KIND_LZSS))
+    hipLaunchKernelGGL(mspack_decode_lzss, grid, block, 0, st, d_units, d_order, (u32) n_units,
+                       (const u8 *) d_in, (u8 *) d_out, d_results);
+  if (kind_mask & (1u << MSPACK_HIP_KIND_KWAJ_LZH))
+    hipLaunchKernelGGL(mspack_decode_kwaj_lzh, grid, block, 0, st, d_units, d_order, (u32) n_units,
                        (const u8 *) d_in, (u8 *) d_out, d_results);
   CK(hipGetLastError());
   return 0;
@@ -210,8 +238,11 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
     in_lo = std::min<uint64_t>(in_lo, local[i].in_off);
     in_hi = std::max<uint64_t>(in_hi, local[i].in_off + local[i].in_len);
     if (local[i].kind != MSPACK_HIP_KIND_LZX_DELTA) local[i].ref_len = 0;
-    if (local[i].ref_len > local[i].out_off) { snprintf(g_err, sizeof(g_err), "reference data outside arena"); return -1; }
-    out_lo = std::min<uint64_t>(out_lo, local[i].out_off - local[i].ref_len);
+    // bytes below out_off that belong to the unit: DELTA reference data, the LZSS / LZH window pre-fill
+    const uint64_t below = (local[i].kind == MSPACK_HIP_KIND_LZSS || local[i].kind == MSPACK_HIP_KIND_KWAJ_LZH)
+                           ? 4096u : local[i].ref_len;
+    if (below > local[i].out_off) { snprintf(g_err, sizeof(g_err), "unit's lower region outside arena"); return -1; }
+    out_lo = std::min<uint64_t>(out_lo, local[i].out_off - below);
     // MSZIP decodes whole blocks: its region carries 32768 bytes of slack (see mszip_kernel.hpp)
     out_hi = std::max<uint64_t>(out_hi, local[i].out_off + local[i].out_len +
                                         (local[i].kind == MSPACK_HIP_KIND_MSZIP ? 32768u : 0u));
@@ -246,7 +277,7 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
                     hipMemcpyHostToDevice));
   rc = mspack_hip_decode_batch_device((const mspack_hip_unit *) d_units, (const uint32_t *) d_order, n_sel,
                                       d_in, in_span, d_out, out_span, (mspack_hip_result *) d_res, d_fm,
-                                      n_frames, kind_mask & 0x1E, nullptr);
+                                      n_frames, kind_mask & 0x7E, nullptr);
   if (rc) goto done;
   TRY(hipDeviceSynchronize());
   {

@@ -24,6 +24,7 @@ typedef uint64_t u64;
 #define ERR_OK        0
 #define ERR_ARGS      1
 #define ERR_READ      3
+#define ERR_DATAFORMAT 8
 #define ERR_DECRUNCH 11
 
 #define WAVE 64

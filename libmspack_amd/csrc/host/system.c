@@ -9,10 +9,10 @@
 int mspack_version(int entity) {
   switch (entity) {
   case MSPACK_VER_MSCHMD: case MSPACK_VER_MSCABD: case MSPACK_VER_MSOABD:
+  case MSPACK_VER_MSSZDDD: case MSPACK_VER_MSKWAJD:
     return 2;                       /* structure revisions this library is layout-compatible with */
   case MSPACK_VER_LIBRARY: case MSPACK_VER_SYSTEM:
     return 1;
-  case MSPACK_VER_MSSZDDD: case MSPACK_VER_MSKWAJD:
   case MSPACK_VER_MSCABC: case MSPACK_VER_MSCHMC: case MSPACK_VER_MSLITD: case MSPACK_VER_MSLITC:
   case MSPACK_VER_MSHLPD: case MSPACK_VER_MSHLPC: case MSPACK_VER_MSSZDDC: case MSPACK_VER_MSKWAJC:
   case MSPACK_VER_MSOABC:

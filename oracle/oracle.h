@@ -26,6 +26,7 @@ extern "C" {
 #define ORC_OK        0
 #define ORC_ARGS      1
 #define ORC_READ      3
+#define ORC_DATAFORMAT 8
 #define ORC_DECRUNCH 11
 
 /* result flags */
@@ -68,6 +69,12 @@ int oracle_qtm_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
 
 /* make_decode_table accept/reject (readhuff.h:83-176): returns 0 if the reference would accept
  * this set of code lengths for a table with `tablebits` direct bits, 1 if it would reject. */
+/* LZSS of SZDD / KWAJ method 2 / MS Help (lzssd.c:36-91); mode 0 EXPAND, 1 MSHELP, 2 QBASIC.  Decoding ends
+ * where the input ends; out_len = bytes produced (may exceed out_cap: the excess is dropped). */
+int oracle_lzss_decode(const uint8_t *in, size_t in_len, int mode, uint8_t *out, size_t out_cap, oracle_result *res);
+/* KWAJ method 3, LZH (kwajd.c:432-563) */
+int oracle_kwaj_lzh_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, oracle_result *res);
+
 int oracle_huff_accepts(const uint8_t *lens, int nsyms, int tablebits);
 
 #ifdef __cplusplus

@@ -441,6 +441,41 @@ int refh_oab(const uint8_t *in, size_t in_len, const uint8_t *base, size_t base_
   return err;
 }
 
+/* SZDD and KWAJ files through the reference's decompressors (szddd.c, kwajd.c): decompress(input, output).
+ * kind 0 = SZDD, 1 = KWAJ.  For KWAJ the header fields are reported too. */
+int refh_szdd_kwaj(int kind, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, size_t *written,
+                   int *comp_type, long long *length, char *filename /* >= 16 bytes */, int *open_err)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) in, in_len, 0 };
+  struct memname dst = { MEMNAME_MAGIC, out, out_cap, 0 };
+  int err;
+  *open_err = 0; if (comp_type) *comp_type = -1; if (length) *length = -1; if (filename) filename[0] = 0;
+  if (kind == 0) {
+    struct msszdd_decompressor *d = mspack_create_szdd_decompressor(&mem_system);
+    struct msszddd_header *h = d->open(d, (const char *) &src);
+    if (!h) { *open_err = d->last_error(d); mspack_destroy_szdd_decompressor(d); return *open_err; }
+    if (comp_type) *comp_type = h->format;
+    if (length) *length = (long long) h->length;
+    if (filename) { filename[0] = h->missing_char; filename[1] = 0; }
+    err = d->extract(d, h, (const char *) &dst);
+    d->close(d, h);
+    mspack_destroy_szdd_decompressor(d);
+  }
+  else {
+    struct mskwaj_decompressor *d = mspack_create_kwaj_decompressor(&mem_system);
+    struct mskwajd_header *h = d->open(d, (const char *) &src);
+    if (!h) { *open_err = d->last_error(d); mspack_destroy_kwaj_decompressor(d); return *open_err; }
+    if (comp_type) *comp_type = h->comp_type;
+    if (length) *length = (long long) h->length;
+    if (filename && h->filename) { strncpy(filename, h->filename, 15); filename[15] = 0; }
+    err = d->extract(d, h, (const char *) &dst);
+    d->close(d, h);
+    mspack_destroy_kwaj_decompressor(d);
+  }
+  if (written) *written = dst.written;
+  return err;
+}
+
 /* ---- timing: the reference codec over a batch of independent units, T threads -------------- */
 struct bench_job {
   int kind;                       /* 0 = LZX, 1 = MSZIP, 2 = Quantum */

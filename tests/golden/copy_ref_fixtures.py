@@ -1,5 +1,5 @@
-"""Copies the DATA files of the reference's regression suites (libmspack/test/test_files/{cabd,chmd}: small
-cabinets and CHMs, incl. the must-fail CVE files) to tests/golden/ref_fixtures/, where the reference's own
+"""Copies the DATA files of the reference's regression suites (libmspack/test/test_files/{cabd,chmd,kwajd}: small
+cabinets, CHMs and KWAJ headers, incl. the must-fail CVE files) to tests/golden/ref_fixtures/, where the reference's own
 test programs -- built against our library by `make -C oracle reftests` -- look for them.  Development
 container only.  Scripts that generated those files upstream (*.pl) are not copied."""
 import os
@@ -7,7 +7,7 @@ import shutil
 
 SRC = "/root/reference/libmspack/test/test_files"
 HERE = os.path.dirname(os.path.abspath(__file__))
-for sub, exts in (("cabd", (".cab",)), ("chmd", (".chm", ".xor"))):
+for sub, exts in (("cabd", (".cab",)), ("chmd", (".chm", ".xor")), ("kwajd", (".kwj",))):
     dst = os.path.join(HERE, "ref_fixtures", sub)
     os.makedirs(dst, exist_ok=True)
     n = 0

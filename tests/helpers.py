@@ -25,7 +25,7 @@ class OracleResult(C.Structure):
 def _build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in
-            ("lzx_oracle.c", "mszip_oracle.c", "qtm_oracle.c", "oracle.h", "oracle_huff.h")]
+            ("lzx_oracle.c", "mszip_oracle.c", "qtm_oracle.c", "lzss_oracle.c", "oracle.h", "oracle_huff.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -46,6 +46,8 @@ def oracle():
         lib.oracle_qtm_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
                                           C.c_int, C.POINTER(OracleResult)]
         lib.oracle_huff_accepts.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        lib.oracle_lzss_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(OracleResult)]
+        lib.oracle_kwaj_lzh_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(OracleResult)]
         lib.oracle_lzxd_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
                                            C.c_uint64, C.c_int, C.c_int, C.c_int32, C.c_int, C.c_char_p, C.c_size_t,
                                            C.POINTER(OracleResult)]
@@ -73,6 +75,22 @@ def oracle_lzxd(data, out_bytes, window_bits, ref=b"", reset_frames=0, length=No
     oracle().oracle_lzxd_decode(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), int(length),
                                 window_bits, reset_frames, e8_base, 1, bytes(ref), len(ref), C.byref(res))
     return res.err, buf.raw[:min(res.out_len, out_bytes)], res
+
+
+def oracle_lzss(data, mode, cap=None):
+    cap = cap if cap is not None else len(data) * 9 + 64
+    buf = C.create_string_buffer(max(cap, 1))
+    res = OracleResult()
+    oracle().oracle_lzss_decode(bytes(data), len(data), mode, buf, cap, C.byref(res))
+    return res.err, buf.raw[:min(res.out_len, cap)], res
+
+
+def oracle_kwaj_lzh(data, cap=None):
+    cap = cap if cap is not None else len(data) * 40 + 4096
+    buf = C.create_string_buffer(max(cap, 1))
+    res = OracleResult()
+    oracle().oracle_kwaj_lzh_decode(bytes(data), len(data), buf, cap, C.byref(res))
+    return res.err, buf.raw[:min(res.out_len, cap)], res
 
 
 def oracle_mszip(data, out_bytes, repair=0):
@@ -130,6 +148,8 @@ def ref():
         lib.refh_chm_find.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         lib.refh_oab.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, sz, C.c_int]
+        lib.refh_szdd_kwaj.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, sz, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_longlong), C.c_char_p, C.POINTER(C.c_int)]
         lib.refh_bench.restype = C.c_double
         lib.refh_bench.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
@@ -248,6 +268,17 @@ def ref_oab(blob, base=None, cap=1 << 26, decompbuf=0):
     w = C.c_size_t(0)
     err = ref().refh_oab(blob, len(blob), base, len(base) if base is not None else 0, buf, cap, C.byref(w), decompbuf)
     return err, buf.raw[:min(w.value, cap)]
+
+
+def ref_szdd_kwaj(kind, blob, cap=1 << 24):
+    """Reference SZDD (kind 0) / KWAJ (kind 1) open + extract
+    -> dict(open_err, err, data, comp_type|format, length, filename|missing char)"""
+    buf = C.create_string_buffer(cap)
+    w = C.c_size_t(0); ct = C.c_int(0); ln = C.c_longlong(0); oe = C.c_int(0)
+    fn = C.create_string_buffer(16)
+    err = ref().refh_szdd_kwaj(kind, blob, len(blob), buf, cap, C.byref(w), C.byref(ct), C.byref(ln), fn, C.byref(oe))
+    return dict(open_err=oe.value, err=err, data=buf.raw[:min(w.value, cap)], comp_type=ct.value, length=ln.value,
+                filename=fn.value)
 
 
 def ref_chm_find(chm, names):

@@ -1,4 +1,4 @@
-"""The reference's OWN regression programs (libmspack/test/cabd_test.c and chmd_test.c), compiled unchanged
+"""The reference's OWN regression programs (libmspack/test/cabd_test.c, chmd_test.c and kwajd_test.c), compiled unchanged
 against include/mspack.h and linked with libmspack_hip.so (`make -C oracle reftests`, development container;
 the binaries travel to the GPU box in oracle/_ref/), run against the reference's own data files
 (tests/golden/ref_fixtures).  Every TEST() of the suites must pass -- the drop-in claim, checked by the
@@ -32,3 +32,8 @@ def test_reference_cabd_test_suite(built):
 def test_reference_chmd_test_suite(built):
     ok, out = _run("chmd_test_hip")
     assert ok >= 150 and "ALL %d TESTS PASSED" % ok in out
+
+
+def test_reference_kwajd_test_suite(built):
+    ok, out = _run("kwajd_test_hip")
+    assert ok >= 100 and "ALL %d TESTS PASSED" % ok in out

@@ -185,3 +185,29 @@ def test_lzx_delta_encoder_and_oracle_vs_reference(built, case):
         e1, o1, w1 = ref_lzxd(m, n, wb, ref)
         e2, o2, r = oracle_lzxd(m, n, wb, ref)
         assert (e1, w1) == (e2, r.out_len), (len(m), e1, w1, e2, r.out_len)
+
+
+def test_szdd_kwaj_corpus_and_oracle_vs_reference(built):
+    """SZDD / KWAJ: every file of the test recipe decodes through the REAL szddd / kwajd to its
+    plaintext, and the LZSS / KWAJ-LZH oracles agree with the reference on the payloads and on damaged ones."""
+    import struct
+    from helpers import ref_szdd_kwaj, oracle_lzss, oracle_kwaj_lzh
+    from test_szdd_kwaj import file_cases, damaged_files
+    for name, kind, blob, want in file_cases():
+        r = ref_szdd_kwaj(kind, blob)
+        assert r["open_err"] == 0 and r["err"] == 0 and r["data"] == want, name
+        variants = [blob] + damaged_files(name, kind, blob, 25)
+        for v in variants:
+            r = ref_szdd_kwaj(kind, v)
+            if r["open_err"]:
+                continue
+            if kind == 0:
+                off, mode = (14, 0) if r["comp_type"] == 0 else (12, 2)
+                e, o, _ = oracle_lzss(v[off:], mode)
+            elif r["comp_type"] == 2:
+                e, o, _ = oracle_lzss(v[struct.unpack_from("<H", v, 10)[0]:], 2)
+            elif r["comp_type"] == 3:
+                e, o, _ = oracle_kwaj_lzh(v[struct.unpack_from("<H", v, 10)[0]:])
+            else:
+                continue
+            assert (e, o) == (r["err"], r["data"]), (name, len(v))
