@@ -323,11 +323,13 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
       int sel = qtm_get_symbol(d, m7, 7, s7);
       if (sel < 0) { err = ERR_READ; stop = true; break; }
       if (sel < 4) {
-        int sym;
-        if (sel == 0) sym = qtm_get_symbol(d, m0, 64, s0);
-        else if (sel == 1) sym = qtm_get_symbol(d, m1, 64, s1);
-        else if (sel == 2) sym = qtm_get_symbol(d, m2, 64, s2);
-        else sym = qtm_get_symbol(d, m3, 64, s3);
+        // ONE copy of the symbol decoder for the four literal models: the model moves through a
+        // temporary (a few selects) instead of four inlined copies of GET_SYMBOL
+        u32 mm = sel == 0 ? m0 : (sel == 1 ? m1 : (sel == 2 ? m2 : m3));
+        int ss = sel == 0 ? s0 : (sel == 1 ? s1 : (sel == 2 ? s2 : s3));
+        int sym = qtm_get_symbol(d, mm, 64, ss);
+        if (sel == 0) { m0 = mm; s0 = ss; } else if (sel == 1) { m1 = mm; s1 = ss; }
+        else if (sel == 2) { m2 = mm; s2 = ss; } else { m3 = mm; s3 = ss; }
         if (sym < 0) { err = ERR_READ; stop = true; break; }
         if (lane == 0 && P < out_len) out[P] = (u8) sym;
         P++; wpos++; frame_todo--;
@@ -335,19 +337,15 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
       }
       u32 moff, mlen, base, extra;
       int sym;
-      if (sel == 4) {
-        sym = qtm_get_symbol(d, m4, n4, s4);
+      if (sel == 4 || sel == 5) {
+        u32 mm = sel == 4 ? m4 : m5;
+        int ss = sel == 4 ? s4 : s5;
+        sym = qtm_get_symbol(d, mm, sel == 4 ? n4 : n5, ss);
+        if (sel == 4) { m4 = mm; s4 = ss; } else { m5 = mm; s5 = ss; }
         if (sym < 0) { err = ERR_READ; stop = true; break; }
         qtm_pos_slot((u32) sym, base, extra);
         if (!d.read_many((int) extra, v)) { err = ERR_READ; stop = true; break; }
-        moff = base + v + 1u; mlen = 3;
-      }
-      else if (sel == 5) {
-        sym = qtm_get_symbol(d, m5, n5, s5);
-        if (sym < 0) { err = ERR_READ; stop = true; break; }
-        qtm_pos_slot((u32) sym, base, extra);
-        if (!d.read_many((int) extra, v)) { err = ERR_READ; stop = true; break; }
-        moff = base + v + 1u; mlen = 4;
+        moff = base + v + 1u; mlen = sel == 4 ? 3u : 4u;
       }
       else if (sel == 6) {
         sym = qtm_get_symbol(d, m6l, 27, s6l);
