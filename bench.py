@@ -113,7 +113,8 @@ def main():
     n, ub = args.units, args.unit_kib * 1024
     # ---- synthetic corpus: every rank its own seeds (weak scaling: fixed work per GPU) ----
     t0 = time.perf_counter()
-    plain, comp, off, ln = M.corpus_lzx_units(D.unit_seed_base(0xBA5E11, rank), args.text, n, ub, 21)
+    plain, comp, off, ln = M.corpus_lzx_units(D.unit_seed_base(0xBA5E11, rank), args.text, n, ub, 21,
+                                              n_threads=max(1, usable_cpus() // max(world, 1)))
     gen_s = time.perf_counter() - t0
     units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21,
                                     reset_frames=ub // 32768)
