@@ -113,3 +113,31 @@ def test_fuzz_qtm(built):
     for i, st in enumerate(streams):
         e, o, r = oracle_qtm(st, lens[i], wbs[i])
         compare("qtm", i, res, units, out, e, o, r)
+
+
+def test_long_runs_overflow_the_match_queue(built):
+    """Back-to-back maximum-length matches: a single round then emits more output than the start-flag ring
+    of spec_queue.hpp covers and more matches than the queue holds, which sends it down the resolve-first /
+    copy-one-by-one paths (LZX, MSZIP) -- and runs with period 1, 2, 3, 7 exercise the overlapping copies."""
+    rng = np.random.default_rng(5)
+    parts = []
+    for period in (1, 2, 3, 7, 64, 300):
+        unit = bytes(rng.integers(0, 256, period, dtype=np.uint8))
+        parts.append(unit * (20000 // period))
+        parts.append(M.gen_plaintext(period, 0, 3000).tobytes())
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    streams, params = [], []
+    for wb, rf, kw in [(17, 0, {}), (21, 2, dict(mode=2)), (15, 0, dict(mode=1))]:
+        n = data.size if rf == 0 else (data.size // 65536) * 65536
+        comp, _ = M.lzx_encode(data[:n], wb, rf, M.lzx_opts(**kw))
+        streams.append(comp.tobytes() + b"\0" * 4); params.append((n, wb, rf, 0))
+    units, out, res = run_lzx(streams, params)
+    for i, (s, p) in enumerate(zip(streams, params)):
+        e, o, r = oracle_lzx(s, p[0], p[1], p[2], length=p[0])
+        compare("lzx", i, res, units, out, e, o, r)
+        assert e == 0 and o == data[:p[0]].tobytes()
+    z = zip_folder(data.tobytes(), 9, zlib.Z_DEFAULT_STRATEGY, history=True)
+    units, out, res = run_mszip([z], [data.size])
+    e, o, r, _ = oracle_mszip(z, data.size)
+    compare("mszip", 0, res, units, out, e, o, r)
+    assert e == 0 and o == data.tobytes()
