@@ -70,7 +70,10 @@ typedef struct mspack_hip_unit {
   uint32_t flags;        /* MSPACK_HIP_UF_*                                                        */
   uint32_t ref_len;      /* LZX DELTA: bytes of reference data (lzxd_set_reference_data, lzxd.c:348-382)
                             that the caller placed in the output arena at [out_off - ref_len, out_off) */
-  uint32_t reserved;     /* 0                                                                      */
+  uint32_t in_chunk;     /* MSZIP repair mode: input_buffer_size of mszipd_init (mszipd.c:338-375), i.e.
+                            the chunking of the folder stream by the reference's feeder; where the
+                            next block is looked for after a failed one depends on it (mszipd.c:404,
+                            readbits.h:184-214).  0 = 4096 (the cabd default).  Else ignored        */
 } mspack_hip_unit;
 
 typedef struct mspack_hip_result {

@@ -23,7 +23,7 @@ ERR_OK, ERR_ARGS, ERR_OPEN, ERR_READ, ERR_WRITE, ERR_SEEK, ERR_NOMEMORY, ERR_SIG
 # struct mspack_hip_unit / mspack_hip_result (include/mspack_hip.h)
 UNIT_DTYPE = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"), ("out_len", "<u4"),
                        ("frame_base", "<u4"), ("e8_base", "<i4"), ("kind", "u1"), ("window_bits", "u1"),
-                       ("reset_frames", "<u2"), ("flags", "<u4"), ("ref_len", "<u4"), ("reserved", "<u4")],
+                       ("reset_frames", "<u2"), ("flags", "<u4"), ("ref_len", "<u4"), ("in_chunk", "<u4")],
                       align=False)
 RESULT_DTYPE = np.dtype([("err", "<i4"), ("flags", "<u4"), ("out_len", "<u4"), ("in_used", "<u4"),
                          ("good_len", "<u4"), ("reserved", "<u4")])

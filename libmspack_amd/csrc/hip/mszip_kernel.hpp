@@ -57,8 +57,13 @@ struct ZipDec {
   u32 B, wpos; bool flushed;
   u32 hist_n;                    // entries in the (B, length) stack, most recent first
   u32 lit_buf, lit_n;
+  // what the reference's stream struct holds (STORE_BITS, readbits.h:119-124): repair mode restarts from it
+  u32 snap_iptr; int snap_rbl;
 
   __device__ __forceinline__ u32 cons_bits() const { return w.wi * 32u - (u32) bl; }
+  // the reference's i_ptr: every byte up to here has been moved into its bit buffer
+  __device__ __forceinline__ u32 abs_iptr() const { return w.origin + ((cons_bits() + (u32) rbl) >> 3); }
+  __device__ __forceinline__ void store_bits() { snap_iptr = abs_iptr(); snap_rbl = rbl; }
   __device__ __forceinline__ void refill() {
     u32 d = w.next_dword(lane);
     bb |= (u64) d << bl;
@@ -294,7 +299,7 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
   for (int l = ZIP_LIT_P + 1; l <= 16; l++) llim[l - ZIP_LIT_P - 1] = rdl(d.hr_lit.limv, (u32) l);
   SpecQueue Q;
   spq_init(sh->spq, Q, P, lane);
-  int rc = 0;
+  int rc = 0, eob_rbl = 0;
   bool stop = false;
 
   for (;;) {
@@ -367,7 +372,12 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
       }
     }
     P = newP;
-    if (eob) { bitpos += q + rdl(t.tot, q); rc = 1; stop = true; }
+    if (eob) {
+      // the reference's bits_left after the end-of-block symbol: ENSURE_BITS(16) at its first bit, minus its length
+      const u32 st = bitpos + q, tl = rdl(t.tot, q);
+      eob_rbl = (int)(16u + ((0u - st) & 7u) - tl);
+      bitpos = st + tl; rc = 1; stop = true;
+    }
     else bitpos += q;
   }
   // hand the exact bit position back to the scalar reader; its bits_left restarts from the byte the
@@ -383,7 +393,7 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
     d.refill(); d.refill();
     u32 sk = bitpos & 31u;
     if (sk) { d.bb >>= sk; d.bl -= (int) sk; }
-    d.rbl = (int)((0u - bitpos) & 7u);
+    d.rbl = rc ? eob_rbl : (int)((0u - bitpos) & 7u);
   }
   return rc;
 }
@@ -403,8 +413,8 @@ __device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
       if (pos + 4u > d.w.in_len + d.w.eofs) return ERR_READ;
       u32 hb = (lane < 4u) ? d.w.byte_at(pos + lane) : 0u;
       u32 length = rdl(hb, 0) | (rdl(hb, 1) << 8), ncomp = rdl(hb, 2) | (rdl(hb, 3) << 8);
-      if (length != (~ncomp & 0xFFFFu)) return ZIP_E_FORMAT;
       pos += 4u;
+      if (length != (~ncomp & 0xFFFFu)) { d.restart(pos); return ZIP_E_FORMAT; }
       d.flush_lits();
       while (length > 0u) {
         u32 n = length, room = ZIP_FRAME - d.wpos;
@@ -415,7 +425,7 @@ __device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
         if (n > avail) n = avail;
         for (u32 k = lane; k < n; k += WAVE) d.out[d.B + d.wpos + k] = (u8) d.w.byte_at(pos + k);
         pos += n; d.wpos += n; length -= n;
-        if (!d.wrap_if_needed()) return ZIP_E_FORMAT;
+        if (!d.wrap_if_needed()) { d.restart(pos); return ZIP_E_FORMAT; }
       }
       d.restart(pos);
     }
@@ -424,7 +434,7 @@ __device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
         for (u32 k = lane; k < 288u; k += WAVE) sh->lit_len[k] = (u8)(k < 144u ? 8 : (k < 256u ? 9 : (k < 280u ? 7 : 8)));
         if (lane < 32u) sh->dist_len[lane] = 5;
       }
-      else { int r = zip_read_dynamic(d); if (r) return r; }
+      else { d.store_bits(); int r = zip_read_dynamic(d); if (r) return r; d.store_bits(); }   // mszipd.c:223,149
       if (huff_build<ZIP_LIT_P>(sh->lit_len, 288, 9, sh->lit_tab, sh->lit_sorted, sh->cnt, d.hr_lit, lane, true)) return ZIP_E_FORMAT;
       if (huff_build<ZIP_DIST_P>(sh->dist_len, 32, 6, sh->dist_tab, sh->dist_sorted, sh->cnt, d.hr_dist, lane, true)) return ZIP_E_FORMAT;
       u32 cooldown = 0;                                // scalar tokens to take before the next speculative run
@@ -498,11 +508,14 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
   const bool kwaj = (u.flags & MSPACK_HIP_UF_MSZIP_KWAJ) != 0u;
   u32 remaining = u.out_len, written = 0, rflags = 0;
   int err = ERR_OK;
+  u32 state0 = 0;                 // 'C','K' scanner state carried over a repair restart
+  d.snap_iptr = 0; d.snap_rbl = 0;
 
   while (remaining > 0u || kwaj) {
     d.byte_align();
-    u32 state = 0, v;
+    u32 state = state0, v;
     bool rd_ok = true;
+    state0 = 0;
     if (kwaj) {
       // mszipd_decompress_kwaj (mszipd.c:462-495): block length (only 0 matters: end of stream), then
       // exactly 'C','K'
@@ -517,16 +530,17 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
     }
     else {
       // skip to the next 'C','K' (mszipd.c:406-414)
-      do {
+      while (state != 2u) {
         if (!d.read_bits(8, v)) { rd_ok = false; break; }
         if (v == 'C') state = 1;
         else if (state == 1u && v == 'K') state = 2;
         else state = 0;
-      } while (state != 2u);
+      }
       if (!rd_ok) { err = ERR_READ; break; }
     }
 
     d.wpos = 0; d.flushed = false;
+    d.store_bits();                                                              // mszipd.c:419
     u32 bytes_output = 0;
     int r = zip_inflate(d, bytes_output);
     if (r) {
@@ -536,6 +550,31 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
         if (bo == 0u && d.wpos > 0u) bo = d.wpos;
         for (u32 k = bo + lane; k < ZIP_FRAME; k += WAVE) d.out[d.B + k] = 0;
         bytes_output = ZIP_FRAME;
+        if (r < 0) {
+          // The next block starts from the reference's STRUCT state (RESTORE_BITS, mszipd.c:404): bit
+          // buffer and bits_left as of the last STORE_BITS (mszipd.c:419,223,149), but i_ptr rewound to
+          // the start of the input chunk when the feeder refilled since then (read_input stores
+          // i_ptr/i_end in the struct, readbits.h:184-214).  Chunks are `bufsz` bytes of the folder stream
+          // and the last one is whatever is left, so refills happen when byte k*bufsz or byte in_len is
+          // first asked for.
+          const u32 bufsz = u.in_chunk ? u.in_chunk : 4096u;
+          const u32 e = d.abs_iptr(), s = d.snap_iptr, in_len = d.w.in_len;
+          u32 R = s;
+          if (e > s) {
+            const u32 m = (e - 1u < in_len) ? e - 1u : in_len;
+            const u32 cand = (in_len <= e - 1u) ? in_len : (m / bufsz) * bufsz;
+            if (cand > s) R = cand;
+          }
+          // whole bytes of the stale bit buffer go through the 'C','K' scanner first, then the stream from R
+          const u32 nb = (u32) d.snap_rbl >> 3;
+          for (u32 k = 0; k < nb; k++) {
+            const u32 c = rfl(d.w.byte_at(s - nb + k));
+            if (c == 'C') state0 = 1;
+            else if (state0 == 1u && c == 'K') state0 = 2;
+            else state0 = 0;
+          }
+          d.restart(R);
+        }
       }
       else { err = (r > 0) ? r : ERR_DECRUNCH; break; }
     }

@@ -741,6 +741,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     units[k].reset_frames = 0; units[k].e8_base = 0;
     units[k].flags = (gs[k].hard_eof ? MSPACK_HIP_UF_HARD_EOF : 0) |
                      ((self->fix_mszip && method == MSCAB_COMP_MSZIP) ? MSPACK_HIP_UF_MSZIP_REPAIR : 0);
+    units[k].in_chunk = (uint32_t)((self->buf_size + 1) & ~1);    /* mszipd.c:348 */
   }
   in_arena = (unsigned char *) sys->alloc(sys, in_bytes + 64);
   out_arena = (unsigned char *) sys->alloc(sys, out_bytes + 64);

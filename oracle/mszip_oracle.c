@@ -20,13 +20,22 @@ typedef struct {
   const uint8_t *in; size_t in_len, pos;
   uint32_t bb; int bl;
   int err;                      /* MSPACK_ERR_READ when the input ran dry */
+  /* What the reference's stream STRUCT holds, as opposed to the decoder's local copies (readbits.h:
+   * 119-131): STORE_BITS writes all four fields, and every refill (read_input, readbits.h:184-214)
+   * rewinds the struct's i_ptr to the start of the new input chunk.  Repair mode restarts from these
+   * after a failed block (mszipd.c:404), so they are observable. */
+  size_t bufsz, s_iptr;
+  uint32_t s_bb; int s_bl;
 } zbits_t;
 
 static int z_byte(zbits_t *b, unsigned *v) {
+  if (b->pos <= b->in_len && (b->pos % b->bufsz == 0 || b->pos == b->in_len)) b->s_iptr = b->pos;   /* refill point */
   if (b->pos < b->in_len) { *v = b->in[b->pos++]; return 0; }
   if (b->pos < b->in_len + 2) { b->pos++; *v = 0; return 0; }
   b->err = ORC_READ; return 1;
 }
+static void z_store(zbits_t *b) { b->s_iptr = b->pos; b->s_bb = b->bb; b->s_bl = b->bl; }
+static void z_restore(zbits_t *b) { b->pos = b->s_iptr; b->bb = b->s_bb; b->bl = b->s_bl; }
 static int z_ensure(zbits_t *b, int n) {
   while (b->bl < n) { unsigned v; if (z_byte(b, &v)) return 1; b->bb |= v << b->bl; b->bl += 8; }
   return 0;
@@ -143,7 +152,7 @@ static int inflate_block_stream(zip_t *z) {
         while (i < 288) z->lit_len[i++] = 8;
         memset(z->dist_len, 5, 32);
       }
-      else { int r = read_dynamic(z); if (r) return r; }
+      else { int r; z_store(b); r = read_dynamic(z); if (r) return r; z_store(b); }   /* mszipd.c:223,149 */
       if (oh_build(&z->lit_t, z->lit_len, 288, 9)) return INF_ERR;
       if (oh_build(&z->dist_t, z->dist_len, 32, 6)) return INF_ERR;
       for (;;) {
@@ -168,6 +177,7 @@ static int inflate_block_stream(zip_t *z) {
     else return INF_ERR;
   } while (!last_block);
   if (z->wpos) { if (flush(z, z->wpos)) return INF_ERR; }
+  z_store(b);                                                       /* mszipd.c:312 */
   return 0;
 }
 
@@ -182,9 +192,11 @@ int oracle_mszip_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t o
   memset(res, 0, sizeof(*res));
   init_tables();
   z->b.in = in; z->b.in_len = in_len;
+  z->b.bufsz = (repair_mode > 1) ? (size_t) repair_mode : 4096;     /* >1: the feeder's buffer size */
   while (remaining > 0) {
     unsigned v; int state = 0, r;
     uint32_t n;
+    z_restore(&z->b);                                               /* mszipd.c:404 */
     ZDROP(&z->b, z->b.bl & 7);
     do {                                                            /* mszipd.c:406-414 */
       if (z_bits(&z->b, 8, &v)) { err = ORC_READ; goto done; }
@@ -193,11 +205,12 @@ int oracle_mszip_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t o
       else state = 0;
     } while (state != 2);
     z->wpos = 0; z->bytes_output = 0;
+    z_store(&z->b);                                                 /* mszipd.c:419 */
     r = inflate_block_stream(z);
     if (r) {
       if (repair_mode) {                                            /* mszipd.c:422-433 */
         if (z->bytes_output == 0 && z->wpos > 0) flush(z, z->wpos);
-        memset(z->window + z->bytes_output, 0, FRAME - z->bytes_output);
+        if (z->bytes_output < FRAME) memset(z->window + z->bytes_output, 0, FRAME - z->bytes_output);
         z->bytes_output = FRAME;
       }
       else { err = (r > 0) ? r : ORC_DECRUNCH; goto done; }

@@ -96,15 +96,23 @@ static void m_msg(struct mspack_file *file, const char *format, ...) { (void) fi
 #define CACHE_SLOTS 8
 struct blk_hdr { size_t size; size_t pad; };
 static __thread struct blk_hdr *blk_cache[CACHE_SLOTS];
+static int zero_alloc;            /* tests: hand out zeroed blocks, so that reads of window bytes the
+                                   * reference never wrote become comparable (oracle windows are zeroed) */
+void refh_zero_alloc(int on) { zero_alloc = on; }
 static void *m_alloc(struct mspack_system *self, size_t bytes) {
   struct blk_hdr *h;
   int i;
   (void) self;
   for (i = 0; i < CACHE_SLOTS; i++)
-    if (blk_cache[i] && blk_cache[i]->size == bytes) { h = blk_cache[i]; blk_cache[i] = NULL; return h + 1; }
+    if (blk_cache[i] && blk_cache[i]->size == bytes) {
+      h = blk_cache[i]; blk_cache[i] = NULL;
+      if (zero_alloc) memset(h + 1, 0, bytes);
+      return h + 1;
+    }
   h = (struct blk_hdr *) malloc(sizeof(*h) + bytes);
   if (!h) return NULL;
   h->size = bytes;
+  if (zero_alloc) memset(h + 1, 0, bytes);
   return h + 1;
 }
 static void m_free(void *p) {
@@ -171,7 +179,7 @@ int refh_mszip(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, l
   struct memname dst = { MEMNAME_MAGIC, out, out_cap, 0 };
   struct mspack_file *fi = m_open(&mem_system, (const char *) &src, MSPACK_SYS_OPEN_READ);
   struct mspack_file *fo = m_open(&mem_system, (const char *) &dst, MSPACK_SYS_OPEN_WRITE);
-  struct mszipd_stream *zip = mszipd_init(&mem_system, fi, fo, 4096, repair_mode);
+  struct mszipd_stream *zip = mszipd_init(&mem_system, fi, fo, repair_mode > 1 ? repair_mode : 4096, repair_mode);
   int err = MSPACK_ERR_ARGS;
   if (zip) { err = mszipd_decompress(zip, (off_t) out_bytes); mszipd_free(zip); }
   if (written) *written = dst.written;

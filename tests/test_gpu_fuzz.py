@@ -101,6 +101,44 @@ def test_fuzz_mszip(built):
     assert bad > len(streams) // 4
 
 
+def repair_corpus():
+    """damaged MSZIP folders for repair mode (MSCABD_PARAM_FIXMSZIP) and the feeder chunk size of each"""
+    rng = np.random.default_rng(5)
+    streams, lens, chunks = [], [], []
+    for ci, (level, strat, hist, bs) in enumerate([(6, 0, False, 32768), (9, 0, True, 32768), (1, zlib.Z_FIXED, True, 32768),
+                                                   (6, 0, True, 20000), (0, 0, False, 32768),
+                                                   (6, zlib.Z_HUFFMAN_ONLY, False, 3000)]):
+        data = M.gen_plaintext(300 + ci, ci % 6, 32768 * 6 if bs == 32768 else 100000).tobytes()
+        s = zip_folder(data, level, strat, history=hist, bs=bs)
+        for k, m in enumerate([s] + mutations(s, rng, 300)):
+            streams.append(m); lens.append(len(data)); chunks.append((0, 64, 512, 2, 4096, 1000)[k % 6])
+    return streams, lens, chunks
+
+
+def test_fuzz_mszip_repair_mode(built):
+    """mszipd repair mode: a failed block is zero-filled and decoding goes on at the next 'CK' -- looked
+    for from where the reference's stream struct was left (last STORE_BITS, or the start of the current
+    input chunk after a refill), which may be before or after the damage: error, length and every byte."""
+    streams, lens, chunks = repair_corpus()
+    offs, pos = [], 0
+    for s in streams:
+        pos = (pos + 15) & ~15
+        offs.append(pos); pos += len(s)
+    arena = np.zeros(pos + 64, dtype=np.uint8)
+    for s, o in zip(streams, offs):
+        arena[o:o + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    units, out_bytes = M.make_units(M.KIND_MSZIP, offs, [len(s) for s in streams], lens, flags=M.UF_MSZIP_REPAIR,
+                                    out_slack=32768)
+    units["in_chunk"] = chunks
+    out, res = M.decode_batch(units, arena, out_bytes)
+    repaired = 0
+    for i, st in enumerate(streams):
+        e, o, r, _ = oracle_mszip(st, lens[i], chunks[i] if chunks[i] else 1)
+        compare("mszip-repair", i, res, units, out, e, o, r)
+        repaired += e == 0 and oracle_mszip(st, lens[i])[0] != 0
+    assert repaired > len(streams) // 8
+
+
 def test_fuzz_qtm(built):
     rng = np.random.default_rng(4242)
     streams, lens, wbs = [], [], []

@@ -149,6 +149,26 @@ def test_fuzz_oracle_vs_reference_mszip_qtm(built):
             assert (e1, w1) == (e2, r.out_len), ("qtm", ci, e1, w1, e2, r.out_len)
 
 
+def test_fuzz_oracle_vs_reference_mszip_repair(built):
+    """Repair mode, several feeder chunk sizes: error, length AND contents against the real reference (its
+    allocator zeroed for this test, so that window bytes it never wrote read as the oracle's zeros)."""
+    from test_gpu_fuzz import repair_corpus
+    from helpers import ref
+    streams, lens, chunks = repair_corpus()
+    ref().refh_zero_alloc(1)
+    try:
+        repaired = 0
+        for m, n, c in zip(streams, lens, chunks):
+            rp = c if c else 1
+            e1, o1, w1 = ref_mszip(m, n, rp)
+            e2, o2, r, _ = oracle_mszip(m, n, rp)
+            assert (e1, w1) == (e2, r.out_len) and o1 == o2, (len(m), rp, e1, w1, e2, r.out_len)
+            repaired += e1 == 0 and ref_mszip(m, n, 0)[0] != 0
+        assert repaired > len(streams) // 8
+    finally:
+        ref().refh_zero_alloc(0)
+
+
 DELTA_CASES = [(70000, 17, 0, {}), (200000, 18, 0, dict(mode=4, block_size=20000)), (100000, 19, 50000, {}),
                (300000, 21, 100000, dict(mode=2)), (5000, 17, 3000, dict(mode=3)),
                (65536, 17, 65536, dict(mode=4, block_size=9999)), (1 << 20, 22, 1 << 20, {}), (100000, 25, 0, {})]
