@@ -32,7 +32,7 @@
 
 #define LZX_FRAME 32768u
 #define LZX_MAIN_P 10
-#define LZX_LEN_P 10
+#define LZX_LEN_P 9
 #define LZX_ALI_P 7
 #define LZX_PRE_P 6
 #undef LZX_MAIN_SYMS
@@ -81,6 +81,7 @@ struct __align__(16) LzxShared {
   u8  pre_len[24];
   u8  ali_len[8];
   SpecQueueLds spq;              /* speculative path: queued matches + start flags (spec_queue.hpp) */
+  u32 tq0[128], tq1[128];        /* speculative path: parsed tokens waiting for their commit (lzx_run_spec) */
 };
 
 struct LzxDec {
@@ -94,7 +95,7 @@ struct LzxDec {
   u8 *out; u32 P;                    // linear position == bytes decoded since unit start
   u32 lit_buf; u32 lit_n;            // lit_buf is per-lane
   u32 st_rounds, st_unknown;         // statistics (LZX_EXP_STATS builds only)
-  u32 st_t[6];
+  u32 st_t[10];
   u32 st_h[3];                       // header timers: pretree, length symbols, table builds
   LzxShared *sh;
   HuffRegs hr_main, hr_len, hr_ali, hr_pre;
@@ -109,7 +110,7 @@ struct LzxDec {
     if (fetched >= w.in_len || w.in_len - fetched <= 64u) near_end = true;
   }
   __device__ __forceinline__ void need(int n) { if (bl < n) refill(); }   // n <= 32
-  __device__ bool ref_ensure(int n) {             // ENSURE_BITS(n) of the reference, EOF-exact
+  __device__ __forceinline__ bool ref_ensure(int n) {             // ENSURE_BITS(n) of the reference, EOF-exact
     while (rbl < n) {
       u32 i = w.origin + ((cons_bits() + (u32) rbl) >> 3);   // the reference's i_ptr
       if (i + 2u > w.in_len + w.eofs) { err = ERR_READ; return false; }   // fake bytes, then ERR_READ
@@ -630,7 +631,8 @@ __device__ __forceinline__ void spec_resync(LzxDec &d, const u32 bitpos, const u
   u32 lo = sh->inbuf[lane], hi = sh->inbuf[64u + lane];
   lo = SWAP16(lo); hi = SWAP16(hi);
   if (ch == cb) { d.w.cur = lo; d.w.nxt = hi; }
-  else { d.w.cur = hi; d.w.nxt = pf; }                  // ch == cb + 1
+  else if (ch == cb + 1u) { d.w.cur = hi; d.w.nxt = pf; }
+  else { d.w.cur = d.w.load_chunk(ch, lane); d.w.nxt = d.w.load_chunk(ch + 1u, lane); }   // went back (end of a run)
   d.w.wi = wi; d.bb = 0; d.bl = 0;
   d.refill(); d.refill();
   u32 sk = bitpos & 31u;
@@ -729,10 +731,61 @@ __device__ __forceinline__ u32 lzx_read_lens_spec(LzxDec &d, u8 *lens, u32 first
   return X;
 }
 
+// ---- R0-R2 as a prefix scan ----------------------------------------------------------------------
+// What a token does to the three recent offsets (lzxd.c:565-586) is a map "new slot i <- old slot j or
+// this token's own offset": an explicit offset is (own, R0, R1), a repeat of R0 changes nothing, a
+// repeat of R1 / R2 swaps it with R0.  Such maps compose associatively, so the state after every token
+// of a batch is an inclusive scan.  A map is three bytes, one per new slot: 0..2 = old slot, 0x80 | lane =
+// the offset of the token in that lane.  v_perm_b32 composes two maps in one instruction.
+#define LRU_ID 0x020100u
+__device__ __forceinline__ u32 lru_compose(u32 first, u32 then)
+{
+  const u32 L = then & 0x808080u;                        // slots `then` fills with a token's own offset
+  const u32 full = (L << 1) - (L >> 7);                  // 0xFF in those bytes
+  const u32 sel = (then & ~full) | (0x060504u & full) | 0x0C000000u;
+  return __builtin_amdgcn_perm(then, first, sel);        // byte i: first[then[i]] or then[i] itself
+}
+__device__ __forceinline__ u32 lru_scan(u32 x)
+{
+  u32 v = x, t;
+  t = (u32) __builtin_amdgcn_update_dpp((int) LRU_ID, (int) v, 0x111, 0xf, 0xf, false); v = lru_compose(t, v);
+  t = (u32) __builtin_amdgcn_update_dpp((int) LRU_ID, (int) v, 0x112, 0xf, 0xf, false); v = lru_compose(t, v);
+  t = (u32) __builtin_amdgcn_update_dpp((int) LRU_ID, (int) v, 0x114, 0xf, 0xf, false); v = lru_compose(t, v);
+  t = (u32) __builtin_amdgcn_update_dpp((int) LRU_ID, (int) v, 0x118, 0xf, 0xf, false); v = lru_compose(t, v);
+  t = (u32) __builtin_amdgcn_update_dpp((int) LRU_ID, (int) v, 0x142, 0xa, 0xf, false); v = lru_compose(t, v);
+  t = (u32) __builtin_amdgcn_update_dpp((int) LRU_ID, (int) v, 0x143, 0xc, 0xf, false); v = lru_compose(t, v);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The speculative decode of a run of tokens (lzxd.c:538-651), in two alternating phases.
+//
+// PARSE (per round of 64 bit positions): every lane decodes the complete token that would start at bit
+// (bitpos + lane); the chain of real tokens is followed with v_readlane; the tokens on the chain are
+// appended to a token queue in LDS (kind, output length, offset or literal, start bit).  Nothing else
+// happens in a round: no output position is needed to find the next token, so the serial chain of the
+// whole decoder is just "decode 64 positions, walk".  A token the lane-parallel decoder does not take
+// (a code beyond the direct length / aligned tables, an invalid one) is decoded on the scalar side from
+// the same 64 bits and queued like the others.
+//
+// COMMIT (per 64 queued tokens, one token per lane, all lanes busy): prefix sum of the output lengths
+// -> positions; literals are stored; R0-R2 are resolved for all matches at once (lru_scan); the
+// reference's checks (lzxd.c:613-634, 678-693) run for all matches at once; the matches go to the
+// deferred-copy queue of spec_queue.hpp, which is resolved 64 output bytes per pass.
+//
+// The parser runs ahead of the committed position, so at the end of a run (lzxd.c:538: tokens are read
+// only while this_run > 0) it has parsed tokens that do not belong to the run -- bits of the next block
+// header read as tokens.  They are dropped and the bit position goes back to the first of them (every
+// record carries the low 16 bits of its start).  For the same reason the parser never fails: what it
+// cannot decode becomes a FAIL marker that only counts when the commit reaches it.
+// ---------------------------------------------------------------------------------------------------
+#define LZX_TQ 128u                /* token queue entries (two commits' worth) */
+#define LZX_TK_BAIL 6u             /* DELTA: a match length that announces an extension (lzxd.c:588-611) */
+#define LZX_TK_FAIL 7u
+
 template <bool ALIGNED>
 __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 run_end_, const u32 wbase_)
 {
-  constexpr bool WIDE = LZX_SPEC_WIDE != 0;
   LzxShared *sh = d.sh;
   const u32 lane = d.lane;
   u8 *const out = d.out;
@@ -744,16 +797,16 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   const bool length_empty = rfl((u32) s.length_empty) != 0u;
   int rc = LZX_RUN_DONE;
 
-  // The speculative rounds stop `margin` bytes before the end of the input.  A round (64 starts + a
-  // 53-bit token) plus one scalar token consumes at most 22 bytes, a block header read without any
-  // symbol decode 17 more and the first symbol after it 7: with 56 the EOF-exact reader
+  // The parser stops `margin` bytes before the end of the input.  A round (64 starts + a 53-bit
+  // token) plus one scalar token consumes at most 22 bytes, a block header read without any symbol
+  // decode 17 more and the first symbol after it 7: with 56 the EOF-exact reader
   // (LzxDec::sym_ensure) still takes over at a symbol boundary at least 6 bytes before the
   // reference's read pointer can reach the end of the input.
-  const u32 bit_limit = spec_bit_limit(d, WIDE ? 72u : 56u);
+  const u32 bit_limit = spec_bit_limit(d, 56u);
   if (rfl(d.cons_bits()) >= bit_limit) return LZX_RUN_SWITCH;
   // pending literals of the scalar path go out first: this path stores literals directly
   d.flush_lits();
-  u32 bitpos, cb, pf;                                   // next unread bit (relative to d.w.origin)
+  u32 bitpos, cb, pf;                                   // next unparsed bit (relative to d.w.origin)
   spec_stage(d, bitpos, cb, pf);
   u32 mlim[16 - LZX_MAIN_P];                            // limits of the code lengths beyond the table
 #pragma unroll
@@ -766,239 +819,213 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
 #else
 #define SPEC_COPY(pos_, len_, moff_, wp_) do { } while (0)
 #endif
-  // one match of the walk: LRU update, the reference's checks, copy.  false = DECRUNCH
-#define SPEC_MATCH(pos_, len_, kind_, off_)                                                  \
-  do {                                                                                       \
-    u32 moff_;                                                                               \
-    if ((kind_) == 1u) { moff_ = (off_); R2 = R1; R1 = R0; R0 = moff_; }                     \
-    else if ((kind_) == 2u) moff_ = R0;                                                      \
-    else if ((kind_) == 3u) { moff_ = R1; R1 = R0; R0 = moff_; }                             \
-    else { moff_ = R2; R2 = R0; R0 = moff_; }                                                \
-    u32 wp_ = (pos_) - wbase;                                                                \
-    if ((pos_) + (len_) > run_end || wp_ + (len_) > wsize ||                                 \
-        LZX_BAD_SOURCE(moff_, wp_, offset_written, ref_size, wsize)) {                        \
-      d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL;                                               \
-    }                                                                                        \
-    else SPEC_COPY(pos_, len_, moff_, wp_);                                                  \
-  } while (0)
 
-  // ---- deferred match resolution: rounds queue their matches, spec_queue.hpp resolves them ----
   SpecQueue Q;
   spq_init(sh->spq, Q, P, lane);
-  u32 &Pf = Q.Pf, &mcount = Q.mcount;
-  uint2 *const mlist = sh->spq.mlist;
-  u8 *const mflag = sh->spq.mflag;
-  bool slow = false;
-  bool bail = false;                                    // DELTA: leave the token at hand to the scalar loop                                    // this round copies its matches one by one
+  u32 *const tq0 = sh->tq0, *const tq1 = sh->tq1;
+  u32 th = 0, tt = 0;                                   // token queue: committed / parsed (counters)
+  bool stop = false;                                    // the parser is done (input margin, marker)
+  bool bail = false;
 
 #ifdef LZX_EXP_STATS
 #define TICK(k) do { u64 n_ = __builtin_amdgcn_s_memtime(); d.st_t[k] += (u32)(n_ - tk_); tk_ = n_; } while (0)
 #else
 #define TICK(k) do { } while (0)
 #endif
-  for (;;) {
+  while (rc == LZX_RUN_DONE && P < run_end && !bail) {
 #ifdef LZX_EXP_STATS
     u64 tk_ = __builtin_amdgcn_s_memtime();
 #endif
-    bool live = (rc == LZX_RUN_DONE) && P < run_end && !bail;
-    if (live && bitpos >= bit_limit) { rc = LZX_RUN_SWITCH; live = false; }
-    const bool fin = !live || slow;
-#ifndef LZX_EXP_NOCOPY
-    if (fin || spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, fin, lane);
-#endif
-    if (!live) break;
-    spec_slide(d, bitpos, cb, pf);
-    TICK(5);
-    // ---- every lane decodes the TWO tokens that would start at bits (bitpos + lane) and
-    //      (bitpos + 64 + lane): two independent instruction streams per lane ----
-    u32 rel = bitpos - (cb << 11) + lane;
-    u32 k = rel >> 5, sft = rel & 31u;
-    u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u], i3 = 0, i4 = 0;
-    if (WIDE) { i3 = sh->inbuf[k + 3u]; i4 = sh->inbuf[k + 4u]; }
-    const u32 w0A = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
-    const u32 w1A = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
-    const u32 w0B = (u32)(((((u64) i2 << 32) | i3) << sft) >> 32);
-    const u32 w1B = (u32)(((((u64) i3 << 32) | i4) << sft) >> 32);
-    const SpecTok tA = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0A, w1A);
-    SpecTok tB; tB.tot = 0; tB.sym = 0; tB.kind = 0; tB.olen = 0; tB.off = 0; tB.unk = false;
-    if (WIDE) tB = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0B, w1B);
-    // next token start (in bits from bitpos) for both positions; >= 256 marks "needs the scalar
-    // decoder" and ends the walk
-    const u32 vnA = tA.unk ? (256u + lane) : (lane + tA.tot);
-    const u32 vnB = tB.unk ? (320u + lane) : (64u + lane + tB.tot);
-
-    TICK(0);
-    // ---- follow the real token boundaries: which positions start a token? ----
-    u64 chainA = 0, chainB = 0;
-    u32 q = 0;
-    do { chainA |= 1ull << q; q = rdl(vnA, q); } while (q < 64u);
-    if (WIDE) while (q < 128u) { chainB |= 1ull << (q - 64u); q = rdl(vnB, q - 64u); }
-    bool hit_unknown = false;
-    if (q >= 256u) {
-      q -= 256u; hit_unknown = true;
-      if (q < 64u) chainA &= ~(1ull << q); else chainB &= ~(1ull << (q - 64u));
-    }
-    // q = where the next round starts (or the token the scalar decoder has to take)
-    TICK(1);
-    bool onA = (chainA >> lane) & 1ull, onB = WIDE && ((chainB >> lane) & 1ull);
-    const u32 xA = onA ? tA.olen : 0u, xB = onB ? tB.olen : 0u;
-    const u32 inclA = wave_incl_scan(xA), inclB = WIDE ? wave_incl_scan(xB) : 0u;
-    const u32 sumA = rdl(inclA, 63u);
-    const u32 oposA = P + inclA - xA;                    // output position of this lane's tokens
-    const u32 oposB = P + sumA + inclB - xB;
-    u32 newP = P + sumA + (WIDE ? rdl(inclB, 63u) : 0u);
-    // tokens are decoded only while the run lasts (lzxd.c:538): cut the chain at the first token
-    // that starts at or after run_end
-    {
-      const u64 lateA = ballot(onA && oposA >= run_end), lateB = WIDE ? ballot(onB && oposB >= run_end) : 0ull;
-      if (lateA) {
-        u32 j = (u32) __ffsll((long long) lateA) - 1u;
-        chainA &= (1ull << j) - 1ull; chainB = 0;
-        q = j; hit_unknown = false; newP = rdl(oposA, j);
-        onA = (chainA >> lane) & 1ull; onB = false;
+    // =================================== PARSE ===================================
+    if (!stop && tt - th < 64u) {
+      spec_slide(d, bitpos, cb, pf);
+      const u32 rel = bitpos - (cb << 11) + lane;
+      const u32 k = rel >> 5, sft = rel & 31u;
+      const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
+      const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+      const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
+      const SpecTok t = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0, w1);
+      // next token start (in bits from bitpos); >= 256 marks "needs the scalar decoder" and ends the walk
+      const u32 vn = t.unk ? (256u + lane) : (lane + t.tot);
+      TICK(0);
+      // ---- follow the real token boundaries: which positions start a token? ----
+      u64 chain = 0;
+      u32 q = 0;
+      do { chain |= 1ull << q; q = rdl(vn, q); } while (q < 64u);
+      bool hit_unknown = false;
+      if (q >= 256u) { q -= 256u; hit_unknown = true; chain &= ~(1ull << q); }
+      TICK(1);
+      // ---- queue the tokens on the chain ----
+      {
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain, 0u));
+        if ((chain >> lane) & 1ull) {
+          const u32 ti = (tt + rank) & (LZX_TQ - 1u);
+          tq0[ti] = t.kind | (t.olen << 3) | (((bitpos + lane) & 0xFFFFu) << 12);
+          tq1[ti] = t.kind == 0u ? t.sym : t.off;
+        }
+        tt += (u32) __popcll(chain);
       }
-      else if (lateB) {
-        u32 j = (u32) __ffsll((long long) lateB) - 1u;
-        chainB &= (1ull << j) - 1ull;
-        q = 64u + j; hit_unknown = false; newP = rdl(oposB, j);
-        onB = (chainB >> lane) & 1ull;
-      }
-    }
-    // literals: one store per position set
-#ifndef LZX_EXP_NOLIT
-    if (onA && tA.kind == 0u) out[oposA] = (u8) tA.sym;
-    if (WIDE && onB && tB.kind == 0u) out[oposB] = (u8) tB.sym;
-#endif
-    TICK(2);
-    // ---- matches ----
-    u64 mmA = ballot(onA && tA.kind != 0u), mmB = WIDE ? ballot(onB && tB.kind != 0u) : 0ull;
-#ifdef LZX_EXP_NOMATCH
-    mmA = 0; mmB = 0;
-#endif
-    // (1) resolve every match's offset through the R0-R2 LRU (lzxd.c:565-586): sequential by
-    //     nature, but branch-free, and the result goes back into the match's own lane
-    const u32 sR0 = R0, sR1 = R1, sR2 = R2;
-    u32 vmoffA = tA.off, vmoffB = tB.off;
-#define SPEC_LRU(mask_, kind_, off_, vm_)                                                     \
-    for (u64 m1 = (mask_); m1; m1 &= m1 - 1ull) {                                             \
-      u32 j = (u32) __ffsll((long long) m1) - 1u;                                             \
-      u32 kj = rdl((kind_), j), oj = rdl((off_), j);                                          \
-      u32 n0 = kj == 1u ? oj : (kj == 2u ? R0 : (kj == 3u ? R1 : R2));                        \
-      u32 n1 = (kj == 1u || kj == 3u) ? R0 : R1;                                              \
-      u32 n2 = kj == 1u ? R1 : (kj == 4u ? R0 : R2);                                          \
-      R0 = n0; R1 = n1; R2 = n2;                                                              \
-      asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vm_) : "s"(n0), "s"(j) : "m0"); \
-    }
-    SPEC_LRU(mmA, tA.kind, tA.off, vmoffA)
-    if (WIDE) { SPEC_LRU(mmB, tB.kind, tB.off, vmoffB) }
-#undef SPEC_LRU
-    TICK(3);
-    // (2) the reference's checks (lzxd.c:613-634, 678-693) for all matches at once
-    bool fail_after = false;
-    {
-      const u32 wpA = oposA - wbase, wpB = oposB - wbase;
-      const bool badA = ((mmA >> lane) & 1ull) &&
-                 (oposA + tA.olen > run_end || wpA + tA.olen > wsize ||
-                  LZX_BAD_SOURCE(vmoffA, wpA, offset_written, ref_size, wsize));
-      const bool badB = WIDE && ((mmB >> lane) & 1ull) &&
-                 (oposB + tB.olen > run_end || wpB + tB.olen > wsize ||
-                  LZX_BAD_SOURCE(vmoffB, wpB, offset_written, ref_size, wsize));
-      const u64 badmA = ballot(badA), badmB = WIDE ? ballot(badB) : 0ull;
-      if (badmA) { mmA &= (1ull << ((u32) __ffsll((long long) badmA) - 1u)) - 1ull; mmB = 0; fail_after = true; }
-      else if (badmB) { mmB &= (1ull << ((u32) __ffsll((long long) badmB) - 1u)) - 1ull; fail_after = true; }
-    }
-    // (3) queue the matches.  Offsets no linear copy can serve (0, or beyond the window: only from
-    //     a stored block's R0-R2) take the slow way: resolve the queue, redo the round one match at
-    //     a time with the reference's ring semantics.  A round that would overflow the queue does too.
-#ifndef LZX_EXP_NOCOPY
-    if (mmA | mmB) {
-      const bool ismA = (mmA >> lane) & 1ull, ismB = WIDE && ((mmB >> lane) & 1ull);
-      const u32 nmA = (u32) __popcll(mmA), nmB = WIDE ? (u32) __popcll(mmB) : 0u;
-      if (!slow) {
-        if (ballot((ismA && (vmoffA == 0u || vmoffA > wsize)) || (ismB && (vmoffB == 0u || vmoffB > wsize))) ||
-            mcount + nmA + nmB > SPQ_CAP || newP - (Pf & ~63u) > SPQ_RING) {
-          slow = true; R0 = sR0; R1 = sR1; R2 = sR2; continue;
-        }
-        const u32 rankA = __builtin_amdgcn_mbcnt_hi((u32)(mmA >> 32), __builtin_amdgcn_mbcnt_lo((u32) mmA, 0u));
-        const u32 rankB = __builtin_amdgcn_mbcnt_hi((u32)(mmB >> 32), __builtin_amdgcn_mbcnt_lo((u32) mmB, 0u));
-        if (ismA) {
-          mlist[mcount + rankA] = make_uint2(oposA, (vmoffA << 9) | tA.olen);
-          mflag[oposA & (SPQ_RING - 1u)] = 1;
-        }
-        if (WIDE && ismB) {
-          mlist[mcount + nmA + rankB] = make_uint2(oposB, (vmoffB << 9) | tB.olen);
-          mflag[oposB & (SPQ_RING - 1u)] = 1;
-        }
-        mcount += nmA + nmB;
-      }
-      else {
-        for (u64 dm = mmA; dm; dm &= dm - 1ull) {
-          u32 l = (u32) __ffsll((long long) dm) - 1u;
-          u32 pos_l = rdl(oposA, l), len_l = rdl(tA.olen, l), off_l = rdl(vmoffA, l);
-          SPEC_COPY(pos_l, len_l, off_l, pos_l - wbase);
-        }
-        if (WIDE) for (u64 dm = mmB; dm; dm &= dm - 1ull) {
-          u32 l = (u32) __ffsll((long long) dm) - 1u;
-          u32 pos_l = rdl(oposB, l), len_l = rdl(tB.olen, l), off_l = rdl(vmoffB, l);
-          SPEC_COPY(pos_l, len_l, off_l, pos_l - wbase);
-        }
-      }
-    }
-#endif
-    TICK(4);
-    if (fail_after) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; slow = false; continue; }
-    P = newP;
-    bitpos += q;
-    d.st_rounds++;
-    if (slow) Pf = P;
-    if (hit_unknown && P < run_end) {
-      // a code longer than the direct table (or an invalid one): decode this one token on the
-      // scalar side from the 64 bits its position extracted
-      u32 tk_kind, tk_val, tk_off;
-      u64 rq = q < 64u ? (((u64) rdl(w0A, q) << 32) | rdl(w1A, q))
-                       : (((u64) rdl(w0B, q - 64u) << 32) | rdl(w1B, q - 64u));
-      u32 tk_tot = lzx_scalar_token<ALIGNED>(d, length_empty, rq, tk_kind, tk_val, tk_off);
-      if (tk_tot == 0u) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; slow = false; continue; }
+      bitpos += q;
+      d.st_rounds++;
+      if (hit_unknown) {
+        u32 tk_kind = 0, tk_val = 0, tk_off = 0;
+        const u64 rq = ((u64) rdl(w0, q) << 32) | rdl(w1, q);
+        const u32 tk_tot = lzx_scalar_token<ALIGNED>(d, length_empty, rq, tk_kind, tk_val, tk_off);
+        u32 r0, r1 = tk_kind == 0u ? tk_val : tk_off;
+        if (tk_tot == 0u) { r0 = LZX_TK_FAIL; stop = true; }
 #ifdef LZX_DELTA
-      // length 257 announces an extension that follows the offset bits (lzxd.c:588-611): that token
-      // belongs to the scalar loop of lzx_decode_unit, which comes back here afterwards
-      if (tk_kind != 0u && tk_val == 257u) { bail = true; slow = false; continue; }
+        else if (tk_kind != 0u && tk_val == 257u) { r0 = LZX_TK_BAIL; stop = true; }
 #endif
-      if (tk_kind == 0u) { if (lane == 0) out[P] = (u8) tk_val; P++; if (slow) Pf = P; }
-      else {
-        u32 moff_;
-        u32 t0 = R0, t1 = R1, t2 = R2;
-        if (tk_kind == 1u) { moff_ = tk_off; t2 = t1; t1 = t0; t0 = moff_; }
-        else if (tk_kind == 2u) moff_ = t0;
-        else if (tk_kind == 3u) { moff_ = t1; t1 = t0; t0 = moff_; }
-        else { moff_ = t2; t2 = t0; t0 = moff_; }
-        u32 wp_ = P - wbase;
-        if (P + tk_val > run_end || wp_ + tk_val > wsize ||
-            LZX_BAD_SOURCE(moff_, wp_, offset_written, ref_size, wsize)) {
-          d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; slow = false; continue;
+        else r0 = tk_kind | ((tk_kind == 0u ? 1u : tk_val) << 3);
+        if (lane == 0u) {
+          const u32 ti = tt & (LZX_TQ - 1u);
+          tq0[ti] = r0 | ((bitpos & 0xFFFFu) << 12);
+          tq1[ti] = r1;
         }
-#ifndef LZX_EXP_NOCOPY
-        if (!slow) {
-          // the round is redone after the queue is resolved: nothing of this token is committed
-          if (moff_ == 0u || moff_ > wsize || mcount >= SPQ_CAP ||
-              P + tk_val - (Pf & ~63u) > SPQ_RING) { slow = true; continue; }
-          if (lane == 0u) {
-            mlist[mcount] = make_uint2(P, (moff_ << 9) | tk_val);
-            mflag[P & (SPQ_RING - 1u)] = 1;
-          }
-          mcount++;
-        }
-        else { SPEC_COPY(P, tk_val, moff_, wp_); }
-#endif
-        R0 = t0; R1 = t1; R2 = t2;
-        P += tk_val;
-        if (slow) Pf = P;
+        tt++;
+        if (!stop) bitpos += tk_tot;
       }
-      bitpos += tk_tot;
+      if (bitpos >= bit_limit) stop = true;
+      TICK(2);
+      if (!stop && tt - th < 64u) continue;
     }
-    slow = false;
+
+    // =================================== COMMIT ===================================
+    u32 n = tt - th;
+    if (n > 64u) n = 64u;
+    if (n == 0u) { rc = LZX_RUN_SWITCH; break; }         // the input margin was reached and all is committed
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const u32 ci = (th + lane) & (LZX_TQ - 1u);
+    const u32 c0 = tq0[ci], c1 = tq1[ci];
+    const u32 kind = c0 & 7u;
+    u32 marker = 0;
+    {
+      const u64 mk = ballot(lane < n && kind >= LZX_TK_BAIL);
+      if (mk) { const u32 jm = (u32) __ffsll((long long) mk) - 1u; marker = rdl(kind, jm); n = jm; }
+    }
+    const u32 olen = lane < n ? ((c0 >> 3) & 511u) : 0u;
+    const u32 incl = wave_incl_scan(olen);
+    const u32 opos = P + incl - olen;                   // output position of this lane's token
+    u32 newP = P + rdl(incl, 63u);
+    // tokens are decoded only while the run lasts (lzxd.c:538): the first one that would start at or
+    // after run_end, and everything parsed behind it, is not part of this run
+    if (newP >= run_end) {
+      const u64 late = ballot(lane < n && opos >= run_end);
+      if (late) { const u32 j = (u32) __ffsll((long long) late) - 1u; n = j; newP = rdl(opos, j); marker = 0; }
+    }
+    const bool valid = lane < n;
+#ifndef LZX_EXP_NOLIT
+    if (valid && kind == 0u) out[opos] = (u8) c1;
+#endif
+    TICK(3);
+    bool fail_after = false;
+    const bool ism0 = valid && kind != 0u;
+    u64 mm = ballot(ism0);
+    if (mm) {
+      // (1) every match's offset through the R0-R2 LRU (lzxd.c:565-586)
+      const u32 sR0 = R0, sR1 = R1, sR2 = R2;
+      u32 vmoff = c1;
+      const u64 k1 = ballot(ism0 && kind == 1u);
+      if (!ballot(ism0 && kind >= 3u)) {
+        // only explicit offsets and repeats of R0: a repeat takes the nearest explicit offset before
+        // it, and the last three explicit offsets are the new R0-R2
+        const u64 below = k1 & ((1ull << lane) - 1ull);
+        const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
+        const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
+        if (kind == 2u) vmoff = below ? pv : sR0;
+        if (k1) {
+          u64 m = k1;
+          const u32 j0 = 63u - (u32) __clzll((long long) m);
+          u32 nb = sR0, nc = sR1;
+          m &= ~(1ull << j0);
+          if (m) {
+            const u32 j1 = 63u - (u32) __clzll((long long) m);
+            nb = rdl(c1, j1); nc = sR0;
+            m &= ~(1ull << j1);
+            if (m) nc = rdl(c1, 63u - (u32) __clzll((long long) m));
+          }
+          R0 = rdl(c1, j0); R1 = nb; R2 = nc;
+        }
+      }
+      else {
+        u32 x = LRU_ID;
+        if (ism0) x = kind == 1u ? (0x010080u | lane) : (kind == 3u ? 0x020001u : (kind == 4u ? 0x000102u : LRU_ID));
+        const u32 C = lru_scan(x);
+        const u32 e0 = C & 0xFFu;
+        const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
+        vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
+        const u32 Cl = rdl(C, 63u);
+        const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
+        R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
+        R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
+        R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
+      }
+      TICK(4);
+      // (2) the reference's checks (lzxd.c:613-634, 678-693) for all matches at once
+      {
+        const u32 wp = opos - wbase;
+        const bool bad = ism0 && (opos + olen > run_end || wp + olen > wsize ||
+                                  LZX_BAD_SOURCE(vmoff, wp, offset_written, ref_size, wsize));
+        const u64 badm = ballot(bad);
+        if (badm) { mm &= (1ull << ((u32) __ffsll((long long) badm) - 1u)) - 1ull; fail_after = true; }
+      }
+#ifdef LZX_EXP_NOMATCH
+      mm = 0;
+#endif
+#ifndef LZX_EXP_NOCOPY
+      // (3) queue the matches
+      if (mm) {
+        bool ism = (mm >> lane) & 1ull;
+        // Offsets no linear copy can serve (0, or beyond the window: only from a stored block's R0-R2;
+        // DELTA: beyond the 23 bits the queue holds) take the slow way: resolve the queue, copy this
+        // batch's matches one at a time with the reference's ring semantics.
+        if (ballot(ism && (vmoff == 0u || vmoff > wsize || (vmoff >> 23) != 0u))) {
+          spq_resolve(sh->spq, Q, out, P, true, lane);
+          for (u64 dm = mm; dm; dm &= dm - 1ull) {
+            const u32 l = (u32) __ffsll((long long) dm) - 1u;
+            const u32 pos_l = rdl(opos, l), len_l = rdl(olen, l), off_l = rdl(vmoff, l);
+            SPEC_COPY(pos_l, len_l, off_l, pos_l - wbase);
+          }
+          Q.Pf = newP;
+        }
+        else {
+          if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
+          for (;;) {
+            // a push must keep every start flag inside the ring (spec_queue.hpp): take the matches that
+            // end inside it, resolve up to the first one that does not, go on
+            const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
+            const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
+            if (fit) {
+              const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+              spq_push(sh->spq, Q, (fit >> lane) & 1ull, rank, (u32) __popcll(fit), opos, vmoff, olen);
+              mm &= ~fit;
+              ism = (mm >> lane) & 1ull;
+            }
+            if (!mm) break;
+            spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
+          }
+        }
+      }
+#endif
+    }
+    th += n;
+    P = newP;
+    TICK(5);
+#ifndef LZX_EXP_NOCOPY
+    if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane);
+#endif
+    TICK(6);
+    if (fail_after || marker == LZX_TK_FAIL) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; }
+    else if (marker == LZX_TK_BAIL) bail = true;
   }
-#undef SPEC_MATCH
+#ifndef LZX_EXP_NOCOPY
+  spq_resolve(sh->spq, Q, out, P, true, lane);
+#endif
+  // parsed but not committed: the bit position goes back to the first such token
+  if (tt != th) {
+    const u32 lo = rfl(tq0[th & (LZX_TQ - 1u)]) >> 12;
+    bitpos -= (bitpos - lo) & 0xFFFFu;
+  }
 #undef SPEC_COPY
   d.P = P;
   s.R0 = R0; s.R1 = R1; s.R2 = R2;
@@ -1032,7 +1059,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
 #endif
   d.lit_buf = 0; d.lit_n = 0;
   d.st_rounds = 0; d.st_unknown = 0;
-  for (int k_ = 0; k_ < 6; k_++) d.st_t[k_] = 0;
+  for (int k_ = 0; k_ < 10; k_++) d.st_t[k_] = 0;
   d.st_h[0] = d.st_h[1] = d.st_h[2] = 0;
 
   s.wsize = 1u << u.window_bits;
@@ -1120,6 +1147,12 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
               if (rc == LZX_RUN_FAIL) { fail = true; break; }
               if (d.P >= run_end) break;
             }
+#ifdef LZX_EXP_STATS
+            u64 ts_ = __builtin_amdgcn_s_memtime();
+#define TS9() d.st_t[9] += (u32)(__builtin_amdgcn_s_memtime() - ts_)
+#else
+#define TS9() do { } while (0)
+#endif
 #ifdef LZX_DELTA
             respec = true;                           // it hands single tokens over (extended match lengths)
 #else
@@ -1132,6 +1165,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
               d.lit_buf = wrl(d.lit_buf, (u32) sym, d.lit_n);
               d.lit_n++; d.P++;
               if (d.lit_n == WAVE) d.flush_lits();
+              TS9();
               continue;
             }
             u32 m = (u32) sym - 256u, slot = m >> 3, len = m & 7u, off;
@@ -1187,6 +1221,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
             d.lit_n = 0;
 #endif
             d.P += len;
+            TS9();
           }
           d.flush_lits();
           if (fail) break;
@@ -1252,6 +1287,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
       for (int k_ = 0; k_ < 6; k_++) so[k_] = d.st_t[k_];
       so[6] = (u32)(__builtin_amdgcn_s_memtime() - tstart_); so[7] = d.st_rounds; so[8] = d.st_unknown;
       so[9] = d.st_h[0]; so[10] = d.st_h[1]; so[11] = d.st_h[2];
+      so[12] = d.st_t[6]; so[13] = d.st_t[7]; so[14] = d.st_t[8]; so[15] = d.st_t[9];
     }
 #endif
   }

@@ -7,5 +7,5 @@ plain, comp, off, ln = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21)
 units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=2)
 out, res = M.decode_batch(units, comp, out_bytes)
 raw = res.view(np.uint32).reshape(n, 6).astype(np.int64)
-names = {0: "c4 (err)", 1: "c0 (flags)", 2: "c1 (out_len)", 3: "c5", 4: "c2 (good_len)", 5: "rounds"}
+names = {0: "rounds with R1/R2 repeat", 1: "explicit matches", 2: "R0 repeats", 3: "rounds with matches", 4: "R1/R2 repeats", 5: "rounds"}
 for k in range(6): print(names[k], raw[:, k].mean())

@@ -8,10 +8,13 @@ plain, comp, off, ln = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21)
 units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=2)
 out, res = M.decode_batch(units, comp, out_bytes)
 oo = np.asarray(units['out_off'], dtype=np.int64)
-raw = np.stack([np.frombuffer(out[o:o + 48].tobytes(), dtype=np.uint32) for o in oo]).astype(np.int64)
+raw = np.stack([np.frombuffer(out[o:o + 64].tobytes(), dtype=np.uint32) for o in oo]).astype(np.int64)
 tot = raw[:, 6].mean(); rounds = raw[:, 7].mean()
 print("units", n, "total ticks/unit %.0f  rounds/unit %.1f  ticks/round %.0f  spec-run ticks (>>6) %.0f" % (tot, rounds, tot / rounds, raw[:, 8].mean()))
-for name, c in [("flush (queue resolve)", 5), ("vector decode", 0), ("chain walk", 1), ("scan+literals", 2), ("LRU pass", 3), ("checks+queue", 4)]:
-    v = raw[:, c].mean(); print("  %-24s %10.0f  %5.1f%%  %7.0f /round" % (name, v, 100 * v / tot, v / rounds))
-print("  %-24s %10.0f  %5.1f%%" % ("outside the round loop", tot - raw[:, :6].sum(1).mean(), 100 * (tot - raw[:, :6].sum(1).mean()) / tot))
+for name, c in [("parse: vector decode", 0), ("parse: chain walk", 1), ("parse: queue tokens + scalar tokens", 2),
+                ("commit: read, scan, literals", 3), ("commit: R0-R2", 4), ("commit: checks + queue", 5), ("flush (queue resolve)", 12)]:
+    v = raw[:, c].mean(); print("  %-36s %10.0f  %5.1f%%  %7.0f /round" % (name, v, 100 * v / tot, v / rounds))
+print("  %-24s %10.0f  %5.1f%%" % ("outside the round loop", tot - raw[:, :6].sum(1).mean() - raw[:, 12].mean(), 100 * (tot - raw[:, :6].sum(1).mean() - raw[:, 12].mean()) / tot))
+for name, c in [("scalar token loop", 15)]:
+    print("    %-24s %10.0f  %5.1f%%" % (name, raw[:, c].mean(), 100 * raw[:, c].mean() / tot))
 print("  headers: total %.0f  pretree read+build %.0f  length symbols %.0f  main/len table builds %.0f" % (raw[:, 8].mean() * 64, raw[:, 9].mean(), raw[:, 10].mean(), raw[:, 11].mean()))
