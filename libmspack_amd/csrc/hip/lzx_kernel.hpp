@@ -568,9 +568,11 @@ __device__ __forceinline__ SpecTok lzx_spec_token(const LzxShared *sh, const u32
 #ifdef LZX_DELTA
   if (is_match && mlen == 257u) unk = true;             // announces an extended length (lzxd.c:588-611)
 #endif
-  u32 extra = slot < 4u ? 0u : (slot < 36u ? (slot >> 1) - 1u : 17u);
-  u32 base = slot < 4u ? slot : (slot < 36u ? ((2u + (slot & 1u)) << extra) : ((slot - 34u) << 17));
-  u32 off = base - 2u;
+  // position_base / extra_bits in closed form (lzxd.c:202-207), branch-free; only slots >= 3 matter here
+  // (0..2 are the repeats): extra = clamp(slot/2 - 1, 0, 17), base = (slot < 36 ? 2 + (slot & 1) : slot - 34) << extra
+  const int ex_ = (int)(slot >> 1) - 1;
+  const u32 extra = (u32)(ex_ < 0 ? 0 : (ex_ > 17 ? 17 : ex_));
+  u32 off = (((slot < 36u) ? 2u + (slot & 1u) : slot - 34u) << extra) - 2u;
   bool expl = is_match && slot >= 3u;
   if (ALIGNED) {
     bool ali = extra >= 3u;
@@ -802,7 +804,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   // decode 17 more and the first symbol after it 7: with 56 the EOF-exact reader
   // (LzxDec::sym_ensure) still takes over at a symbol boundary at least 6 bytes before the
   // reference's read pointer can reach the end of the input.
-  const u32 bit_limit = spec_bit_limit(d, 56u);
+  const u32 bit_limit = spec_bit_limit(d, LZX_SPEC_WIDE ? 72u : 56u);
   if (rfl(d.cons_bits()) >= bit_limit) return LZX_RUN_SWITCH;
   // pending literals of the scalar path go out first: this path stores literals directly
   d.flush_lits();
@@ -844,16 +846,41 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
       const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
       const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
+#if LZX_SPEC_WIDE
+      // second position set: bits (bitpos + 64 + lane), an independent instruction stream per lane
+      const u32 i3 = sh->inbuf[k + 3u], i4 = sh->inbuf[k + 4u];
+      const u32 x0 = (u32)(((((u64) i2 << 32) | i3) << sft) >> 32);
+      const u32 x1 = (u32)(((((u64) i3 << 32) | i4) << sft) >> 32);
+      const SpecTok u = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, x0, x1);
+      const u32 un = u.unk ? (320u + lane) : (64u + lane + u.tot);
+#endif
       const SpecTok t = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0, w1);
       // next token start (in bits from bitpos); >= 256 marks "needs the scalar decoder" and ends the walk
       const u32 vn = t.unk ? (256u + lane) : (lane + t.tot);
       TICK(0);
       // ---- follow the real token boundaries: which positions start a token? ----
-      u64 chain = 0;
+      u64 chain = 0, chain2 = 0;
       u32 q = 0;
       do { chain |= 1ull << q; q = rdl(vn, q); } while (q < 64u);
+#if LZX_SPEC_WIDE
+      while (q < 128u) { chain2 |= 1ull << (q - 64u); q = rdl(un, q - 64u); }
+#endif
       bool hit_unknown = false;
-      if (q >= 256u) { q -= 256u; hit_unknown = true; chain &= ~(1ull << q); }
+      if (q >= 256u) {
+        q -= 256u; hit_unknown = true;
+        if (q < 64u) chain &= ~(1ull << q); else chain2 &= ~(1ull << (q - 64u));
+      }
+      u32 nA = (u32) __popcll(chain), nB = (u32) __popcll(chain2);
+#if LZX_SPEC_WIDE
+      if (nA + nB > 64u) {
+        // more tokens than a commit takes (codes of 1 bit): give the last ones back
+        while (nA + nB > 64u) {
+          q = 127u - (u32) __clzll((long long) chain2);
+          chain2 &= ~(1ull << (q - 64u)); nB--;
+        }
+        hit_unknown = false;
+      }
+#endif
       TICK(1);
       // ---- queue the tokens on the chain ----
       {
@@ -863,13 +890,26 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
           tq0[ti] = t.kind | (t.olen << 3) | (((bitpos + lane) & 0xFFFFu) << 12);
           tq1[ti] = t.kind == 0u ? t.sym : t.off;
         }
-        tt += (u32) __popcll(chain);
+#if LZX_SPEC_WIDE
+        const u32 rank2 = __builtin_amdgcn_mbcnt_hi((u32)(chain2 >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain2, 0u));
+        if ((chain2 >> lane) & 1ull) {
+          const u32 ti = (tt + nA + rank2) & (LZX_TQ - 1u);
+          tq0[ti] = u.kind | (u.olen << 3) | (((bitpos + 64u + lane) & 0xFFFFu) << 12);
+          tq1[ti] = u.kind == 0u ? u.sym : u.off;
+        }
+#endif
+        tt += nA + nB;
       }
       bitpos += q;
       d.st_rounds++;
       if (hit_unknown) {
+        CNT(0);
         u32 tk_kind = 0, tk_val = 0, tk_off = 0;
+#if LZX_SPEC_WIDE
+        const u64 rq = q < 64u ? (((u64) rdl(w0, q) << 32) | rdl(w1, q)) : (((u64) rdl(x0, q - 64u) << 32) | rdl(x1, q - 64u));
+#else
         const u64 rq = ((u64) rdl(w0, q) << 32) | rdl(w1, q);
+#endif
         const u32 tk_tot = lzx_scalar_token<ALIGNED>(d, length_empty, rq, tk_kind, tk_val, tk_off);
         u32 r0, r1 = tk_kind == 0u ? tk_val : tk_off;
         if (tk_tot == 0u) { r0 = LZX_TK_FAIL; stop = true; }
@@ -891,6 +931,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     }
 
     // =================================== COMMIT ===================================
+    CNT(1);
     u32 n = tt - th;
     if (n > 64u) n = 64u;
     if (n == 0u) { rc = LZX_RUN_SWITCH; break; }         // the input margin was reached and all is committed
@@ -948,6 +989,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
         }
       }
       else {
+        CNT(2);
         u32 x = LRU_ID;
         if (ism0) x = kind == 1u ? (0x010080u | lane) : (kind == 3u ? 0x020001u : (kind == 4u ? 0x000102u : LRU_ID));
         const u32 C = lru_scan(x);
@@ -989,7 +1031,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
           Q.Pf = newP;
         }
         else {
-          if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
+          if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) { CNT(5); spq_resolve(sh->spq, Q, out, P, true, lane); }
           for (;;) {
             // a push must keep every start flag inside the ring (spec_queue.hpp): take the matches that
             // end inside it, resolve up to the first one that does not, go on
@@ -1002,6 +1044,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
               ism = (mm >> lane) & 1ull;
             }
             if (!mm) break;
+            CNT(4);
             spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
           }
         }
