@@ -40,6 +40,7 @@ struct __align__(16) MszipShared {
   u8  lens[324];
   u32 inbuf[128 + 4];            /* speculative path: two 256-byte input chunks */
   SpecQueueLds spq;              /* speculative path: queued matches + start flags (spec_queue.hpp) */
+  u32 tq0[128], tq1[128];        /* speculative path: parsed tokens waiting for their commit (zip_run_spec) */
 };
 
 // inflate() failure classes: <0 = format error (-> MSPACK_ERR_DECRUNCH), >0 = MSPACK_ERR_READ
@@ -211,15 +212,16 @@ __device__ __forceinline__ int zip_read_dynamic(ZipDec &d)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Speculative window decode of the literal/length + distance token loop (mszipd.c:228-303), the same
-// scheme as lzx_run_spec: all 64 lanes decode a COMPLETE token (literal/length symbol, length extra
-// bits, distance symbol, distance extra bits) starting at bit (bitpos + lane) of the LSB-first stream;
-// the chain of real tokens is followed with v_readlane; a DPP prefix sum gives every token its output
-// position; literals go out in one store and matches are queued for spec_queue.hpp.
-// The run stops -- always at a token boundary -- at the end-of-block symbol (consumed here), at a
-// token this path does not take (a code longer than the direct tables or an invalid one, a match that
-// reaches into an earlier block's bytes, output reaching the 32 KiB mark) and near the end of the
-// input; the EOF-exact scalar loop of zip_inflate takes over from there.
+// Speculative decode of the literal/length + distance token loop (mszipd.c:228-303), the same two-phase
+// scheme as lzx_run_spec.  PARSE, per round: all 64 lanes decode a COMPLETE token (literal/length symbol,
+// length extra bits, distance symbol, distance extra bits) starting at bit (bitpos + lane) of the
+// LSB-first stream; the chain of real tokens is followed with v_readlane; the on-chain tokens go into a
+// token queue in LDS.  COMMIT, per 64 queued tokens (one per lane): a DPP prefix sum gives every token its
+// output position, literals go out in one store and matches are queued for spec_queue.hpp.
+// The parse stops -- always at a token boundary -- at the end-of-block symbol, at a token this path does
+// not take (an invalid code, a long distance code) and near the end of the input; the commit stops at a
+// match that reaches into an earlier block's bytes and where the output reaches the 32 KiB mark, and
+// hands the bit position of that token back; the EOF-exact scalar loop of zip_inflate takes over from there.
 // Returns 1 when the end-of-block symbol was consumed, 0 otherwise.
 // ---------------------------------------------------------------------------------------------------
 struct ZipTok { u32 tot, sym, kind, olen, dist; bool unk; };      // kind 0 literal, 1 match, 2 end of block
@@ -299,86 +301,111 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
   for (int l = ZIP_LIT_P + 1; l <= 16; l++) llim[l - ZIP_LIT_P - 1] = rdl(d.hr_lit.limv, (u32) l);
   SpecQueue Q;
   spq_init(sh->spq, Q, P, lane);
+  u32 *const tq0 = sh->tq0, *const tq1 = sh->tq1;
+  u32 th = 0, tt = 0;                                  // token queue: committed / parsed (counters)
+  bool stop = false;                                   // the parser is done
   int rc = 0, eob_rbl = 0;
-  bool stop = false;
+  u32 eob_end = 0;                                     // bit position behind the end-of-block symbol
 
   for (;;) {
-    const bool live = !stop && bitpos < bit_limit;
-    if (!live || spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, !live, lane);
-    if (!live) break;
-    if ((bitpos >> 11) != cb) {                       // slide the LDS window by one chunk
-      u32 up = sh->inbuf[64u + lane];
-      sh->inbuf[lane] = up; sh->inbuf[64u + lane] = pf;
-      cb++;
-      pf = d.w.load_chunk(cb + 2u, lane);
+    // =================================== PARSE ===================================
+    if (!stop && tt - th < 64u) {
+      if ((bitpos >> 11) != cb) {                       // slide the LDS window by one chunk
+        u32 up = sh->inbuf[64u + lane];
+        sh->inbuf[lane] = up; sh->inbuf[64u + lane] = pf;
+        cb++;
+        pf = d.w.load_chunk(cb + 2u, lane);
+      }
+      // ---- every lane decodes the token that would start at bit (bitpos + lane) ----
+      const u32 rel = bitpos - (cb << 11) + lane;
+      const u32 k = rel >> 5, sft = rel & 31u;
+      const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
+      const u64 q01 = ((u64) i1 << 32) | i0, q12 = ((u64) i2 << 32) | i1;
+      const u64 r = (u64)(u32)(q01 >> sft) | ((u64)(u32)(q12 >> sft) << 32);
+      const ZipTok t = zip_spec_token(sh, d.hr_lit.fov, llim, r);
+      // next token start; >= 128 ends the walk: 128 + lane = not for this path, 192 + lane = end of block
+      const u32 vnext = t.unk ? (128u + lane) : (t.kind == 2u ? (192u + lane) : (lane + t.tot));
+      // ---- follow the real token boundaries ----
+      u64 chain = 0;
+      u32 q = 0;
+      do { chain |= 1ull << q; q = rdl(vnext, q); } while (q < WAVE);
+      if (q >= 192u) {
+        // the end-of-block symbol stays on the chain and ends the parse.  The reference's bits_left
+        // behind it: ENSURE_BITS(16) at its first bit, minus its length
+        q -= 192u;
+        const u32 st = bitpos + q, tl = rdl(t.tot, q);
+        eob_rbl = (int)(16u + ((0u - st) & 7u) - tl);
+        eob_end = st + tl;
+        stop = true;
+      }
+      else if (q >= 128u) { q -= 128u; chain &= ~(1ull << q); stop = true; }   // the scalar loop takes this token
+      // ---- queue the tokens on the chain ----
+      {
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain, 0u));
+        if ((chain >> lane) & 1ull) {
+          const u32 ti = (tt + rank) & 127u;
+          tq0[ti] = t.kind | (t.olen << 3) | (((bitpos + lane) & 0xFFFFu) << 12);
+          tq1[ti] = t.kind == 0u ? t.sym : t.dist;
+        }
+        tt += (u32) __popcll(chain);
+      }
+      bitpos += q;
+      if (bitpos >= bit_limit) stop = true;
+      if (!stop && tt - th < 64u) continue;
     }
-    // ---- every lane decodes the token that would start at bit (bitpos + lane) ----
-    const u32 rel = bitpos - (cb << 11) + lane;
-    const u32 k = rel >> 5, sft = rel & 31u;
-    const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
-    const u64 q01 = ((u64) i1 << 32) | i0, q12 = ((u64) i2 << 32) | i1;
-    const u64 r = (u64)(u32)(q01 >> sft) | ((u64)(u32)(q12 >> sft) << 32);
-    const ZipTok t = zip_spec_token(sh, d.hr_lit.fov, llim, r);
-    // next token start; >= 128 ends the walk: 128 + lane = not for this path, 192 + lane = end of block
-    const u32 vnext = t.unk ? (128u + lane) : (t.kind == 2u ? (192u + lane) : (lane + t.tot));
-
-    // ---- follow the real token boundaries ----
-    u64 chain = 0;
-    u32 q = 0;
-    do { chain |= 1ull << q; q = rdl(vnext, q); } while (q < WAVE);
-    bool eob = false;
-    if (q >= 192u) { q -= 192u; eob = true; }                      // the end-of-block token stays on the chain
-    else if (q >= 128u) { q -= 128u; chain &= ~(1ull << q); stop = true; }
-    bool on = (chain >> lane) & 1ull;
-    const u32 x = on ? t.olen : 0u;
-    const u32 incl = wave_incl_scan(x);
-    const u32 opos = P + incl - x;
+    // =================================== COMMIT ===================================
+    u32 n = tt - th;
+    if (n > 64u) n = 64u;
+    if (n == 0u) break;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const u32 ci = (th + lane) & 127u;
+    const u32 c0 = tq0[ci], c1 = tq1[ci];
+    const u32 kind = c0 & 7u;
+    const u32 olen = lane < n ? ((c0 >> 3) & 511u) : 0u;
+    const u32 incl = wave_incl_scan(olen);
+    const u32 opos = P + incl - olen;
     u32 newP = P + rdl(incl, 63u);
     // tokens this path leaves to the scalar loop: output reaching the 32 KiB mark (FLUSH_IF_NEEDED,
     // mszipd.c:37-44) and matches whose source lies before the start of this block (mszipd.c:267-268)
+    bool cut = false;
     {
-      const u64 cut = ballot(on && (opos - B + t.olen >= ZIP_FRAME ||
-                                    (t.kind == 1u && t.dist > opos - B && !lin_hist)));
-      if (cut) {
-        u32 j = (u32) __ffsll((long long) cut) - 1u;
-        chain &= (1ull << j) - 1ull;
-        on = (chain >> lane) & 1ull;
-        q = j; eob = false; stop = true; newP = rdl(opos, j);
-      }
+      const u64 cm = ballot(lane < n && (opos - B + olen >= ZIP_FRAME ||
+                                         (kind == 1u && c1 > opos - B && !lin_hist)));
+      if (cm) { const u32 j = (u32) __ffsll((long long) cm) - 1u; n = j; newP = rdl(opos, j); cut = true; }
     }
-    if (on && t.kind == 0u) out[opos] = (u8) t.sym;
-    const u64 mm = ballot(on && t.kind == 1u);
+    const bool valid = lane < n;
+    if (valid && kind == 0u) out[opos] = (u8) c1;
+    const bool eob = ballot(valid && kind == 2u) != 0ull;
+    u64 mm = ballot(valid && kind == 1u);
     if (mm) {
-      const u32 nm = (u32) __popcll(mm);
-      if (Q.mcount + nm > SPQ_CAP || newP - (Q.Pf & ~63u) > SPQ_RING) spq_resolve(sh->spq, Q, out, P, true, lane);
-      if (newP - (Q.Pf & ~63u) > SPQ_RING) {
-        // a round that is larger than the flag ring by itself: copy its matches one by one
-        for (u64 dm = mm; dm; dm &= dm - 1ull) {
-          u32 l = (u32) __ffsll((long long) dm) - 1u;
-          u32 pos_l = rdl(opos, l), len_l = rdl(t.olen, l), dist_l = rdl(t.dist, l);
-          const u8 *src = out + pos_l - dist_l;
-          for (u32 i = 0; i < len_l; i += WAVE) {
-            // distance >= 64: a step only reads bytes below it; shorter: the periodic source, i.e. only
-            // the bytes that existed before the match
-            u32 kk = i + lane;
-            if (kk < len_l) out[pos_l + kk] = (dist_l >= WAVE) ? src[kk] : src[kk % dist_l];
-          }
+      bool ism = (mm >> lane) & 1ull;
+      if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
+      for (;;) {
+        // a push must keep every start flag inside the ring (spec_queue.hpp): take the matches that end
+        // inside it, resolve up to the first one that does not, go on
+        const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
+        const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
+        if (fit) {
+          const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+          spq_push(sh->spq, Q, (fit >> lane) & 1ull, rank, (u32) __popcll(fit), opos, c1, olen);
+          mm &= ~fit;
+          ism = (mm >> lane) & 1ull;
         }
-        Q.Pf = newP;
-      }
-      else {
-        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(mm >> 32), __builtin_amdgcn_mbcnt_lo((u32) mm, 0u));
-        spq_push(sh->spq, Q, (mm >> lane) & 1ull, rank, nm, opos, t.dist, t.olen);
+        if (!mm) break;
+        spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
       }
     }
+    th += n;
     P = newP;
-    if (eob) {
-      // the reference's bits_left after the end-of-block symbol: ENSURE_BITS(16) at its first bit, minus its length
-      const u32 st = bitpos + q, tl = rdl(t.tot, q);
-      eob_rbl = (int)(16u + ((0u - st) & 7u) - tl);
-      bitpos = st + tl; rc = 1; stop = true;
-    }
-    else bitpos += q;
+    if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane);
+    if (eob) { rc = 1; bitpos = eob_end; break; }       // (the end-of-block symbol is the last token parsed)
+    if (cut) break;
+  }
+  spq_resolve(sh->spq, Q, out, P, true, lane);
+  // parsed but not committed: the bit position goes back to the first such token
+  if (!rc && tt != th) {
+    const u32 lo = rfl(tq0[th & 127u]) >> 12;
+    bitpos -= (bitpos - lo) & 0xFFFFu;
   }
   // hand the exact bit position back to the scalar reader; its bits_left restarts from the byte the
   // position lies in (every later ENSURE_BITS re-derives the reference's value from there)
@@ -388,7 +415,8 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     u32 lo = sh->inbuf[lane], hi = sh->inbuf[64u + lane];
     if (ch == cb) { d.w.cur = lo; d.w.nxt = hi; }
-    else { d.w.cur = hi; d.w.nxt = pf; }
+    else if (ch == cb + 1u) { d.w.cur = hi; d.w.nxt = pf; }
+    else { d.w.cur = d.w.load_chunk(ch, lane); d.w.nxt = d.w.load_chunk(ch + 1u, lane); }   // went back
     d.w.wi = wi; d.bb = 0; d.bl = 0;
     d.refill(); d.refill();
     u32 sk = bitpos & 31u;
