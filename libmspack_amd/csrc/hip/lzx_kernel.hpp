@@ -534,7 +534,11 @@ __device__ __forceinline__ u32 lzx_scalar_token(const LzxDec &d, bool length_emp
 
 
 // one speculative token: everything lane-local, decoded from 64 bits of the stream
-struct SpecTok { u32 tot, sym, kind, olen, off; bool unk; };
+struct SpecTok { u32 tot, sym, kind, olen, off; bool unk;
+#ifdef LZX_EXP_CNT
+  bool mlong;
+#endif
+};
 
 template <bool ALIGNED>
 __device__ __forceinline__ SpecTok lzx_spec_token(const LzxShared *sh, const u32 main_fov, const u32 *mlim,
@@ -554,6 +558,9 @@ __device__ __forceinline__ SpecTok lzx_spec_token(const LzxShared *sh, const u32
     u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
     if (idx >= LZX_MAIN_SYMS) idx = 0;
     u32 ls = sh->main_sorted[idx];
+#ifdef LZX_EXP_CNT
+    t.mlong = (e == 0u && lq != 0u);
+#endif
     if (e == 0u && lq != 0u) e = ls | (lq << LZX_MSH);
   }
   bool unk = (e == 0u);
@@ -900,6 +907,10 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
 #endif
         tt += nA + nB;
       }
+#ifdef LZX_EXP_CNT
+      d.st_t[5] += (u32) __popcll(ballot(((chain >> lane) & 1ull) && t.mlong));
+      if (ballot(t.mlong)) d.st_t[4]++;
+#endif
       bitpos += q;
       d.st_rounds++;
       if (hit_unknown) {
@@ -1031,7 +1042,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
           Q.Pf = newP;
         }
         else {
-          if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) { CNT(5); spq_resolve(sh->spq, Q, out, P, true, lane); }
+          if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
           for (;;) {
             // a push must keep every start flag inside the ring (spec_queue.hpp): take the matches that
             // end inside it, resolve up to the first one that does not, go on
@@ -1044,7 +1055,6 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
               ism = (mm >> lane) & 1ull;
             }
             if (!mm) break;
-            CNT(4);
             spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
           }
         }

@@ -18,3 +18,10 @@ print("  %-24s %10.0f  %5.1f%%" % ("outside the round loop", tot - raw[:, :6].su
 for name, c in [("scalar token loop", 15)]:
     print("    %-24s %10.0f  %5.1f%%" % (name, raw[:, c].mean(), 100 * raw[:, c].mean() / tot))
 print("  headers: total %.0f  pretree read+build %.0f  length symbols %.0f  main/len table builds %.0f" % (raw[:, 8].mean() * 64, raw[:, 9].mean(), raw[:, 10].mean(), raw[:, 11].mean()))
+t = raw[:, 6].astype(float)
+print("unit time (ticks): min %.0f  p10 %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f  mean %.0f" %
+      (t.min(), np.percentile(t, 10), np.median(t), np.percentile(t, 90), np.percentile(t, 99), t.max(), t.mean()))
+r = np.asarray(ln, dtype=float) / ub
+for lo, hi in [(0, .2), (.2, .3), (.3, .4), (.4, .5), (.5, .7), (.7, 2)]:
+    m = (r >= lo) & (r < hi)
+    if m.any(): print("  ratio %.1f-%.1f: %4d units, mean time %.0f, rounds %.0f" % (lo, hi, m.sum(), t[m].mean(), raw[m, 7].mean()))
