@@ -81,6 +81,46 @@ def test_fuzz_lzx(built):
     assert bad > len(streams) // 4                               # the damage does reach the decoder
 
 
+@pytest.mark.parametrize("seed", [11, 12])
+def test_sweep_lzx_random_configs(built, seed):
+    """Random LZX configurations rather than hand-picked ones: window 15..21, reset interval 0..4 frames,
+    every block mode with random block sizes (block ends fall anywhere in a frame, so the parser of
+    lzx_run_spec overshoots and rewinds at arbitrary places), E8 on/off, all plaintext families, lengths from
+    1 byte up, a shorter request per stream, and 8 damaged copies of each."""
+    rng = np.random.default_rng(seed)
+    streams, params = [], []
+    for c in range(60):
+        wb = int(rng.integers(15, 22)); reset = int(rng.choice([0, 0, 1, 2, 3, 4]))
+        n = int(rng.integers(1, 200000))
+        kw = {}
+        m = int(rng.integers(0, 5))
+        if m:
+            kw["mode"] = m
+        if m in (0, 4):
+            kw["block_size"] = int(rng.integers(1, 70000))
+        if rng.random() < .2:
+            kw["intel_filesize"] = int(rng.integers(1, 400000))
+        if rng.random() < .2:
+            kw["repeats"] = 0
+        if rng.random() < .2:
+            kw["lazy"] = 0
+        data = M.gen_plaintext(1000 * seed + c, int(rng.integers(0, 6)), n)
+        try:
+            comp = M.lzx_encode(data, wb, reset, M.lzx_opts(**kw))[0].tobytes()
+        except M.MspackHipError:
+            continue                    # the corpus encoder's output estimate (tiny blocks of noise)
+        tail = b"\0" * 4 if reset else b""
+        streams.append(comp + tail); params.append((n, wb, reset, 0))
+        for mu in mutations(comp, rng, 8):
+            streams.append(mu + tail); params.append((n, wb, reset, 0))
+        streams.append(comp + tail); params.append((int(rng.integers(0, n + 1)), wb, reset, 0))
+    units, out, res = run_lzx(streams, params)
+    for i, (st, p) in enumerate(zip(streams, params)):
+        e, o, r = oracle_lzx(st, p[0], p[1], p[2], length=p[0], e8_base=p[3])
+        compare("lzx-sweep", i, res, units, out, e, o, r)
+        assert res["flags"][i] == r.flags, (i, res[i], r.flags)
+
+
 def test_fuzz_mszip(built):
     rng = np.random.default_rng(777)
     streams, lens = [], []
