@@ -175,7 +175,9 @@ def main():
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         w = tj["workload"]
         if (w["units_per_gpu"], w["unit_bytes"], w["text"]) == (n, ub, args.text):
-            traffic = int((tj["fetch_kib_per_launch"] + tj["write_kib_per_launch"]) * 1024)
+            # FETCH_SIZE counts 64 B per 128-B request on gfx950 (the guide's x2; calibrated on this
+            # kernel's stored-block copy, see profiles/traffic.json)
+            traffic = int((tj["fetch_kib_per_launch"] * tj.get("fetch_correction", 1.0) + tj["write_kib_per_launch"]) * 1024)
     except Exception:
         traffic = None
     algo_bytes = comp_bytes + n * ub                      # in + out, per launch
