@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <chrono>
 #include <vector>
 #include <algorithm>
 #include "wave_common.hpp"
@@ -255,6 +256,12 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
     return local[a].in_len + (local[a].out_len >> 2) > local[b].in_len + (local[b].out_len >> 2); });
 
   size_t in_span = (size_t)(in_hi - in_lo), out_span = (size_t)(out_hi - out_lo);
+  // MSPACK_HIP_TRACE=1: phase times of the host-buffer path on stderr
+  static const bool trace = getenv("MSPACK_HIP_TRACE") != nullptr;
+  auto tnow = []() { return std::chrono::steady_clock::now(); };
+  auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count(); };
+  auto t0 = tnow(), t1 = t0, t2 = t0, t3 = t0, t4 = t0;
   void *d_in = nullptr, *d_out = nullptr, *d_units = nullptr, *d_order = nullptr, *d_res = nullptr, *d_fm = nullptr;
   int rc = 0;
   hipError_t e;
@@ -265,6 +272,7 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
   TRY(hipMalloc(&d_order, n_sel * sizeof(uint32_t)));
   TRY(hipMalloc(&d_res, n_sel * sizeof(mspack_hip_result)));
   TRY(hipMalloc(&d_fm, mspack_hip_frame_scratch_bytes(n_frames)));
+  t1 = tnow();
   TRY(hipMemcpy(d_in, (const char *) in + in_lo, in_span, hipMemcpyHostToDevice));
   TRY(hipMemset((char *) d_in + in_span, 0, 64));
   TRY(hipMemcpy(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice));
@@ -275,11 +283,13 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
       TRY(hipMemcpy((char *) d_out + local[i].out_off - local[i].ref_len,
                     (const char *) out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
                     hipMemcpyHostToDevice));
+  t2 = tnow();
   rc = mspack_hip_decode_batch_device((const mspack_hip_unit *) d_units, (const uint32_t *) d_order, n_sel,
                                       d_in, in_span, d_out, out_span, (mspack_hip_result *) d_res, d_fm,
                                       n_frames, kind_mask & 0x7E, nullptr);
   if (rc) goto done;
   TRY(hipDeviceSynchronize());
+  t3 = tnow();
   {
     std::vector<mspack_hip_result> r(n_sel);
     TRY(hipMemcpy(r.data(), d_res, n_sel * sizeof(mspack_hip_result), hipMemcpyDeviceToHost));
@@ -292,8 +302,12 @@ static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel,
                       local[i].out_len, hipMemcpyDeviceToHost));
     }
   }
+  t4 = tnow();
 done:
   hipFree(d_in); hipFree(d_out); hipFree(d_units); hipFree(d_order); hipFree(d_res); hipFree(d_fm);
+  if (trace && rc == 0)
+    fprintf(stderr, "mspack_hip: %zu units: alloc %.2f ms, H2D %.1f MB %.2f ms, kernels %.2f ms, D2H %.1f MB %.2f ms, free %.2f ms\n",
+            n_sel, tms(t0, t1), in_span / 1e6, tms(t1, t2), tms(t2, t3), out_span / 1e6, tms(t3, t4), tms(t4, tnow()));
   return rc;
 #undef TRY
 }
