@@ -7,11 +7,15 @@
 //   READ_HUFFSYM ...... readhuff.h:39-66 -> one LDS lookup (10/8/7/6 direct bits); long codes by a
 //                       wave-wide limit compare + ballot (wave_common.hpp)
 //   make_decode_table . readhuff.h:83-176 -> lane-parallel build, same accept/reject set
-//   lzxd_read_lens .... lzxd.c:138-183 (serial by nature: each length is a delta on the previous
-//                       block's value)
-//   main decode loop .. lzxd.c:538-651 -> literals are gathered 64 at a time into one coalesced
-//                       store; a match is one coalesced 64-lane load/store per 64 bytes, with the
-//                       overlapping case (offset < length) served from the periodic source
+//   lzxd_read_lens .... lzxd.c:138-183 -> lzx_read_lens_spec: pretree tokens decoded 64 bit positions at a
+//                       time, run lengths prefix-summed into indices (each length is a delta on the
+//                       previous block's value, so the lengths array itself stays in LDS)
+//   main decode loop .. lzxd.c:538-651 -> lzx_run_spec: speculative parse of 64 bit positions per round +
+//                       commit of 64 tokens at a time (positions, literals, R0-R2 by prefix scan, checks),
+//                       match copies deferred to spec_queue.hpp.  The EOF-exact scalar loop (last bytes of
+//                       the input, DELTA's extended lengths) gathers literals 64 at a time into one
+//                       coalesced store and copies a match with one coalesced 64-lane load/store per 64
+//                       bytes, the overlapping case (offset < length) served from the periodic source
 //   frame logic ....... lzxd.c:419-466, 677-697, 749-754
 //   E8 translation .... lzxd.c:706-736 -> NOT done here: the window must keep untranslated bytes
 //                       and our window IS the output, so the decode kernel only records, per frame,
