@@ -81,15 +81,14 @@ def test_fuzz_lzx(built):
     assert bad > len(streams) // 4                               # the damage does reach the decoder
 
 
-@pytest.mark.parametrize("seed", [11, 12])
-def test_sweep_lzx_random_configs(built, seed):
+def lzx_sweep(seed, n_cfg=60):
     """Random LZX configurations rather than hand-picked ones: window 15..21, reset interval 0..4 frames,
     every block mode with random block sizes (block ends fall anywhere in a frame, so the parser of
     lzx_run_spec overshoots and rewinds at arbitrary places), E8 on/off, all plaintext families, lengths from
-    1 byte up, a shorter request per stream, and 8 damaged copies of each."""
+    1 byte up, a shorter request per stream, and 8 damaged copies of each.  -> streams, params"""
     rng = np.random.default_rng(seed)
     streams, params = [], []
-    for c in range(60):
+    for c in range(n_cfg):
         wb = int(rng.integers(15, 22)); reset = int(rng.choice([0, 0, 1, 2, 3, 4]))
         n = int(rng.integers(1, 200000))
         kw = {}
@@ -114,6 +113,16 @@ def test_sweep_lzx_random_configs(built, seed):
         for mu in mutations(comp, rng, 8):
             streams.append(mu + tail); params.append((n, wb, reset, 0))
         streams.append(comp + tail); params.append((int(rng.integers(0, n + 1)), wb, reset, 0))
+    return streams, params
+
+
+SWEEP_SEEDS = [11, 12]
+
+
+@pytest.mark.parametrize("seed", SWEEP_SEEDS)
+def test_sweep_lzx_random_configs(built, seed):
+    """GPU vs oracle on lzx_sweep(); tests/test_oracle_vs_ref.py runs the same streams oracle vs reference."""
+    streams, params = lzx_sweep(seed)
     units, out, res = run_lzx(streams, params)
     for i, (st, p) in enumerate(zip(streams, params)):
         e, o, r = oracle_lzx(st, p[0], p[1], p[2], length=p[0], e8_base=p[3])

@@ -125,6 +125,29 @@ def test_fuzz_oracle_vs_reference_lzx(built):
     assert n_bad > 300
 
 
+def test_sweep_oracle_vs_reference_lzx(built):
+    """The random-configuration sweep of tests/test_gpu_fuzz.py (same generator, same seeds), oracle against
+    the REAL reference: error code, byte count and -- for streams that decode to the plaintext prefix --
+    bytes.  (A request shorter than the stream: the reference driver here sets output_length = the request.)"""
+    from test_gpu_fuzz import lzx_sweep, SWEEP_SEEDS
+    from helpers import ref
+    n = 0
+    ref().refh_zero_alloc(1)        # a damaged stream may read window bytes nobody wrote: zeros on both sides
+    try:
+        for seed in SWEEP_SEEDS:
+            streams, params = lzx_sweep(seed)
+            for st, p in zip(streams, params):
+                e1, o1, w1 = ref_lzx(st, p[0], p[1], p[2])
+                e2, o2, r = oracle_lzx(st, p[0], p[1], p[2], length=p[0])
+                assert (e1, w1) == (e2, r.out_len), (seed, p, e1, w1, e2, r.out_len)
+                if e1 == 0:
+                    assert o1 == o2
+                n += 1
+    finally:
+        ref().refh_zero_alloc(0)
+    assert n > 1000
+
+
 def test_fuzz_oracle_vs_reference_mszip_qtm(built):
     mutations = _mutations()
     from test_gpu_mszip import folder as zip_folder
