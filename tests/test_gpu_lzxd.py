@@ -7,7 +7,7 @@ import pytest
 
 import libmspack_amd as M
 from helpers import oracle_lzxd
-from test_oracle_vs_ref import DELTA_CASES, delta_case
+from test_oracle_vs_ref import DELTA_CASES, delta_case, far_offset_case
 from test_gpu_fuzz import mutations
 
 pytestmark = pytest.mark.gpu
@@ -57,3 +57,16 @@ def test_lzx_delta_window_limits(built):
     comp = M.lzxd_encode(data, 17).tobytes()
     units, out, res = run_delta([comp] * 3, [(40000, 16), (40000, 26), (40000, 17)], [b""] * 3)
     assert list(res["err"][:2]) == [1, 1] and res["err"][2] == 0
+
+
+def test_lzx_delta_offsets_beyond_the_match_list_field(built):
+    """A 2^25 window with matches 9.5 MB back: offsets above 2^23 do not fit the 23-bit offset field of a
+    queued match (spec_queue.hpp) and must take the one-by-one copy path -- every byte against the
+    plaintext and the oracle.  (The same stream decodes to the plaintext in the real lzxd:
+    test_oracle_vs_ref.py::test_lzx_delta_far_offsets.)"""
+    data, comp = far_offset_case()
+    units, out, res = run_delta([comp + b"\0" * 8], [(data.size, 25)], [b""])
+    e, o, rr = oracle_lzxd(comp + b"\0" * 8, data.size, 25)
+    assert e == 0 and res["err"][0] == 0 and res["out_len"][0] == rr.out_len == data.size
+    got = out[units["out_off"][0]:units["out_off"][0] + data.size]
+    assert np.array_equal(got, data) and got.tobytes() == o

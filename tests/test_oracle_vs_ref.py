@@ -210,6 +210,22 @@ def delta_case(n, wb, refn, kw):
     return data, ref, M.lzxd_encode(data, wb, ref, **kw).tobytes()
 
 
+def far_offset_case():
+    """10.4 MB whose tail repeats parts of its first megabyte: match offsets of about 9.5 MB (> 2^23)"""
+    a = M.gen_plaintext(77, 0, 9_500_000)
+    data = np.concatenate([a, a[:600_000], a[100_000:400_000]])
+    return data, M.lzxd_encode(data, 25).tobytes()
+
+
+def test_lzx_delta_far_offsets(built):
+    from helpers import ref_lzxd, oracle_lzxd
+    data, comp = far_offset_case()
+    assert len(comp) < 0.36 * data.size          # the far copies were found (the tail costs next to nothing)
+    e1, o1, w1 = ref_lzxd(comp + b"\0" * 8, data.size, 25)
+    e2, o2, r = oracle_lzxd(comp + b"\0" * 8, data.size, 25)
+    assert e1 == e2 == 0 and w1 == r.out_len == data.size and o1 == o2 == data.tobytes()
+
+
 @pytest.mark.parametrize("case", DELTA_CASES, ids=[str(c[:3]) for c in DELTA_CASES])
 def test_lzx_delta_encoder_and_oracle_vs_reference(built, case):
     """LZX DELTA: our encoder's streams through the real lzxd (is_delta, reference data)
