@@ -150,6 +150,38 @@ def test_fuzz_mszip(built):
     assert bad > len(streams) // 4
 
 
+def test_sweep_mszip_random_configs(built):
+    """Random deflate levels / strategies / block sizes / plaintext families, a shorter request and 8 damaged
+    copies per folder, a third of the units in repair mode with random feeder chunk sizes."""
+    rng = np.random.default_rng(21)
+    streams, lens, flags, chunks = [], [], [], []
+    for c in range(50):
+        n = int(rng.integers(1, 250000))
+        data = M.gen_plaintext(5000 + c, int(rng.integers(0, 6)), n).tobytes()
+        strat = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
+        bs = 32768 if rng.random() < .6 else int(rng.integers(1, 32769))
+        hist = bool(rng.random() < .6) and bs == 32768          # history is only well defined after full blocks
+        s = zip_folder(data, int(rng.integers(0, 10)), strat, history=hist, bs=bs)
+        for k, m in enumerate([s, s] + mutations(s, rng, 8)):
+            rep = rng.random() < .3
+            streams.append(m); flags.append(M.UF_MSZIP_REPAIR if rep else 0)
+            chunks.append(int(rng.choice([0, 2, 64, 512, 1000, 4096])) if rep else 0)
+            lens.append(n if k != 1 else int(rng.integers(0, n + 1)))
+    offs, pos = [], 0
+    for s in streams:
+        pos = (pos + 15) & ~15
+        offs.append(pos); pos += len(s)
+    arena = np.zeros(pos + 64, dtype=np.uint8)
+    for s, o in zip(streams, offs):
+        arena[o:o + len(s)] = np.frombuffer(s, dtype=np.uint8)
+    units, out_bytes = M.make_units(M.KIND_MSZIP, offs, [len(s) for s in streams], lens, flags=flags, out_slack=32768)
+    units["in_chunk"] = chunks
+    out, res = M.decode_batch(units, arena, out_bytes)
+    for i, st in enumerate(streams):
+        e, o, r, _ = oracle_mszip(st, lens[i], 0 if not flags[i] else (chunks[i] if chunks[i] else 1))
+        compare("mszip-sweep", i, res, units, out, e, o, r)
+
+
 def repair_corpus():
     """damaged MSZIP folders for repair mode (MSCABD_PARAM_FIXMSZIP) and the feeder chunk size of each"""
     rng = np.random.default_rng(5)
