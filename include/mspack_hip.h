@@ -44,6 +44,10 @@ extern "C" {
 #define MSPACK_HIP_F_LOOKAHEAD_READ 2u  /* all bytes produced; the one-frame look-ahead of
                                            lzxd.c:419 then hit end of input (err = MSPACK_ERR_READ)  */
 #define MSPACK_HIP_F_INTEL_HEADER   4u  /* an LZX interval header carried intel_filesize != 0        */
+#define MSPACK_HIP_F_BLOCK_OPEN    16u  /* LZX: the unit's last frame ended inside a block (block_remaining != 0).
+                                           At a reset point the reference only warns and goes on with that
+                                           block (lzxd.c:424-431): the next interval is then NOT an
+                                           independent unit, and drivers decode such a stream serially     */
 #define MSPACK_HIP_F_OUT_FULL       8u  /* KWAJ-framed MSZIP: the next block did not fit out_len (give the
                                            unit more room and decode again)                          */
 
@@ -85,7 +89,10 @@ typedef struct mspack_hip_result {
                             request that ends at or before good_len succeeds in the reference too
                             (it decodes no further than asked): LZX counts whole frames, MSZIP
                             whole blocks, Quantum the position of the failing symbol              */
-  uint32_t reserved;
+  uint32_t in_next;      /* LZX: input byte offset (from in_off) right after the 16-bit realignment that
+                            follows the last completely decoded non-empty frame (lzxd.c:695-697), i.e.
+                            where a decoder that keeps going reads the next frame from.  The CHM driver
+                            checks the reset table against it; 0 if no frame was completed            */
 } mspack_hip_result;
 
 /* ---- library / device ----------------------------------------------------------------------- */
@@ -129,6 +136,19 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *
 int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const void *in,
                                   size_t in_bytes, void *out, size_t out_bytes,
                                   mspack_hip_result *results, int n_devices);
+
+/* ---- process-wide defaults for the object API (mspack.h) ----------------------------------------------
+ * mscab_decompressor has set_param (MSCABD_PARAM_HIP_DEVICES / _HIP_CACHE_MB); the CHM, OAB, SZDD and KWAJ
+ * objects of the reference API have no parameter call, so their drivers use these defaults:
+ *   devices  : GPUs a driver's batches are sharded over (mspack_hip_decode_batch_multi); initial value from
+ *              the environment variable MSPACK_HIP_DEVICES, else 1
+ *   cache_mb : upper bound, in MiB, on decoded bytes a CHM object keeps in host memory (least recently used
+ *              batches are dropped and decoded again on demand); MSPACK_HIP_CACHE_MB, else 1024
+ * Values < 1 are rejected (return -1). */
+int mspack_hip_set_default_devices(int n_devices);
+int mspack_hip_default_devices(void);
+int mspack_hip_set_cache_mb(int mb);
+int mspack_hip_cache_mb(void);
 
 /* ---- timing helper for bench.py (HIP events on the launch stream) ------------------------------- */
 /* Runs `iters` back-to-back device-resident decodes and returns the average milliseconds per

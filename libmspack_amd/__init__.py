@@ -26,7 +26,7 @@ UNIT_DTYPE = np.dtype([("in_off", "<u8"), ("out_off", "<u8"), ("in_len", "<u4"),
                        ("reset_frames", "<u2"), ("flags", "<u4"), ("ref_len", "<u4"), ("in_chunk", "<u4")],
                       align=False)
 RESULT_DTYPE = np.dtype([("err", "<i4"), ("flags", "<u4"), ("out_len", "<u4"), ("in_used", "<u4"),
-                         ("good_len", "<u4"), ("reserved", "<u4")])
+                         ("good_len", "<u4"), ("in_next", "<u4")])
 assert UNIT_DTYPE.itemsize == 48 and RESULT_DTYPE.itemsize == 24
 
 
@@ -65,6 +65,7 @@ EXPORTED_SYMBOLS = [
     "mspack_hip_device_count", "mspack_hip_set_device", "mspack_hip_version", "mspack_hip_last_error",
     "mspack_hip_decode_batch_device", "mspack_hip_frame_scratch_bytes", "mspack_hip_decode_batch",
     "mspack_hip_decode_batch_multi", "mspack_hip_time_batch_device",
+    "mspack_hip_set_default_devices", "mspack_hip_default_devices", "mspack_hip_set_cache_mb", "mspack_hip_cache_mb",
 ]
 
 

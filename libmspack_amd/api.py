@@ -3,7 +3,9 @@
 Names and argument meaning follow the reference API (mspack_create_cab_decompressor -> open /
 extract / close, mspack_create_chm_decompressor -> open / fast_open / fast_find / extract / close),
 so tests read like libmspack/test/cabd_test.c.  File I/O goes through the library's default
-stdio mspack_system (sys = NULL)."""
+stdio mspack_system (sys = NULL), or -- mem=True -- through an in-memory mspack_system handed to
+mspack_create_*_decompressor(sys) (MemSystem below: the same semantics as the memory system the goldens
+were recorded with, oracle/ref_harness.c: reads are clipped at the end, a seek beyond the end fails)."""
 import ctypes as C
 import os
 import tempfile
@@ -104,8 +106,11 @@ MSCABD_PARAM_SEARCHBUF, MSCABD_PARAM_FIXMSZIP, MSCABD_PARAM_DECOMPBUF, MSCABD_PA
 MSCABD_PARAM_HIP_DEVICES, MSCABD_PARAM_HIP_CACHE_MB = 100, 101
 
 
-def _setup():
-    L = lib()
+def _setup(L=None):
+    """L: an already loaded library exporting the mspack.h API (tests of the host logic pass their CPU
+    stand-in build here); default = libmspack_hip.so"""
+    if L is None:
+        L = lib()
     L.mspack_create_cab_decompressor.restype = _P(MscabDecompressor)
     L.mspack_create_cab_decompressor.argtypes = [C.c_void_p]
     L.mspack_destroy_cab_decompressor.argtypes = [_P(MscabDecompressor)]
@@ -115,6 +120,91 @@ def _setup():
     L.mspack_version.argtypes = [C.c_int]
     L.mspack_sys_selftest_internal.argtypes = [C.c_int]
     return L
+
+
+class MspackSystem(C.Structure):
+    """struct mspack_system (mspack.h:285-455): 10 function pointers + a NULL"""
+    _fields_ = [("open", C.c_void_p), ("close", C.c_void_p), ("read", C.c_void_p), ("write", C.c_void_p),
+                ("seek", C.c_void_p), ("tell", C.c_void_p), ("message", C.c_void_p), ("alloc", C.c_void_p),
+                ("free", C.c_void_p), ("copy", C.c_void_p), ("null_ptr", C.c_void_p)]
+
+
+class MemSystem:
+    """An in-memory mspack_system implemented with ctypes callbacks.  "File names" are keys of
+    self.files (bytes -> bytes for inputs); files opened for writing collect into self.outputs.
+    alloc / free / copy are the library's own defaults; messages are collected in self.messages."""
+
+    def __init__(self, L):
+        self.files = {}
+        self.outputs = {}
+        self._open = {}
+        self._next = 1
+        dflt = C.POINTER(MspackSystem).in_dll(L, "mspack_default_system").contents
+        OPEN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_char_p, C.c_int)
+        CLOSE = C.CFUNCTYPE(None, C.c_void_p)
+        RW = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+        SEEK = C.CFUNCTYPE(C.c_int, C.c_void_p, off_t, C.c_int)
+        TELL = C.CFUNCTYPE(off_t, C.c_void_p)
+
+        def m_open(_self, name, mode):
+            if mode == 0:
+                if name not in self.files:
+                    return None
+                f = dict(data=self.files[name], pos=0, w=None)
+            else:
+                self.outputs[name] = bytearray()
+                f = dict(data=None, pos=0, w=self.outputs[name])
+            h = self._next; self._next += 1
+            self._open[h] = f
+            return h
+
+        def m_close(h):
+            self._open.pop(h, None)
+
+        def m_read(h, buf, n):
+            f = self._open.get(h)
+            if f is None or f["w"] is not None or n < 0:
+                return -1
+            d = f["data"]
+            n = min(n, len(d) - f["pos"])
+            if n > 0:
+                C.memmove(buf, d[f["pos"]:f["pos"] + n], n)
+                f["pos"] += n
+            return max(n, 0)
+
+        def m_write(h, buf, n):
+            f = self._open.get(h)
+            if f is None or f["w"] is None or n < 0:
+                return -1
+            f["w"] += C.string_at(buf, n)
+            return n
+
+        def m_seek(h, off, mode):
+            f = self._open.get(h)
+            if f is None or f["data"] is None:
+                return -1
+            base = (0, f["pos"], len(f["data"]))[mode] if 0 <= mode <= 2 else None
+            if base is None or base + off < 0 or base + off > len(f["data"]):
+                return -1
+            f["pos"] = base + off
+            return 0
+
+        def m_tell(h):
+            f = self._open.get(h)
+            return f["pos"] if f else 0
+
+        def m_message(_h, fmt):           # variadic in C; the extra arguments are simply not looked at
+            self.messages.append(fmt)
+
+        self.messages = []
+        MSG = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
+        self._cbs = [OPEN(m_open), CLOSE(m_close), RW(m_read), RW(m_write), SEEK(m_seek), TELL(m_tell), MSG(m_message)]
+        vp = [C.cast(cb, C.c_void_p).value for cb in self._cbs]
+        self.sys = MspackSystem(vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], dflt.alloc, dflt.free,
+                                dflt.copy, None)
+
+    def ptr(self):
+        return C.addressof(self.sys)
 
 
 def _walk(ptr):
@@ -127,15 +217,21 @@ class Cab:
     """with Cab(path_or_bytes) as cab: cab.files -> [(name, length, offset, comp_type)];
     cab.extract(i) -> (err, bytes)"""
 
-    def __init__(self, src, fix_mszip=0, salvage=0):
-        self.L = _setup()
+    def __init__(self, src, fix_mszip=0, salvage=0, mem=False, L=None):
+        self.L = _setup(L)
         self._tmp = None
-        if isinstance(src, (bytes, bytearray)):
-            fd, self._tmp = tempfile.mkstemp(suffix=".cab")
-            os.write(fd, src); os.close(fd)
-            src = self._tmp
-        self.path = os.fsencode(src)
-        self.d = self.L.mspack_create_cab_decompressor(None)
+        self.mem = None
+        if mem:
+            self.mem = MemSystem(self.L)
+            self.mem.files[b"mem:in"] = bytes(src)
+            self.path = b"mem:in"
+        else:
+            if isinstance(src, (bytes, bytearray)):
+                fd, self._tmp = tempfile.mkstemp(suffix=".cab")
+                os.write(fd, src); os.close(fd)
+                src = self._tmp
+            self.path = os.fsencode(src)
+        self.d = self.L.mspack_create_cab_decompressor(self.mem.ptr() if self.mem else None)
         if not self.d:
             raise RuntimeError("mspack_create_cab_decompressor failed")
         self.d.contents.set_param(self.d, MSCABD_PARAM_FIXMSZIP, fix_mszip)
@@ -150,6 +246,9 @@ class Cab:
                  f.contents.folder.contents.comp_type if f.contents.folder else -1) for f in self._files]
 
     def extract(self, i):
+        if self.mem:
+            err = self.d.contents.extract(self.d, self._files[i], b"mem:out")
+            return err, bytes(self.mem.outputs.get(b"mem:out", b""))
         fd, out = tempfile.mkstemp(suffix=".out")
         os.close(fd)
         try:
@@ -295,15 +394,21 @@ def cab_search(src, searchbuf=0):
 
 
 class Chm:
-    def __init__(self, src, fast=False):
-        self.L = _setup()
+    def __init__(self, src, fast=False, mem=False, L=None):
+        self.L = _setup(L)
         self._tmp = None
-        if isinstance(src, (bytes, bytearray)):
-            fd, self._tmp = tempfile.mkstemp(suffix=".chm")
-            os.write(fd, src); os.close(fd)
-            src = self._tmp
-        self.path = os.fsencode(src)
-        self.d = self.L.mspack_create_chm_decompressor(None)
+        self.mem = None
+        if mem:
+            self.mem = MemSystem(self.L)
+            self.mem.files[b"mem:in"] = bytes(src)
+            self.path = b"mem:in"
+        else:
+            if isinstance(src, (bytes, bytearray)):
+                fd, self._tmp = tempfile.mkstemp(suffix=".chm")
+                os.write(fd, src); os.close(fd)
+                src = self._tmp
+            self.path = os.fsencode(src)
+        self.d = self.L.mspack_create_chm_decompressor(self.mem.ptr() if self.mem else None)
         m = self.d.contents
         self.chm = (m.fast_open if fast else m.open)(self.d, self.path)
         self.open_error = m.last_error(self.d)
@@ -315,6 +420,9 @@ class Chm:
                 for f in self._files]
 
     def _extract_ptr(self, fptr):
+        if self.mem:
+            err = self.d.contents.extract(self.d, fptr, b"mem:out")
+            return err, bytes(self.mem.outputs.get(b"mem:out", b""))
         fd, out = tempfile.mkstemp(suffix=".out")
         os.close(fd)
         try:

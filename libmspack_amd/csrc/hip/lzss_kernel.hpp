@@ -37,7 +37,7 @@ __device__ void lzss_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u
   const u32 in_len = u.in_len, mode = u.window_bits;     // 0 EXPAND, 1 MSHELP, 2 QBASIC (lzssd.c:49-51)
   u8 *buf = out_arena + u.out_off - LZSS_WINDOW;         // biased: output byte k lives at buf[4096 + k]
   const u32 cap = LZSS_WINDOW + u.out_len;
-  if (mode > 2u) { if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->reserved = 0; } return; }
+  if (mode > 2u) { if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->in_next = 0; } return; }
   for (u32 k = lane; k < LZSS_WINDOW; k += WAVE) buf[k] = 0x20;
   const u32 start = LZSS_WINDOW - (mode == 2u ? 18u : 16u);   // ring position of the first output byte
   const u32 invert = (mode == 1u) ? 0xFFu : 0u;
@@ -77,7 +77,7 @@ __device__ void lzss_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u
   }
   if (lane == 0) {
     res->err = ERR_OK; res->flags = 0; res->out_len = P - LZSS_WINDOW; res->good_len = P - LZSS_WINDOW;
-    res->in_used = ip; res->reserved = 0;
+    res->in_used = ip; res->in_next = 0;
   }
 }
 
@@ -216,6 +216,6 @@ __device__ void kwaj_lzh_decode_unit(const mspack_hip_unit &u, const u8 *in_aren
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   if (lane == 0) {
     res->err = err; res->flags = 0; res->out_len = P - LZSS_WINDOW; res->good_len = P - LZSS_WINDOW;
-    res->in_used = b.ip; res->reserved = 0;
+    res->in_used = b.ip; res->in_next = 0;
   }
 }

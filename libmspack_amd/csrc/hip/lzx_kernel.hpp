@@ -1101,6 +1101,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   u32 flags = 0;
   const u32 out_bytes = u.out_len;
   u32 remaining = out_bytes;
+  u32 in_next = 0;
 
   d.lane = lane; d.sh = sh; d.err = 0;
   d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
@@ -1136,7 +1137,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
 #endif
   }
   if (s.num_offsets == 0u) {
-    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->reserved = 0; }
+    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->in_next = 0; }
     return;
   }
   lzx_reset_state(d, s);
@@ -1310,6 +1311,10 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
         if (d.bl < n) d.refill();
         if (n) d.drop(n);
       }
+      if (frame_size) {            // for callers that chain units (CHM reset intervals): where the next frame starts
+        in_next = s.raw_mode ? s.raw_pos : d.w.origin + (d.cons_bits() >> 3);
+        flags = s.block_remaining ? (flags | MSPACK_HIP_F_BLOCK_OPEN) : (flags & ~MSPACK_HIP_F_BLOCK_OPEN);
+      }
 
       // E8: record what the translation pass must do for this frame (lzxd.c:707-708)
       {
@@ -1332,7 +1337,7 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   if (err == 0 && remaining) err = ERR_DECRUNCH;                                  // lzxd.c:758-761
   if (err == ERR_READ && remaining == 0u) flags |= MSPACK_HIP_F_LOOKAHEAD_READ;
   if (lane == 0) {
-    res->err = err; res->flags = flags; res->out_len = s.offset; res->good_len = s.offset; res->reserved = 0;
+    res->err = err; res->flags = flags; res->out_len = s.offset; res->good_len = s.offset; res->in_next = in_next;
     res->in_used = s.raw_mode ? s.raw_pos : d.iptr();
 #ifdef LZX_EXP_CNT
     res->flags = d.st_t[0]; res->out_len = d.st_t[1]; res->good_len = d.st_t[2]; res->err = (int) d.st_t[4];

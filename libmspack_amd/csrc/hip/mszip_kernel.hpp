@@ -639,7 +639,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
     d.B += n;
   }
   if (lane == 0) {
-    res->err = err; res->flags = rflags; res->out_len = written; res->good_len = written; res->reserved = 0;
+    res->err = err; res->flags = rflags; res->out_len = written; res->good_len = written; res->in_next = 0;
     res->in_used = d.w.origin + ((d.cons_bits() + (d.careful ? (u32) d.rbl : 0u)) >> 3);
   }
 }

@@ -265,7 +265,7 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   const u32 lane = threadIdx.x;
   const u32 wb = u.window_bits;
   if (wb < 10u || wb > 21u) {
-    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->reserved = 0; }
+    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->in_next = 0; }
     return;
   }
   QtmDec d;
@@ -412,7 +412,7 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   if (err == ERR_OK && need) { written += (u32) need; }
   if (err == ERR_OK) good = written;
   if (lane == 0) {
-    res->err = err; res->flags = 0; res->out_len = written; res->good_len = good; res->reserved = 0;
+    res->err = err; res->flags = 0; res->out_len = written; res->good_len = good; res->in_next = 0;
     res->in_used = d.w.origin + ((d.cons_bits() + (u32) d.rbl) >> 3);
   }
 }

@@ -27,24 +27,41 @@ static const char spaninfo_name[] = "::DataSpace/Storage/MSCompressed/SpanInfo";
 static const char rtable_name[]   = "::DataSpace/Storage/MSCompressed/Transform/"
                                     "{7FC28940-9D31-11D0-9B27-00A0C91E9C7C}/InstanceData/ResetTable";
 
+struct chm_chunk {                /* a run of reset intervals decoded in one GPU batch */
+  unsigned char *buf;             /* decoded bytes (E8 origin 0), or NULL when evicted               */
+  unsigned long stamp;            /* LRU clock                                                      */
+  int res_valid;                  /* ires[] of these intervals is filled in                         */
+};
 struct chm_p {
   struct mschmd_header base;
-  /* decoded section 1 */
+  /* section 1 */
   int sec1_state;                 /* 0 = not set up, 1 = ready, <0 = -(setup error)                 */
-  int window_bits, use_table;
-  off_t interval_bytes, padded_len, stream_len;
-  unsigned int n_intervals;
-  unsigned char *arena; size_t arena_len;     /* the Content stream (+ a few following bytes)      */
-  uint64_t *ioff;                 /* compressed offset of every interval                            */
-  unsigned char *dec;             /* padded_len decoded bytes, E8 origin = each interval's own start */
-  mspack_hip_result *ires;        /* per interval                                                   */
+  int window_bits;
+  unsigned int fper;              /* frames per reset interval                                      */
+  off_t interval_bytes, padded_len;
+  unsigned int n_intervals;       /* padded_len / interval_bytes                                    */
+  unsigned int n_fast;            /* intervals [0, n_fast) have a reset-table entry                 */
+  int span_err; off_t span_len;   /* SpanInfo: the fallback stream length (chmd.c:1159-1166)        */
+  unsigned char *arena; size_t arena_len;     /* the CHM file from the start of Content to its end  */
+  off_t content_start;            /* file offset of the Content stream                              */
+  uint64_t *ioff;                 /* reset-table entry (compressed offset) of intervals [0, n_fast)  */
+  mspack_hip_result *ires;        /* stand-alone result per interval                                */
+  struct chm_chunk *chunks; unsigned int n_chunks, chunk_int; unsigned long stamp;
+  /* the serial span of the virtual decoder (damaged / table-less files) */
+  int s_valid, s_mode; off_t s_init, s_cover; unsigned char *s_buf; mspack_hip_result s_res;
+};
+struct vdec {                     /* the reference's lzxd instance, replayed (chmd.c:989-1040)       */
+  int alive, mode, serial, seek_pending;   /* mode 0: created at a reset-table entry, 1: at offset 0 with SpanInfo */
+  off_t init, length, offset;     /* creation point, stream length it was created with, position    */
+  off_t decoded_end;              /* end of the last frame it has decoded: [offset, decoded_end) is stored
+                                     up in its window and handed out without decoding (lzxd.c:397-408)  */
+  uint64_t in_off;                /* compressed offset it was created at                            */
 };
 struct chmd_p {
   struct mschm_decompressor base;
   struct mspack_system *system;
   int error;
-  /* emulated lzxd lifetime (chmd.c:989-1040) */
-  struct chm_p *v_chm; off_t v_init, v_offset; int v_alive;
+  struct chm_p *v_chm; struct vdec v;
 };
 
 static off_t read_encint(const unsigned char **p, const unsigned char *end, int *err) {
@@ -167,10 +184,7 @@ static int read_headers(struct mspack_system *sys, struct mspack_file *fh, struc
   return errors ? MSPACK_ERR_DATAFORMAT : MSPACK_ERR_OK;
 }
 
-static void free_sec1(struct mspack_system *sys, struct chm_p *c) {
-  sys->free(c->arena); sys->free(c->ioff); sys->free(c->dec); sys->free(c->ires);
-  c->arena = NULL; c->ioff = NULL; c->dec = NULL; c->ires = NULL; c->sec1_state = 0;
-}
+static void free_sec1(struct mspack_system *sys, struct chm_p *c);
 
 static void chmd_close(struct mschm_decompressor *base, struct mschmd_header *chm)
 {
@@ -184,7 +198,7 @@ static void chmd_close(struct mschm_decompressor *base, struct mschmd_header *ch
   if (!chm) return;
   for (fi = chm->files; fi; fi = nfi) { nfi = fi->next; sys->free(fi); }
   for (fi = chm->sysfiles; fi; fi = nfi) { nfi = fi->next; sys->free(fi); }
-  if (self->v_chm == (struct chm_p *) chm) { self->v_chm = NULL; self->v_alive = 0; }
+  if (self->v_chm == (struct chm_p *) chm) { self->v_chm = NULL; self->v.alive = 0; }
   if (chm->chunk_cache) {
     for (i = 0; i < chm->num_chunks; i++) sys->free(chm->chunk_cache[i]);
     sys->free(chm->chunk_cache);
@@ -418,11 +432,42 @@ static unsigned char *read_sec0_file(struct chmd_p *self, struct mspack_file *fh
   return data;
 }
 
-/* ---- section 1: set up the interval table and decode everything in one batch ------------------------- */
-static int decode_intervals(struct chmd_p *self, struct chm_p *c, unsigned int first, unsigned int count,
-                            int32_t e8_shift, unsigned char *out, mspack_hip_result *res)
+/* ---- section 1 (reference chmd.c:989-1041, 1072-1315) ---------------------------------------------------
+ *
+ * What the reference does: extract() keeps ONE lzxd instance alive.  It is (re)created when there is none
+ * or the request lies behind its position: at the reset point of the file's interval if the reset table
+ * has an entry for it (stream length = UncompLen padded to the interval), else at offset 0 with SpanInfo's
+ * length.  A request is lzxd_decompress(skip) + lzxd_decompress(length); every decompress call decodes
+ * whole frames up to and INCLUDING the frame that holds the first byte after the request (lzxd.c:419), and
+ * any error kills the instance.
+ *
+ * What we do: every reset interval with a table entry is an independent unit ("fast" results: decoded in
+ * GPU batches of CHM_CHUNK_BYTES, buffers kept LRU within the cache budget, per-interval results kept
+ * for good).  A virtual decoder (struct vdec) replays the reference's instance on top of those results.
+ * An interval's stand-alone result IS the live decoder's result when the decoder was created AT it.  For
+ * an interval the live decoder crosses INTO, that only holds if the stand-alone decode is clean (an
+ * error there may be a match that reaches before the interval: legal for a decoder that has that
+ * history, lzxd.c:622-634), the table entry is where the previous interval's bits really end
+ * (result.in_next) and no block spans the reset (MSPACK_HIP_F_BLOCK_OPEN, lzxd.c:424-431).  Otherwise --
+ * damaged or odd files only -- the virtual decoder goes SERIAL: one unit from its creation point on, which
+ * is the reference's own control flow, exact by construction.  E8: the translation origin is the creation
+ * point (lzxd.c:712); fast results use origin 0, so intervals that applied E8 are decoded again with the
+ * shifted origin when the decoder was created elsewhere. */
+#define CHM_CHUNK_BYTES ((off_t) 64 << 20)
+#define CHM_SERIAL_SLACK 16                 /* serial spans are decoded this many intervals past the need */
+
+static int hip_batch(mspack_hip_unit *units, size_t n, const void *in, size_t in_bytes, void *out, size_t out_bytes,
+                     mspack_hip_result *res)
 {
-  /* interval i is unit i-first; its E8 origin is shifted by e8_shift bytes (0 = its own start) */
+  int dv = mspack_hip_default_devices();
+  return dv > 1 ? mspack_hip_decode_batch_multi(units, n, in, in_bytes, out, out_bytes, res, dv)
+                : mspack_hip_decode_batch(units, n, in, in_bytes, out, out_bytes, res);
+}
+
+/* decode intervals [first, first+count) stand-alone; interval i's E8 origin is i*interval - e8_origin */
+static int decode_intervals(struct chmd_p *self, struct chm_p *c, unsigned int first, unsigned int count,
+                            off_t e8_origin, unsigned char *out, mspack_hip_result *res)
+{
   struct mspack_system *sys = self->system;
   mspack_hip_unit *units = (mspack_hip_unit *) sys->alloc(sys, (size_t) count * sizeof(*units));
   unsigned int k;
@@ -431,34 +476,40 @@ static int decode_intervals(struct chmd_p *self, struct chm_p *c, unsigned int f
   memset(units, 0, (size_t) count * sizeof(*units));
   for (k = 0; k < count; k++) {
     uint64_t off = c->ioff[first + k];
+    if (off > (uint64_t) c->arena_len) off = c->arena_len;        /* an entry beyond the file: nothing to read */
     units[k].in_off = off;
-    units[k].in_len = (uint32_t)((uint64_t) c->arena_len > off ? (uint64_t) c->arena_len - off : 0);
+    units[k].in_len = (uint32_t)((uint64_t) c->arena_len - off > 0xFFFFFFF0u ? 0xFFFFFFF0u : (uint64_t) c->arena_len - off);
     units[k].out_off = (uint64_t) k * (uint64_t) c->interval_bytes;
     units[k].out_len = (uint32_t) c->interval_bytes;
     units[k].kind = MSPACK_HIP_KIND_LZX;
     units[k].window_bits = (uint8_t) c->window_bits;
-    units[k].reset_frames = (uint16_t)(c->interval_bytes / FRAME);
-    units[k].e8_base = e8_shift + (int32_t)((int64_t) k * c->interval_bytes);
+    units[k].reset_frames = (uint16_t) c->fper;
+    units[k].e8_base = (int32_t)((off_t)(first + k) * c->interval_bytes - e8_origin);
   }
-  if (!c->use_table) {            /* no usable reset table: one serial unit from offset 0 (chmd.c:1159-1166) */
-    units[0].out_len = (uint32_t) c->stream_len;
-    units[0].e8_base = 0;
-  }
-  rc = mspack_hip_decode_batch(units, count, c->arena, c->arena_len + 64, out,
-                               (size_t)(c->use_table ? (off_t) count * c->interval_bytes : c->stream_len) + 64, res);
+  rc = hip_batch(units, count, c->arena, c->arena_len + 64, out, (size_t) count * (size_t) c->interval_bytes + 64, res);
   sys->free(units);
   if (rc) { sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error()); return MSPACK_ERR_DECRUNCH; }
   return MSPACK_ERR_OK;
 }
 
+static void free_sec1(struct mspack_system *sys, struct chm_p *c) {
+  unsigned int i;
+  if (c->chunks) for (i = 0; i < c->n_chunks; i++) sys->free(c->chunks[i].buf);
+  sys->free(c->chunks); sys->free(c->arena); sys->free(c->ioff); sys->free(c->ires); sys->free(c->s_buf);
+  c->chunks = NULL; c->arena = NULL; c->ioff = NULL; c->ires = NULL; c->s_buf = NULL; c->sec1_state = 0;
+  c->n_chunks = 0; c->s_valid = 0;
+}
+
+/* ControlData, the compressed stream, ResetTable and SpanInfo: everything chmd_init_decomp (chmd.c:1072-1188)
+ * reads, parsed once.  Returns the error the reference's init would return for EVERY file. */
 static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *fh)
 {
   struct mspack_system *sys = self->system;
   struct mschmd_sec_mscompressed *sec = &c->base.sec1;
   unsigned char *data;
   int err = MSPACK_ERR_OK;
-  unsigned int version, wsize, frames_per;
-  off_t reset_interval, total = 0;
+  unsigned int version, wsize;
+  off_t reset_interval;
 
   if ((err = find_sys_file(self, sec, &sec->content, content_name))) return err;
   if ((err = find_sys_file(self, sec, &sec->control, control_name))) return err;
@@ -478,108 +529,262 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
   case 0x200000: c->window_bits = 21; break;
   default: return MSPACK_ERR_DATAFORMAT;
   }
+  /* the reference computes in `int` (chmd.c:1075,1114-1121): an interval beyond 2^31 wraps there */
+  reset_interval = (off_t)(int)(unsigned int) reset_interval;
   if (reset_interval == 0 || reset_interval % FRAME) return MSPACK_ERR_DATAFORMAT;
-  if (reset_interval / FRAME > 65535) return MSPACK_ERR_DATAFORMAT;
+  if (reset_interval < 0 || reset_interval / FRAME > 65535) return MSPACK_ERR_DATAFORMAT;   /* ours: unit field width */
   c->interval_bytes = reset_interval;
-  frames_per = (unsigned int)(reset_interval / FRAME);
+  c->fper = (unsigned int)(reset_interval / FRAME);
 
-  /* the compressed stream: Content, plus the few bytes the reference could read past it */
+  /* the compressed stream: from the start of Content to the end of the FILE -- the reference's decoder
+   * reads on from wherever it is (sys->read on the CHM itself), not just inside Content */
   {
     off_t start = c->base.sec0.offset + sec->content->offset, flen = 0, avail;
     size_t want;
     if (sec->content->section->id != 0) return MSPACK_ERR_DATAFORMAT;
     if (mspack_sys_filelen(sys, fh, &flen)) return MSPACK_ERR_SEEK;
-    avail = flen > start ? flen - start : 0;
-    want = (size_t) sec->content->length + 64;
-    if ((off_t) want > avail) want = (size_t) avail;
+    avail = (start >= 0 && flen > start) ? flen - start : 0;
+    want = (size_t) avail;
     if (!(c->arena = (unsigned char *) sys->alloc(sys, want + 128))) return MSPACK_ERR_NOMEMORY;
     memset(c->arena, 0, want + 128);
-    if (sys->seek(fh, start, MSPACK_SYS_SEEK_START)) return MSPACK_ERR_SEEK;
-    if (want && sys->read(fh, c->arena, (int) want) != (int) want) return MSPACK_ERR_READ;
+    if (want) {
+      if (sys->seek(fh, start, MSPACK_SYS_SEEK_START)) return MSPACK_ERR_SEEK;
+      if (sys->read(fh, c->arena, (int) want) != (int) want) return MSPACK_ERR_READ;
+    }
     c->arena_len = want;
+    c->content_start = start;
   }
 
-  /* reset table: every interval's compressed offset (chmd.c:1195-1267) */
-  c->use_table = 0;
+  /* reset table (read_reset_table, chmd.c:1195-1267): which intervals have a usable entry */
+  c->n_fast = 0; c->n_intervals = 0; c->padded_len = 0;
   if (!find_sys_file(self, sec, &sec->rtable, rtable_name) && sec->rtable->length >= 0x28 &&
       sec->rtable->length <= 1000000 && (data = read_sec0_file(self, fh, sec->rtable, &err))) {
     unsigned int nent = rd_le32(data + 4), esz = rd_le32(data + 8), toff = rd_le32(data + 0x0C);
     if (rd_le32(data + 0x20) == FRAME && (esz == 4 || esz == 8)) {
-      unsigned int ni, k, ok = 1;
-      total = (off_t) rd_le64(data + 0x10);
+      off_t total = (off_t) rd_le64(data + 0x10);
+      uint64_t ni;
       c->padded_len = (total + reset_interval - 1) & -reset_interval;      /* chmd.c:1153-1157 */
-      ni = (unsigned int)(c->padded_len / reset_interval);
+      ni = c->padded_len > 0 ? (uint64_t)(c->padded_len / reset_interval) : 0;
+      if (ni > 0x7FFFFFFFu / c->fper) ni = 0x7FFFFFFFu / c->fper;
+      /* entries exist for the intervals whose first frame index is below NumEntries and inside the file */
       if (ni && (c->ioff = (uint64_t *) sys->alloc(sys, (size_t) ni * sizeof(uint64_t)))) {
+        unsigned int k;
         for (k = 0; k < ni; k++) {
-          unsigned int entry = k * frames_per;
-          uint64_t pos = (uint64_t) toff + (uint64_t) entry * esz;
-          if (entry >= nent || pos > (uint64_t) sec->rtable->length - esz) { ok = 0; break; }
+          unsigned int entry = k * c->fper;
+          unsigned int pos = toff + entry * esz;                              /* unsigned wrap as in chmd.c:1237 */
+          if (entry >= nent || (off_t) pos > sec->rtable->length - (off_t) esz) break;
           c->ioff[k] = (esz == 4) ? rd_le32(data + pos) : (uint64_t) rd_le64(data + pos);
         }
-        if (ok) { c->use_table = 1; c->n_intervals = ni; }
-        else { sys->free(c->ioff); c->ioff = NULL; }
+        c->n_fast = k;
+        c->n_intervals = (unsigned int) ni;
       }
     }
     sys->free(data);
   }
-  if (!c->use_table) {
-    /* fall back to SpanInfo: one stream from offset 0 (chmd.c:1159-1166, 1275-1315) */
-    if (find_sys_file(self, sec, &sec->spaninfo, spaninfo_name)) return MSPACK_ERR_DATAFORMAT;
-    if (sec->spaninfo->length != 8) return MSPACK_ERR_DATAFORMAT;
-    if (!(data = read_sec0_file(self, fh, sec->spaninfo, &err))) return err;
-    total = (off_t) rd_le64(data);
+  /* SpanInfo (read_spaninfo, chmd.c:1275-1315): the fallback's stream length, or the error it ends in */
+  c->span_err = MSPACK_ERR_OK; c->span_len = 0;
+  if (find_sys_file(self, sec, &sec->spaninfo, spaninfo_name)) c->span_err = MSPACK_ERR_DATAFORMAT;
+  else if (sec->spaninfo->length != 8) c->span_err = MSPACK_ERR_DATAFORMAT;
+  else if (!(data = read_sec0_file(self, fh, sec->spaninfo, &err))) c->span_err = err;
+  else {
+    c->span_len = (off_t) rd_le64(data);
     sys->free(data);
-    if (total <= 0 || total > 0xFFFF0000LL) return MSPACK_ERR_DATAFORMAT;
-    if (!(c->ioff = (uint64_t *) sys->alloc(sys, sizeof(uint64_t)))) return MSPACK_ERR_NOMEMORY;
-    c->ioff[0] = 0; c->n_intervals = 1; c->padded_len = total;
+    if (c->span_len <= 0) c->span_err = MSPACK_ERR_DATAFORMAT;
+    else if (c->span_len > 0xFFFF0000LL) c->span_err = MSPACK_ERR_DATAFORMAT;   /* ours: a unit's out_len is 32 bits */
   }
-  c->stream_len = c->use_table ? c->padded_len : total;
 
-  /* decode every interval of the CHM in one batch */
-  if (!(c->dec = (unsigned char *) sys->alloc(sys, (size_t) c->stream_len + 128))) return MSPACK_ERR_NOMEMORY;
-  if (!(c->ires = (mspack_hip_result *) sys->alloc(sys, (size_t) c->n_intervals * sizeof(mspack_hip_result)))) return MSPACK_ERR_NOMEMORY;
-  return decode_intervals(self, c, 0, c->n_intervals, 0, c->dec, c->ires);
+  /* fast-result bookkeeping */
+  if (c->n_fast) {
+    unsigned int i;
+    c->chunk_int = (unsigned int)(CHM_CHUNK_BYTES / c->interval_bytes); if (!c->chunk_int) c->chunk_int = 1;
+    c->n_chunks = (c->n_fast + c->chunk_int - 1) / c->chunk_int;
+    if (!(c->chunks = (struct chm_chunk *) sys->alloc(sys, (size_t) c->n_chunks * sizeof(*c->chunks)))) return MSPACK_ERR_NOMEMORY;
+    for (i = 0; i < c->n_chunks; i++) { c->chunks[i].buf = NULL; c->chunks[i].stamp = 0; c->chunks[i].res_valid = 0; }
+    if (!(c->ires = (mspack_hip_result *) sys->alloc(sys, (size_t) c->n_fast * sizeof(mspack_hip_result)))) return MSPACK_ERR_NOMEMORY;
+  }
+  return MSPACK_ERR_OK;
 }
 
-/* how far can a decoder that starts at `from` (an interval start) produce bytes without error?
- * returns MSPACK_ERR_OK if [from, end] (incl. the look-ahead frame, lzxd.c:419) decodes, else the
- * error; *good = first byte position that is not available */
-static int range_status(struct chm_p *c, off_t from, off_t end, off_t *good)
+/* fast results (and, if `need_buf`, the decoded bytes) of the chunk that holds interval k */
+static int ensure_chunk(struct chmd_p *self, struct chm_p *c, unsigned int k, int need_buf, struct chm_chunk **out)
 {
-  off_t need_frame = end / FRAME;                          /* last frame index the reference decodes */
-  if (!c->use_table) {
-    mspack_hip_result *r = &c->ires[0];
-    off_t nframes = (c->stream_len + FRAME - 1) / FRAME;
-    *good = r->good_len;
-    if (r->err == MSPACK_ERR_OK) return (end <= c->stream_len) ? MSPACK_ERR_OK : MSPACK_ERR_DECRUNCH;
-    if ((off_t) r->good_len >= c->stream_len) return (need_frame < nframes) ? MSPACK_ERR_OK : r->err;
-    return (need_frame < (off_t)(r->good_len / FRAME)) ? MSPACK_ERR_OK : r->err;
+  struct mspack_system *sys = self->system;
+  unsigned int ci = k / c->chunk_int, first = ci * c->chunk_int, i;
+  unsigned int count = (first + c->chunk_int <= c->n_fast) ? c->chunk_int : c->n_fast - first;
+  struct chm_chunk *ch = &c->chunks[ci];
+  int err;
+  if (out) *out = ch;
+  ch->stamp = ++c->stamp;
+  if (ch->buf || (ch->res_valid && !need_buf)) return MSPACK_ERR_OK;
+  /* stay inside the cache budget: drop the least recently used buffers */
+  {
+    size_t budget = (size_t) mspack_hip_cache_mb() << 20, each = (size_t) c->chunk_int * (size_t) c->interval_bytes;
+    for (;;) {
+      size_t used = 0; struct chm_chunk *lru = NULL;
+      for (i = 0; i < c->n_chunks; i++)
+        if (c->chunks[i].buf) { used += each; if (&c->chunks[i] != ch && (!lru || c->chunks[i].stamp < lru->stamp)) lru = &c->chunks[i]; }
+      if (used + each <= budget || !lru) break;
+      sys->free(lru->buf); lru->buf = NULL;
+    }
   }
-  else {
-    unsigned int fper = (unsigned int)(c->interval_bytes / FRAME);
-    unsigned int i0 = (unsigned int)(from / c->interval_bytes), i;
-    off_t last_needed = need_frame / fper;                  /* interval holding the last needed frame */
-    for (i = i0; i < c->n_intervals && (off_t) i <= last_needed; i++) {
-      mspack_hip_result *r = &c->ires[i];
-      off_t base = (off_t) i * c->interval_bytes;
-      if (r->err != MSPACK_ERR_OK && !(r->flags & MSPACK_HIP_F_LOOKAHEAD_READ)) {
-        /* frames of this interval before the failing one are fine */
-        off_t good_frames = base / FRAME + r->good_len / FRAME;
-        *good = base + r->good_len;
-        if (need_frame < good_frames) return MSPACK_ERR_OK;
-        return r->err;
+  if (!(ch->buf = (unsigned char *) sys->alloc(sys, (size_t) count * (size_t) c->interval_bytes + 128))) return MSPACK_ERR_NOMEMORY;
+  err = decode_intervals(self, c, first, count, 0, ch->buf, &c->ires[first]);
+  if (err) { sys->free(ch->buf); ch->buf = NULL; return err; }
+  ch->res_valid = 1;
+  if (!need_buf && count * (size_t) c->interval_bytes > ((size_t) mspack_hip_cache_mb() << 20)) { sys->free(ch->buf); ch->buf = NULL; }
+  return MSPACK_ERR_OK;
+}
+
+static int interval_clean(const mspack_hip_result *r) {
+  return r->err == MSPACK_ERR_OK || (r->err == MSPACK_ERR_READ && (r->flags & MSPACK_HIP_F_LOOKAHEAD_READ));
+}
+
+/* the serial span of the virtual decoder: ONE unit from its creation point covering at least `need` bytes */
+static int ensure_serial(struct chmd_p *self, struct chm_p *c, off_t need)
+{
+  struct mspack_system *sys = self->system;
+  struct vdec *v = &self->v;
+  off_t full = v->length - v->init, cover;
+  mspack_hip_unit u;
+  uint64_t off = v->in_off;
+  if (need > full) need = full;
+  if (c->s_valid && c->s_init == v->init && c->s_mode == v->mode && c->s_cover >= need) return MSPACK_ERR_OK;
+  cover = need + (off_t) CHM_SERIAL_SLACK * c->interval_bytes;
+  cover = (cover + FRAME - 1) & ~(off_t)(FRAME - 1);
+  if (cover >= full) cover = full;
+  if (cover > 0xFFFF0000LL) return MSPACK_ERR_DATAFORMAT;                /* ours: 32-bit unit length */
+  sys->free(c->s_buf); c->s_buf = NULL; c->s_valid = 0;
+  if (!(c->s_buf = (unsigned char *) sys->alloc(sys, (size_t) cover + 128))) return MSPACK_ERR_NOMEMORY;
+  memset(&u, 0, sizeof(u));
+  if (off > (uint64_t) c->arena_len) off = c->arena_len;
+  u.in_off = off;
+  u.in_len = (uint32_t)((uint64_t) c->arena_len - off > 0xFFFFFFF0u ? 0xFFFFFFF0u : (uint64_t) c->arena_len - off);
+  u.out_off = 0; u.out_len = (uint32_t) cover;
+  u.kind = MSPACK_HIP_KIND_LZX; u.window_bits = (uint8_t) c->window_bits; u.reset_frames = (uint16_t) c->fper;
+  u.e8_base = 0;
+  if (mspack_hip_decode_batch(&u, 1, c->arena, c->arena_len + 64, c->s_buf, (size_t) cover + 64, &c->s_res)) {
+    sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error());
+    return MSPACK_ERR_DECRUNCH;
+  }
+  c->s_valid = 1; c->s_init = v->init; c->s_mode = v->mode; c->s_cover = cover;
+  return MSPACK_ERR_OK;
+}
+
+static int vdec_decode(struct chmd_p *self, struct chm_p *c, off_t A, off_t B, off_t *good);
+
+/* One lzxd_decompress(B - A) of the virtual decoder standing at A.  Returns the reference's code; *good =
+ * first byte position that was not produced (>= B on success). */
+static int vdec_phase(struct chmd_p *self, struct chm_p *c, off_t A, off_t B, off_t *good)
+{
+  struct vdec *v = &self->v;
+  off_t fe = B / FRAME;                         /* last frame the call decodes (lzxd.c:419), absolute index */
+  int err;
+  *good = B;
+  (void) A;
+  /* bytes of the frame decoded last are stored up: a call they satisfy decodes nothing (lzxd.c:397-408) */
+  if (B <= v->decoded_end) return MSPACK_ERR_OK;
+  err = vdec_decode(self, c, v->decoded_end, B, good);
+  if (!err) { v->decoded_end = (fe + 1) * FRAME; if (v->decoded_end > v->length) v->decoded_end = v->length; }
+  return err;
+}
+
+/* the frames from position A (a frame start the decoder has not decoded yet) up to and INCLUDING the frame
+ * that holds B -- a call that has to decode always goes one frame past an end on a frame boundary (lzxd.c:419) */
+static int vdec_decode(struct chmd_p *self, struct chm_p *c, off_t A, off_t B, off_t *good)
+{
+  struct vdec *v = &self->v;
+  off_t fe = B / FRAME;
+  int err;
+  if (!v->serial) {
+    unsigned int k0 = (unsigned int)(v->init / c->interval_bytes), k, k_hi;
+    off_t total_frames = v->length / FRAME;     /* table mode: the length is padded to whole intervals */
+    off_t kh = fe / c->fper;
+    k_hi = (kh >= (off_t) c->n_intervals) ? c->n_intervals - 1 : (unsigned int) kh;
+    for (k = (unsigned int)(A / c->interval_bytes); k <= k_hi && (off_t) k * c->interval_bytes < v->length; k++) {
+      if (k >= c->n_fast) { v->serial = 1; break; }
+      if ((err = ensure_chunk(self, c, k, 0, NULL))) return err;
+      if (k > k0) {
+        const mspack_hip_result *p;
+        if ((err = ensure_chunk(self, c, k - 1, 0, NULL))) return err;
+        p = &c->ires[k - 1];
+        if (!interval_clean(&c->ires[k]) || (p->flags & MSPACK_HIP_F_BLOCK_OPEN) ||
+            c->ioff[k] != c->ioff[k - 1] + p->in_next) { v->serial = 1; break; }
+      }
+      else if (!interval_clean(&c->ires[k])) {
+        off_t g = (off_t) k * c->interval_bytes + c->ires[k].good_len;
+        if (fe >= g / FRAME) { *good = g; return c->ires[k].err; }
       }
     }
-    *good = c->padded_len;
-    if (need_frame >= c->padded_len / FRAME) {
-      /* the request ends exactly at the end of the stream: the reference still starts one more
-       * (empty) frame, which only fails if the input is exhausted there */
-      mspack_hip_result *r = &c->ires[c->n_intervals - 1];
-      if (end > c->padded_len) return MSPACK_ERR_DECRUNCH;
-      if (r->flags & MSPACK_HIP_F_LOOKAHEAD_READ) return MSPACK_ERR_READ;
+    if (!v->serial) {
+      if (fe >= total_frames) {
+        /* the request reaches the end of the stream: the reference still enters one more (empty) frame,
+         * at a reset point, and reads the header bit there -- which fails only if the input is exhausted */
+        if (c->n_intervals && c->n_intervals <= c->n_fast) {
+          if ((err = ensure_chunk(self, c, c->n_intervals - 1, 0, NULL))) return err;
+          if (c->ires[c->n_intervals - 1].flags & MSPACK_HIP_F_LOOKAHEAD_READ) { *good = v->length; return MSPACK_ERR_READ; }
+        }
+        if (B > v->length) { *good = v->length; return MSPACK_ERR_DECRUNCH; }         /* lzxd.c:758-761 */
+      }
+      return MSPACK_ERR_OK;
     }
-    return MSPACK_ERR_OK;
   }
+  /* serial: the decoder's own unit, positions relative to its creation point */
+  {
+    off_t full = v->length - v->init, need = (fe + 1) * FRAME - v->init, nframes, rfe = fe - v->init / FRAME, g;
+    const mspack_hip_result *r = &c->s_res;
+    if ((err = ensure_serial(self, c, need))) return err;
+    nframes = (c->s_cover + FRAME - 1) / FRAME;
+    if (c->s_cover < full) {
+      /* a partial span is good for the frames it holds completely */
+      if ((off_t) r->good_len / FRAME > rfe) return MSPACK_ERR_OK;
+      g = v->init + r->good_len; *good = g;
+      return r->err ? r->err : MSPACK_ERR_DECRUNCH;
+    }
+    if (r->err == MSPACK_ERR_OK) {
+      if (B > v->length) { *good = v->length; return MSPACK_ERR_DECRUNCH; }
+      return MSPACK_ERR_OK;
+    }
+    if ((off_t) r->good_len >= full) {                 /* everything came out; the look-ahead failed */
+      if (rfe < nframes) return MSPACK_ERR_OK;
+      *good = v->length; return r->err;
+    }
+    if (rfe < (off_t)(r->good_len / FRAME)) return MSPACK_ERR_OK;
+    *good = v->init + r->good_len;
+    return r->err;
+  }
+}
+
+/* write [from, to) of the uncompressed stream as the virtual decoder produced it */
+static int vdec_emit(struct chmd_p *self, struct chm_p *c, struct mspack_file *fh, off_t from, off_t to)
+{
+  struct mspack_system *sys = self->system;
+  struct vdec *v = &self->v;
+  if (to <= from) return MSPACK_ERR_OK;
+  if (v->serial) return write_slice(sys, fh, c->s_buf + (from - v->init), (size_t)(to - from));
+  while (from < to) {
+    unsigned int k = (unsigned int)(from / c->interval_bytes), ci = k / c->chunk_int;
+    unsigned int cfirst = ci * c->chunk_int, clast = cfirst + c->chunk_int - 1;   /* this chunk's intervals */
+    off_t cend = ((off_t) clast + 1) * c->interval_bytes, stop = to < cend ? to : cend;
+    unsigned int k1 = (unsigned int)((stop - 1) / c->interval_bytes), i;
+    struct chm_chunk *ch;
+    int err, shifted = 0;
+    if ((err = ensure_chunk(self, c, k, 1, &ch))) return err;
+    /* E8: fast results have origin 0; the reference's origin is where its decoder was created (lzxd.c:712) */
+    if (v->init != 0)
+      for (i = k; i <= k1; i++) if (c->ires[i].flags & MSPACK_HIP_F_E8_APPLIED) shifted = 1;
+    if (shifted) {
+      unsigned int cnt = k1 - k + 1;
+      mspack_hip_result *r2 = (mspack_hip_result *) sys->alloc(sys, cnt * sizeof(*r2));
+      unsigned char *tmp = (unsigned char *) sys->alloc(sys, (size_t) cnt * (size_t) c->interval_bytes + 128);
+      err = (!r2 || !tmp) ? MSPACK_ERR_NOMEMORY : decode_intervals(self, c, k, cnt, v->init, tmp, r2);
+      if (!err) err = write_slice(sys, fh, tmp + (from - (off_t) k * c->interval_bytes), (size_t)(stop - from));
+      sys->free(r2); sys->free(tmp);
+      if (err) return err;
+    }
+    else if ((err = write_slice(sys, fh, ch->buf + (from - (off_t) cfirst * c->interval_bytes), (size_t)(stop - from)))) return err;
+    from = stop;
+  }
+  return MSPACK_ERR_OK;
 }
 
 static int chmd_extract(struct mschm_decompressor *base, struct mschmd_file *file, const char *filename)
@@ -595,7 +800,7 @@ static int chmd_extract(struct mschm_decompressor *base, struct mschmd_file *fil
   c = (struct chm_p *) file->section->chm;
 
   if (!(infh = sys->open(sys, c->base.filename, MSPACK_SYS_OPEN_READ))) return self->error = MSPACK_ERR_OPEN;
-  if (self->v_chm != c) { self->v_chm = c; self->v_alive = 0; self->v_offset = 0; }
+  if (self->v_chm != c) { self->v_chm = c; self->v.alive = 0; }
   if (!(fh = sys->open(sys, filename, MSPACK_SYS_OPEN_WRITE))) { sys->close(infh); return self->error = MSPACK_ERR_OPEN; }
   if (!file->length) { sys->close(fh); sys->close(infh); return self->error = MSPACK_ERR_OK; }
   self->error = MSPACK_ERR_OK;
@@ -615,69 +820,49 @@ static int chmd_extract(struct mschm_decompressor *base, struct mschmd_file *fil
     }
   }
   else {
+    struct vdec *v = &self->v;
     int err = MSPACK_ERR_OK;
     if (c->sec1_state == 0) {
       err = setup_sec1(self, c, infh);
       if (err) { free_sec1(sys, c); c->sec1_state = -err; } else c->sec1_state = 1;
     }
     else if (c->sec1_state < 0) err = -c->sec1_state;
+
+    /* (re)create the decoder: none alive, or the request lies behind it (chmd.c:993-999) */
+    if (!err && (!v->alive || file->offset < v->offset)) {
+      off_t k0 = file->offset / c->interval_bytes;
+      v->alive = 0;
+      if (file->offset >= 0 && k0 < (off_t) c->n_fast) {
+        v->mode = 0; v->init = k0 * c->interval_bytes; v->length = c->padded_len; v->in_off = c->ioff[k0];
+      }
+      else if (c->span_err) err = c->span_err;                              /* chmd.c:1159-1166 */
+      else { v->mode = 1; v->init = 0; v->length = c->span_len; v->in_off = 0; }
+      if (!err) { v->alive = 1; v->serial = (v->mode == 1); v->offset = v->decoded_end = v->init; v->seek_pending = 1; }
+    }
     if (!err) {
-      /* emulate the reference decoder's lifetime (chmd.c:993-999): restart at the file's reset
-       * point when there is no live decoder or the request goes backwards */
-      off_t start, end, good = 0, length = file->length, maxlen;
-      if (!self->v_alive || file->offset < self->v_offset) {
-        self->v_init = c->use_table ? (file->offset / c->interval_bytes) * c->interval_bytes : 0;
-        self->v_offset = self->v_init;
-        self->v_alive = 1;
-      }
-      start = self->v_offset;
-      if (file->offset > c->stream_len) err = MSPACK_ERR_DECRUNCH;               /* chmd.c:1002-1005 */
+      if (file->offset > v->length) err = MSPACK_ERR_DECRUNCH;              /* chmd.c:1002-1005; the decoder lives on */
+      else if (v->seek_pending && sys->seek(infh, c->content_start + (off_t) v->in_off, MSPACK_SYS_SEEK_START))
+        err = MSPACK_ERR_SEEK;                                              /* chmd.c:1008-1011; it lives on, too */
       else {
-        maxlen = c->stream_len - file->offset;
-        if (length > maxlen) {
-          sys->message(fh, "WARNING; file is %lld bytes longer than compressed section", (long long)(length - maxlen));
-          length = maxlen + 1;                        /* decodes what exists, then errors out */
-        }
-        /* skip phase, then emit phase */
-        if (file->offset > start) err = range_status(c, start, file->offset, &good);
+        off_t length = file->length, maxlen = v->length - file->offset, good = 0;
+        v->seek_pending = 0;
+        if (file->offset > v->offset) err = vdec_phase(self, c, v->offset, file->offset, &good);   /* skip */
         if (!err) {
-          const unsigned char *src = c->dec;
-          unsigned char *tmp = NULL;
-          off_t have;
-          end = file->offset + length;
-          err = range_status(c, start, end, &good);
-          have = (good > file->offset) ? good - file->offset : 0;
-          if (have > length) have = length;
-          if (file->offset + have > c->stream_len) have = c->stream_len - file->offset;
-          /* E8: intervals whose header enables the translation depend on where the reference's
-           * decoder was initialised; re-decode those with that origin */
-          if (c->use_table && have > 0) {
-            unsigned int i0 = (unsigned int)(file->offset / c->interval_bytes);
-            unsigned int i1 = (unsigned int)((file->offset + have - 1) / c->interval_bytes), i;
-            int any = 0;
-            for (i = i0; i <= i1; i++)
-              if ((c->ires[i].flags & MSPACK_HIP_F_E8_APPLIED) && (off_t) i * c->interval_bytes != self->v_init) any = 1;
-            if (any) {
-              unsigned int cnt = i1 - i0 + 1;
-              mspack_hip_result *r2 = (mspack_hip_result *) sys->alloc(sys, cnt * sizeof(*r2));
-              tmp = (unsigned char *) sys->alloc(sys, (size_t) cnt * (size_t) c->interval_bytes + 128);
-              if (!r2 || !tmp) err = MSPACK_ERR_NOMEMORY;
-              else {
-                int e2 = decode_intervals(self, c, i0, cnt, (int32_t)((off_t) i0 * c->interval_bytes - self->v_init), tmp, r2);
-                if (e2) err = e2;
-                else src = tmp - (off_t) i0 * c->interval_bytes;
-              }
-              sys->free(r2);
-            }
+          int werr;
+          if (length > maxlen) {
+            sys->message(fh, "WARNING; file is %lld bytes longer than compressed section", (long long)(length - maxlen));
+            length = maxlen + 1;                        /* decodes what exists, then errors out */
           }
-          if (have > 0 && err != MSPACK_ERR_NOMEMORY) {
-            if (write_slice(sys, fh, src + file->offset, (size_t) have) != MSPACK_ERR_OK) err = MSPACK_ERR_WRITE;
+          err = vdec_phase(self, c, file->offset, file->offset + length, &good);                    /* emit */
+          if (good > file->offset + length) good = file->offset + length;
+          if (err != MSPACK_ERR_NOMEMORY && good > file->offset) {
+            if (good > v->length) good = v->length;
+            if ((werr = vdec_emit(self, c, fh, file->offset, good))) err = werr;
           }
-          sys->free(tmp);
         }
+        if (err) v->alive = 0;                          /* chmd.c:1036-1040 */
+        else v->offset = file->offset + length;
       }
-      if (err) self->v_alive = 0;                       /* chmd.c:1036-1040 */
-      else self->v_offset = file->offset + length;
     }
     self->error = err;
   }

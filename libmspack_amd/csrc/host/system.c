@@ -101,3 +101,15 @@ static struct mspack_system std_system = {
   &std_alloc, &std_free, &std_copy, NULL
 };
 struct mspack_system *mspack_default_system = &std_system;
+
+/* ---- process-wide driver defaults (include/mspack_hip.h) ------------------------------------------------ */
+static int dflt_devices = 0, dflt_cache_mb = 0;
+static int env_int(const char *name, int fallback) {
+  const char *e = getenv(name);
+  int v = e ? atoi(e) : 0;
+  return v >= 1 ? v : fallback;
+}
+int mspack_hip_set_default_devices(int n) { if (n < 1) return -1; dflt_devices = n; return 0; }
+int mspack_hip_default_devices(void) { if (!dflt_devices) dflt_devices = env_int("MSPACK_HIP_DEVICES", 1); return dflt_devices; }
+int mspack_hip_set_cache_mb(int mb) { if (mb < 1) return -1; dflt_cache_mb = mb; return 0; }
+int mspack_hip_cache_mb(void) { if (!dflt_cache_mb) dflt_cache_mb = env_int("MSPACK_HIP_CACHE_MB", 1024); return dflt_cache_mb; }

@@ -238,7 +238,7 @@ int oracle_lzxd_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t ou
                        int32_t e8_base, int is_delta, const uint8_t *ref, size_t ref_len, oracle_result *res)
 {
   lzx_t *z;
-  uint64_t written = 0, remaining = out_bytes;
+  uint64_t written = 0, remaining = out_bytes, in_next = 0;
   uint32_t end_frame, flags = 0;
   int err = ORC_OK;
 
@@ -308,6 +308,10 @@ int oracle_lzxd_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t ou
 
     if (z->b.bl > 0) { if (ensure(&z->b, 16)) goto fail; }          /* lzxd.c:695-697 */
     if (z->b.bl & 15) DROP(&z->b, z->b.bl & 15);
+    if (frame_size) {                     /* diagnostics for callers that chain units (CHM reset intervals) */
+      in_next = z->b.pos - (uint64_t)(z->b.bl >> 3);
+      flags = z->block_remaining ? (flags | ORC_F_BLOCK_OPEN) : (flags & ~ORC_F_BLOCK_OPEN);
+    }
 
     fsrc = &z->win[z->frame_posn];
     if (z->intel_started && z->intel_filesize && z->frame < 32768 && frame_size > 10) {
@@ -349,7 +353,7 @@ fail:
   }
   if (err == ORC_OK && remaining) err = ORC_DECRUNCH;                /* lzxd.c:758-761 */
 done:
-  res->err = err; res->flags = flags; res->out_len = written; res->in_used = z->b.pos;
+  res->err = err; res->flags = flags; res->out_len = written; res->in_used = z->b.pos; res->in_next = in_next;
   free(z->win); free(z);
   return err;
 }

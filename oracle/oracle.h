@@ -34,12 +34,17 @@ extern "C" {
 #define ORC_F_LOOKAHEAD_READ  2u  /* LZX: all requested bytes were produced, but the one-frame
                                      look-ahead (lzxd.c:419) then ran out of input (ERR_READ)  */
 #define ORC_F_INTEL_HEADER    4u  /* LZX: an interval header carried intel_filesize != 0      */
+#define ORC_F_BLOCK_OPEN     16u  /* LZX: the last decoded frame ended inside a block (block_remaining != 0;
+                                     at a reset point the reference warns and goes on, lzxd.c:424-431)   */
 
 typedef struct oracle_result {
   int32_t  err;       /* MSPACK_ERR_* the reference would return from the decompress call      */
   uint32_t flags;
   uint64_t out_len;   /* bytes the codec handed to sys->write                                   */
   uint64_t in_used;   /* the reference's i_ptr position (bytes pulled into the bit buffer)      */
+  uint64_t in_next;   /* LZX: input byte position right after the 16-bit realignment that follows the
+                         last completely decoded non-empty frame (lzxd.c:695-697) = where the next frame's
+                         bits start; 0 if no frame was completed                                        */
 } oracle_result;
 
 /* LZX: equivalent to lzxd_init(window_bits, reset_frames, bufsize, length, is_delta=0) followed

@@ -1,0 +1,65 @@
+"""Synthetic CHM files for the chmd->extract() goldens (tests/golden/chm_extract.json).
+
+A case is a small JSON recipe -- plaintext seed/kind/size, LZX options, the file table, and a list of
+byte-level mutations of the finished CHM -- from which build() reproduces the CHM byte for byte
+(corpus generators are deterministic; the golden keeps the CHM's MD5 to prove it).  The recipe is
+shared by tests/golden/make_chm_extract_golden.py (development container: asks the REAL reference chmd
+what every extract() call returns) and tests/test_gpu_chm_extract.py (GPU box: replays the calls
+through include/mspack.h on libmspack_hip.so).
+
+CHM layout written by libmspack_amd/csrc/corpus/containers.c (format: chm.h:17-92, chmd.c:1072-1315):
+u64 @0x58 = offset of section 0; section 0 = ControlData (0x1C) | ResetTable (0x28 + 8 n_frames) |
+SpanInfo (8) | Content."""
+import struct
+
+import numpy as np
+
+import libmspack_amd as M
+
+FRAME = 32768
+
+
+def layout(chm, n_frames):
+    sec0, = struct.unpack_from("<Q", chm, 0x58)
+    rt = sec0 + 0x1C
+    span = rt + 0x28 + 8 * n_frames
+    return dict(control=sec0, rtable=rt, spaninfo=span, content=span + 8)
+
+
+def build(case):
+    """-> (chm bytes, plaintext np.uint8, files [(name, offset, length)])"""
+    n = case["n_bytes"]
+    d = M.gen_plaintext(case["seed"], case["text"], n)
+    o = M.lzx_opts(mode=case.get("block_mode", 0), block_size=case.get("block_size", 0),
+                   intel_filesize=case.get("intel_filesize", 0), e8_base=0)
+    lz, fo = M.lzx_encode(d, case["window_bits"], case["reset_frames"], o)
+    files = [(nm.encode(), off, ln) for nm, off, ln in case["files"]]
+    chm = bytearray(M.chm_write(lz, fo, case.get("uncomp_len", n), case["window_bits"], case["reset_frames"], files))
+    nfr = len(fo) - 1
+    lay = layout(chm, nfr)
+    for m in case.get("mutations", []):
+        op = m[0]
+        if op == "flip_content":            # [op, frame, delta, bit]: damage the compressed stream
+            chm[lay["content"] + int(fo[m[1]]) + m[2]] ^= 1 << m[3]
+        elif op == "rtable_u32":            # [op, field offset, value]
+            struct.pack_into("<I", chm, lay["rtable"] + m[1], m[2])
+        elif op == "rtable_entry":          # [op, frame index, value]
+            struct.pack_into("<Q", chm, lay["rtable"] + 0x28 + 8 * m[1], m[2])
+        elif op == "control_u32":
+            struct.pack_into("<I", chm, lay["control"] + m[1], m[2])
+        elif op == "spaninfo":
+            struct.pack_into("<Q", chm, lay["spaninfo"], m[1])
+        elif op == "cut":                   # [op, bytes to drop from the end]
+            del chm[len(chm) - m[1]:]
+        else:
+            raise ValueError(op)
+    return bytes(chm), d, files
+
+
+def spread_files(n_bytes, n_files, seed, interval, pinned=()):
+    """file table that tiles [0, n_bytes): random cuts plus the pinned ones (reset points, frame ends)"""
+    rng = np.random.default_rng(seed)
+    cuts = set(int(x) for x in rng.choice(np.arange(1, n_bytes), size=n_files - 1, replace=False))
+    cuts |= set(p for p in pinned if 0 < p < n_bytes)
+    cuts = sorted(cuts | {0, n_bytes})
+    return [["/f%04d.bin" % i, cuts[i], cuts[i + 1] - cuts[i]] for i in range(len(cuts) - 1)]

@@ -21,3 +21,25 @@ def built():
     build.build_oracle()
     build.build_hip()
     return True
+
+
+@pytest.fixture(scope="session")
+def hostlogic(built):
+    """tests/_build/libhostlogic_cpu.so: the host drivers' C files (libmspack_amd/csrc/host/*.c) linked with
+    tests/csrc/batch_standin.c, a CPU stand-in for the batch ABI built on the oracle -- so that the HOST logic
+    behind include/mspack.h can be tested without a GPU.  Test infrastructure only; the product library never
+    contains or loads it."""
+    import ctypes
+    import glob
+    import subprocess
+    bdir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    so = os.path.join(bdir, "libhostlogic_cpu.so")
+    srcs = sorted(glob.glob(os.path.join(ROOT, "libmspack_amd", "csrc", "host", "*.c"))) + \
+        [os.path.join(ROOT, "tests", "csrc", "batch_standin.c")] + \
+        sorted(glob.glob(os.path.join(ROOT, "oracle", "*_oracle.c")))
+    deps = srcs + glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(ROOT, "oracle", "*.h"))
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in deps):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+                               "-I", os.path.join(ROOT, "include"), "-o", so] + srcs + ["-lpthread"])
+    return ctypes.CDLL(so)

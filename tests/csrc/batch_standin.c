@@ -1,0 +1,65 @@
+/* tests/csrc/batch_standin.c -- TEST INFRASTRUCTURE ONLY.  Never built into, linked with or loaded by
+ * libmspack_hip.so; tests/conftest.py compiles it together with the host drivers' C files
+ * (libmspack_amd/csrc/host/*.c) into tests/_build/libhostlogic_cpu.so so that the HOST logic of the
+ * libmspack-compatible API (container parsing, unit gathering, skip-then-emit, error mapping, decoder
+ * lifetime emulation) can be exercised by the `-m "not gpu"` suite on a machine without a GPU.
+ *
+ * It provides the batch ABI of include/mspack_hip.h (host-buffer entry points only) on top of the CPU
+ * oracle (oracle/liboracle.so): one oracle call per unit.  Supported: LZX units (CAB folders, CHM reset
+ * intervals, E8 origin) and plain MSZIP / Quantum folder units without MSPACK_HIP_UF_* flags; anything
+ * else makes the call fail, and the tests that need it run on the GPU.  The `-m gpu` parity tests never
+ * see this file: they load the real library. */
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include "../../include/mspack_hip.h"
+#include "../../oracle/oracle.h"
+
+static char g_err[160] = "";
+const char *mspack_hip_version(void) { return "host-logic stand-in (CPU oracle; tests only)"; }
+const char *mspack_hip_last_error(void) { return g_err; }
+int mspack_hip_device_count(void) { return 1; }
+int mspack_hip_set_device(int d) { (void) d; return 0; }
+
+int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
+                            void *out, size_t out_bytes, mspack_hip_result *results)
+{
+  size_t i;
+  for (i = 0; i < n_units; i++) {
+    const mspack_hip_unit *u = &units[i];
+    mspack_hip_result *r = &results[i];
+    oracle_result o;
+    const uint8_t *src = (const uint8_t *) in + u->in_off;
+    uint8_t *dst = (uint8_t *) out + u->out_off;
+    memset(&o, 0, sizeof(o));
+    memset(r, 0, sizeof(*r));
+    if (u->in_off + u->in_len > in_bytes || u->out_off + u->out_len > out_bytes) {
+      snprintf(g_err, sizeof(g_err), "unit outside arena"); return -1;
+    }
+    if (u->flags) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
+    switch (u->kind) {
+    case MSPACK_HIP_KIND_LZX:
+      oracle_lzx_decode(src, u->in_len, dst, u->out_len, u->out_len, u->out_len, u->window_bits, u->reset_frames,
+                        u->e8_base, &o);
+      break;
+    case MSPACK_HIP_KIND_MSZIP:
+      oracle_mszip_decode(src, u->in_len, dst, u->out_len, u->out_len, 0, NULL, 0, NULL, &o);
+      break;
+    case MSPACK_HIP_KIND_QUANTUM:
+      oracle_qtm_decode(src, u->in_len, dst, u->out_len, u->out_len, u->window_bits, &o);
+      break;
+    default:
+      snprintf(g_err, sizeof(g_err), "stand-in: kind %d unsupported", u->kind); return -1;
+    }
+    r->err = o.err; r->flags = o.flags; r->out_len = (uint32_t) o.out_len; r->in_used = (uint32_t) o.in_used;
+    r->good_len = (uint32_t) o.out_len; r->in_next = (uint32_t) o.in_next;
+  }
+  return 0;
+}
+
+int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
+                                  void *out, size_t out_bytes, mspack_hip_result *results, int n_devices)
+{
+  (void) n_devices;
+  return mspack_hip_decode_batch(units, n_units, in, in_bytes, out, out_bytes, results);
+}

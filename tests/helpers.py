@@ -14,12 +14,12 @@ REF_DIR = "/root/reference"
 ERR_OK, ERR_ARGS, ERR_OPEN, ERR_READ, ERR_WRITE, ERR_SEEK, ERR_NOMEMORY, ERR_SIGNATURE, \
     ERR_DATAFORMAT, ERR_CHECKSUM, ERR_CRUNCH, ERR_DECRUNCH = range(12)
 
-F_E8_APPLIED, F_LOOKAHEAD_READ, F_INTEL_HEADER = 1, 2, 4
+F_E8_APPLIED, F_LOOKAHEAD_READ, F_INTEL_HEADER, F_BLOCK_OPEN = 1, 2, 4, 16
 
 
 class OracleResult(C.Structure):
     _fields_ = [("err", C.c_int32), ("flags", C.c_uint32), ("out_len", C.c_uint64),
-                ("in_used", C.c_uint64)]
+                ("in_used", C.c_uint64), ("in_next", C.c_uint64)]
 
 
 def _build_oracle():

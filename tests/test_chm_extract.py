@@ -1,0 +1,51 @@
+"""chmd->extract() pinned to the REAL reference chmd.
+
+tests/golden/chm_extract.json holds, for 22 synthetic CHMs (tests/chm_extract_recipe.py rebuilds them
+byte for byte from the recipe; the golden keeps their MD5), what the reference's chmd answered for every
+extract() call of several call orders on ONE decompressor: error code, bytes written, MD5 of those bytes
+(made by tests/golden/make_chm_extract_golden.py with oracle/_ref in the development container).  The
+calls are replayed through include/mspack.h with the same in-memory mspack_system semantics
+(api.MemSystem) -- cf. libmspack/test/chmd_order.c:55-129, chmd.c:906-1041,1072-1315.
+
+  * `-m gpu`: against libmspack_hip.so, i.e. the HIP kernels (the parity test proper);
+  * `-m "not gpu"`: the same host driver code (csrc/host/chmd.c) linked with the CPU stand-in for the
+    batch ABI (tests/csrc/batch_standin.c) -- host logic only, the big config-3 case is left to the GPU."""
+import hashlib
+import json
+import os
+
+import pytest
+
+from libmspack_amd import api
+import chm_extract_recipe as R
+
+VECS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "chm_extract.json")))
+
+
+def replay(v, L=None):
+    chm, _d, files = R.build(v["case"])
+    assert hashlib.md5(chm).hexdigest() == v["chm_md5"], "recipe no longer reproduces the golden CHM"
+    for run in v["runs"] or [None]:
+        with api.Chm(chm, mem=True, L=L) as c:
+            assert c.open_error == v["open_err"], v["tag"]
+            if run is None:
+                continue
+            assert [(n, off, ln) for n, ln, off, _s in c.files] == files
+            for k, (idx, exp) in enumerate(zip(run["order"], run["results"])):
+                err, data = c.extract(idx)
+                tag = "%s order %s call %d (file %d)" % (v["tag"], run["order"], k, idx)
+                assert err == exp["err"], (tag, err, exp)
+                assert len(data) == exp["n"], (tag, len(data), exp)
+                assert hashlib.md5(data).hexdigest() == exp["md5"], tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", VECS, ids=[v["tag"] for v in VECS])
+def test_chm_extract_vs_reference_gpu(built, v):
+    replay(v)
+
+
+@pytest.mark.parametrize("v", [v for v in VECS if v["case"]["n_bytes"] <= (8 << 20)],
+                         ids=[v["tag"] for v in VECS if v["case"]["n_bytes"] <= (8 << 20)])
+def test_chm_extract_host_logic_cpu(built, hostlogic, v):
+    replay(v, L=hostlogic)

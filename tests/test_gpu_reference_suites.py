@@ -14,8 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(name):
     exe = os.path.join(ROOT, "oracle", "_ref", name)
-    if not os.path.exists(exe):
-        pytest.skip("%s not built (make -C oracle reftests needs the reference's sources)" % name)
+    # never skip: a missing binary on the GPU box would silently drop the strongest boundary evidence
+    assert os.path.exists(exe), "%s missing: run `make -C oracle reftests` in the development container " \
+        "(build() does) so that oracle/_ref/ travels to the GPU box" % name
     p = subprocess.run([exe], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     out = p.stdout.decode("latin-1")
     ok = out.count(" SUCCESS ")
