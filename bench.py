@@ -4,12 +4,28 @@
 
 A "step" = one pass of the hot path (mspack_hip_decode_batch_device) over the whole batch of
 independent CHM-style reset intervals (64 KiB each = reset interval of 2 frames).
-Prints ONE JSON line on rank 0.  Multi-GPU: one process per GPU, no data-path collective (units are
-independent); torch.distributed (RCCL) is used only for the barrier and the max-over-ranks time.
+Prints ONE JSON line on rank 0.
+
+Multi-GPU: one process per GPU, no data-path collective (units are independent); torch.distributed
+(backend nccl = RCCL) is used only for the barrier and the max-over-ranks time.  `--gpus N` without a
+launcher (no WORLD_SIZE in the environment) spawns the N ranks itself; under torchrun the launcher's world
+size must equal --gpus.  A box with fewer GPUs than ranks is an error, never a silent 1-GPU run.
+  --scaling weak   (default) every rank decodes its own --units intervals (BASELINE metric, 4096 per GPU)
+  --scaling strong --total-units T: BASELINE config 5 (T = 65536): one global list of T intervals, rank r
+                   decodes the contiguous shard libmspack_amd.dist.shard_range(T, r, world) of it.
+
+At N=1 the line also carries (same process, after the timed region):
+  roofline        the LZX kernel's duration from HIP events on the launch stream vs algorithmic bytes
+  host_inclusive  SURVEY 8(d)'s metric as written: from compressed units in HOST memory to decoded bytes in
+                  device memory (mspack_hip_decode_batch_to_device) and, separately, back in host memory
+                  (mspack_hip_decode_batch) -- what a cabd/chmd extract() caller gets
+  secondary       BASELINE configs 2 (4096 MSZIP blocks) and 4 (512 Quantum folders, window 21, 32 frames)
+  cpu_baseline    the real reference lzxd on the host cores (oracle/_ref), or -- loudly -- our CPU port
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -20,6 +36,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "decompressed MB/s (whole node), LZX 21-bit window, 4096-interval batch"
 
 
 def usable_cpus():
@@ -45,18 +62,21 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(comp, off, ln, n_units, unit_bytes, budget_s=12.0):
+def cpu_baseline(comp, off, ln, n_units, unit_bytes):
     """Reference CPU path (oracle/_ref = the real libmspack lzxd, built from /root/reference in the
-    dev container) over the same units on the host cores; falls back to our CPU restatement."""
+    dev container) over the same units on the host cores.  If oracle/_ref did not travel, the line says so
+    in so many words and times our CPU restatement instead (kind "port")."""
     import ctypes as C
+    import helpers
     cores = usable_cpus()
-    try:
-        import helpers
-        if helpers.have_ref():
+    why = "oracle/_ref/librefharness.so is missing"
+    if helpers.have_ref():
+        try:
             R = helpers.ref()
             off64 = np.ascontiguousarray(off, dtype=np.uint64)
             ilen = np.ascontiguousarray(ln + 4, dtype=np.uint32)
             olen = np.full(n_units, unit_bytes, dtype=np.uint32)
+
             def run(threads, reps):
                 b = C.c_ulonglong(0); e = C.c_int(0)
                 t = R.refh_bench(0, comp.ctypes.data, off64.ctypes.data, ilen.ctypes.data, olen.ctypes.data,
@@ -65,18 +85,18 @@ def cpu_baseline(comp, off, ln, n_units, unit_bytes, budget_s=12.0):
                     raise RuntimeError("reference failed on %d units" % e.value)
                 return b.value / t / 1e6, t
             one, _t = run(1, 1)                                   # one core, one pass: MB/s per core
-            # one thread per usable CPU; enough passes for ~15 s of wall time
             est_pass_s = n_units * unit_bytes / (one * 1e6) / cores
             reps = max(2, min(256, int(15.0 / max(est_pass_s, 1e-3))))
             allv, tall = run(cores, reps)
             return {"value": round(allv, 1), "unit": "MB/s", "cores": cores, "kind": "reference",
                     "one_core_MBps": round(one, 1), "host_threads": os.cpu_count(),
-                    "sample": "%d passes over the same %d-unit batch (%.0f MiB decoded per pass) on %d threads (= usable CPUs: affinity and cgroup quota) in "
-                              "%.2f s, threads released together; libmspack lzxd_decompress memory-to-memory, one "
-                              "decompressor per thread" % (reps, n_units, n_units * unit_bytes / 2**20, cores, tall)}
-    except Exception as ex:          # pragma: no cover
-        sys.stderr.write("cpu_baseline: reference unavailable (%s); using the port\n" % ex)
-    import helpers
+                    "sample": "%d passes over the same %d-unit batch (%.0f MiB decoded per pass) on %d threads (= usable "
+                              "CPUs: affinity and cgroup quota) in %.2f s, threads released together; libmspack "
+                              "lzxd_decompress memory-to-memory, one decompressor per thread" %
+                              (reps, n_units, n_units * unit_bytes / 2**20, cores, tall)}
+        except Exception as ex:          # pragma: no cover
+            why = "the reference harness failed: %s" % ex
+    sys.stderr.write("bench.py: WARNING: cpu_baseline is NOT the reference (%s); timing the CPU port instead\n" % why)
     sample = min(n_units, 256)
     t0 = time.perf_counter()
     for i in range(sample):
@@ -85,7 +105,181 @@ def cpu_baseline(comp, off, ln, n_units, unit_bytes, budget_s=12.0):
         assert e == 0
     dt = time.perf_counter() - t0
     return {"value": round(sample * unit_bytes / dt / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": "port",
-            "sample": "first %d units, single thread, oracle/liboracle.so" % sample}
+            "fallback": True, "fallback_reason": why,
+            "sample": "first %d units, single thread, oracle/liboracle.so (NOT the reference)" % sample}
+
+
+# ---- device-resident batch: upload once, time launches with HIP events on the launch stream ----------------
+class DeviceBatch:
+    def __init__(self, M, torch, dev, units, comp, out_bytes, kind):
+        self.M, self.torch, self.kind = M, torch, kind
+        self.n = len(units)
+        self.units, self.comp_size, self.out_bytes = units, int(comp.size), int(out_bytes)
+        self.n_frames = int(M.frames_of(units).sum())
+        order = np.argsort(-(units["in_len"].astype(np.int64)), kind="stable").astype(np.uint32)   # longest first
+        self.d_in = torch.zeros(comp.size + 64, dtype=torch.uint8, device=dev)
+        self.d_in[:comp.size] = torch.from_numpy(comp).to(dev)
+        self.d_units = torch.from_numpy(units.view(np.uint8)).to(dev)
+        self.d_order = torch.from_numpy(order.view(np.uint8)).to(dev)
+        self.d_out = torch.zeros(out_bytes + 64, dtype=torch.uint8, device=dev)
+        self.d_res = torch.zeros(self.n * M.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        self.d_fm = torch.zeros(max(64, M.lib().mspack_hip_frame_scratch_bytes(self.n_frames)), dtype=torch.uint8, device=dev)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.L = M.lib()
+
+    def _args(self):
+        return (self.d_units.data_ptr(), self.d_order.data_ptr(), self.n, self.d_in.data_ptr(), self.comp_size,
+                self.d_out.data_ptr(), self.out_bytes, self.d_res.data_ptr(), self.d_fm.data_ptr(), self.n_frames,
+                1 << self.kind, self.stream)
+
+    def step(self):
+        rc = self.L.mspack_hip_decode_batch_device(*self._args())
+        if rc:
+            raise RuntimeError(self.L.mspack_hip_last_error().decode())
+
+    def kernel_ms(self, iters):
+        ms = self.L.mspack_hip_time_batch_device(*(self._args() + (iters,)))
+        self.torch.cuda.synchronize()
+        if ms < 0:
+            raise RuntimeError("mspack_hip_time_batch_device failed")
+        return ms
+
+    def results(self):
+        return self.d_res.cpu().numpy().view(self.M.RESULT_DTYPE)
+
+    def output(self):
+        return self.d_out.cpu().numpy()
+
+
+def roofline(algo_bytes, ms, kernel, **extra):
+    gbs = algo_bytes / (ms * 1e-3) / 1e9
+    d = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(gbs / HBM_PEAK_GBS, 5), "kernel": kernel, "kernel_ms": round(ms, 4),
+         "algorithmic_bytes_per_launch": int(algo_bytes)}
+    d.update(extra)
+    return d
+
+
+def secondary_mszip(M, torch, dev, n=4096, ub=32768, iters=10):
+    """BASELINE config 2: n independent MSZIP CFDATA blocks ('CK' + raw deflate, zlib level 6), one per unit"""
+    import zlib
+    plain = M.gen_plaintext(0xC0FFEE, 0, n * ub)
+    parts, offs, lens, pos = [], [], [], 0
+    for i in range(n):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        blob = b"CK" + co.compress(plain[i * ub:(i + 1) * ub].tobytes()) + co.flush()
+        pad = (-len(blob)) % 16
+        offs.append(pos); lens.append(len(blob)); parts.append(blob + b"\0" * pad); pos += len(blob) + pad
+    comp = np.frombuffer(b"".join(parts) + b"\0" * 64, dtype=np.uint8).copy()
+    off = np.array(offs, dtype=np.uint64); ln = np.array(lens, dtype=np.uint32)
+    units, out_bytes = M.make_units(M.KIND_MSZIP, off, ln, np.full(n, ub), out_slack=32768)
+    b = DeviceBatch(M, torch, dev, units, comp, out_bytes, M.KIND_MSZIP)
+    b.step(); torch.cuda.synchronize()
+    ms = b.kernel_ms(iters)
+    res, out = b.results(), b.output()
+    oo = units["out_off"].astype(np.int64)
+    ok = bool((res["err"] == 0).all()) and all(np.array_equal(out[oo[i]:oo[i] + ub], plain[i * ub:(i + 1) * ub]) for i in range(n))
+    return {"config": "BASELINE config 2: %d independent MSZIP CFDATA blocks of %d KiB (zlib level 6), ratio %.3f" %
+                      (n, ub // 1024, float(ln.sum()) / (n * ub)),
+            "value": round(n * ub / ms / 1e3, 1), "unit": "MB/s", "kernel_ms": round(ms, 4), "bit_exact": ok,
+            "roofline": roofline(float(ln.sum()) + n * ub, ms, "mspack_decode_mszip")}
+
+
+def secondary_qtm(M, torch, dev, n=512, frames=32, window_bits=21, iters=2):
+    """BASELINE config 4 as SURVEY 8(d) specifies it: comp_type 0x1572 -- Quantum, window 2^21 -- n folders of
+    `frames` 32 KiB blocks each (the folder stream as cabd feeds it: every block followed by the 0xFF trailer)"""
+    from concurrent.futures import ThreadPoolExecutor
+    ub = frames * 32768
+    plain = M.gen_plaintext(0xC0FFEE, 0, n * ub)
+
+    def enc(i):
+        st, _fs = M.qtm_encode(plain[i * ub:(i + 1) * ub], window_bits)
+        return bytes(st)
+    with ThreadPoolExecutor(max_workers=usable_cpus()) as ex:
+        blobs = list(ex.map(enc, range(n)))
+    parts, offs, lens, pos = [], [], [], 0
+    for blob in blobs:
+        pad = (-len(blob)) % 16
+        offs.append(pos); lens.append(len(blob)); parts.append(blob + b"\0" * pad); pos += len(blob) + pad
+    comp = np.frombuffer(b"".join(parts) + b"\0" * 64, dtype=np.uint8).copy()
+    off = np.array(offs, dtype=np.uint64); ln = np.array(lens, dtype=np.uint32)
+    units, out_bytes = M.make_units(M.KIND_QUANTUM, off, ln, np.full(n, ub), window_bits=window_bits)
+    b = DeviceBatch(M, torch, dev, units, comp, out_bytes, M.KIND_QUANTUM)
+    b.step(); torch.cuda.synchronize()
+    ms = b.kernel_ms(iters)
+    res, out = b.results(), b.output()
+    oo = units["out_off"].astype(np.int64)
+    ok = bool((res["err"] == 0).all()) and all(np.array_equal(out[oo[i]:oo[i] + ub], plain[i * ub:(i + 1) * ub]) for i in range(n))
+    return {"config": "BASELINE config 4: %d Quantum folders (comp_type 0x1572: window 2^%d), %d blocks = %d KiB each, ratio %.3f" %
+                      (n, window_bits, frames, ub // 1024, float(ln.sum()) / (n * ub)),
+            "value": round(n * ub / ms / 1e3, 1), "unit": "MB/s", "kernel_ms": round(ms, 4), "bit_exact": ok,
+            "roofline": roofline(float(ln.sum()) + n * ub, ms, "mspack_decode_qtm")}
+
+
+def host_inclusive(M, torch, dev, units, comp, out_bytes, plain, n, ub, reps=5):
+    """SURVEY 8(d)'s metric as written: compressed units in (pageable) HOST memory -> decoded bytes in device
+    memory, and -> decoded bytes back in host memory; the host-buffer entry points the C drivers call."""
+    L = M.lib()
+    u = np.ascontiguousarray(units.copy())
+    res = np.zeros(n, dtype=M.RESULT_DTYPE)
+    d_out = torch.zeros(out_bytes + 64, dtype=torch.uint8, device=dev)
+    h_out = np.zeros(out_bytes + 64, dtype=np.uint8)            # written once here: pages exist (a reused buffer)
+
+    def to_dev():
+        rc = L.mspack_hip_decode_batch_to_device(u.ctypes.data, n, comp.ctypes.data, comp.size, d_out.data_ptr(),
+                                                 out_bytes + 64, res.ctypes.data)
+        if rc:
+            raise RuntimeError(L.mspack_hip_last_error().decode())
+
+    def to_host():
+        rc = L.mspack_hip_decode_batch(u.ctypes.data, n, comp.ctypes.data, comp.size, h_out.ctypes.data,
+                                       out_bytes + 64, res.ctypes.data)
+        if rc:
+            raise RuntimeError(L.mspack_hip_last_error().decode())
+
+    def best(fn):
+        fn()                                                    # grows the persistent context
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return min(ts), sum(ts) / len(ts)
+    bd, md = best(to_dev)
+    ok_d = bool((res["err"] == 0).all()) and np.array_equal(d_out[:n * ub].cpu().numpy(), plain)
+    bh, mh = best(to_host)
+    ok_h = bool((res["err"] == 0).all()) and np.array_equal(h_out[:n * ub], plain)
+    # the bare copies of the same arenas, for scale (pageable host memory, existing device tensors)
+    d_in = torch.zeros(comp.size, dtype=torch.uint8, device=dev)
+    src = torch.from_numpy(comp)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); d_in.copy_(src); torch.cuda.synchronize(); h2d = time.perf_counter() - t0
+    dst = torch.from_numpy(h_out)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); dst.copy_(d_out); torch.cuda.synchronize(); d2h = time.perf_counter() - t0
+    tot = n * ub
+    return {"MBps": round(tot / md / 1e6, 1), "MBps_best": round(tot / bd / 1e6, 1), "ms": round(md * 1e3, 3),
+            "what": "mspack_hip_decode_batch_to_device: pageable host input -> decoded bytes in HBM (mean of %d calls)" % reps,
+            "to_host_MBps": round(tot / mh / 1e6, 1), "to_host_MBps_best": round(tot / bh / 1e6, 1),
+            "to_host_ms": round(mh * 1e3, 3),
+            "to_host_what": "mspack_hip_decode_batch: ... -> decoded bytes in (pageable, already touched) host memory",
+            "h2d_ms": round(h2d * 1e3, 3), "d2h_ms": round(d2h * 1e3, 3), "h2d_MB": round(comp.size / 1e6, 1),
+            "d2h_MB": round(out_bytes / 1e6, 1), "bit_exact": bool(ok_d and ok_h)}
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks ourselves (one process per GPU)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s); refusing to report a %d-GPU line from fewer devices"
+                         % (args.gpus, have, args.gpus))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %s" % rcs)
 
 
 def main():
@@ -93,51 +287,47 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--units", type=int, default=4096, help="reset intervals per GPU")
+    ap.add_argument("--units", type=int, default=4096, help="reset intervals per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--total-units", type=int, default=65536, help="strong scaling: intervals in the global list (BASELINE config 5)")
     ap.add_argument("--unit-kib", type=int, default=64)
     ap.add_argument("--text", type=int, default=0, help="plaintext family (0 = mix)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive and the secondary configs")
     ap.add_argument("--exp", action="store_true", help="kernel experiments: skip the parity gate and the CPU leg (the line is then NOT a valid result)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+
     import torch
     import libmspack_amd as M
-
     from libmspack_amd import dist as D
     rank, world, local = D.env_rank_world()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s); refusing to print a line whose n_gpus "
+                         "differs from the request" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants GPU %d but this box has %d" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
-    dist = D.init("nccl", torch.device("cuda", local))
-
-    n, ub = args.units, args.unit_kib * 1024
-    # ---- synthetic corpus: every rank its own seeds (weak scaling: fixed work per GPU) ----
-    t0 = time.perf_counter()
-    plain, comp, off, ln = M.corpus_lzx_units(D.unit_seed_base(0xBA5E11, rank), args.text, n, ub, 21,
-                                              n_threads=max(1, usable_cpus() // max(world, 1)))
-    gen_s = time.perf_counter() - t0
-    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21,
-                                    reset_frames=ub // 32768)
-    order = np.argsort(-(ln.astype(np.int64)), kind="stable").astype(np.uint32)   # longest first
-    n_frames = int(M.frames_of(units).sum())
-
     dev = torch.device("cuda", local)
-    d_in = torch.zeros(comp.size + 64, dtype=torch.uint8, device=dev)
-    d_in[:comp.size] = torch.from_numpy(comp).to(dev)
-    d_units = torch.from_numpy(units.view(np.uint8)).to(dev)
-    d_order = torch.from_numpy(order.view(np.uint8)).to(dev)
-    d_out = torch.zeros(out_bytes + 64, dtype=torch.uint8, device=dev)
-    d_res = torch.zeros(n * M.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-    d_fm = torch.zeros(M.lib().mspack_hip_frame_scratch_bytes(n_frames), dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    L = M.lib()
+    dist = D.init("nccl", dev)
 
-    def step():
-        rc = L.mspack_hip_decode_batch_device(d_units.data_ptr(), d_order.data_ptr(), n, d_in.data_ptr(), comp.size,
-                                              d_out.data_ptr(), out_bytes, d_res.data_ptr(), d_fm.data_ptr(),
-                                              n_frames, 1 << M.KIND_LZX, stream)
-        if rc:
-            raise RuntimeError(L.mspack_hip_last_error().decode())
+    ub = args.unit_kib * 1024
+    threads = max(1, usable_cpus() // max(world, 1))
+    t0 = time.perf_counter()
+    if args.scaling == "strong":
+        lo, hi = D.shard_range(args.total_units, rank, world)      # contiguous shard of ONE global list
+        n = hi - lo
+        plain, comp, off, ln = M.corpus_lzx_units(0xC0F165, args.text, n, ub, 21, n_threads=threads, first_unit=lo)
+    else:
+        n = args.units                                             # every rank its own corpus: fixed work per GPU
+        plain, comp, off, ln = M.corpus_lzx_units(D.unit_seed_base(0xBA5E11, rank), args.text, n, ub, 21, n_threads=threads)
+    gen_s = time.perf_counter() - t0
+    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=ub // 32768)
+    batch = DeviceBatch(M, torch, dev, units, comp, out_bytes, M.KIND_LZX)
 
     def barrier():
         if dist is not None:
@@ -145,67 +335,73 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        batch.step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        batch.step()
     barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed, total_out = D.reduce_scalars(dist, dev, elapsed, float(n * ub))
+    my_elapsed = time.perf_counter() - t0
+    elapsed, total_out = D.reduce_scalars(dist, dev, my_elapsed, float(n * ub))
+    per_rank_ms = D.gather_scalar(dist, dev, my_elapsed / args.steps * 1e3)
 
-    # ---- kernel-only duration with HIP events on the launch stream (roofline numerator) ----
-    ms_kernel = L.mspack_hip_time_batch_device(d_units.data_ptr(), d_order.data_ptr(), n, d_in.data_ptr(), comp.size,
-                                               d_out.data_ptr(), out_bytes, d_res.data_ptr(), d_fm.data_ptr(),
-                                               n_frames, 1 << M.KIND_LZX, stream, max(3, min(args.steps, 10)))
-    torch.cuda.synchronize()
+    ms_kernel = batch.kernel_ms(max(3, min(args.steps, 10)))       # roofline numerator: HIP events on the launch stream
 
     # ---- parity: every unit, every byte, outside the timed region ----
-    res = d_res.cpu().numpy().view(M.RESULT_DTYPE)
-    out = d_out[:n * ub].cpu().numpy()
+    res = batch.results()
+    out = batch.output()[:n * ub]
     ok = bool((res["err"] == 0).all() and (res["out_len"] == ub).all() and np.array_equal(out, plain))
-    if not ok and not args.exp:
-        raise SystemExit("rank %d: GPU output is NOT bit-exact; refusing to report a number" % rank)
+    all_ok = D.all_true(dist, dev, ok)
+    if not all_ok and not args.exp:
+        raise SystemExit("rank %d: GPU output is NOT bit-exact on some rank; refusing to report a number" % rank)
 
     comp_bytes = float(ln.sum())
-    # HBM traffic per launch: PMC counters cannot be collected from inside this process; the latest
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload are kept in profiles/
-    traffic = None
+    algo_bytes = comp_bytes + n * ub                      # SURVEY.md 8(d): in + out, per launch
+    # HBM traffic per launch: PMC counters cannot be collected from inside this process; the latest rocprofv3
+    # --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload are kept in profiles/traffic.json
+    traffic, traffic_source = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         w = tj["workload"]
-        if (w["units_per_gpu"], w["unit_bytes"], w["text"]) == (n, ub, args.text):
-            # FETCH_SIZE counts 64 B per 128-B request on gfx950 (the guide's x2; calibrated on this
-            # kernel's stored-block copy, see profiles/traffic.json)
+        if (w["units_per_gpu"], w["unit_bytes"], w["text"]) == (n, ub, args.text) and args.scaling == "weak":
             traffic = int((tj["fetch_kib_per_launch"] * tj.get("fetch_correction", 1.0) + tj["write_kib_per_launch"]) * 1024)
+            traffic_source = "profiles/traffic.json (rocprofv3 --pmc passes of this workload, %s; replayed, not measured in this run)" % tj.get("round", "earlier round")
     except Exception:
         traffic = None
-    algo_bytes = comp_bytes + n * ub                      # SURVEY.md 8(d): in + out, per launch
     if rank == 0:
+        if args.scaling == "strong":
+            wl = ("BASELINE config 5: CHM-style LZX, window_bits=21, reset interval %d frames (%d KiB), %d intervals in one "
+                  "global list sharded contiguously over %d GPU(s) (%d on rank 0), plaintext family %d" %
+                  (ub // 32768, args.unit_kib, args.total_units, world, n, args.text))
+        else:
+            wl = ("CHM-style LZX, window_bits=21, reset interval %d frames (%d KiB), %d intervals per GPU, plaintext family "
+                  "%d, ratio %.3f" % (ub // 32768, args.unit_kib, n, args.text, comp_bytes / (n * ub)))
         line = {
-            "metric": "decompressed MB/s (whole node), LZX 21-bit window, 4096-interval batch",
+            "metric": METRIC,
             "value": round(total_out * args.steps / elapsed / 1e6, 1),
             "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "CHM-style LZX, window_bits=21, reset interval %d frames (%d KiB), %d "
-                                   "intervals per GPU, plaintext family %d, ratio %.3f" %
-                                   (ub // 32768, args.unit_kib, n, args.text, comp_bytes / (n * ub)),
-                       "units_per_gpu": n, "unit_bytes": ub, "bit_exact": ok,
-                       "corpus_gen_s": round(gen_s, 2)},
-            "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (ms_kernel * 1e-3) / 1e9, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(algo_bytes / (ms_kernel * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "kernel": "mspack_decode_lzx", "kernel_ms": round(ms_kernel, 4),
-                         "algorithmic_bytes_per_launch": int(algo_bytes)},
+            "config": {"workload": wl, "units_per_gpu": n, "unit_bytes": ub, "bit_exact": all_ok,
+                       "corpus_gen_s": round(gen_s, 2), "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+                       "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else ("self-spawned" if world > 1 else "single")},
+            "roofline": roofline(algo_bytes, ms_kernel, "mspack_decode_lzx", traffic=traffic, traffic_source=traffic_source),
         }
+        extras = world == 1 and not args.exp and not args.no_extras
+        if extras:
+            line["host_inclusive"] = host_inclusive(M, torch, dev, units, comp, out_bytes, plain, n, ub)
+        del batch
+        torch.cuda.empty_cache()
+        if extras:
+            line["secondary"] = [secondary_mszip(M, torch, dev), secondary_qtm(M, torch, dev)]
         if world == 1 and not args.no_cpu and not args.exp:
             line["cpu_baseline"] = cpu_baseline(comp, off, ln, n, ub)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

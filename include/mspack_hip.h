@@ -125,17 +125,32 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
                                    void *stream);
 size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total);
 
-/* ---- host-buffer convenience (what the C drivers in mspack.h use) ------------------------------
- * Same semantics with HOST pointers: stages the arenas to the current device, decodes, copies the
- * outputs and results back.  `units[i].frame_base` is filled in by the call.  Synchronous. */
+/* ---- host-buffer entry points (what the C drivers in mspack.h use) -------------------------------------
+ * Same semantics with HOST pointers.  Each device keeps a persistent context (device arenas and pinned
+ * staging grown on demand, a set of streams; MSPACK_HIP_NSTREAMS, default 8): the batch is cut into chunks
+ * of units that are contiguous in the arenas, and chunk c's input copy, its launches (one per codec over a
+ * compact list of that codec's units) and its copy-back run on stream c, so copies overlap the decode of the
+ * other chunks.  `units[i].frame_base` is filled in by the call.  Synchronous.  Bytes of the output arena
+ * BETWEEN units that lie inside a copied span (alignment padding, the MSZIP slack) are unspecified afterwards.
+ * Thread-safe; calls that target the same device are serialised. */
 int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
                             void *out, size_t out_bytes, mspack_hip_result *results);
 
+/* Host input, DEVICE output: as above, but the decoded bytes stay in the caller's device buffer `d_out` on
+ * the current device (unit out_off relative to it; LZX DELTA reference data must already be there). */
+int mspack_hip_decode_batch_to_device(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
+                                      void *d_out, size_t out_bytes, mspack_hip_result *results);
+
 /* Shard the same host batch across `n_devices` GPUs (devices 0..n_devices-1), one host thread per
- * device, no inter-device traffic.  Units are dealt longest-first. */
+ * device, no inter-device traffic: the units, in arena order, are cut into n_devices
+ * contiguous ranges of about equal compressed size, so every device stages one contiguous span of each
+ * arena.  (MSPACK_HIP_FORCE_SHARDS=k cuts into k shards even on fewer devices -- tests of this path.) */
 int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const void *in,
                                   size_t in_bytes, void *out, size_t out_bytes,
                                   mspack_hip_result *results, int n_devices);
+
+/* Free every persistent per-device context of this process (arenas, pinned staging, streams). */
+void mspack_hip_release(void);
 
 /* ---- process-wide defaults for the object API (mspack.h) ----------------------------------------------
  * mscab_decompressor has set_param (MSCABD_PARAM_HIP_DEVICES / _HIP_CACHE_MB); the CHM, OAB, SZDD and KWAJ

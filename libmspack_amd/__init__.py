@@ -57,6 +57,8 @@ def lib():
         L.mspack_hip_time_batch_device.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, vp, sz, C.c_uint, vp, C.c_int]
         L.mspack_hip_decode_batch.argtypes = [vp, sz, vp, sz, vp, sz, vp]
         L.mspack_hip_decode_batch_multi.argtypes = [vp, sz, vp, sz, vp, sz, vp, C.c_int]
+        L.mspack_hip_decode_batch_to_device.argtypes = [vp, sz, vp, sz, vp, sz, vp]
+        L.mspack_hip_release.restype = None
         _lib = L
     return _lib
 
@@ -65,6 +67,7 @@ EXPORTED_SYMBOLS = [
     "mspack_hip_device_count", "mspack_hip_set_device", "mspack_hip_version", "mspack_hip_last_error",
     "mspack_hip_decode_batch_device", "mspack_hip_frame_scratch_bytes", "mspack_hip_decode_batch",
     "mspack_hip_decode_batch_multi", "mspack_hip_time_batch_device",
+    "mspack_hip_decode_batch_to_device", "mspack_hip_release",
     "mspack_hip_set_default_devices", "mspack_hip_default_devices", "mspack_hip_set_cache_mb", "mspack_hip_cache_mb",
 ]
 
@@ -157,6 +160,9 @@ def corpus():
         L.mspk_corpus_lzx_units.restype = sz
         L.mspk_corpus_lzx_units.argtypes = [C.c_uint64, C.c_int, C.c_int, sz, C.c_int, C.POINTER(LzxOpts),
                                             C.c_int, vp, vp, sz, vp, vp]
+        L.mspk_corpus_lzx_units_at.restype = sz
+        L.mspk_corpus_lzx_units_at.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, sz, C.c_int, C.POINTER(LzxOpts),
+                                               C.c_int, vp, vp, sz, vp, vp]
         L.mspk_cab_write.restype = sz
         L.mspk_cab_write.argtypes = [vp, C.c_int, vp, C.c_int, vp, sz]
         L.mspk_chm_write.restype = sz
@@ -212,8 +218,9 @@ def lzx_encode(data, window_bits, reset_frames, opts=None):
     return dst[:m].copy(), fo
 
 
-def corpus_lzx_units(base_seed, kind, n_units, unit_bytes, window_bits, opts=None, n_threads=None):
-    """Batch of independent LZX units (one reset interval each).
+def corpus_lzx_units(base_seed, kind, n_units, unit_bytes, window_bits, opts=None, n_threads=None, first_unit=0):
+    """Batch of independent LZX units (one reset interval each); first_unit: global index of the first
+    one when the call makes a shard of a larger list (unit seeds follow the global index).
     -> (plain [n_units*unit_bytes], comp arena, comp_off u64[n], comp_len u32[n])"""
     L = corpus()
     if n_threads is None:
@@ -224,8 +231,9 @@ def corpus_lzx_units(base_seed, kind, n_units, unit_bytes, window_bits, opts=Non
     off = np.zeros(n_units, dtype=np.uint64)
     ln = np.zeros(n_units, dtype=np.uint32)
     o = opts if opts is not None else lzx_opts()
-    total = L.mspk_corpus_lzx_units(base_seed, kind, n_units, unit_bytes, window_bits, C.byref(o), n_threads,
-                                    plain.ctypes.data, comp.ctypes.data, cap, off.ctypes.data, ln.ctypes.data)
+    total = L.mspk_corpus_lzx_units_at(base_seed, first_unit, kind, n_units, unit_bytes, window_bits, C.byref(o),
+                                       n_threads, plain.ctypes.data, comp.ctypes.data, cap, off.ctypes.data,
+                                       ln.ctypes.data)
     if total == 0:
         raise MspackHipError("mspk_corpus_lzx_units failed")
     return plain, comp[:total + 64].copy(), off, ln

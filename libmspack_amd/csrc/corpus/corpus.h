@@ -96,6 +96,12 @@ size_t mspk_corpus_lzx_units(uint64_t base_seed, int kind, int n_units, size_t u
                              int window_bits, const mspk_lzx_opts *opts, int n_threads,
                              uint8_t *plain, uint8_t *comp, size_t comp_cap,
                              uint64_t *comp_off, uint32_t *comp_len);
+/* the same for units [first_unit, first_unit + n_units) of a larger global list (a rank's shard of a
+ * strong-scaling corpus): unit i of the call gets the seed of global unit first_unit + i */
+size_t mspk_corpus_lzx_units_at(uint64_t base_seed, uint64_t first_unit, int kind, int n_units, size_t unit_bytes,
+                                int window_bits, const mspk_lzx_opts *opts, int n_threads,
+                                uint8_t *plain, uint8_t *comp, size_t comp_cap,
+                                uint64_t *comp_off, uint32_t *comp_len);
 
 #ifdef __cplusplus
 }

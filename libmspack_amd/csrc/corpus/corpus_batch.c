@@ -10,6 +10,7 @@ typedef struct {
   const mspk_lzx_opts *opts;
   uint8_t *plain; uint8_t **tmp; size_t *tmp_len;
   int first, last;
+  uint64_t index0;               /* global index of unit 0 of this call (strong-scaling shards) */
 } job_t;
 
 static void *worker(void *arg) {
@@ -20,7 +21,7 @@ static void *worker(void *arg) {
     uint8_t *p = j->plain + (size_t) u * j->unit_bytes;
     int reset = (int)((j->unit_bytes + 32767) / 32768);
     /* unit_seed = golden-ratio hash of (config<<32 | unit) */
-    mspk_gen_plaintext(j->base_seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(u + 1)), j->kind, p, j->unit_bytes);
+    mspk_gen_plaintext(j->base_seed ^ (0x9E3779B97F4A7C15ull * (j->index0 + (uint64_t) u + 1ull)), j->kind, p, j->unit_bytes);
     j->tmp[u] = (uint8_t *) malloc(bound);
     j->tmp_len[u] = mspk_lzx_encode(p, j->unit_bytes, j->window_bits, reset, j->opts, j->tmp[u], bound, NULL);
   }
@@ -31,6 +32,15 @@ size_t mspk_corpus_lzx_units(uint64_t base_seed, int kind, int n_units, size_t u
                              int window_bits, const mspk_lzx_opts *opts, int n_threads,
                              uint8_t *plain, uint8_t *comp, size_t comp_cap,
                              uint64_t *comp_off, uint32_t *comp_len)
+{
+  return mspk_corpus_lzx_units_at(base_seed, 0, kind, n_units, unit_bytes, window_bits, opts, n_threads,
+                                  plain, comp, comp_cap, comp_off, comp_len);
+}
+
+size_t mspk_corpus_lzx_units_at(uint64_t base_seed, uint64_t first_unit, int kind, int n_units, size_t unit_bytes,
+                                int window_bits, const mspk_lzx_opts *opts, int n_threads,
+                                uint8_t *plain, uint8_t *comp, size_t comp_cap,
+                                uint64_t *comp_off, uint32_t *comp_len)
 {
   pthread_t th[256];
   job_t jobs[256];
@@ -44,7 +54,7 @@ size_t mspk_corpus_lzx_units(uint64_t base_seed, int kind, int n_units, size_t u
   for (t = 0; t < n_threads; t++) {
     jobs[t].base_seed = base_seed; jobs[t].kind = kind; jobs[t].window_bits = window_bits;
     jobs[t].unit_bytes = unit_bytes; jobs[t].opts = opts; jobs[t].plain = plain;
-    jobs[t].tmp = tmp; jobs[t].tmp_len = tmp_len;
+    jobs[t].tmp = tmp; jobs[t].tmp_len = tmp_len; jobs[t].index0 = first_unit;
     jobs[t].first = (int)((long long) n_units * t / n_threads);
     jobs[t].last  = (int)((long long) n_units * (t + 1) / n_threads);
     pthread_create(&th[t], NULL, worker, &jobs[t]);

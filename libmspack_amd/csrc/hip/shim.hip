@@ -8,6 +8,7 @@
 #include <chrono>
 #include <vector>
 #include <algorithm>
+#include <array>
 #include "wave_common.hpp"
 #include "spec_queue.hpp"
 // lzx_kernel.hpp is compiled twice: plain LZX (CAB, CHM) and LZX DELTA (OAB) -- see its header
@@ -134,6 +135,10 @@ void mspack_decode_kwaj_lzh(const mspack_hip_unit *units, const u32 *order, u32 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Host side of the C ABI.
+// ---------------------------------------------------------------------------------------------------
+#include <mutex>
+#include <atomic>
 static thread_local char g_err[256] = "";
 static int fail(hipError_t e, const char *what) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
@@ -141,9 +146,38 @@ static int fail(hipError_t e, const char *what) {
 }
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(e_, #call); } while (0)
 
+// one launch per codec over a COMPACT list of that codec's units (order[0..n) = unit indices)
+static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
+                        const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, hipStream_t st)
+{
+  if (n == 0) return;
+  const dim3 grid((unsigned) n), block(64);
+  switch (kind) {
+  case MSPACK_HIP_KIND_LZX:
+    hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
+                       d_results, (int32_t *) d_fm); break;
+  case MSPACK_HIP_KIND_LZX_DELTA:
+    hipLaunchKernelGGL(mspack_decode_lzxd, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
+                       d_results, (int32_t *) d_fm); break;
+  case MSPACK_HIP_KIND_MSZIP:
+    hipLaunchKernelGGL(mspack_decode_mszip, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
+                       d_results); break;
+  case MSPACK_HIP_KIND_QUANTUM:
+    hipLaunchKernelGGL(mspack_decode_qtm, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
+                       d_results); break;
+  case MSPACK_HIP_KIND_LZSS:
+    hipLaunchKernelGGL(mspack_decode_lzss, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
+                       d_results); break;
+  case MSPACK_HIP_KIND_KWAJ_LZH:
+    hipLaunchKernelGGL(mspack_decode_kwaj_lzh, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
+                       d_results); break;
+  default: break;
+  }
+}
+
 extern "C" {
 
-const char *mspack_hip_version(void) { return "mspack-hip 0.2 (gfx950; LZX/LZX-DELTA/Quantum/MSZIP batch decode)"; }
+const char *mspack_hip_version(void) { return "mspack-hip 0.3 (gfx950; LZX/LZX-DELTA/Quantum/MSZIP batch decode)"; }
 const char *mspack_hip_last_error(void) { return g_err; }
 
 int mspack_hip_device_count(void) {
@@ -165,26 +199,12 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
   (void) in_bytes; (void) out_bytes; (void) n_frames_total;
   if (n_units == 0) return 0;
   if (kind_mask == 0) kind_mask = 0x7E;     // bit k = units of kind k may be present
-  const dim3 grid((unsigned) n_units), block(64);
-  hipStream_t st = (hipStream_t) stream;
-  if (kind_mask & (1u << MSPACK_HIP_KIND_LZX))
-    hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n_units,
-                       (const u8 *) d_in, (u8 *) d_out, d_results, (int32_t *) d_frame_scratch);
-  if (kind_mask & (1u << MSPACK_HIP_KIND_LZX_DELTA))
-    hipLaunchKernelGGL(mspack_decode_lzxd, grid, block, 0, st, d_units, d_order, (u32) n_units,
-                       (const u8 *) d_in, (u8 *) d_out, d_results, (int32_t *) d_frame_scratch);
-  if (kind_mask & (1u << MSPACK_HIP_KIND_MSZIP))
-    hipLaunchKernelGGL(mspack_decode_mszip, grid, block, 0, st, d_units, d_order, (u32) n_units,
-                       (const u8 *) d_in, (u8 *) d_out, d_results);
-  if (kind_mask & (1u << MSPACK_HIP_KIND_QUANTUM))
-    hipLaunchKernelGGL(mspack_decode_qtm, grid, block, 0, st, d_units, d_order, (u32) n_units,
-                       (const u8 *) d_in, (u8 *) d_out, d_results);
-  if (kind_mask & (1u << MSPACK_HIP_KIND_LZSS))
-    hipLaunchKernelGGL(mspack_decode_lzss, grid, block, 0, st, d_units, d_order, (u32) n_units,
-                       (const u8 *) d_in, (u8 *) d_out, d_results);
-  if (kind_mask & (1u << MSPACK_HIP_KIND_KWAJ_LZH))
-    hipLaunchKernelGGL(mspack_decode_kwaj_lzh, grid, block, 0, st, d_units, d_order, (u32) n_units,
-                       (const u8 *) d_in, (u8 *) d_out, d_results);
+  // the caller's unit table lives on the device, so the kinds cannot be compacted here: every codec in the
+  // mask gets the whole grid and blocks of other kinds leave at once.  Callers with mixed batches pass one
+  // order list per codec and a one-bit mask (what the host-buffer entry points below do).
+  for (unsigned k = 1; k <= 6; k++)
+    if (kind_mask & (1u << k))
+      launch_kind(k, d_units, d_order, n_units, d_in, d_out, d_results, d_frame_scratch, (hipStream_t) stream);
   CK(hipGetLastError());
   return 0;
 }
@@ -212,110 +232,241 @@ double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32
   return (double) ms / iters;
 }
 
-// frames (incl. the look-ahead slot) a unit needs in the per-frame scratch
-static inline size_t unit_frames(const mspack_hip_unit *u) {
-  return (u->kind == MSPACK_HIP_KIND_LZX || u->kind == MSPACK_HIP_KIND_LZX_DELTA) ? (size_t) u->out_len / 32768u + 1u : 0u;
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// Host-buffer path: a persistent context per device (device arenas and pinned staging grown on demand,
+// never freed per call; MSPACK_HIP_NSTREAMS streams) and a chunked pipeline.  The batch is cut into chunks of
+// units that are contiguous in the caller's arenas; chunk c lives on stream c mod NS:
+//     H2D of the chunk's input span -> one launch per codec over the chunk's compact unit lists -> D2H.
+// Chunks on different streams run concurrently, so the copy of chunk c+1 overlaps the decode of chunk c and
+// the copy-back of chunk c overlaps the decode of chunk c+1 -- and, because one unit is one wavefront's
+// serial chain, all chunks' kernels are resident together once their input has landed.
+// ---------------------------------------------------------------------------------------------------
+#define MSPK_MAX_DEV 16
+#define MSPK_MAX_STREAMS 8
+struct DevBuf { void *p = nullptr; size_t cap = 0; };
+struct DevCtx {
+  std::mutex mu;
+  bool ready = false;
+  int ns = 0;
+  hipStream_t st[MSPK_MAX_STREAMS];
+  DevBuf d_in, d_out, d_units, d_order, d_res, d_fm;
+  DevBuf h_stage;                       // pinned: results + (optionally) the output on its way to pageable memory
+};
+static DevCtx g_ctx[MSPK_MAX_DEV];
+
+static int env_int(const char *name, int dflt, int lo, int hi) {
+  const char *e = getenv(name);
+  int v = e ? atoi(e) : dflt;
+  return v < lo ? lo : (v > hi ? hi : v);
 }
 
-static int decode_on_current_device(mspack_hip_unit *units, const uint32_t *sel, size_t n_sel,
-                                    const void *in, size_t in_bytes, void *out, size_t out_bytes,
-                                    mspack_hip_result *results)
-{
-  // `sel` lists the unit indices this device handles (NULL = all n_sel units, identity).
-  // Units keep their arena offsets; only the arenas' touched extents are staged.
-  if (n_sel == 0) return 0;
-  std::vector<mspack_hip_unit> local(n_sel);
-  std::vector<uint32_t> order(n_sel);
-  size_t n_frames = 0;
-  unsigned kind_mask = 0;
-  uint64_t in_lo = ~0ull, in_hi = 0, out_lo = ~0ull, out_hi = 0;
-  for (size_t i = 0; i < n_sel; i++) {
-    size_t ui = sel ? sel[i] : i;
-    local[i] = units[ui];
-    local[i].frame_base = (uint32_t) n_frames;
-    units[ui].frame_base = (uint32_t) n_frames;
-    n_frames += unit_frames(&local[i]);
-    kind_mask |= 1u << (local[i].kind & 31u);
-    in_lo = std::min<uint64_t>(in_lo, local[i].in_off);
-    in_hi = std::max<uint64_t>(in_hi, local[i].in_off + local[i].in_len);
-    if (local[i].kind != MSPACK_HIP_KIND_LZX_DELTA) local[i].ref_len = 0;
-    // bytes below out_off that belong to the unit: DELTA reference data, the LZSS / LZH window pre-fill
-    const uint64_t below = (local[i].kind == MSPACK_HIP_KIND_LZSS || local[i].kind == MSPACK_HIP_KIND_KWAJ_LZH)
-                           ? 4096u : local[i].ref_len;
-    if (below > local[i].out_off) { snprintf(g_err, sizeof(g_err), "unit's lower region outside arena"); return -1; }
-    out_lo = std::min<uint64_t>(out_lo, local[i].out_off - below);
-    // MSZIP decodes whole blocks: its region carries 32768 bytes of slack (see mszip_kernel.hpp)
-    out_hi = std::max<uint64_t>(out_hi, local[i].out_off + local[i].out_len +
-                                        (local[i].kind == MSPACK_HIP_KIND_MSZIP ? 32768u : 0u));
-    order[i] = (uint32_t) i;
-  }
-  if (in_hi > in_bytes || out_hi > out_bytes) { snprintf(g_err, sizeof(g_err), "unit outside arena"); return -1; }
-  in_lo &= ~15ull;                                    // keep the units' alignment
-  for (size_t i = 0; i < n_sel; i++) { local[i].in_off -= in_lo; local[i].out_off -= out_lo; }
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    return local[a].in_len + (local[a].out_len >> 2) > local[b].in_len + (local[b].out_len >> 2); });
+static hipError_t grow(DevBuf &b, size_t need, bool pinned) {
+  if (need <= b.cap) return hipSuccess;
+  hipError_t e;
+  if (b.p) { hipDeviceSynchronize(); e = pinned ? hipHostFree(b.p) : hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return e; }
+  size_t cap = need + need / 4 + 4096;
+  e = pinned ? hipHostMalloc(&b.p, cap, hipHostMallocDefault) : hipMalloc(&b.p, cap);
+  if (e != hipSuccess) { b.p = nullptr; return e; }
+  b.cap = cap;
+  return hipSuccess;
+}
 
-  size_t in_span = (size_t)(in_hi - in_lo), out_span = (size_t)(out_hi - out_lo);
-  // MSPACK_HIP_TRACE=1: phase times of the host-buffer path on stderr
+struct Chunk {
+  size_t a, b;                          // local unit range [a, b)
+  uint64_t in_lo, in_hi, out_lo, out_hi;
+  size_t order_off[8], order_n[8];      // per kind: slice of the order array
+  size_t fm_lo, fm_n;
+};
+
+// bytes below out_off that belong to the unit, and the room it may write past out_len
+static inline uint64_t unit_below(const mspack_hip_unit &u) {
+  return (u.kind == MSPACK_HIP_KIND_LZSS || u.kind == MSPACK_HIP_KIND_KWAJ_LZH) ? 4096u
+       : (u.kind == MSPACK_HIP_KIND_LZX_DELTA ? u.ref_len : 0u);
+}
+static inline uint64_t unit_above(const mspack_hip_unit &u) { return u.kind == MSPACK_HIP_KIND_MSZIP ? 32768u : 0u; }
+static inline size_t unit_frames(const mspack_hip_unit &u) {
+  return (u.kind == MSPACK_HIP_KIND_LZX || u.kind == MSPACK_HIP_KIND_LZX_DELTA) ? (size_t) u.out_len / 32768u + 1u : 0u;
+}
+
+// `sel` lists the unit indices this device handles (NULL = all n_sel units).  host_out != NULL: outputs are
+// copied back into it; dev_out != NULL: the caller's DEVICE buffer receives them (out_off relative to it).
+static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uint32_t *sel, size_t n_sel,
+                                      const void *in, size_t in_bytes, void *host_out, void *dev_out,
+                                      size_t out_bytes, mspack_hip_result *results, char *errbuf, size_t errcap)
+{
+  if (n_sel == 0) return 0;
+  if (dev < 0 || dev >= MSPK_MAX_DEV) { snprintf(errbuf, errcap, "device index %d out of range", dev); return -1; }
+  DevCtx &cx = g_ctx[dev];
+  std::lock_guard<std::mutex> lock(cx.mu);
+  hipError_t e;
+  int rc = 0;
+#define TRY(call) do { e = (call); if (e != hipSuccess) { snprintf(errbuf, errcap, "%s: %s", #call, hipGetErrorString(e)); rc = -(int) e; goto done; } } while (0)
   static const bool trace = getenv("MSPACK_HIP_TRACE") != nullptr;
   auto tnow = []() { return std::chrono::steady_clock::now(); };
   auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count(); };
-  auto t0 = tnow(), t1 = t0, t2 = t0, t3 = t0, t4 = t0;
-  void *d_in = nullptr, *d_out = nullptr, *d_units = nullptr, *d_order = nullptr, *d_res = nullptr, *d_fm = nullptr;
-  int rc = 0;
-  hipError_t e;
-#define TRY(call) do { e = (call); if (e != hipSuccess) { rc = fail(e, #call); goto done; } } while (0)
-  TRY(hipMalloc(&d_in, in_span + 64));
-  TRY(hipMalloc(&d_out, out_span + 64));
-  TRY(hipMalloc(&d_units, n_sel * sizeof(mspack_hip_unit)));
-  TRY(hipMalloc(&d_order, n_sel * sizeof(uint32_t)));
-  TRY(hipMalloc(&d_res, n_sel * sizeof(mspack_hip_result)));
-  TRY(hipMalloc(&d_fm, mspack_hip_frame_scratch_bytes(n_frames)));
-  t1 = tnow();
-  TRY(hipMemcpy(d_in, (const char *) in + in_lo, in_span, hipMemcpyHostToDevice));
-  TRY(hipMemset((char *) d_in + in_span, 0, 64));
-  TRY(hipMemcpy(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice));
-  TRY(hipMemcpy(d_order, order.data(), n_sel * sizeof(uint32_t), hipMemcpyHostToDevice));
-  TRY(hipMemset(d_fm, 0, mspack_hip_frame_scratch_bytes(n_frames)));
-  for (size_t i = 0; i < n_sel; i++)                  // LZX DELTA reference data sits below the unit's output
-    if (local[i].ref_len)
-      TRY(hipMemcpy((char *) d_out + local[i].out_off - local[i].ref_len,
-                    (const char *) out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
-                    hipMemcpyHostToDevice));
-  t2 = tnow();
-  rc = mspack_hip_decode_batch_device((const mspack_hip_unit *) d_units, (const uint32_t *) d_order, n_sel,
-                                      d_in, in_span, d_out, out_span, (mspack_hip_result *) d_res, d_fm,
-                                      n_frames, kind_mask & 0x7E, nullptr);
-  if (rc) goto done;
-  TRY(hipDeviceSynchronize());
-  t3 = tnow();
-  {
-    std::vector<mspack_hip_result> r(n_sel);
-    TRY(hipMemcpy(r.data(), d_res, n_sel * sizeof(mspack_hip_result), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n_sel; i++) results[sel ? sel[i] : i] = r[i];
-    // copy back each unit's produced bytes (units may interleave with other devices' ranges)
-    if (!sel) TRY(hipMemcpy((char *) out + out_lo, d_out, out_span, hipMemcpyDeviceToHost));
-    else {
-      for (size_t i = 0; i < n_sel; i++)
-        TRY(hipMemcpy((char *) out + out_lo + local[i].out_off, (char *) d_out + local[i].out_off,
-                      local[i].out_len, hipMemcpyDeviceToHost));
-    }
+  auto t0 = tnow(), t1 = t0, t2 = t0, t3 = t0;
+
+  // ---- plan: units in arena order, cut into chunks ----
+  std::vector<uint32_t> idx(n_sel);
+  for (size_t i = 0; i < n_sel; i++) idx[i] = sel ? sel[i] : (uint32_t) i;
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return units[x].in_off < units[y].in_off; });
+  std::vector<mspack_hip_unit> local(n_sel);
+  bool monotone = true;
+  uint64_t in_lo = ~0ull, in_hi = 0, out_lo = ~0ull, out_hi = 0, prev_hi = 0, in_sum = 0;
+  size_t n_frames = 0;
+  for (size_t i = 0; i < n_sel; i++) {
+    mspack_hip_unit &u = local[i];
+    u = units[idx[i]];
+    if (u.kind != MSPACK_HIP_KIND_LZX_DELTA) u.ref_len = 0;
+    if (u.kind < 1 || u.kind > 6) { snprintf(errbuf, errcap, "unit %u: unknown kind %u", idx[i], u.kind); return -1; }
+    const uint64_t below = unit_below(u);
+    if (below > u.out_off) { snprintf(errbuf, errcap, "unit's lower region outside arena"); return -1; }
+    const uint64_t lo = u.out_off - below, hi = u.out_off + u.out_len + unit_above(u);
+    if (u.in_off + u.in_len > in_bytes || hi > out_bytes) { snprintf(errbuf, errcap, "unit outside arena"); return -1; }
+    if (i && lo < prev_hi) monotone = false;
+    prev_hi = hi;
+    in_lo = std::min<uint64_t>(in_lo, u.in_off); in_hi = std::max<uint64_t>(in_hi, u.in_off + u.in_len);
+    out_lo = std::min(out_lo, lo); out_hi = std::max(out_hi, hi);
+    in_sum += u.in_len;
+    u.frame_base = (uint32_t) n_frames; units[idx[i]].frame_base = (uint32_t) n_frames;
+    n_frames += unit_frames(u);
   }
-  t4 = tnow();
+  in_lo &= ~15ull;                                     // keep the units' alignment
+  if (dev_out) out_lo = 0;                             // the caller's device buffer is addressed as is
+  const size_t in_span = (size_t)(in_hi - in_lo), out_span = (size_t)(out_hi - out_lo);
+
+  if (!cx.ready) {
+    cx.ns = env_int("MSPACK_HIP_NSTREAMS", 8, 1, MSPK_MAX_STREAMS);
+    for (int i = 0; i < cx.ns; i++) TRY(hipStreamCreateWithFlags(&cx.st[i], hipStreamNonBlocking));
+    cx.ready = true;
+  }
+  {
+    // chunks: arena-contiguous runs of units; enough of them to overlap the copies with the decode, each
+    // big enough to be worth a launch.  Outputs that interleave (not monotone) are copied back unit by unit.
+    size_t want = monotone ? std::min<size_t>((size_t) cx.ns, std::max<size_t>(1, in_sum >> 22)) : 1;
+    want = std::min(want, std::max<size_t>(1, n_sel / 64));
+    std::vector<Chunk> chunks;
+    {
+      size_t a = 0; uint64_t acc = 0; const uint64_t per = in_sum / want + 1;
+      for (size_t i = 0; i < n_sel; i++) {
+        acc += local[i].in_len;
+        if (i + 1 == n_sel || (acc >= per && chunks.size() + 1 < want)) { Chunk c; c.a = a; c.b = i + 1; chunks.push_back(c); a = i + 1; acc = 0; }
+      }
+    }
+    // per chunk: spans, per-kind launch lists (longest compressed unit first: the slowest chain starts first)
+    std::vector<uint32_t> order(n_sel);
+    size_t op = 0;
+    for (Chunk &c : chunks) {
+      c.in_lo = ~0ull; c.in_hi = 0; c.out_lo = ~0ull; c.out_hi = 0;
+      c.fm_lo = local[c.a].frame_base; c.fm_n = 0;
+      for (size_t i = c.a; i < c.b; i++) {
+        const mspack_hip_unit &u = local[i];
+        c.in_lo = std::min<uint64_t>(c.in_lo, u.in_off); c.in_hi = std::max<uint64_t>(c.in_hi, u.in_off + u.in_len);
+        c.out_lo = std::min<uint64_t>(c.out_lo, u.out_off - unit_below(u));
+        c.out_hi = std::max<uint64_t>(c.out_hi, u.out_off + u.out_len + unit_above(u));
+        c.fm_n += unit_frames(u);
+      }
+      c.in_lo &= ~15ull;
+      for (unsigned k = 1; k <= 6; k++) {
+        c.order_off[k] = op;
+        for (size_t i = c.a; i < c.b; i++) if (local[i].kind == k) order[op++] = (uint32_t) i;
+        c.order_n[k] = op - c.order_off[k];
+        std::stable_sort(order.begin() + c.order_off[k], order.begin() + op, [&](uint32_t x, uint32_t y) {
+          return local[x].in_len + (local[x].out_len >> 2) > local[y].in_len + (local[y].out_len >> 2); });
+      }
+    }
+    for (size_t i = 0; i < n_sel; i++) { local[i].in_off -= in_lo; local[i].out_off -= out_lo; }
+
+    // ---- buffers (persistent) ----
+    TRY(grow(cx.d_in, in_span + 64, false));
+    if (!dev_out) TRY(grow(cx.d_out, out_span + 64, false));
+    TRY(grow(cx.d_units, n_sel * sizeof(mspack_hip_unit), false));
+    TRY(grow(cx.d_order, n_sel * sizeof(uint32_t), false));
+    TRY(grow(cx.d_res, n_sel * sizeof(mspack_hip_result), false));
+    TRY(grow(cx.d_fm, mspack_hip_frame_scratch_bytes(n_frames), false));
+    TRY(grow(cx.h_stage, n_sel * sizeof(mspack_hip_result), true));
+    u8 *const d_in = (u8 *) cx.d_in.p;
+    u8 *const d_out = dev_out ? (u8 *) dev_out : (u8 *) cx.d_out.p;
+    mspack_hip_unit *const d_units = (mspack_hip_unit *) cx.d_units.p;
+    uint32_t *const d_order = (uint32_t *) cx.d_order.p;
+    mspack_hip_result *const d_res = (mspack_hip_result *) cx.d_res.p;
+    mspack_hip_result *const h_res = (mspack_hip_result *) cx.h_stage.p;
+    t1 = tnow();
+
+    // ---- issue: tables on stream 0, then every chunk on its own stream ----
+    hipEvent_t ev_tab;
+    TRY(hipEventCreateWithFlags(&ev_tab, hipEventDisableTiming));
+    TRY(hipMemcpyAsync(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice, cx.st[0]));
+    TRY(hipMemcpyAsync(d_order, order.data(), n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, cx.st[0]));
+    TRY(hipMemsetAsync(cx.d_fm.p, 0, mspack_hip_frame_scratch_bytes(n_frames), cx.st[0]));
+    TRY(hipMemsetAsync(d_in + in_span, 0, 64, cx.st[0]));
+    TRY(hipEventRecord(ev_tab, cx.st[0]));
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+      const Chunk &c = chunks[ci];
+      hipStream_t st = cx.st[ci % cx.ns];
+      if (ci != 0) TRY(hipStreamWaitEvent(st, ev_tab, 0));
+      TRY(hipMemcpyAsync(d_in + (c.in_lo - in_lo), (const char *) in + c.in_lo, (size_t)(c.in_hi - c.in_lo),
+                         hipMemcpyHostToDevice, st));
+      if (host_out)
+        for (size_t i = c.a; i < c.b; i++)               // LZX DELTA reference data sits below the unit's output
+          if (local[i].ref_len)
+            TRY(hipMemcpyAsync(d_out + local[i].out_off - local[i].ref_len,
+                               (const char *) host_out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
+                               hipMemcpyHostToDevice, st));
+      for (unsigned k = 1; k <= 6; k++)
+        launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, st);
+      TRY(hipGetLastError());
+      TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
+    }
+    t2 = tnow();
+    // ---- copy-back, chunk by chunk (each call waits for its own chunk only) ----
+    if (host_out) {
+      for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const Chunk &c = chunks[ci];
+        hipStream_t st = cx.st[ci % cx.ns];
+        if (monotone)
+          TRY(hipMemcpyAsync((char *) host_out + c.out_lo, d_out + (c.out_lo - out_lo), (size_t)(c.out_hi - c.out_lo),
+                             hipMemcpyDeviceToHost, st));
+        else
+          for (size_t i = c.a; i < c.b; i++)
+            TRY(hipMemcpyAsync((char *) host_out + out_lo + local[i].out_off, d_out + local[i].out_off, local[i].out_len,
+                               hipMemcpyDeviceToHost, st));
+      }
+    }
+    for (int i = 0; i < cx.ns; i++) TRY(hipStreamSynchronize(cx.st[i]));
+    hipEventDestroy(ev_tab);
+    for (size_t i = 0; i < n_sel; i++) results[idx[i]] = h_res[i];
+    t3 = tnow();
+    if (trace)
+      fprintf(stderr, "mspack_hip[dev %d]: %zu units in %zu chunks on %d streams: plan+alloc %.2f ms, issue (H2D %.1f MB) %.2f ms, "
+              "drain (D2H %.1f MB) %.2f ms\n", dev, n_sel, chunks.size(), cx.ns, tms(t0, t1), in_span / 1e6, tms(t1, t2),
+              host_out ? out_span / 1e6 : 0.0, tms(t2, t3));
+  }
 done:
-  hipFree(d_in); hipFree(d_out); hipFree(d_units); hipFree(d_order); hipFree(d_res); hipFree(d_fm);
-  if (trace && rc == 0)
-    fprintf(stderr, "mspack_hip: %zu units: alloc %.2f ms, H2D %.1f MB %.2f ms, kernels %.2f ms, D2H %.1f MB %.2f ms, free %.2f ms\n",
-            n_sel, tms(t0, t1), in_span / 1e6, tms(t1, t2), tms(t2, t3), out_span / 1e6, tms(t3, t4), tms(t4, tnow()));
+  if (rc) for (int i = 0; i < cx.ns; i++) hipStreamSynchronize(cx.st[i]);
   return rc;
 #undef TRY
 }
 
+static int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d; }
+
+extern "C" {
+
 int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
                             void *out, size_t out_bytes, mspack_hip_result *results)
 {
-  return decode_on_current_device(units, nullptr, n_units, in, in_bytes, out, out_bytes, results);
+  return pipeline_on_current_device(current_device(), units, nullptr, n_units, in, in_bytes, out, nullptr, out_bytes,
+                                    results, g_err, sizeof(g_err));
+}
+
+int mspack_hip_decode_batch_to_device(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
+                                      void *d_out, size_t out_bytes, mspack_hip_result *results)
+{
+  return pipeline_on_current_device(current_device(), units, nullptr, n_units, in, in_bytes, nullptr, d_out, out_bytes,
+                                    results, g_err, sizeof(g_err));
 }
 
 int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const void *in,
@@ -324,24 +475,63 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
 {
   int have = mspack_hip_device_count();
   if (n_devices > have) n_devices = have;
-  if (n_devices <= 1) return decode_on_current_device(units, nullptr, n_units, in, in_bytes, out, out_bytes, results);
-  // deal units longest-first round-robin: static sharding, no inter-device traffic
+  if (n_devices > MSPK_MAX_DEV) n_devices = MSPK_MAX_DEV;
+  const bool force_shards = getenv("MSPACK_HIP_FORCE_SHARDS") != nullptr;   // tests: exercise the sharded path on one GPU
+  int n_shards = n_devices;
+  if (force_shards) n_shards = env_int("MSPACK_HIP_FORCE_SHARDS", 2, 1, MSPK_MAX_DEV);
+  if (n_shards <= 1 || n_units < 2) return mspack_hip_decode_batch(units, n_units, in, in_bytes, out, out_bytes, results);
+  if (n_devices < 1) { snprintf(g_err, sizeof(g_err), "no HIP device"); return -1; }
+  // static sharding, no inter-device traffic: units in arena order are cut into n_shards CONTIGUOUS ranges of
+  // about equal compressed size, so that every device stages one contiguous span of each arena
   std::vector<uint32_t> idx(n_units);
   for (size_t i = 0; i < n_units; i++) idx[i] = (uint32_t) i;
-  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return units[a].in_len > units[b].in_len; });
-  std::vector<std::vector<uint32_t>> shard(n_devices);
-  for (size_t i = 0; i < n_units; i++) shard[i % n_devices].push_back(idx[i]);
-  std::vector<int> rcs(n_devices, 0);
+  std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return units[a].in_off < units[b].in_off; });
+  uint64_t total = 0;
+  for (size_t i = 0; i < n_units; i++) total += (uint64_t) units[i].in_len + (units[i].out_len >> 2) + 256u;
+  std::vector<std::vector<uint32_t>> shard(n_shards);
+  {
+    uint64_t acc = 0; int s = 0;
+    for (size_t i = 0; i < n_units; i++) {
+      shard[s].push_back(idx[i]);
+      acc += (uint64_t) units[idx[i]].in_len + (units[idx[i]].out_len >> 2) + 256u;
+      if (s + 1 < n_shards && acc * n_shards >= total * (uint64_t)(s + 1)) s++;
+    }
+  }
+  std::vector<int> rcs(n_shards, 0);
+  std::vector<std::array<char, 256>> errs(n_shards);
   std::vector<std::thread> th;
-  for (int dv = 0; dv < n_devices; dv++) {
-    th.emplace_back([&, dv]() {
-      if (hipSetDevice(dv) != hipSuccess) { rcs[dv] = -1; return; }
-      rcs[dv] = decode_on_current_device(units, shard[dv].data(), shard[dv].size(), in, in_bytes, out, out_bytes, results);
+  for (int sh = 0; sh < n_shards; sh++) {
+    th.emplace_back([&, sh]() {
+      const int dv = sh % n_devices;
+      errs[sh][0] = 0;
+      hipError_t e = hipSetDevice(dv);
+      if (e != hipSuccess) { snprintf(errs[sh].data(), 256, "hipSetDevice(%d): %s", dv, hipGetErrorString(e)); rcs[sh] = -(int) e; return; }
+      rcs[sh] = pipeline_on_current_device(dv, units, shard[sh].data(), shard[sh].size(), in, in_bytes, out, nullptr,
+                                           out_bytes, results, errs[sh].data(), 256);
     });
   }
   for (auto &t : th) t.join();
-  for (int dv = 0; dv < n_devices; dv++) if (rcs[dv]) return rcs[dv];
+  for (int sh = 0; sh < n_shards; sh++)
+    if (rcs[sh]) { snprintf(g_err, sizeof(g_err), "shard %d: %s", sh, errs[sh].data()); return rcs[sh]; }
   return 0;
+}
+
+// free every persistent context (device arenas, pinned staging, streams) of this process
+void mspack_hip_release(void)
+{
+  int keep = current_device();
+  for (int d = 0; d < MSPK_MAX_DEV; d++) {
+    DevCtx &cx = g_ctx[d];
+    std::lock_guard<std::mutex> lock(cx.mu);
+    if (!cx.ready && !cx.d_in.p && !cx.h_stage.p) continue;
+    if (hipSetDevice(d) != hipSuccess) continue;
+    hipDeviceSynchronize();
+    for (DevBuf *b : { &cx.d_in, &cx.d_out, &cx.d_units, &cx.d_order, &cx.d_res, &cx.d_fm }) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
+    if (cx.h_stage.p) { hipHostFree(cx.h_stage.p); cx.h_stage.p = nullptr; cx.h_stage.cap = 0; }
+    if (cx.ready) for (int i = 0; i < cx.ns; i++) hipStreamDestroy(cx.st[i]);
+    cx.ready = false;
+  }
+  hipSetDevice(keep);
 }
 
 } // extern "C"

@@ -94,7 +94,7 @@ static int oab_run(struct oabd_p *self, const char *input, const char *base, con
   while (target_size) {
     struct oab_blk b;
     long got;
-    size_t room;
+    size_t room, want;
     memset(&b, 0, sizeof(b));
     if (sys->read(infh, bh, 16) != 16) { tail_err = MSPACK_ERR_READ; break; }
     if (patch) {
@@ -116,7 +116,14 @@ static int oab_run(struct oabd_p *self, const char *input, const char *base, con
     }
     /* the block's bytes (compressed stream, or the stored data) */
     in_bytes = (in_bytes + 15) & ~(size_t) 15;
-    room = (size_t) b.csize + 64;
+    /* csize is untrusted: never reserve more than the file still holds (a 32-byte file must not be able to
+     * ask for gigabytes; the reference streams with window-sized memory) */
+    {
+      off_t flen = 0, here = sys->tell(infh);
+      want = (size_t) b.csize;
+      if (!mspack_sys_filelen(sys, infh, &flen) && flen >= here && (off_t) want > flen - here) want = (size_t)(flen - here);
+      room = want + 64;
+    }
     if (in_bytes + room > in_cap) {
       size_t ncap = (in_bytes + room) * 2 + 65536;
       unsigned char *n = (unsigned char *) sys->alloc(sys, ncap);
@@ -124,7 +131,7 @@ static int oab_run(struct oabd_p *self, const char *input, const char *base, con
       if (in_arena) { sys->copy(in_arena, n, in_bytes); sys->free(in_arena); }
       in_arena = n; in_cap = ncap;
     }
-    got = read_upto(sys, infh, in_arena + in_bytes, b.csize);
+    got = read_upto(sys, infh, in_arena + in_bytes, want);
     if (got < 0) { tail_err = MSPACK_ERR_READ; break; }
     b.in_pos = in_bytes; b.in_have = (size_t) got;
     memset(in_arena + in_bytes + got, 0, 64);

@@ -262,10 +262,14 @@ static struct mskwajd_header *kwaj_open(struct mskwaj_decompressor *base, const 
   struct mspack_file *fh;
   if (!self) return NULL;
   sys = self->system;
-  fh = sys->open(sys, filename, MSPACK_SYS_OPEN_READ);
+  /* like kwajd_open (kwajd.c:95-123): no file, no header object */
+  if (!(fh = sys->open(sys, filename, MSPACK_SYS_OPEN_READ))) { self->error = MSPACK_ERR_OPEN; return NULL; }
   hdr = (struct kwaj_hdr_p *) sys->alloc(sys, sizeof(*hdr));
-  if (fh && hdr) { hdr->fh = fh; self->error = kwaj_headers(sys, fh, &hdr->base); }
-  else { if (!fh) self->error = MSPACK_ERR_OPEN; if (!hdr) self->error = MSPACK_ERR_NOMEMORY; }
+  if (hdr) {
+    memset(hdr, 0, sizeof(*hdr));                 /* filename / extra are freed on every error path */
+    hdr->fh = fh; self->error = kwaj_headers(sys, fh, &hdr->base);
+  }
+  else self->error = MSPACK_ERR_NOMEMORY;
   if (self->error) {
     if (fh) sys->close(fh);
     if (hdr) { sys->free(hdr->base.filename); sys->free(hdr->base.extra); }

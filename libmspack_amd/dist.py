@@ -47,3 +47,24 @@ def reduce_scalars(dist, device, elapsed, bytes_out):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(b, op=dist.ReduceOp.SUM)
     return float(t.item()), float(b.item())
+
+
+def gather_scalar(dist, device, value):
+    """-> [value of rank 0, value of rank 1, ...] on every rank (per-rank step times: imbalance made visible)"""
+    if dist is None:
+        return [float(value)]
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
+def all_true(dist, device, flag):
+    """logical AND over ranks (the bit-exactness gate: one bad rank voids the line)"""
+    if dist is None:
+        return bool(flag)
+    import torch
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)

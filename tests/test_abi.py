@@ -101,3 +101,34 @@ def test_no_gpu_means_loud_failure_not_fallback(built):
     units, out_bytes = M.make_units(M.KIND_LZX, [0], [16], [32768], window_bits=15)
     with pytest.raises(M.MspackHipError):
         M.decode_batch(units, np.zeros(64, dtype=np.uint8), out_bytes)
+
+
+def test_open_of_missing_files_is_an_error_not_a_crash(built):
+    """open() of a file that does not exist returns NULL with MSPACK_ERR_OPEN for every decompressor kind, also when
+    malloc hands out dirty memory (MALLOC_PERTURB_: kwaj_open once freed two uninitialised pointers there)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import libmspack_amd as M
+L = M.lib()
+for kind in ("cab", "chm", "szdd", "kwaj"):
+    create = getattr(L, "mspack_create_%%s_decompressor" %% kind); destroy = getattr(L, "mspack_destroy_%%s_decompressor" %% kind)
+    create.restype = C.c_void_p; create.argtypes = [C.c_void_p]; destroy.argtypes = [C.c_void_p]
+    d = create(None)
+    assert d
+    vt = C.cast(d, C.POINTER(C.c_void_p))
+    OPEN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_char_p)
+    for _ in range(3):
+        h = OPEN(vt[0])(d, b"/nonexistent/really/not/there.bin")
+        assert not h
+    n_err = {"cab": 7, "chm": 3, "szdd": 4, "kwaj": 4}[kind]          # index of last_error in the method table
+    ERR = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    assert ERR(vt[n_err])(d) == 2, kind                                # MSPACK_ERR_OPEN
+    destroy(d)
+print("OPEN_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MALLOC_PERTURB_="165")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert p.returncode == 0 and b"OPEN_OK" in p.stdout, p.stdout.decode()[-2000:]

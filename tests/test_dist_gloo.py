@@ -32,6 +32,14 @@ assert bool((cover == 1).all())
 # reductions used for the JSON line
 el, total = D.reduce_scalars(dist, torch.device("cpu"), 1.0 + rank, 100.0 * (rank + 1))
 assert el == 2.0 and total == 300.0
+assert D.gather_scalar(dist, torch.device("cpu"), 10.0 + rank) == [10.0, 11.0]
+assert D.all_true(dist, torch.device("cpu"), True) is True
+assert D.all_true(dist, torch.device("cpu"), rank == 0) is False
+# strong-scaling corpus: the two shards of a 6-unit global list are the halves of the list one rank would make
+lo, hi = D.shard_range(6, rank, world)
+pl, _c, _o, _l = M.corpus_lzx_units(0xC0F165, 0, hi - lo, 65536, 21, n_threads=1, first_unit=lo)
+full, _c, _o, _l = M.corpus_lzx_units(0xC0F165, 0, 6, 65536, 21, n_threads=1)
+assert np.array_equal(pl, full[lo * 65536:hi * 65536])
 dist.barrier()
 if rank == 0:
     print("GLOO_OK")
@@ -52,3 +60,19 @@ def test_two_rank_gloo(built, tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GLOO_OK" in outs[0]
+
+
+def test_bench_refuses_wrong_world(built):
+    """bench.py never prints a line whose n_gpus differs from the request: more ranks asked for than GPUs present
+    (here: none) is an error before anything is spawned, and a launcher world size != --gpus is one too."""
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        assert p.returncode != 0 and b"refusing" in p.stderr and b'"metric"' not in p.stdout
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env2,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert p.returncode != 0 and b"refusing" in p.stderr and b'"metric"' not in p.stdout

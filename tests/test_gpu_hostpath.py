@@ -1,0 +1,157 @@
+"""The host-buffer entry points of include/mspack_hip.h on the GPU: the chunked multi-stream pipeline
+(mspack_hip_decode_batch), host input -> device output (mspack_hip_decode_batch_to_device) and the sharded
+multi-device path (mspack_hip_decode_batch_multi; MSPACK_HIP_FORCE_SHARDS cuts the batch into shards even on
+a one-GPU box, so the per-shard staging, the contiguous partition and the result scatter all execute).
+Mixed batches (LZX + MSZIP + Quantum units in one call) exercise the per-codec compact launch lists; a batch
+whose output regions are laid out in another order than its inputs exercises the per-unit copy-back.
+Everything is compared with the CPU oracle and the plaintext."""
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+import libmspack_amd as M
+from helpers import oracle_lzx, oracle_mszip, oracle_qtm
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def mixed_batch(n_each=40, seed=11):
+    """-> (units, arena, out_bytes, expect[list of (kind, stream bytes, out_len, wb, plain)])"""
+    rng = np.random.default_rng(seed)
+    items = []
+    for i in range(n_each):
+        d = M.gen_plaintext(seed * 1000 + i, int(rng.integers(0, 4)), 65536)
+        lz, _fo = M.lzx_encode(d, 21, 2)
+        items.append((M.KIND_LZX, lz.tobytes() + b"\0" * 4, d.size, 21, 2, d))
+        d2 = M.gen_plaintext(seed * 2000 + i, 0, 32768 * int(rng.integers(1, 4)))
+        blocks, prev = [], None
+        for k in range(0, d2.size, 32768):
+            b = d2[k:k + 32768].tobytes()
+            c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, 0, prev) if prev else zlib.compressobj(6, zlib.DEFLATED, -15)
+            blocks.append(b"CK" + c.compress(b) + c.flush()); prev = b
+        items.append((M.KIND_MSZIP, b"".join(blocks), d2.size, 0, 0, d2))
+        if i % 4 == 0:
+            d3 = M.gen_plaintext(seed * 3000 + i, 0, 40000)
+            qs, _fs = M.qtm_encode(d3, 17)
+            items.append((M.KIND_QUANTUM, bytes(qs), d3.size, 17, 0, d3))
+    order = rng.permutation(len(items))
+    items = [items[i] for i in order]
+    offs, pos = [], 0
+    for it in items:
+        pos = (pos + 15) & ~15
+        offs.append(pos); pos += len(it[1])
+    arena = np.zeros(pos + 64, dtype=np.uint8)
+    for it, o in zip(items, offs):
+        arena[o:o + len(it[1])] = np.frombuffer(it[1], dtype=np.uint8)
+    kinds = np.array([it[0] for it in items], dtype=np.uint8)
+    units, out_bytes = M.make_units(kinds, offs, [len(it[1]) for it in items], [it[2] for it in items],
+                                    window_bits=[it[3] for it in items], reset_frames=[it[4] for it in items],
+                                    out_slack=32768)
+    return units, arena, out_bytes, items
+
+
+def check(units, out, res, items):
+    for i, (kind, stream, olen, wb, rf, plain) in enumerate(items):
+        assert res["err"][i] == 0 and res["out_len"][i] == olen, (i, kind, res[i])
+        o = int(units["out_off"][i])
+        assert np.array_equal(out[o:o + olen], plain), (i, kind)
+    # the oracle on a sample of every kind
+    seen = set()
+    for i, (kind, stream, olen, wb, rf, plain) in enumerate(items):
+        if kind in seen:
+            continue
+        seen.add(kind)
+        if kind == M.KIND_LZX:
+            e, o, r = oracle_lzx(stream, olen, wb, rf)
+        elif kind == M.KIND_MSZIP:
+            e, o, r, _ = oracle_mszip(stream, olen)
+        else:
+            e, o, r = oracle_qtm(stream, olen, wb)
+        assert e == 0 and o == plain.tobytes()
+
+
+def test_mixed_batch_pipeline(built):
+    units, arena, out_bytes, items = mixed_batch()
+    out, res = M.decode_batch(units, arena, out_bytes)
+    check(units, out, res, items)
+
+
+def test_mixed_batch_interleaved_outputs(built):
+    """output regions in reverse order of the inputs: copy-back falls back to one copy per unit"""
+    units, arena, out_bytes, items = mixed_batch(n_each=12, seed=5)
+    rev = units["out_off"].copy()
+    sizes = np.diff(np.concatenate([units["out_off"], [out_bytes]])).astype(np.int64)
+    pos = 0
+    for i in range(len(units) - 1, -1, -1):
+        rev[i] = pos; pos += int(sizes[i])
+    units["out_off"] = rev
+    out, res = M.decode_batch(units, arena, out_bytes)
+    check(units, out, res, items)
+
+
+def test_to_device(built):
+    import torch
+    units, arena, out_bytes, items = mixed_batch(n_each=16, seed=7)
+    d_out = torch.zeros(out_bytes + 64, dtype=torch.uint8, device="cuda:0")
+    res = np.zeros(len(units), dtype=M.RESULT_DTYPE)
+    u = np.ascontiguousarray(units)
+    rc = M.lib().mspack_hip_decode_batch_to_device(u.ctypes.data, len(u), arena.ctypes.data, arena.size, d_out.data_ptr(),
+                                                   out_bytes + 64, res.ctypes.data)
+    assert rc == 0, M.lib().mspack_hip_last_error()
+    check(units, d_out.cpu().numpy(), res, items)
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import libmspack_amd as M
+import test_gpu_hostpath as T
+units, arena, out_bytes, items = T.mixed_batch(n_each=48, seed=int(sys.argv[1]))
+out, res = M.decode_batch(units, arena, out_bytes, n_devices=max(2, M.lib().mspack_hip_device_count()))
+T.check(units, out, res, items)
+# a failing shard reports through the CALLER's last_error (the workers are other threads)
+bad = units.copy(); bad["in_off"][3] = arena.size + 1000
+try:
+    M.decode_batch(bad, arena, out_bytes, n_devices=2)
+    raise SystemExit("no error for a unit outside the arena")
+except M.MspackHipError as e:
+    assert "outside arena" in str(e), str(e)
+print("SHARDS_OK")
+'''
+
+
+@pytest.mark.parametrize("shards", [2, 3, 7])
+def test_multi_sharded_path(built, shards, tmp_path):
+    """mspack_hip_decode_batch_multi through its sharded code path (sel != NULL), in a fresh process so that the
+    environment switch is seen; on a multi-GPU box the shards really go to different devices."""
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MSPACK_HIP_FORCE_SHARDS=str(shards))
+    p = subprocess.run([sys.executable, str(script), str(shards)], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0 and b"SHARDS_OK" in p.stdout, p.stdout.decode()[-3000:]
+
+
+def test_headline_batch_host_entry_points(built):
+    """the 4096-interval headline batch through both host entry points (what bench.py's host_inclusive times)"""
+    import torch
+    n, ub = 4096, 65536
+    plain, comp, off, ln = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21)
+    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=2)
+    out, res = M.decode_batch(units, comp, out_bytes)
+    assert (res["err"] == 0).all() and np.array_equal(out[:n * ub], plain)
+    d_out = torch.zeros(out_bytes + 64, dtype=torch.uint8, device="cuda:0")
+    res2 = np.zeros(n, dtype=M.RESULT_DTYPE)
+    u = np.ascontiguousarray(units)
+    rc = M.lib().mspack_hip_decode_batch_to_device(u.ctypes.data, n, comp.ctypes.data, comp.size, d_out.data_ptr(),
+                                                   out_bytes + 64, res2.ctypes.data)
+    assert rc == 0 and (res2["err"] == 0).all() and np.array_equal(d_out[:n * ub].cpu().numpy(), plain)
+    M.lib().mspack_hip_release()
+    out, res = M.decode_batch(units[:64], comp, out_bytes)                 # contexts come back after a release
+    assert (res["err"] == 0).all() and np.array_equal(out[:64 * ub], plain[:64 * ub])

@@ -36,6 +36,7 @@ def check_against_oracle(streams, params, units, out, res):
         assert res["err"][i] == e, (i, res[i], e)
         assert res["flags"][i] == r.flags, (i, res[i], r.flags)
         assert res["out_len"][i] == r.out_len, (i, res[i], r.out_len)
+        assert res["in_next"][i] == r.in_next, (i, res[i], r.in_next)   # where the next frame's bits start
         got = out[units["out_off"][i]:units["out_off"][i] + r.out_len].tobytes()
         assert got == o[:r.out_len], "unit %d differs at byte %d" % (
             i, next(k for k in range(len(got)) if got[k] != o[k]))

@@ -64,10 +64,13 @@ def test_qtm_partial_truncated_corrupt(built):
 
 
 def test_qtm_batch_512_folders(built):
-    """BASELINE config 4 shape: 512 independent folders (here 4 frames each), window 21."""
-    n, ub = 512, 4 * 32768
+    """BASELINE config 4 as SURVEY 8(d) specifies it: 512 independent folders of 32 blocks (1 MiB) each,
+    window 21 (comp_type 0x1572)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, ub = 512, 32 * 32768
     plain = M.gen_plaintext(123, M.TEXT_MIX, n * ub)
-    streams = [M.qtm_encode(plain[i * ub:(i + 1) * ub], 21)[0] for i in range(n)]
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        streams = list(ex.map(lambda i: M.qtm_encode(plain[i * ub:(i + 1) * ub], 21)[0], range(n)))
     units, out, res = run(streams, [ub] * n, [21] * n)
     assert (res["err"] == 0).all() and (res["out_len"] == ub).all()
     for i in range(n):
