@@ -339,7 +339,9 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
   const size_t in_span = (size_t)(in_hi - in_lo), out_span = (size_t)(out_hi - out_lo);
 
   if (!cx.ready) {
-    cx.ns = env_int("MSPACK_HIP_NSTREAMS", 8, 1, MSPK_MAX_STREAMS);
+    // ROCm multiplexes a process's streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES): two chunks on
+    // the same queue would run one after the other, and a chunk's launch lasts as long as its slowest unit
+    cx.ns = env_int("MSPACK_HIP_NSTREAMS", 4, 1, MSPK_MAX_STREAMS);
     for (int i = 0; i < cx.ns; i++) TRY(hipStreamCreateWithFlags(&cx.st[i], hipStreamNonBlocking));
     cx.ready = true;
   }

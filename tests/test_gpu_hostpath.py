@@ -20,6 +20,33 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+class DevBuf:
+    """a device buffer through the HIP runtime the library itself is linked with (torch brings its own copy of the
+    runtime, which cannot initialise in a process where /opt/rocm's already has)"""
+
+    def __init__(self, nbytes):
+        import ctypes as C
+        M.lib()
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        self.n = nbytes
+        p = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(p), nbytes) == 0
+        self.ptr = p.value
+        assert self.hip.hipMemset(self.ptr, 0, nbytes) == 0
+
+    def to_host(self):
+        out = np.empty(self.n, dtype=np.uint8)
+        assert self.hip.hipMemcpy(out.ctypes.data, self.ptr, self.n, 2) == 0          # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
 def mixed_batch(n_each=40, seed=11):
     """-> (units, arena, out_bytes, expect[list of (kind, stream bytes, out_len, wb, plain)])"""
     rng = np.random.default_rng(seed)
@@ -95,15 +122,15 @@ def test_mixed_batch_interleaved_outputs(built):
 
 
 def test_to_device(built):
-    import torch
     units, arena, out_bytes, items = mixed_batch(n_each=16, seed=7)
-    d_out = torch.zeros(out_bytes + 64, dtype=torch.uint8, device="cuda:0")
+    d_out = DevBuf(out_bytes + 64)
     res = np.zeros(len(units), dtype=M.RESULT_DTYPE)
     u = np.ascontiguousarray(units)
-    rc = M.lib().mspack_hip_decode_batch_to_device(u.ctypes.data, len(u), arena.ctypes.data, arena.size, d_out.data_ptr(),
+    rc = M.lib().mspack_hip_decode_batch_to_device(u.ctypes.data, len(u), arena.ctypes.data, arena.size, d_out.ptr,
                                                    out_bytes + 64, res.ctypes.data)
     assert rc == 0, M.lib().mspack_hip_last_error()
-    check(units, d_out.cpu().numpy(), res, items)
+    check(units, d_out.to_host(), res, items)
+    d_out.free()
 
 
 WORKER = r'''
@@ -140,18 +167,18 @@ def test_multi_sharded_path(built, shards, tmp_path):
 
 def test_headline_batch_host_entry_points(built):
     """the 4096-interval headline batch through both host entry points (what bench.py's host_inclusive times)"""
-    import torch
     n, ub = 4096, 65536
     plain, comp, off, ln = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21)
     units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=2)
     out, res = M.decode_batch(units, comp, out_bytes)
     assert (res["err"] == 0).all() and np.array_equal(out[:n * ub], plain)
-    d_out = torch.zeros(out_bytes + 64, dtype=torch.uint8, device="cuda:0")
+    d_out = DevBuf(out_bytes + 64)
     res2 = np.zeros(n, dtype=M.RESULT_DTYPE)
     u = np.ascontiguousarray(units)
-    rc = M.lib().mspack_hip_decode_batch_to_device(u.ctypes.data, n, comp.ctypes.data, comp.size, d_out.data_ptr(),
+    rc = M.lib().mspack_hip_decode_batch_to_device(u.ctypes.data, n, comp.ctypes.data, comp.size, d_out.ptr,
                                                    out_bytes + 64, res2.ctypes.data)
-    assert rc == 0 and (res2["err"] == 0).all() and np.array_equal(d_out[:n * ub].cpu().numpy(), plain)
+    assert rc == 0 and (res2["err"] == 0).all() and np.array_equal(d_out.to_host()[:n * ub], plain)
+    d_out.free()
     M.lib().mspack_hip_release()
     out, res = M.decode_batch(units[:64], comp, out_bytes)                 # contexts come back after a release
     assert (res["err"] == 0).all() and np.array_equal(out[:64 * ub], plain[:64 * ub])
