@@ -127,10 +127,9 @@ size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total);
 
 /* ---- host-buffer entry points (what the C drivers in mspack.h use) -------------------------------------
  * Same semantics with HOST pointers.  Each device keeps a persistent context (device arenas and pinned
- * staging grown on demand, a set of streams; MSPACK_HIP_NSTREAMS, default 4 = the hardware queues of a process): the batch is cut into chunks
- * of units that are contiguous in the arenas, and chunk c's input copy, its launches (one per codec over a
- * compact list of that codec's units) and its copy-back run on stream c, so copies overlap the decode of the
- * other chunks.  `units[i].frame_base` is filled in by the call.  Synchronous.  Bytes of the output arena
+ * staging grown on demand, never freed per call; MSPACK_HIP_NSTREAMS streams, default 1): the batch is cut
+ * into as many chunks of arena-contiguous units as there are streams, and chunk c's input copy, its launches
+ * (one per codec over a compact list of that codec's units) and its copy-back run on stream c.  `units[i].frame_base` is filled in by the call.  Synchronous.  Bytes of the output arena
  * BETWEEN units that lie inside a copied span (alignment padding, the MSZIP slack) are unspecified afterwards.
  * Thread-safe; calls that target the same device are serialised. */
 int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,

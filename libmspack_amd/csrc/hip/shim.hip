@@ -339,9 +339,12 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
   const size_t in_span = (size_t)(in_hi - in_lo), out_span = (size_t)(out_hi - out_lo);
 
   if (!cx.ready) {
-    // ROCm multiplexes a process's streams onto 4 hardware queues by default (GPU_MAX_HW_QUEUES): two chunks on
-    // the same queue would run one after the other, and a chunk's launch lasts as long as its slowest unit
-    cx.ns = env_int("MSPACK_HIP_NSTREAMS", 4, 1, MSPK_MAX_STREAMS);
+    // Default: ONE chunk.  Measured on the box (profiles/round2_hostpath_streams.txt): a chunk's launch lasts as
+    // long as its slowest unit whatever its size (one unit = one wavefront's serial chain), so the last
+    // chunk still ends at H2D_total + 4.7 ms; and hipMemcpyAsync from PAGEABLE memory on a third stream does
+    // not start before an earlier chunk's kernel has finished.  More streams (MSPACK_HIP_NSTREAMS=2..8) only
+    // pay once units are short against the copies.
+    cx.ns = env_int("MSPACK_HIP_NSTREAMS", 1, 1, MSPK_MAX_STREAMS);
     for (int i = 0; i < cx.ns; i++) TRY(hipStreamCreateWithFlags(&cx.st[i], hipStreamNonBlocking));
     cx.ready = true;
   }
