@@ -293,6 +293,7 @@ def main():
     ap.add_argument("--unit-kib", type=int, default=64)
     ap.add_argument("--text", type=int, default=0, help="plaintext family (0 = mix)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-frame-tables", action="store_true", help="units without frame tables: the serial-per-unit LZX path only")
     ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive and the secondary configs")
     ap.add_argument("--exp", action="store_true", help="kernel experiments: skip the parity gate and the CPU leg (the line is then NOT a valid result)")
     args = ap.parse_args()
@@ -321,12 +322,17 @@ def main():
     if args.scaling == "strong":
         lo, hi = D.shard_range(args.total_units, rank, world)      # contiguous shard of ONE global list
         n = hi - lo
-        plain, comp, off, ln = M.corpus_lzx_units(0xC0F165, args.text, n, ub, 21, n_threads=threads, first_unit=lo)
+        plain, comp, off, ln, tab = M.corpus_lzx_units(0xC0F165, args.text, n, ub, 21, n_threads=threads, first_unit=lo,
+                                                       frame_tables=True)
     else:
         n = args.units                                             # every rank its own corpus: fixed work per GPU
-        plain, comp, off, ln = M.corpus_lzx_units(D.unit_seed_base(0xBA5E11, rank), args.text, n, ub, 21, n_threads=threads)
+        plain, comp, off, ln, tab = M.corpus_lzx_units(D.unit_seed_base(0xBA5E11, rank), args.text, n, ub, 21,
+                                                       n_threads=threads, frame_tables=True)
     gen_s = time.perf_counter() - t0
-    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=ub // 32768)
+    # every unit carries its frame table (where each 32 KiB frame starts in the compressed stream), as a CHM's
+    # reset table states it per frame (chmd.c:1146-1149): the frames' tokens are parsed by one wavefront each
+    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=ub // 32768,
+                                    frame_tabs=None if args.no_frame_tables else tab)
     batch = DeviceBatch(M, torch, dev, units, comp, out_bytes, M.KIND_LZX)
 
     def barrier():
@@ -351,6 +357,7 @@ def main():
     res = batch.results()
     out = batch.output()[:n * ub]
     ok = bool((res["err"] == 0).all() and (res["out_len"] == ub).all() and np.array_equal(out, plain))
+    adopted = float(((res["flags"] & M.F_FRAMES_ADOPTED) != 0).mean())
     all_ok = D.all_true(dist, dev, ok)
     if not all_ok and not args.exp:
         raise SystemExit("rank %d: GPU output is NOT bit-exact on some rank; refusing to report a number" % rank)
@@ -384,9 +391,11 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "units_per_gpu": n, "unit_bytes": ub, "bit_exact": all_ok,
+                       "frame_tables": not args.no_frame_tables, "units_on_frame_parallel_path": round(adopted, 4),
                        "corpus_gen_s": round(gen_s, 2), "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
                        "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else ("self-spawned" if world > 1 else "single")},
-            "roofline": roofline(algo_bytes, ms_kernel, "mspack_decode_lzx", traffic=traffic, traffic_source=traffic_source),
+            "roofline": roofline(algo_bytes, ms_kernel, "mspack_lzx_parse + mspack_decode_lzx" if not args.no_frame_tables else "mspack_decode_lzx",
+                                 traffic=traffic, traffic_source=traffic_source),
         }
         extras = world == 1 and not args.exp and not args.no_extras
         if extras:

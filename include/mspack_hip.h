@@ -48,6 +48,8 @@ extern "C" {
                                            At a reset point the reference only warns and goes on with that
                                            block (lzxd.c:424-431): the next interval is then NOT an
                                            independent unit, and drivers decode such a stream serially     */
+#define MSPACK_HIP_F_FRAMES_ADOPTED 32u /* LZX, diagnostic: at least one frame's tokens came from a parse wavefront
+                                           (MSPACK_HIP_UF_FRAME_TABLE); says nothing about the decoded bytes      */
 #define MSPACK_HIP_F_OUT_FULL       8u  /* KWAJ-framed MSZIP: the next block did not fit out_len (give the
                                            unit more room and decode again)                          */
 
@@ -56,6 +58,14 @@ extern "C" {
 #define MSPACK_HIP_UF_MSZIP_KWAJ    4u  /* MSZIP as KWAJ files frame it (mszipd_decompress_kwaj, mszipd.c:462-495):
                                            16-bit block length (0 ends the stream), 'C','K', one deflate stream;
                                            out_len is the room available, the result's out_len what was produced */
+#define MSPACK_HIP_UF_FRAME_TABLE   8u  /* LZX: the container states where every 32 KiB frame of the unit starts in the
+                                           compressed stream (a cabinet: one CFDATA block per frame, cabd.c:1362-1479;
+                                           a CHM: one reset-table entry per frame, chmd.c:1146-1149).  in_chunk * 4 is the
+                                           byte offset, in the input arena, of a uint32 table with one entry per frame:
+                                           the frame's offset from in_off.  With it the frames' tokens are parsed by one
+                                           wavefront each before the unit's own wavefront commits them; the table is a
+                                           HINT -- a wrong one costs time, never correctness (the unit's wavefront checks
+                                           every frame's bit position and falls back to decoding serially)           */
 #define MSPACK_HIP_UF_HARD_EOF      2u  /* the feeder's read FAILED at in_len (sys->read < 0, e.g. a bad
                                            CFDATA block, cabd.c:1322-1324): ERR_READ at once, without the
                                            two fabricated zero bytes of a clean EOF (readbits.h:194-208) */
@@ -77,7 +87,8 @@ typedef struct mspack_hip_unit {
   uint32_t in_chunk;     /* MSZIP repair mode: input_buffer_size of mszipd_init (mszipd.c:338-375), i.e.
                             the chunking of the folder stream by the reference's feeder; where the
                             next block is looked for after a failed one depends on it (mszipd.c:404,
-                            readbits.h:184-214).  0 = 4096 (the cabd default).  Else ignored        */
+                            readbits.h:184-214).  0 = 4096 (the cabd default).
+                            LZX with MSPACK_HIP_UF_FRAME_TABLE: arena offset / 4 of the frame table.  Else ignored */
 } mspack_hip_unit;
 
 typedef struct mspack_hip_result {
@@ -112,8 +123,10 @@ const char *mspack_hip_last_error(void);
  *                or in_bytes must leave 8 bytes of head-room inside the allocation)
  *   d_out      : output arena (every unit owns [out_off, out_off + out_len))
  *   d_results  : n_units results
- *   d_frame_scratch : >= mspack_hip_frame_scratch_bytes(total LZX frames incl. 1 spare per unit);
- *                may be NULL if the batch has no LZX units
+ *   d_frame_scratch : >= mspack_hip_frame_scratch_bytes(total LZX frames incl. 1 spare per unit) bytes of LZX
+ *                work space: per frame the E8 decision, and -- for units with a frame table -- the parse
+ *                waves' records and token lists (about 129 KiB per frame slot).  Contents need no
+ *                initialisation; may be NULL if the batch has no LZX units (LZX then decodes serially only)
  *   kind_mask  : bit k set = units of kind k may be present (one kernel per codec is launched;
  *                units of other kinds are skipped); 0 = all three codecs
  * MSZIP units need 32768 bytes of slack after out_len in their output region.

@@ -15,7 +15,7 @@ HIP_SO = os.environ.get("MSPACK_HIP_SO", os.path.join(HERE, "libmspack_hip.so"))
 CORPUS_SO = os.path.join(HERE, "libmspack_corpus.so")
 
 KIND_MSZIP, KIND_QUANTUM, KIND_LZX, KIND_LZX_DELTA, KIND_LZSS, KIND_KWAJ_LZH = 1, 2, 3, 4, 5, 6
-F_E8_APPLIED, F_LOOKAHEAD_READ, F_INTEL_HEADER = 1, 2, 4
+F_E8_APPLIED, F_LOOKAHEAD_READ, F_INTEL_HEADER, F_BLOCK_OPEN, F_FRAMES_ADOPTED = 1, 2, 4, 16, 32
 UF_MSZIP_REPAIR = 1
 ERR_OK, ERR_ARGS, ERR_OPEN, ERR_READ, ERR_WRITE, ERR_SEEK, ERR_NOMEMORY, ERR_SIGNATURE, \
     ERR_DATAFORMAT, ERR_CHECKSUM, ERR_CRUNCH, ERR_DECRUNCH = range(12)
@@ -83,8 +83,11 @@ def frames_of(units):
                     units["out_len"] // 32768 + 1, 0).astype(np.int64)
 
 
+UF_FRAME_TABLE = 8
+
+
 def make_units(kind, in_offs, in_lens, out_lens, window_bits=0, reset_frames=0, e8_base=0, flags=0,
-               out_slack=0, ref_lens=0):
+               out_slack=0, ref_lens=0, frame_tabs=None):
     """Build a unit table; output regions are laid out back to back (16-byte aligned, plus
     `out_slack` bytes each: MSZIP units need 32768 bytes of slack after out_len).  LZX DELTA units
     get `ref_lens` bytes of room for their reference data right below their output."""
@@ -99,6 +102,9 @@ def make_units(kind, in_offs, in_lens, out_lens, window_bits=0, reset_frames=0, 
     u["e8_base"] = e8_base
     u["flags"] = flags
     u["ref_len"] = ref_lens
+    if frame_tabs is not None:               # LZX: arena offsets of the units' frame tables (MSPACK_HIP_UF_FRAME_TABLE)
+        u["flags"] |= UF_FRAME_TABLE
+        u["in_chunk"] = np.asarray(frame_tabs, dtype=np.uint64) // 4
     rl = (u["ref_len"].astype(np.int64) + 15) & ~15
     rl = np.where((u["kind"] == KIND_LZSS) | (u["kind"] == KIND_KWAJ_LZH), 4096, rl)   # window pre-fill room
     sizes = ((np.asarray(out_lens, dtype=np.int64) + out_slack + 15) & ~15) + rl
@@ -163,6 +169,9 @@ def corpus():
         L.mspk_corpus_lzx_units_at.restype = sz
         L.mspk_corpus_lzx_units_at.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, sz, C.c_int, C.POINTER(LzxOpts),
                                                C.c_int, vp, vp, sz, vp, vp]
+        L.mspk_corpus_lzx_units_ft.restype = sz
+        L.mspk_corpus_lzx_units_ft.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, sz, C.c_int, C.POINTER(LzxOpts),
+                                               C.c_int, vp, vp, sz, vp, vp, vp]
         L.mspk_cab_write.restype = sz
         L.mspk_cab_write.argtypes = [vp, C.c_int, vp, C.c_int, vp, sz]
         L.mspk_chm_write.restype = sz
@@ -218,24 +227,32 @@ def lzx_encode(data, window_bits, reset_frames, opts=None):
     return dst[:m].copy(), fo
 
 
-def corpus_lzx_units(base_seed, kind, n_units, unit_bytes, window_bits, opts=None, n_threads=None, first_unit=0):
+def corpus_lzx_units(base_seed, kind, n_units, unit_bytes, window_bits, opts=None, n_threads=None, first_unit=0,
+                     frame_tables=False):
     """Batch of independent LZX units (one reset interval each); first_unit: global index of the first
     one when the call makes a shard of a larger list (unit seeds follow the global index).
-    -> (plain [n_units*unit_bytes], comp arena, comp_off u64[n], comp_len u32[n])"""
+    -> (plain [n_units*unit_bytes], comp arena, comp_off u64[n], comp_len u32[n])
+    frame_tables=True: every unit's frame table (where each 32 KiB frame starts in the compressed stream -- what a
+    CHM reset table or a cabinet's CFDATA sizes state) is written into the arena behind the unit, and a fifth
+    value tab_off u64[n] (arena offsets) is returned: make_units(..., frame_tabs=tab_off)."""
     L = corpus()
     if n_threads is None:
         n_threads = os.cpu_count() or 1
     plain = np.empty(n_units * unit_bytes, dtype=np.uint8)
-    cap = n_units * (L.mspk_lzx_bound(unit_bytes) + 16)
+    nfr = (unit_bytes + 32767) // 32768
+    cap = n_units * (L.mspk_lzx_bound(unit_bytes) + 24 + 4 * nfr)
     comp = np.zeros(cap, dtype=np.uint8)
     off = np.zeros(n_units, dtype=np.uint64)
     ln = np.zeros(n_units, dtype=np.uint32)
+    tab = np.zeros(n_units, dtype=np.uint64)
     o = opts if opts is not None else lzx_opts()
-    total = L.mspk_corpus_lzx_units_at(base_seed, first_unit, kind, n_units, unit_bytes, window_bits, C.byref(o),
+    total = L.mspk_corpus_lzx_units_ft(base_seed, first_unit, kind, n_units, unit_bytes, window_bits, C.byref(o),
                                        n_threads, plain.ctypes.data, comp.ctypes.data, cap, off.ctypes.data,
-                                       ln.ctypes.data)
+                                       ln.ctypes.data, tab.ctypes.data if frame_tables else None)
     if total == 0:
         raise MspackHipError("mspk_corpus_lzx_units failed")
+    if frame_tables:
+        return plain, comp[:total + 64].copy(), off, ln, tab
     return plain, comp[:total + 64].copy(), off, ln
 
 

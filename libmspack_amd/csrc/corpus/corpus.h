@@ -102,6 +102,12 @@ size_t mspk_corpus_lzx_units_at(uint64_t base_seed, uint64_t first_unit, int kin
                                 int window_bits, const mspk_lzx_opts *opts, int n_threads,
                                 uint8_t *plain, uint8_t *comp, size_t comp_cap,
                                 uint64_t *comp_off, uint32_t *comp_len);
+/* the same, and every unit's frame table written into `comp` behind the unit (tab_off[i] = its arena offset,
+ * 4-byte aligned; one uint32 per 32 KiB frame: the frame's compressed offset from the unit's first byte) */
+size_t mspk_corpus_lzx_units_ft(uint64_t base_seed, uint64_t first_unit, int kind, int n_units, size_t unit_bytes,
+                                int window_bits, const mspk_lzx_opts *opts, int n_threads,
+                                uint8_t *plain, uint8_t *comp, size_t comp_cap,
+                                uint64_t *comp_off, uint32_t *comp_len, uint64_t *tab_off);
 
 #ifdef __cplusplus
 }

@@ -253,7 +253,7 @@ __device__ __forceinline__ void lzx_leave_raw(LzxDec &d, LzxState &s) {
 }
 
 // block header (lzxd.c:467-523); returns false on error (d.err set)
-__device__ __forceinline__ bool lzx_block_header(LzxDec &d, LzxState &s)
+__device__ __forceinline__ bool lzx_block_header(LzxDec &d, LzxState &s, const bool tables = true)
 {
   LzxShared *sh = d.sh;
   u32 v, hi, lo;
@@ -287,7 +287,7 @@ __device__ __forceinline__ bool lzx_block_header(LzxDec &d, LzxState &s)
       u32 last = (part == 0) ? 256u : (part == 1 ? 256u + s.num_offsets : 249u);
       if (!lzx_read_lens(d, lens, first, last)) return false;
       HT0();
-      if (part == 1) {
+      if (part == 1 && tables) {
         if (huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
                                    sh->cnt, d.hr_main, d.lane, false)) {
           d.err = ERR_DECRUNCH; return false;
@@ -296,6 +296,7 @@ __device__ __forceinline__ bool lzx_block_header(LzxDec &d, LzxState &s)
         HT(2);
       }
     }
+    if (!tables) return true;              // a parse wave walking the headers in front of its own frame: lengths only
     HT0();
     r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt,
                               d.hr_len, d.lane, false);
@@ -770,6 +771,141 @@ __device__ __forceinline__ u32 lru_scan(u32 x)
   return v;
 }
 
+// ---- COMMIT: one batch of parsed tokens, one token per lane ---------------------------------------------
+// Shared by the speculative run (tokens from the LDS queue) and by the frame-parallel path (tokens a parse
+// wave left in global memory, lzx_run_tokens).
+struct LzxCommit {                  // wave-uniform commit-side state of a run
+  u32 P, R0, R1, R2;
+  u32 run_end, wbase, wsize, offset_written, ref_size;
+  SpecQueue Q;
+};
+#define LZX_TK_BAIL 6u             /* DELTA: a match length that announces an extension (lzxd.c:588-611) */
+#define LZX_TK_FAIL 7u
+
+// c0 = kind | output length << 3 | ..., c1 = literal or explicit offset; lanes >= n are idle.  Returns the number
+// of tokens taken: fewer than n at a marker (its kind in `marker`) or where the run ends (lzxd.c:538).
+__device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u32 c0, const u32 c1, u32 n,
+                                                u32 &marker, bool &fail_after)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  u8 *const out = d.out;
+  const u32 run_end = C.run_end, wbase = C.wbase, wsize = C.wsize;
+  const u32 P = C.P;
+  const u32 kind = c0 & 7u;
+  marker = 0; fail_after = false;
+  {
+    const u64 mk = ballot(lane < n && kind >= LZX_TK_BAIL);
+    if (mk) { const u32 jm = (u32) __ffsll((long long) mk) - 1u; marker = rdl(kind, jm); n = jm; }
+  }
+  const u32 olen = lane < n ? ((c0 >> 3) & 511u) : 0u;
+  const u32 incl = wave_incl_scan(olen);
+  const u32 opos = P + incl - olen;                   // output position of this lane's token
+  u32 newP = P + rdl(incl, 63u);
+  // tokens are decoded only while the run lasts (lzxd.c:538): the first one that would start at or
+  // after run_end, and everything parsed behind it, is not part of this run
+  if (newP >= run_end) {
+    const u64 late = ballot(lane < n && opos >= run_end);
+    if (late) { const u32 j = (u32) __ffsll((long long) late) - 1u; n = j; newP = rdl(opos, j); marker = 0; }
+  }
+  const bool valid = lane < n;
+#ifndef LZX_EXP_NOLIT
+  if (valid && kind == 0u) out[opos] = (u8) c1;
+#endif
+  const bool ism0 = valid && kind != 0u;
+  u64 mm = ballot(ism0);
+  if (mm) {
+    // (1) every match's offset through the R0-R2 LRU (lzxd.c:565-586)
+    const u32 sR0 = C.R0, sR1 = C.R1, sR2 = C.R2;
+    u32 vmoff = c1;
+    const u64 k1 = ballot(ism0 && kind == 1u);
+    if (!ballot(ism0 && kind >= 3u)) {
+      // only explicit offsets and repeats of R0: a repeat takes the nearest explicit offset before
+      // it, and the last three explicit offsets are the new R0-R2
+      const u64 below = k1 & ((1ull << lane) - 1ull);
+      const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
+      const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
+      if (kind == 2u) vmoff = below ? pv : sR0;
+      if (k1) {
+        u64 m = k1;
+        const u32 j0 = 63u - (u32) __clzll((long long) m);
+        u32 nb = sR0, nc = sR1;
+        m &= ~(1ull << j0);
+        if (m) {
+          const u32 j1 = 63u - (u32) __clzll((long long) m);
+          nb = rdl(c1, j1); nc = sR0;
+          m &= ~(1ull << j1);
+          if (m) nc = rdl(c1, 63u - (u32) __clzll((long long) m));
+        }
+        C.R0 = rdl(c1, j0); C.R1 = nb; C.R2 = nc;
+      }
+    }
+    else {
+      CNT(2);
+      u32 x = LRU_ID;
+      if (ism0) x = kind == 1u ? (0x010080u | lane) : (kind == 3u ? 0x020001u : (kind == 4u ? 0x000102u : LRU_ID));
+      const u32 Cm = lru_scan(x);
+      const u32 e0 = Cm & 0xFFu;
+      const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
+      vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
+      const u32 Cl = rdl(Cm, 63u);
+      const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
+      C.R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
+      C.R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
+      C.R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
+    }
+    // (2) the reference's checks (lzxd.c:613-634, 678-693) for all matches at once
+    {
+      const u32 wp = opos - wbase;
+      const bool bad = ism0 && (opos + olen > run_end || wp + olen > wsize ||
+                                LZX_BAD_SOURCE(vmoff, wp, C.offset_written, C.ref_size, wsize));
+      const u64 badm = ballot(bad);
+      if (badm) { mm &= (1ull << ((u32) __ffsll((long long) badm) - 1u)) - 1ull; fail_after = true; }
+    }
+#ifdef LZX_EXP_NOMATCH
+    mm = 0;
+#endif
+#ifndef LZX_EXP_NOCOPY
+    // (3) queue the matches
+    if (mm) {
+      bool ism = (mm >> lane) & 1ull;
+      // Offsets no linear copy can serve (0, or beyond the window: only from a stored block's R0-R2;
+      // DELTA: beyond the 23 bits the queue holds) take the slow way: resolve the queue, copy this
+      // batch's matches one at a time with the reference's ring semantics.
+      if (ballot(ism && (vmoff == 0u || vmoff > wsize || (vmoff >> 23) != 0u))) {
+        spq_resolve(sh->spq, C.Q, out, P, true, lane);
+        for (u64 dm = mm; dm; dm &= dm - 1ull) {
+          const u32 l = (u32) __ffsll((long long) dm) - 1u;
+          const u32 pos_l = rdl(opos, l), len_l = rdl(olen, l), off_l = rdl(vmoff, l);
+          if (off_l != 0u && off_l <= wsize) lzx_copy_match(out, pos_l, off_l, len_l, lane);
+          else { if (lane == 0) lzx_copy_match_odd(out, pos_l, pos_l - wbase, wsize, off_l, len_l); }
+        }
+        C.Q.Pf = newP;
+      }
+      else {
+        if (C.Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, C.Q, out, P, true, lane);
+        for (;;) {
+          // a push must keep every start flag inside the ring (spec_queue.hpp): take the matches that
+          // end inside it, resolve up to the first one that does not, go on
+          const u32 limit = (C.Q.Pf & ~63u) + SPQ_RING;
+          const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
+          if (fit) {
+            const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+            spq_push(sh->spq, C.Q, (fit >> lane) & 1ull, rank, (u32) __popcll(fit), opos, vmoff, olen);
+            mm &= ~fit;
+            ism = (mm >> lane) & 1ull;
+          }
+          if (!mm) break;
+          spq_resolve(sh->spq, C.Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
+        }
+      }
+    }
+#endif
+  }
+  C.P = newP;
+  return n;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The speculative decode of a run of tokens (lzxd.c:538-651), in two alternating phases.
 //
@@ -793,8 +929,6 @@ __device__ __forceinline__ u32 lru_scan(u32 x)
 // cannot decode becomes a FAIL marker that only counts when the commit reaches it.
 // ---------------------------------------------------------------------------------------------------
 #define LZX_TQ 128u                /* token queue entries (two commits' worth) */
-#define LZX_TK_BAIL 6u             /* DELTA: a match length that announces an extension (lzxd.c:588-611) */
-#define LZX_TK_FAIL 7u
 
 template <bool ALIGNED>
 __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 run_end_, const u32 wbase_)
@@ -803,10 +937,11 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   const u32 lane = d.lane;
   u8 *const out = d.out;
   // everything below is wave-uniform; readfirstlane tells the compiler so (SGPRs, scalar branches)
-  const u32 run_end = rfl(run_end_), wbase = rfl(wbase_);
-  u32 P = rfl(d.P);
-  u32 R0 = rfl(s.R0), R1 = rfl(s.R1), R2 = rfl(s.R2);
-  const u32 wsize = rfl(s.wsize), offset_written = rfl(s.offset), ref_size = rfl(s.ref_size);
+  LzxCommit C;
+  C.run_end = rfl(run_end_); C.wbase = rfl(wbase_);
+  C.P = rfl(d.P);
+  C.R0 = rfl(s.R0); C.R1 = rfl(s.R1); C.R2 = rfl(s.R2);
+  C.wsize = rfl(s.wsize); C.offset_written = rfl(s.offset); C.ref_size = rfl(s.ref_size);
   const bool length_empty = rfl((u32) s.length_empty) != 0u;
   int rc = LZX_RUN_DONE;
 
@@ -825,16 +960,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
 #pragma unroll
   for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
 
-#ifndef LZX_EXP_NOCOPY
-#define SPEC_COPY(pos_, len_, moff_, wp_)                                                    \
-  do { if ((moff_) != 0u && (moff_) <= wsize) lzx_copy_match(out, (pos_), (moff_), (len_), lane); \
-       else { if (lane == 0) lzx_copy_match_odd(out, (pos_), (wp_), wsize, (moff_), (len_)); } } while (0)
-#else
-#define SPEC_COPY(pos_, len_, moff_, wp_) do { } while (0)
-#endif
-
-  SpecQueue Q;
-  spq_init(sh->spq, Q, P, lane);
+  spq_init(sh->spq, C.Q, C.P, lane);
   u32 *const tq0 = sh->tq0, *const tq1 = sh->tq1;
   u32 th = 0, tt = 0;                                   // token queue: committed / parsed (counters)
   bool stop = false;                                    // the parser is done (input margin, marker)
@@ -845,7 +971,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
 #else
 #define TICK(k) do { } while (0)
 #endif
-  while (rc == LZX_RUN_DONE && P < run_end && !bail) {
+  while (rc == LZX_RUN_DONE && C.P < C.run_end && !bail) {
 #ifdef LZX_EXP_STATS
     u64 tk_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -953,147 +1079,265 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const u32 ci = (th + lane) & (LZX_TQ - 1u);
     const u32 c0 = tq0[ci], c1 = tq1[ci];
-    const u32 kind = c0 & 7u;
-    u32 marker = 0;
-    {
-      const u64 mk = ballot(lane < n && kind >= LZX_TK_BAIL);
-      if (mk) { const u32 jm = (u32) __ffsll((long long) mk) - 1u; marker = rdl(kind, jm); n = jm; }
-    }
-    const u32 olen = lane < n ? ((c0 >> 3) & 511u) : 0u;
-    const u32 incl = wave_incl_scan(olen);
-    const u32 opos = P + incl - olen;                   // output position of this lane's token
-    u32 newP = P + rdl(incl, 63u);
-    // tokens are decoded only while the run lasts (lzxd.c:538): the first one that would start at or
-    // after run_end, and everything parsed behind it, is not part of this run
-    if (newP >= run_end) {
-      const u64 late = ballot(lane < n && opos >= run_end);
-      if (late) { const u32 j = (u32) __ffsll((long long) late) - 1u; n = j; newP = rdl(opos, j); marker = 0; }
-    }
-    const bool valid = lane < n;
-#ifndef LZX_EXP_NOLIT
-    if (valid && kind == 0u) out[opos] = (u8) c1;
-#endif
-    TICK(3);
-    bool fail_after = false;
-    const bool ism0 = valid && kind != 0u;
-    u64 mm = ballot(ism0);
-    if (mm) {
-      // (1) every match's offset through the R0-R2 LRU (lzxd.c:565-586)
-      const u32 sR0 = R0, sR1 = R1, sR2 = R2;
-      u32 vmoff = c1;
-      const u64 k1 = ballot(ism0 && kind == 1u);
-      if (!ballot(ism0 && kind >= 3u)) {
-        // only explicit offsets and repeats of R0: a repeat takes the nearest explicit offset before
-        // it, and the last three explicit offsets are the new R0-R2
-        const u64 below = k1 & ((1ull << lane) - 1ull);
-        const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
-        const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
-        if (kind == 2u) vmoff = below ? pv : sR0;
-        if (k1) {
-          u64 m = k1;
-          const u32 j0 = 63u - (u32) __clzll((long long) m);
-          u32 nb = sR0, nc = sR1;
-          m &= ~(1ull << j0);
-          if (m) {
-            const u32 j1 = 63u - (u32) __clzll((long long) m);
-            nb = rdl(c1, j1); nc = sR0;
-            m &= ~(1ull << j1);
-            if (m) nc = rdl(c1, 63u - (u32) __clzll((long long) m));
-          }
-          R0 = rdl(c1, j0); R1 = nb; R2 = nc;
-        }
-      }
-      else {
-        CNT(2);
-        u32 x = LRU_ID;
-        if (ism0) x = kind == 1u ? (0x010080u | lane) : (kind == 3u ? 0x020001u : (kind == 4u ? 0x000102u : LRU_ID));
-        const u32 C = lru_scan(x);
-        const u32 e0 = C & 0xFFu;
-        const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
-        vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
-        const u32 Cl = rdl(C, 63u);
-        const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
-        R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
-        R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
-        R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
-      }
-      TICK(4);
-      // (2) the reference's checks (lzxd.c:613-634, 678-693) for all matches at once
-      {
-        const u32 wp = opos - wbase;
-        const bool bad = ism0 && (opos + olen > run_end || wp + olen > wsize ||
-                                  LZX_BAD_SOURCE(vmoff, wp, offset_written, ref_size, wsize));
-        const u64 badm = ballot(bad);
-        if (badm) { mm &= (1ull << ((u32) __ffsll((long long) badm) - 1u)) - 1ull; fail_after = true; }
-      }
-#ifdef LZX_EXP_NOMATCH
-      mm = 0;
-#endif
-#ifndef LZX_EXP_NOCOPY
-      // (3) queue the matches
-      if (mm) {
-        bool ism = (mm >> lane) & 1ull;
-        // Offsets no linear copy can serve (0, or beyond the window: only from a stored block's R0-R2;
-        // DELTA: beyond the 23 bits the queue holds) take the slow way: resolve the queue, copy this
-        // batch's matches one at a time with the reference's ring semantics.
-        if (ballot(ism && (vmoff == 0u || vmoff > wsize || (vmoff >> 23) != 0u))) {
-          spq_resolve(sh->spq, Q, out, P, true, lane);
-          for (u64 dm = mm; dm; dm &= dm - 1ull) {
-            const u32 l = (u32) __ffsll((long long) dm) - 1u;
-            const u32 pos_l = rdl(opos, l), len_l = rdl(olen, l), off_l = rdl(vmoff, l);
-            SPEC_COPY(pos_l, len_l, off_l, pos_l - wbase);
-          }
-          Q.Pf = newP;
-        }
-        else {
-          if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
-          for (;;) {
-            // a push must keep every start flag inside the ring (spec_queue.hpp): take the matches that
-            // end inside it, resolve up to the first one that does not, go on
-            const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
-            const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
-            if (fit) {
-              const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
-              spq_push(sh->spq, Q, (fit >> lane) & 1ull, rank, (u32) __popcll(fit), opos, vmoff, olen);
-              mm &= ~fit;
-              ism = (mm >> lane) & 1ull;
-            }
-            if (!mm) break;
-            spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
-          }
-        }
-      }
-#endif
-    }
-    th += n;
-    P = newP;
+    u32 marker; bool fail_after;
+    th += lzx_commit_batch(d, C, c0, c1, n, marker, fail_after);
     TICK(5);
 #ifndef LZX_EXP_NOCOPY
-    if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane);
+    if (spq_due(C.Q, C.P)) spq_resolve(sh->spq, C.Q, out, C.P, false, lane);
 #endif
     TICK(6);
     if (fail_after || marker == LZX_TK_FAIL) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; }
     else if (marker == LZX_TK_BAIL) bail = true;
   }
 #ifndef LZX_EXP_NOCOPY
-  spq_resolve(sh->spq, Q, out, P, true, lane);
+  spq_resolve(sh->spq, C.Q, out, C.P, true, lane);
 #endif
   // parsed but not committed: the bit position goes back to the first such token
   if (tt != th) {
     const u32 lo = rfl(tq0[th & (LZX_TQ - 1u)]) >> 12;
     bitpos -= (bitpos - lo) & 0xFFFFu;
   }
-#undef SPEC_COPY
-  d.P = P;
-  s.R0 = R0; s.R1 = R1; s.R2 = R2;
+  d.P = C.P;
+  s.R0 = C.R0; s.R1 = C.R1; s.R2 = C.R2;
   spec_resync(d, bitpos, cb, pf);
   return rc;
 }
 
+#ifndef LZX_DELTA
+// ---------------------------------------------------------------------------------------------------
+// Frame-level parse parallelism (plain LZX; units that carry a frame table, MSPACK_HIP_UF_FRAME_TABLE).
+//
+// Every 32 KiB frame starts on a 16-bit boundary of the compressed stream (lzxd.c:695-697) at an offset the
+// container states up front -- one CFDATA block per frame in a cabinet (cabd.c:1362-1479), one reset-table
+// entry per frame in a CHM (chmd.c:1146-1149).  The serial chain of a unit is "where does the next token
+// start"; it needs the Huffman tables, not the window and not R0-R2.  So a PARSE wave per frame
+// (mspack_lzx_parse) walks the block headers from the last reset point to its own frame (code lengths are
+// deltas on the previous block's, lzxd.c:138-183), builds the tables, parses the frame's tokens with the same
+// 64-positions-per-round scheme as lzx_run_spec and leaves them in global memory with a record of what it
+// assumed.  It works on the guess that every frame on the way holds exactly ONE verbatim / aligned block that
+// begins where the frame begins -- what encoders do -- and gives up silently otherwise.
+// The unit's own wave (mspack_decode_lzx) stays the only judge: frame by frame it checks that its bit
+// position is the one the record was parsed from and that no block is open, adopts the record, and commits
+// the tokens 64 at a time (lzx_run_tokens: positions, literals, R0-R2, the reference's checks, match queue).
+// Whatever a record does not cover -- the last bytes of the input, a frame with several blocks, stored blocks,
+// a damaged stream, a wrong table -- is decoded by the serial path exactly as before, so error codes and
+// byte counts cannot differ.
+// ---------------------------------------------------------------------------------------------------
+#define LZX_TOK_CAP 16384u          /* tokens a parse wave stores per frame (8 bytes each) */
+#define LZX_CHAIN_MAX 8u            /* headers a parse wave walks in front of its own frame, at most */
+
+struct __align__(16) LzxFrameRec {
+  u32 status;                       /* 1 = parsed */
+  u32 n_tokens;
+  u32 hdr_start_bit;                /* bit positions count from the unit's first compressed byte */
+  u32 end_bit;                      /* first bit that was not parsed */
+  u32 block_type, block_length;
+  u32 flags;                        /* 1: the length tree is empty, 2: literal 0xE8 has a code */
+  u32 pad0;
+  u8 ali_len[8];
+  u8 pad1[8];
+  u8 main_len[LZX_MAIN_SYMS + 16];
+  u8 len_len[LZX_LEN_SYMS + 70];
+  u8 pad2[48];
+};
+static_assert(sizeof(LzxFrameRec) == 1152, "LzxFrameRec layout");
+
+// continue reading at an absolute bit position (from the unit's first byte)
+__device__ __forceinline__ void lzx_seek_bit(LzxDec &d, const u32 abs_bit)
+{
+  const u32 par = d.w.origin & 1u;                       // 16-bit words start at bytes of this parity
+  const u32 wbyte = ((((abs_bit >> 3) - par) >> 1) << 1) + par;
+  const u32 sk = abs_bit - wbyte * 8u;
+  d.w.seek(wbyte, d.lane);
+  d.bb = 0; d.bl = 0; d.rbl = 0;
+  d.near_end = (wbyte >= d.w.in_len || d.w.in_len - wbyte <= 64u);
+  d.refill(); d.refill();
+  if (sk) { d.bb <<= sk; d.bl -= (int) sk; }
+}
+
+// the PARSE phase of lzx_run_spec alone, tokens to global memory
+template <bool ALIGNED>
+__device__ __forceinline__ void lzx_parse_tokens(LzxDec &d, const bool length_empty, const u32 frame_size,
+                                                 uint2 *tok, u32 &n_tok, u32 &end_bit)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  const u32 bit_limit = spec_bit_limit(d, 56u);
+  const u32 base_bit = rfl(d.w.origin) * 8u;
+  u32 bitpos, cb, pf;
+  spec_stage(d, bitpos, cb, pf);
+  u32 mlim[16 - LZX_MAIN_P];
+#pragma unroll
+  for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
+  u32 tt = 0, outc = 0;
+  while (bitpos < bit_limit && outc < frame_size && tt <= LZX_TOK_CAP - 64u) {
+    spec_slide(d, bitpos, cb, pf);
+    const u32 rel = bitpos - (cb << 11) + lane;
+    const u32 k = rel >> 5, sft = rel & 31u;
+    const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
+    const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+    const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
+    const SpecTok t = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0, w1);
+    const u32 vn = t.unk ? (256u + lane) : (lane + t.tot);
+    u64 chain = 0;
+    u32 q = 0;
+    do { chain |= 1ull << q; q = rdl(vn, q); } while (q < 64u);
+    bool hit_unknown = false;
+    if (q >= 256u) { q -= 256u; hit_unknown = true; chain &= ~(1ull << q); }
+    const bool on = (chain >> lane) & 1ull;
+    const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain, 0u));
+    if (on) tok[tt + rank] = make_uint2(t.kind | (t.olen << 3) | (((base_bit + bitpos + lane) & 0xFFFFu) << 12),
+                                        t.kind == 0u ? t.sym : t.off);
+    tt += (u32) __popcll(chain);
+    outc += rdl(wave_incl_scan(on ? t.olen : 0u), 63u);
+    bitpos += q;
+    if (hit_unknown) break;                              // the unit's own wave takes (and judges) this token
+  }
+  n_tok = tt; end_bit = base_bit + bitpos;
+}
+
+// one parse wave: frame f of unit u
+__device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, LzxFrameRec *rec,
+                                uint2 *tok, LzxShared *sh)
+{
+  const u32 lane = threadIdx.x;
+  LzxDec d;
+  LzxState s;
+  d.lane = lane; d.sh = sh; d.err = 0;
+  d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
+  d.w.eofs = (u.flags & MSPACK_HIP_UF_HARD_EOF) ? 0u : 2u;
+  d.out = nullptr; d.P = 0; d.lit_buf = 0; d.lit_n = 0;
+  d.st_rounds = 0; d.st_unknown = 0;
+  for (int k_ = 0; k_ < 10; k_++) d.st_t[k_] = 0;
+  d.st_h[0] = d.st_h[1] = d.st_h[2] = 0;
+  d.bb = 0; d.bl = 0; d.rbl = 0; d.near_end = false; d.careful = false;
+  d.w.origin = 0; d.w.wi = 0; d.w.cur = 0; d.w.nxt = 0;
+  s.wsize = 1u << u.window_bits;
+  s.wpos = 0; s.frame_posn = 0; s.frame = 0; s.reset_frames = u.reset_frames;
+  s.offset = 0; s.length = u.out_len;
+  s.intel_filesize = 0; s.intel_started = false; s.length_empty = false;
+  s.raw_mode = false; s.raw_pos = 0; s.ref_size = 0;
+  {
+    static const u16 slots[11] = { 30, 32, 34, 36, 38, 42, 50, 66, 98, 162, 290 };
+    const u32 wb = u.window_bits;
+    s.num_offsets = (wb >= 15u && wb <= 21u) ? ((u32) slots[wb - 15u] << 3) : 0u;
+  }
+  if (s.num_offsets == 0u) return;
+  const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
+  const u32 rf = u.reset_frames;
+  const u32 g0 = rf ? f - f % rf : 0u;
+  if (f - g0 >= LZX_CHAIN_MAX) return;
+  lzx_reset_state(d, s);
+  u32 hdr_start = 0, fsz = 0;
+  for (u32 g = g0; g <= f; g++) {
+    const u32 fo = rfl(ftab[g]);
+    if (fo >= u.in_len || u.in_len - fo <= 64u) return;   // the last bytes of the input belong to the EOF-exact reader
+    d.w.seek(fo, lane);
+    d.bb = 0; d.bl = 0; d.rbl = 0; d.near_end = false; d.careful = false;
+    if (g == g0) {                                        // the interval's (stream's) 1 + 32 header bits, lzxd.c:447-453
+      u32 v, hi, lo;
+      if (!d.read_bits(1, v)) return;
+      if (v) { if (!d.read_bits(16, hi) || !d.read_bits(16, lo)) return; }
+    }
+    hdr_start = fo * 8u + d.cons_bits();
+    if (!lzx_block_header(d, s, g == f)) return;
+    if (d.careful || d.near_end) return;
+    fsz = u.out_len - g * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
+    if ((s.block_type != 1u && s.block_type != 2u) || s.block_length != fsz) return;   // one block per frame, or no guess
+  }
+  u32 n_tok = 0, end_bit = 0;
+  if (s.block_type == 2u) lzx_parse_tokens<true>(d, s.length_empty, fsz, tok, n_tok, end_bit);
+  else lzx_parse_tokens<false>(d, s.length_empty, fsz, tok, n_tok, end_bit);
+  for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) rec->main_len[i] = sh->main_len[i];
+  for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) rec->len_len[i] = sh->len_len[i];
+  if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
+  if (lane == 0) {
+    rec->n_tokens = n_tok; rec->hdr_start_bit = hdr_start; rec->end_bit = end_bit;
+    rec->block_type = s.block_type; rec->block_length = s.block_length;
+    rec->flags = (s.length_empty ? 1u : 0u) | (sh->main_len[0xE8] != 0 ? 2u : 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    rec->status = 1u;
+  }
+}
+
+// an adopted record's code lengths back into LDS (a later block header works on them, lzxd.c:138-183) ...
+__device__ __forceinline__ void lzx_restore_lens(LzxDec &d, const LzxFrameRec *rec)
+{
+  LzxShared *sh = d.sh;
+  for (u32 i = d.lane; i < LZX_MAIN_SYMS + 16; i += WAVE) sh->main_len[i] = rec->main_len[i];
+  for (u32 i = d.lane; i < LZX_LEN_SYMS + 70; i += WAVE) sh->len_len[i] = rec->len_len[i];
+  if (d.lane < 8u) sh->ali_len[d.lane] = rec->ali_len[d.lane];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+// ... and its decode tables, when the serial path has to finish the block itself
+__device__ __forceinline__ void lzx_restore_tables(LzxDec &d, LzxState &s)
+{
+  LzxShared *sh = d.sh;
+  huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+                                               sh->cnt, d.hr_main, d.lane, false);
+  const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, d.lane, false);
+  s.length_empty = (r == 2);
+  if (s.block_type == 2u) huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, d.lane, false);
+}
+
+// commit a frame's pre-parsed tokens; next_bit = where the stream goes on
+__device__ __forceinline__ int lzx_run_tokens(LzxDec &d, LzxState &s, const u32 run_end_, const u32 wbase_,
+                                              const uint2 *tok, const u32 n_tok_, const u32 end_bit_, u32 &next_bit)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  u8 *const out = d.out;
+  const u32 n_tok = rfl(n_tok_), end_bit = rfl(end_bit_);
+  LzxCommit C;
+  C.run_end = rfl(run_end_); C.wbase = rfl(wbase_);
+  C.P = rfl(d.P);
+  C.R0 = rfl(s.R0); C.R1 = rfl(s.R1); C.R2 = rfl(s.R2);
+  C.wsize = rfl(s.wsize); C.offset_written = rfl(s.offset); C.ref_size = 0;
+  int rc = LZX_RUN_DONE;
+  d.flush_lits();
+  spq_init(sh->spq, C.Q, C.P, lane);
+  u32 th = 0;
+  uint2 cur = make_uint2(0u, 0u);
+  if (lane < n_tok) cur = tok[lane];
+  while (C.P < C.run_end && th < n_tok) {
+    u32 n = n_tok - th; if (n > 64u) n = 64u;
+    uint2 nxt = make_uint2(0u, 0u);
+    if (th + 64u + lane < n_tok) nxt = tok[th + 64u + lane];          // in flight while this batch commits
+    u32 marker; bool fail_after;
+    const u32 took = lzx_commit_batch(d, C, cur.x, cur.y, n, marker, fail_after);
+    th += took;
+#ifndef LZX_EXP_NOCOPY
+    if (spq_due(C.Q, C.P)) spq_resolve(sh->spq, C.Q, out, C.P, false, lane);
+#endif
+    if (fail_after) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; break; }
+    if (took < n) break;                                              // the run ended inside this batch
+    cur = nxt;
+  }
+#ifndef LZX_EXP_NOCOPY
+  spq_resolve(sh->spq, C.Q, out, C.P, true, lane);
+#endif
+  next_bit = end_bit;
+  if (th < n_tok) {                                                   // parsed beyond the run: back to the first such token
+    const u32 s16 = rfl(tok[th].x) >> 12;
+    next_bit = end_bit - ((end_bit - s16) & 0xFFFFu);
+  }
+  d.P = C.P;
+  s.R0 = C.R0; s.R1 = C.R1; s.R2 = C.R2;
+  return rc;
+}
+#endif  /* !LZX_DELTA */
+
 // decode one LZX unit.  frame_meta[frame_base + f] receives the intel_filesize to apply to frame f
 // (0 = none).  Returns via *res.
-__device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
+#ifdef LZX_DELTA
+__device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
                                 int32_t *frame_meta, mspack_hip_result *res, LzxShared *sh)
+#else
+// recs / toks: the parse waves' records and tokens for this launch (NULL: none), indexed by frame slot
+__device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
+                                int32_t *frame_meta, mspack_hip_result *res, LzxShared *sh,
+                                const LzxFrameRec *recs, const uint2 *toks)
+#endif
 {
   const u32 lane = threadIdx.x;
   LzxDec d;
@@ -1145,12 +1389,21 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   u64 tstart_ = __builtin_amdgcn_s_memtime();
 #endif
 
+#ifndef LZX_DELTA
+  const bool use_recs = recs != nullptr && (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u;
+  bool chain_ok = use_recs;                 // every frame since the last reset point was adopted
+  const LzxFrameRec *stale = nullptr;       // adopted record whose code lengths / tables are not in LDS (yet)
+  bool stale_tables = false;
+#endif
   if (out_bytes != 0u) {
     const u32 end_frame = out_bytes / LZX_FRAME + 1u;                      // lzxd.c:419
     while (s.frame < end_frame) {
       if (s.reset_frames && (s.frame % s.reset_frames) == 0u) {
         // a reset in raw mode keeps reading bits from raw_pos (no pad byte: block_type is cleared)
         lzx_reset_state(d, s);
+#ifndef LZX_DELTA
+        chain_ok = use_recs; stale = nullptr; stale_tables = false;
+#endif
       }
 #ifdef LZX_DELTA
       {                                                               // chunk size (lzxd.c:440-444)
@@ -1177,9 +1430,31 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
 
       int todo = (int)(s.frame_posn + frame_size - s.wpos);
       bool fail = false;
+#ifndef LZX_DELTA
+      // ---- a parse wave's record for this frame?  adopt it if it was parsed from exactly this state ----
+      const LzxFrameRec *adopt = nullptr;
+      if (chain_ok && todo > 0 && s.block_remaining == 0u && !s.raw_mode && !d.careful && !d.near_end) {
+        const LzxFrameRec *r = &recs[u.frame_base + s.frame];
+        if (rfl(r->status) == 1u && rfl(r->hdr_start_bit) == rfl(d.w.origin) * 8u + rfl(d.cons_bits()) &&
+            rfl(r->block_length) == frame_size) adopt = r;
+      }
+      if (adopt) {
+        s.block_type = rfl(adopt->block_type);
+        s.block_length = s.block_remaining = rfl(adopt->block_length);
+        const u32 rfl_ = rfl(adopt->flags);
+        s.length_empty = (rfl_ & 1u) != 0u;
+        if (rfl_ & 2u) s.intel_started = true;
+        stale = adopt; stale_tables = true;
+        flags |= MSPACK_HIP_F_FRAMES_ADOPTED;
+      }
+      else chain_ok = false;
+#endif
       while (todo > 0) {
 #ifdef LZX_EXP_STATS
         u64 t0_ = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef LZX_DELTA
+        if (s.block_remaining == 0u && stale) { lzx_restore_lens(d, stale); stale = nullptr; stale_tables = false; }
 #endif
         if (s.block_remaining == 0u) { if (!lzx_block_header(d, s)) { fail = true; break; } }
 #ifdef LZX_EXP_STATS
@@ -1195,6 +1470,21 @@ __device__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
           const u32 run_end = d.P + (u32) run;
           const u32 wbase = d.P - s.wpos;          // linear position of window index 0
           bool respec = true;                      // try the speculative path (again)
+#ifndef LZX_DELTA
+          if (adopt) {
+            u32 next_bit;
+            const int rc = lzx_run_tokens(d, s, run_end, wbase, toks + (size_t)(u.frame_base + s.frame) * LZX_TOK_CAP,
+                                          adopt->n_tokens, adopt->end_bit, next_bit);
+            adopt = nullptr;
+            if (rc == LZX_RUN_FAIL) { fail = true; }
+            else lzx_seek_bit(d, next_bit);
+          }
+          if (!fail && d.P < run_end && stale_tables) {      // the record did not reach the end of the run
+            if (stale) { lzx_restore_lens(d, stale); stale = nullptr; }
+            lzx_restore_tables(d, s); stale_tables = false;
+          }
+          if (fail) break;
+#endif
           while (d.P < run_end) {
             if (respec && !d.careful && !d.near_end) {
 #ifndef LZX_NO_SPEC

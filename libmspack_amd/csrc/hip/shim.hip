@@ -36,10 +36,58 @@ __device__ __forceinline__ bool pick_unit(const mspack_hip_unit *units, const u3
   return units[ui].kind == kind;
 }
 
+// ---- LZX work scratch (d_frame_scratch of the C ABI), n = n_frames_total + 1 frame slots ----------------
+//   int32  meta[n]        per frame: intel_filesize to apply in the E8 pass (0 = none)
+//   u32    frame_unit[n]  per frame slot: the unit it belongs to when a parse wave should take it, else ~0
+//   LzxFrameRec recs[n]   what the parse wave of that frame assumed and found (lzx_kernel.hpp)
+//   uint2  toks[n][LZX_TOK_CAP]  its tokens
+struct LzxScratch { int32_t *meta; u32 *frame_unit; lzxn::LzxFrameRec *recs; uint2 *toks; size_t bytes; };
+__host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_frames_total)
+{
+  const size_t n = n_frames_total + 1, a = 255;
+  const size_t o_fu = (n * 4 + a) & ~a, o_rec = o_fu + ((n * 4 + a) & ~a), o_tok = o_rec + n * sizeof(lzxn::LzxFrameRec);
+  LzxScratch L;
+  char *b = (char *) base;
+  L.meta = (int32_t *) b; L.frame_unit = (u32 *)(b + o_fu); L.recs = (lzxn::LzxFrameRec *)(b + o_rec);
+  L.toks = (uint2 *)(b + o_tok);
+  L.bytes = o_tok + n * (size_t) LZX_TOK_CAP * sizeof(uint2);
+  return L;
+}
+
+// which frame slots get a parse wave: the real frames of LZX units that carry a frame table
+__global__ __launch_bounds__(64)
+void mspack_lzx_frame_map(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 *frame_unit,
+                          lzxn::LzxFrameRec *recs)
+{
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) return;
+  const mspack_hip_unit u = units[ui];
+  const u32 nslots = u.out_len / LZX_FRAME + 1u, nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
+  const bool usable = (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u;
+  for (u32 f = threadIdx.x; f < nslots; f += 64u) {
+    frame_unit[u.frame_base + f] = (usable && f < nreal) ? ui : 0xFFFFFFFFu;
+    recs[u.frame_base + f].status = 0u;
+  }
+}
+
+// one parse wave per frame slot (lzx_kernel.hpp: "Frame-level parse parallelism")
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void mspack_lzx_parse(const mspack_hip_unit *units, u32 slot_lo, u32 n_slots, const u8 *in_arena,
+                      const u32 *frame_unit, lzxn::LzxFrameRec *recs, uint2 *toks)
+{
+  __shared__ lzxn::LzxShared sh;
+  if (blockIdx.x >= n_slots) return;
+  const u32 slot = slot_lo + blockIdx.x;
+  const u32 ui = rfl(frame_unit[slot]);
+  if (ui == 0xFFFFFFFFu) return;
+  const mspack_hip_unit u = units[ui];
+  lzxn::lzx_parse_frame(u, slot - u.frame_base, in_arena, &recs[slot], toks + (size_t) slot * LZX_TOK_CAP, &sh);
+}
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_units,
                        const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
-                       int32_t *frame_meta)
+                       int32_t *frame_meta, const lzxn::LzxFrameRec *recs, const uint2 *toks)
 {
   __shared__ lzxn::LzxShared sh;
   u32 ui;
@@ -47,7 +95,7 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
   const mspack_hip_unit u = units[ui];
   mspack_hip_result *res = &results[ui];
   const u32 lane = threadIdx.x;
-  lzxn::lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, &sh);
+  lzxn::lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, &sh, recs, toks);
   // E8 translation, frame by frame, once the unit no longer needs its window (lzxd.c:706-736)
   if (frame_meta) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -146,16 +194,30 @@ static int fail(hipError_t e, const char *what) {
 }
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(e_, #call); } while (0)
 
-// one launch per codec over a COMPACT list of that codec's units (order[0..n) = unit indices)
+// one launch per codec over a COMPACT list of that codec's units (order[0..n) = unit indices).  LZX units
+// that carry a frame table get their frames parsed by one wave each first (slots [slot_lo, slot_lo + n_slots)
+// of the work scratch belong to this launch).
+static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
 static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
-                        const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, hipStream_t st)
+                        const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
+                        size_t slot_lo, size_t n_slots, hipStream_t st)
 {
   if (n == 0) return;
   const dim3 grid((unsigned) n), block(64);
   switch (kind) {
-  case MSPACK_HIP_KIND_LZX:
+  case MSPACK_HIP_KIND_LZX: {
+    LzxScratch L = lzx_scratch(d_fm, n_frames_total);
+    const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames;
+    if (frames) {
+      hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
+      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs);
+      hipLaunchKernelGGL(mspack_lzx_parse, dim3((unsigned) n_slots), block, 0, st, d_units, (u32) slot_lo, (u32) n_slots,
+                         (const u8 *) d_in, (const u32 *) L.frame_unit, L.recs, L.toks);
+    }
     hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results, (int32_t *) d_fm); break;
+                       d_results, d_fm ? L.meta : nullptr, frames ? (const lzxn::LzxFrameRec *) L.recs : nullptr,
+                       (const uint2 *) L.toks);
+    break; }
   case MSPACK_HIP_KIND_LZX_DELTA:
     hipLaunchKernelGGL(mspack_decode_lzxd, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
                        d_results, (int32_t *) d_fm); break;
@@ -188,7 +250,7 @@ int mspack_hip_device_count(void) {
 }
 int mspack_hip_set_device(int device) { CK(hipSetDevice(device)); return 0; }
 
-size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total) { return (n_frames_total + 1) * sizeof(int32_t); }
+size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total) { return lzx_scratch(nullptr, n_frames_total).bytes; }
 
 int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_t *d_order,
                                    size_t n_units, const void *d_in, size_t in_bytes,
@@ -196,7 +258,7 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
                                    void *d_frame_scratch, size_t n_frames_total, unsigned kind_mask,
                                    void *stream)
 {
-  (void) in_bytes; (void) out_bytes; (void) n_frames_total;
+  (void) in_bytes; (void) out_bytes;
   if (n_units == 0) return 0;
   if (kind_mask == 0) kind_mask = 0x7E;     // bit k = units of kind k may be present
   // the caller's unit table lives on the device, so the kinds cannot be compacted here: every codec in the
@@ -204,7 +266,8 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
   // order list per codec and a one-bit mask (what the host-buffer entry points below do).
   for (unsigned k = 1; k <= 6; k++)
     if (kind_mask & (1u << k))
-      launch_kind(k, d_units, d_order, n_units, d_in, d_out, d_results, d_frame_scratch, (hipStream_t) stream);
+      launch_kind(k, d_units, d_order, n_units, d_in, d_out, d_results, d_frame_scratch, n_frames_total, 0, n_frames_total,
+                  (hipStream_t) stream);
   CK(hipGetLastError());
   return 0;
 }
@@ -286,6 +349,10 @@ static inline uint64_t unit_below(const mspack_hip_unit &u) {
        : (u.kind == MSPACK_HIP_KIND_LZX_DELTA ? u.ref_len : 0u);
 }
 static inline uint64_t unit_above(const mspack_hip_unit &u) { return u.kind == MSPACK_HIP_KIND_MSZIP ? 32768u : 0u; }
+static inline bool unit_has_ftab(const mspack_hip_unit &u) {
+  return u.kind == MSPACK_HIP_KIND_LZX && (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u;
+}
+static inline uint64_t unit_ftab_bytes(const mspack_hip_unit &u) { return (((uint64_t) u.out_len + 32767u) / 32768u) * 4u; }
 static inline size_t unit_frames(const mspack_hip_unit &u) {
   return (u.kind == MSPACK_HIP_KIND_LZX || u.kind == MSPACK_HIP_KIND_LZX_DELTA) ? (size_t) u.out_len / 32768u + 1u : 0u;
 }
@@ -329,6 +396,11 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     if (i && lo < prev_hi) monotone = false;
     prev_hi = hi;
     in_lo = std::min<uint64_t>(in_lo, u.in_off); in_hi = std::max<uint64_t>(in_hi, u.in_off + u.in_len);
+    if (unit_has_ftab(u)) {
+      const uint64_t tl = (uint64_t) u.in_chunk * 4u, th = tl + unit_ftab_bytes(u);
+      if (th > in_bytes) { snprintf(errbuf, errcap, "unit's frame table outside arena"); return -1; }
+      in_lo = std::min(in_lo, tl); in_hi = std::max(in_hi, th);
+    }
     out_lo = std::min(out_lo, lo); out_hi = std::max(out_hi, hi);
     in_sum += u.in_len;
     u.frame_base = (uint32_t) n_frames; units[idx[i]].frame_base = (uint32_t) n_frames;
@@ -370,6 +442,10 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       for (size_t i = c.a; i < c.b; i++) {
         const mspack_hip_unit &u = local[i];
         c.in_lo = std::min<uint64_t>(c.in_lo, u.in_off); c.in_hi = std::max<uint64_t>(c.in_hi, u.in_off + u.in_len);
+        if (unit_has_ftab(u)) {
+          c.in_lo = std::min<uint64_t>(c.in_lo, (uint64_t) u.in_chunk * 4u);
+          c.in_hi = std::max<uint64_t>(c.in_hi, (uint64_t) u.in_chunk * 4u + unit_ftab_bytes(u));
+        }
         c.out_lo = std::min<uint64_t>(c.out_lo, u.out_off - unit_below(u));
         c.out_hi = std::max<uint64_t>(c.out_hi, u.out_off + u.out_len + unit_above(u));
         c.fm_n += unit_frames(u);
@@ -383,7 +459,10 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
           return local[x].in_len + (local[x].out_len >> 2) > local[y].in_len + (local[y].out_len >> 2); });
       }
     }
-    for (size_t i = 0; i < n_sel; i++) { local[i].in_off -= in_lo; local[i].out_off -= out_lo; }
+    for (size_t i = 0; i < n_sel; i++) {
+      if (unit_has_ftab(local[i])) local[i].in_chunk -= (uint32_t)(in_lo >> 2);      // in_lo is a multiple of 16
+      local[i].in_off -= in_lo; local[i].out_off -= out_lo;
+    }
 
     // ---- buffers (persistent) ----
     TRY(grow(cx.d_in, in_span + 64, false));
@@ -406,7 +485,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     TRY(hipEventCreateWithFlags(&ev_tab, hipEventDisableTiming));
     TRY(hipMemcpyAsync(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice, cx.st[0]));
     TRY(hipMemcpyAsync(d_order, order.data(), n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, cx.st[0]));
-    TRY(hipMemsetAsync(cx.d_fm.p, 0, mspack_hip_frame_scratch_bytes(n_frames), cx.st[0]));
+    TRY(hipMemsetAsync(cx.d_fm.p, 0, (n_frames + 1) * sizeof(int32_t), cx.st[0]));
     TRY(hipMemsetAsync(d_in + in_span, 0, 64, cx.st[0]));
     TRY(hipEventRecord(ev_tab, cx.st[0]));
     for (size_t ci = 0; ci < chunks.size(); ci++) {
@@ -422,7 +501,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
                                (const char *) host_out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
                                hipMemcpyHostToDevice, st));
       for (unsigned k = 1; k <= 6; k++)
-        launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, st);
+        launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st);
       TRY(hipGetLastError());
       TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
     }

@@ -102,7 +102,7 @@ struct HuffRegs { u32 limv; u32 fov; };
 // Table entries are symbol | length << SH: 10 bits of symbol in u16 entries everywhere, except alphabets
 // above 1023 symbols (LZX DELTA main tree: 12 bits of symbol in u32 entries).
 template <int P, int SH = 10, typename TabT = u16>
-__device__ int huff_build(const u8 *lens, int nsyms, int ref_tablebits, TabT *tab, u16 *sorted,
+__device__ __forceinline__ int huff_build(const u8 *lens, int nsyms, int ref_tablebits, TabT *tab, u16 *sorted,
                           u32 *cnt_scratch /* >= 20 u32 in LDS */, HuffRegs &hr, u32 lane, bool lsb)
 {
   // 1. histogram of code lengths

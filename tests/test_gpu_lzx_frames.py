@@ -1,0 +1,137 @@
+"""Frame-level parse parallelism of the LZX path (MSPACK_HIP_UF_FRAME_TABLE): units that carry the container's
+frame table get their frames parsed by one wavefront each; the unit's own wavefront adopts what was parsed from
+exactly its state and decodes everything else serially.  Whatever the table says -- right, wrong, garbage -- the
+result must be the oracle's: error code, byte count, flags (but the diagnostic FRAMES_ADOPTED bit), in_next and
+every byte.  And where the guess holds (one block per frame) the fast path must really have been taken."""
+import numpy as np
+import pytest
+
+import libmspack_amd as M
+from helpers import oracle_lzx
+
+pytestmark = pytest.mark.gpu
+ADOPTED = M.F_FRAMES_ADOPTED
+
+
+def run(streams, params, tabs):
+    """streams: bytes; params: (out_len, wb, reset, e8); tabs: per unit a uint32 array (frame offsets) or None"""
+    offs, toff, pos = [], [], 0
+    for s, t in zip(streams, tabs):
+        pos = (pos + 15) & ~15
+        offs.append(pos); pos += len(s) + 8
+        pos = (pos + 3) & ~3
+        toff.append(pos); pos += 4 * (0 if t is None else len(t))
+    arena = np.zeros(pos + 64, dtype=np.uint8)
+    for s, o, t, to in zip(streams, offs, tabs, toff):
+        arena[o:o + len(s)] = np.frombuffer(s, dtype=np.uint8)
+        if t is not None:
+            arena[to:to + 4 * len(t)] = np.asarray(t, dtype=np.uint32).view(np.uint8)
+    units, out_bytes = M.make_units(M.KIND_LZX, offs, [len(s) for s in streams], [p[0] for p in params],
+                                    window_bits=[p[1] for p in params], reset_frames=[p[2] for p in params],
+                                    e8_base=[p[3] for p in params], frame_tabs=toff)
+    for i, t in enumerate(tabs):
+        if t is None:
+            units["flags"][i] &= ~np.uint32(M.UF_FRAME_TABLE)
+    out, res = M.decode_batch(units, arena, out_bytes)
+    return units, out, res
+
+
+def check(streams, params, units, out, res, compare_bytes=True):
+    for i, (s, p) in enumerate(zip(streams, params)):
+        e, o, r = oracle_lzx(s, p[0], p[1], p[2], length=p[0], e8_base=p[3])
+        assert res["err"][i] == e, (i, res[i], e)
+        assert (res["flags"][i] & ~ADOPTED) == r.flags, (i, res[i], r.flags)
+        assert res["out_len"][i] == r.out_len, (i, res[i], r.out_len)
+        assert res["in_next"][i] == r.in_next, (i, res[i], r.in_next)
+        if compare_bytes:
+            got = out[units["out_off"][i]:units["out_off"][i] + r.out_len].tobytes()
+            assert got == o[:r.out_len], "unit %d differs at byte %d" % (
+                i, next(k for k in range(len(got)) if got[k] != o[k]))
+
+
+MODES = [dict(mode=1), dict(mode=2), dict(mode=0), dict(mode=3), dict(mode=4, block_size=20000),
+         dict(mode=0, block_size=9999), dict(mode=1, block_size=65536), dict(repeats=0, lazy=0),
+         dict(intel_filesize=250000), dict(intel_filesize=12345, e8_base=5000, mode=2)]
+
+
+@pytest.mark.parametrize("kw", MODES, ids=[str(k) for k in MODES])
+def test_frames_vs_oracle(built, kw):
+    data = M.gen_plaintext(17, M.TEXT_MIX, 10 * 32768 + 12345)
+    streams, params, tabs = [], [], []
+    for wb, reset in [(21, 2), (16, 0), (17, 3), (15, 1), (21, 16)]:
+        comp, fo = M.lzx_encode(data, wb, reset, M.lzx_opts(**kw))
+        e8 = kw.get("e8_base", 0)
+        fo = fo.astype(np.int64)
+        streams.append(comp.tobytes()); params.append((data.size, wb, reset, e8)); tabs.append(fo[:-1])
+        if reset:
+            ib = reset * 32768
+            for k in range(0, data.size, ib):
+                f0 = k // 32768
+                f1 = min((k + ib + 32767) // 32768, len(fo) - 1)
+                streams.append(comp[int(fo[f0]):].tobytes())
+                params.append((min(ib, data.size - k), wb, reset, e8 + k))
+                tabs.append(fo[f0:f1] - fo[f0])
+    units, out, res = run(streams, params, tabs)
+    check(streams, params, units, out, res)
+    one_block_per_frame = kw.get("mode", 0) in (0, 1, 2) and kw.get("block_size", 0) == 0
+    if one_block_per_frame:
+        assert (res["flags"] & ADOPTED).all(), "the frame-parallel path was not taken where its guess holds"
+    if "e8_base" not in kw:
+        assert res["err"][0] == 0 and np.array_equal(out[units["out_off"][0]:units["out_off"][0] + data.size], data)
+
+
+def test_wrong_tables_cost_time_not_correctness(built):
+    data = M.gen_plaintext(23, M.TEXT_MIX, 6 * 32768)
+    comp, fo = M.lzx_encode(data, 21, 2)
+    fo = fo.astype(np.int64)[:-1]
+    rng = np.random.default_rng(3)
+    variants = [fo, fo + 2, fo - 2, np.zeros_like(fo), fo[::-1].copy(), rng.integers(0, comp.size, fo.size),
+                fo + 1, np.full_like(fo, comp.size + 1000), np.concatenate([fo[:3], fo[3:] + 4]), fo * 2,
+                np.concatenate([fo[:2], [fo[1]], fo[3:]])]
+    streams = [comp.tobytes()] * len(variants)
+    params = [(data.size, 21, 2, 0)] * len(variants)
+    units, out, res = run(streams, params, variants)
+    check(streams, params, units, out, res)
+    assert (res["err"] == 0).all()
+    for i in range(len(variants)):
+        assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
+    assert res["flags"][0] & ADOPTED
+
+
+def test_damaged_streams_with_tables(built):
+    data = M.gen_plaintext(29, M.TEXT_MIX, 4 * 32768)
+    rng = np.random.default_rng(9)
+    streams, params, tabs = [], [], []
+    for wb, reset, kw in [(21, 2, {}), (17, 0, dict(mode=2)), (16, 4, dict(mode=4, block_size=30000))]:
+        comp, fo = M.lzx_encode(data, wb, reset, M.lzx_opts(**kw))
+        fo = fo.astype(np.int64)[:-1]
+        c = comp.tobytes()
+        for _ in range(60):
+            b = bytearray(c)
+            for _k in range(int(rng.integers(1, 4))):
+                k = int(rng.integers(0, len(b))); b[k] ^= 1 << int(rng.integers(0, 8))
+            streams.append(bytes(b)); params.append((data.size, wb, reset, 0)); tabs.append(fo)
+        for cut in (1, 2, 7, 100, len(c) // 3, int(fo[1]), int(fo[2]) + 1, len(c) - 70, len(c) - 5, len(c) - 1):
+            streams.append(c[:cut]); params.append((data.size, wb, reset, 0)); tabs.append(fo)
+    units, out, res = run(streams, params, tabs)
+    # damaged streams may copy from window bytes the reference never wrote (tests/test_gpu_fuzz.py): bytes are
+    # compared only where the oracle's own output is the plaintext
+    check(streams, params, units, out, res, compare_bytes=False)
+    for i, (s, p) in enumerate(zip(streams, params)):
+        e, o, r = oracle_lzx(s, p[0], p[1], p[2], length=p[0])
+        if o[:r.out_len] == data.tobytes()[:r.out_len]:
+            assert out[units["out_off"][i]:units["out_off"][i] + r.out_len].tobytes() == o[:r.out_len], i
+
+
+def test_headline_batch_with_tables(built):
+    """the 4096-interval batch as bench.py runs it: frame tables on, bit-exact, fast path taken everywhere"""
+    n, ub = 4096, 65536
+    plain, comp, off, ln, tab = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21, frame_tables=True)
+    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=2, frame_tabs=tab)
+    out, res = M.decode_batch(units, comp, out_bytes)
+    assert (res["err"] == 0).all() and (res["out_len"] == ub).all()
+    assert np.array_equal(out[:n * ub], plain)
+    assert (res["flags"] & ADOPTED).all()
+    for i in (0, 1, 777, n - 1):
+        e, o, r = oracle_lzx(comp[int(off[i]):int(off[i]) + int(ln[i]) + 4].tobytes(), ub, 21, 2)
+        assert e == 0 and r.in_next == res["in_next"][i] and (res["flags"][i] & ~ADOPTED) == r.flags
