@@ -35,7 +35,16 @@
 #include "spec_queue.hpp"
 
 #define LZX_FRAME 32768u
+#undef LZX_MAIN_P
+#ifdef LZX_PARSE_ONLY
+/* third compilation (namespace lzxp, shim.hip): the parse waves of the frame-parallel path.  They need no match
+ * queue and no token queue, and a main-tree table of 8 direct bits (codes beyond it are resolved lane-parallel
+ * anyway): 5.5 KiB of LDS instead of 9.75, i.e. 7 waves per SIMD instead of 4 -- parse throughput is a matter of
+ * how many serial chains a SIMD can interleave */
+#define LZX_MAIN_P 8
+#else
 #define LZX_MAIN_P 10
+#endif
 #define LZX_LEN_P 9
 #define LZX_ALI_P 7
 #define LZX_PRE_P 6
@@ -84,8 +93,10 @@ struct __align__(16) LzxShared {
   u8  len_len[LZX_LEN_SYMS + 70];
   u8  pre_len[24];
   u8  ali_len[8];
+#ifndef LZX_PARSE_ONLY
   SpecQueueLds spq;              /* speculative path: queued matches + start flags (spec_queue.hpp) */
   u32 tq0[128], tq1[128];        /* speculative path: parsed tokens waiting for their commit (lzx_run_spec) */
+#endif
 };
 
 struct LzxDec {
@@ -771,6 +782,7 @@ __device__ __forceinline__ u32 lru_scan(u32 x)
   return v;
 }
 
+#ifndef LZX_PARSE_ONLY
 // ---- COMMIT: one batch of parsed tokens, one token per lane ---------------------------------------------
 // Shared by the speculative run (tokens from the LDS queue) and by the frame-parallel path (tokens a parse
 // wave left in global memory, lzx_run_tokens).
@@ -1103,6 +1115,8 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   return rc;
 }
 
+#endif  /* !LZX_PARSE_ONLY */
+
 #ifndef LZX_DELTA
 // ---------------------------------------------------------------------------------------------------
 // Frame-level parse parallelism (plain LZX; units that carry a frame table, MSPACK_HIP_UF_FRAME_TABLE).
@@ -1260,6 +1274,7 @@ __device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 
   }
 }
 
+#ifndef LZX_PARSE_ONLY
 // an adopted record's code lengths back into LDS (a later block header works on them, lzxd.c:138-183) ...
 __device__ __forceinline__ void lzx_restore_lens(LzxDec &d, const LzxFrameRec *rec)
 {
@@ -1325,8 +1340,10 @@ __device__ __forceinline__ int lzx_run_tokens(LzxDec &d, LzxState &s, const u32 
   s.R0 = C.R0; s.R1 = C.R1; s.R2 = C.R2;
   return rc;
 }
+#endif  /* !LZX_PARSE_ONLY */
 #endif  /* !LZX_DELTA */
 
+#ifndef LZX_PARSE_ONLY
 // decode one LZX unit.  frame_meta[frame_base + f] receives the intel_filesize to apply to frame f
 // (0 = none).  Returns via *res.
 #ifdef LZX_DELTA
@@ -1681,3 +1698,4 @@ __device__ void lzx_e8_frame(u8 *frame, u32 frame_size, int32_t curpos0, int32_t
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
 }
+#endif  /* !LZX_PARSE_ONLY */

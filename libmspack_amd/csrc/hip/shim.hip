@@ -20,6 +20,12 @@ namespace lzxd {
 #include "lzx_kernel.hpp"
 }
 #undef LZX_DELTA
+#define LZX_PARSE_ONLY 1
+namespace lzxp {
+#include "lzx_kernel.hpp"
+}
+#undef LZX_PARSE_ONLY
+static_assert(sizeof(lzxp::LzxFrameRec) == sizeof(lzxn::LzxFrameRec), "one record layout");
 #include "mszip_kernel.hpp"
 #include "qtm_kernel.hpp"
 #include "lzss_kernel.hpp"
@@ -41,14 +47,16 @@ __device__ __forceinline__ bool pick_unit(const mspack_hip_unit *units, const u3
 //   u32    frame_unit[n]  per frame slot: the unit it belongs to when a parse wave should take it, else ~0
 //   LzxFrameRec recs[n]   what the parse wave of that frame assumed and found (lzx_kernel.hpp)
 //   uint2  toks[n][LZX_TOK_CAP]  its tokens
-struct LzxScratch { int32_t *meta; u32 *frame_unit; lzxn::LzxFrameRec *recs; uint2 *toks; size_t bytes; };
+//   u32    hdr[64]        per launch: [0] = most, [1] = fewest frames of a unit with a frame table
+struct LzxScratch { int32_t *meta; u32 *frame_unit; u32 *hdr; lzxn::LzxFrameRec *recs; uint2 *toks; size_t bytes; };
 __host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_frames_total)
 {
   const size_t n = n_frames_total + 1, a = 255;
-  const size_t o_fu = (n * 4 + a) & ~a, o_rec = o_fu + ((n * 4 + a) & ~a), o_tok = o_rec + n * sizeof(lzxn::LzxFrameRec);
+  const size_t o_fu = (n * 4 + a) & ~a, o_hdr = o_fu + ((n * 4 + a) & ~a), o_rec = o_hdr + 256,
+               o_tok = o_rec + n * sizeof(lzxn::LzxFrameRec);
   LzxScratch L;
   char *b = (char *) base;
-  L.meta = (int32_t *) b; L.frame_unit = (u32 *)(b + o_fu); L.recs = (lzxn::LzxFrameRec *)(b + o_rec);
+  L.meta = (int32_t *) b; L.frame_unit = (u32 *)(b + o_fu); L.hdr = (u32 *)(b + o_hdr); L.recs = (lzxn::LzxFrameRec *)(b + o_rec);
   L.toks = (uint2 *)(b + o_tok);
   L.bytes = o_tok + n * (size_t) LZX_TOK_CAP * sizeof(uint2);
   return L;
@@ -57,31 +65,46 @@ __host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_fr
 // which frame slots get a parse wave: the real frames of LZX units that carry a frame table
 __global__ __launch_bounds__(64)
 void mspack_lzx_frame_map(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 *frame_unit,
-                          lzxn::LzxFrameRec *recs)
+                          lzxn::LzxFrameRec *recs, u32 *hdr)
 {
   u32 ui;
-  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) return;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) { if (threadIdx.x == 0 && hdr[1] != 0u) atomicMin(&hdr[1], 0u); return; }
   const mspack_hip_unit u = units[ui];
   const u32 nslots = u.out_len / LZX_FRAME + 1u, nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
   const bool usable = (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u;
+  if (threadIdx.x == 0) {                   // (a plain look first: 4096 atomics on one word take 0.1 ms)
+    const u32 v = usable ? nreal : 0u;
+    if (hdr[0] < v) atomicMax(&hdr[0], v);
+    if (hdr[1] > v) atomicMin(&hdr[1], v);
+  }
   for (u32 f = threadIdx.x; f < nslots; f += 64u) {
     frame_unit[u.frame_base + f] = (usable && f < nreal) ? ui : 0xFFFFFFFFu;
     recs[u.frame_base + f].status = 0u;
   }
 }
 
-// one parse wave per frame slot (lzx_kernel.hpp: "Frame-level parse parallelism")
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
-void mspack_lzx_parse(const mspack_hip_unit *units, u32 slot_lo, u32 n_slots, const u8 *in_arena,
-                      const u32 *frame_unit, lzxn::LzxFrameRec *recs, uint2 *toks)
+// one parse wave per frame slot (lzx_kernel.hpp: "Frame-level parse parallelism"; the LZX_PARSE_ONLY build)
+__global__ __launch_bounds__(64)
+void mspack_lzx_parse(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
+                      const u8 *in_arena, const u32 *frame_unit, const u32 *hdr, lzxn::LzxFrameRec *recs, uint2 *toks)
 {
-  __shared__ lzxn::LzxShared sh;
+  __shared__ lzxp::LzxShared sh;
   if (blockIdx.x >= n_slots) return;
-  const u32 slot = slot_lo + blockIdx.x;
+  u32 slot = slot_lo + blockIdx.x;
+  // When every unit of the launch has the same number of frames (CHM intervals), blocks follow the LAUNCH order of
+  // the units (longest compressed unit first): the frames that start last are then the short ones, and the
+  // launch ends with the longest chain instead of one that started late
+  const u32 F = rfl(hdr[0]);
+  if (F != 0u && F == rfl(hdr[1])) {
+    const u32 j = blockIdx.x / F, f = blockIdx.x % F;
+    if (j >= n_units) return;
+    const u32 uj = rfl(order ? order[j] : j);
+    slot = units[uj].frame_base + f;
+  }
   const u32 ui = rfl(frame_unit[slot]);
   if (ui == 0xFFFFFFFFu) return;
   const mspack_hip_unit u = units[ui];
-  lzxn::lzx_parse_frame(u, slot - u.frame_base, in_arena, &recs[slot], toks + (size_t) slot * LZX_TOK_CAP, &sh);
+  lzxp::lzx_parse_frame(u, slot - u.frame_base, in_arena, (lzxp::LzxFrameRec *) &recs[slot], toks + (size_t) slot * LZX_TOK_CAP, &sh);
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
@@ -209,10 +232,15 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
     LzxScratch L = lzx_scratch(d_fm, n_frames_total);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames;
     if (frames) {
+      static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
+      // launches of one batch that run on different streams (host path, several chunks) use different header words;
+      // a clash would only change the order in which frames are taken, never which tokens a frame yields
+      u32 *hdr = L.hdr + 2u * (u32)((slot_lo ^ (slot_lo >> 5) ^ (slot_lo >> 11)) & 31u);
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
-      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs);
-      hipLaunchKernelGGL(mspack_lzx_parse, dim3((unsigned) n_slots), block, 0, st, d_units, (u32) slot_lo, (u32) n_slots,
-                         (const u8 *) d_in, (const u32 *) L.frame_unit, L.recs, L.toks);
+      hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
+      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr);
+      hipLaunchKernelGGL(mspack_lzx_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
+                         (u32) n_slots, (const u8 *) d_in, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
     }
     hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
                        d_results, d_fm ? L.meta : nullptr, frames ? (const lzxn::LzxFrameRec *) L.recs : nullptr,

@@ -40,7 +40,7 @@ def check(streams, params, units, out, res, compare_bytes=True):
     for i, (s, p) in enumerate(zip(streams, params)):
         e, o, r = oracle_lzx(s, p[0], p[1], p[2], length=p[0], e8_base=p[3])
         assert res["err"][i] == e, (i, res[i], e)
-        assert (res["flags"][i] & ~ADOPTED) == r.flags, (i, res[i], r.flags)
+        assert (int(res["flags"][i]) & ~ADOPTED) == r.flags, (i, res[i], r.flags)
         assert res["out_len"][i] == r.out_len, (i, res[i], r.out_len)
         assert res["in_next"][i] == r.in_next, (i, res[i], r.in_next)
         if compare_bytes:
@@ -92,7 +92,9 @@ def test_wrong_tables_cost_time_not_correctness(built):
     params = [(data.size, 21, 2, 0)] * len(variants)
     units, out, res = run(streams, params, variants)
     check(streams, params, units, out, res)
-    assert (res["err"] == 0).all()
+    # (the stream ends on a reset point: the reference's look-ahead then runs out of input, MSPACK_ERR_READ after
+    # every byte has been produced -- for the right table and for the wrong ones alike)
+    assert (res["out_len"] == data.size).all()
     for i in range(len(variants)):
         assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
     assert res["flags"][0] & ADOPTED
@@ -134,4 +136,4 @@ def test_headline_batch_with_tables(built):
     assert (res["flags"] & ADOPTED).all()
     for i in (0, 1, 777, n - 1):
         e, o, r = oracle_lzx(comp[int(off[i]):int(off[i]) + int(ln[i]) + 4].tobytes(), ub, 21, 2)
-        assert e == 0 and r.in_next == res["in_next"][i] and (res["flags"][i] & ~ADOPTED) == r.flags
+        assert e == 0 and r.in_next == res["in_next"][i] and (int(res["flags"][i]) & ~ADOPTED) == r.flags
