@@ -84,18 +84,33 @@ struct __align__(16) LzxShared {
   u16 len_tab[1 << LZX_LEN_P];
   u16 len_sorted[256];
   u16 ali_tab[1 << LZX_ALI_P];
-  u16 pre_tab[1 << LZX_PRE_P];
   u16 ali_sorted[8];
+#if defined(LZX_DELTA) || defined(LZX_PARSE_ONLY)
+  u16 pre_tab[1 << LZX_PRE_P];
   u16 pre_sorted[24];
   u32 cnt[20];
+  u8  pre_len[24];
   u32 inbuf[128 + 4];            /* speculative path: two 256-byte input chunks, words pre-swapped */
+#else
+  /* lzx_run_spec2's token queue (start bits of parsed tokens) shares its room with what only block headers
+   * use (pretree tables, the table builder's counters): a header is never decoded while tokens are queued */
+  union {
+    u32 tq0[256];
+    struct { u16 pre_tab[1 << LZX_PRE_P]; u16 pre_sorted[24]; u32 cnt[20]; u8 pre_len[24]; };
+  };
+  u32 inbuf[192 + 4];            /* lzx_run_spec2: three chunks (the one behind the parse position too: queued
+                                    tokens are decoded from their start bit at commit time) */
+#endif
   u8  main_len[LZX_MAIN_SYMS + 16];
   u8  len_len[LZX_LEN_SYMS + 70];
-  u8  pre_len[24];
   u8  ali_len[8];
 #ifndef LZX_PARSE_ONLY
   SpecQueueLds spq;              /* speculative path: queued matches + start flags (spec_queue.hpp) */
-  u32 tq0[128], tq1[128];        /* speculative path: parsed tokens waiting for their commit (lzx_run_spec) */
+#ifdef LZX_DELTA
+  u32 tq0[128], tq1[128];        /* lzx_run_spec keeps whole tokens (kind/length, value) */
+#else
+  u32 side0[16], side1[16];      /* lzx_run_spec2 keeps start bits; the few tokens the scalar decoder took are here */
+#endif
 #endif
 };
 
@@ -941,6 +956,7 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
 // cannot decode becomes a FAIL marker that only counts when the commit reaches it.
 // ---------------------------------------------------------------------------------------------------
 #define LZX_TQ 128u                /* token queue entries (two commits' worth) */
+#ifdef LZX_DELTA
 
 template <bool ALIGNED>
 __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 run_end_, const u32 wbase_)
@@ -1114,6 +1130,278 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   spec_resync(d, bitpos, cb, pf);
   return rc;
 }
+
+#endif  /* LZX_DELTA: lzx_run_spec */
+
+#ifndef LZX_DELTA
+// ---------------------------------------------------------------------------------------------------
+// lzx_run_spec2 -- the speculative run of plain LZX: parse token LENGTHS, decode token VALUES at commit time.
+//
+// Measured on the box (profiles/round2_*): the kernel is bound by how many instructions a SIMD can issue, not by
+// latency -- and three quarters of the vector instructions were the 64-position token decode, executed for 64
+// lanes of which ~7 hold a real token.  What the chain needs from a position is only HOW LONG the token that
+// would start there is.  So a round computes just that (main-tree entry -> code length, length footer's code
+// length, number of offset bits, aligned symbol's length) and queues the START BITS of the tokens on the chain;
+// the values (literal, match length, offset) are decoded when 64 queued tokens are committed -- one real token
+// per lane, every lane busy.  A main code longer than the direct table stops the walk; only then are the long
+// codes of the round resolved (lane-parallel, once) and the walk resumes.  Tokens the scalar decoder had to take
+// wait in 16 side slots.  The LDS input window holds three 256-byte chunks (the one behind the parse position
+// too), and the parser never runs more than a chunk ahead of the oldest queued token.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void spec3_stage(LzxDec &d, u32 &bitpos, u32 &cb, u32 &pf)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  bitpos = rfl(d.cons_bits());
+  cb = bitpos >> 11;                                    // the window is chunks cb-1, cb, cb+1
+  const u32 lo = d.w.load_chunk(cb, lane), hi = d.w.load_chunk(cb + 1u, lane);
+  sh->inbuf[lane] = 0; sh->inbuf[64u + lane] = SWAP16(lo); sh->inbuf[128u + lane] = SWAP16(hi);
+  if (lane < 4u) sh->inbuf[192u + lane] = 0;
+  pf = d.w.load_chunk(cb + 2u, lane);
+}
+__device__ __forceinline__ void spec3_slide(LzxDec &d, const u32 bitpos, u32 &cb, u32 &pf)
+{
+  if ((bitpos >> 11) != cb) {
+    LzxShared *sh = d.sh;
+    const u32 lane = d.lane;
+    const u32 mid = sh->inbuf[64u + lane], up = sh->inbuf[128u + lane];
+    sh->inbuf[lane] = mid; sh->inbuf[64u + lane] = up; sh->inbuf[128u + lane] = SWAP16(pf);
+    cb++;
+    pf = d.w.load_chunk(cb + 2u, lane);
+  }
+}
+__device__ __forceinline__ void spec3_resync(LzxDec &d, const u32 bitpos, const u32 cb, const u32 pf)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  const u32 wi = bitpos >> 5, ch = wi >> 6;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  u32 lo = sh->inbuf[64u + lane], hi = sh->inbuf[128u + lane], lw = sh->inbuf[lane];
+  lo = SWAP16(lo); hi = SWAP16(hi); lw = SWAP16(lw);
+  if (ch == cb) { d.w.cur = lo; d.w.nxt = hi; }
+  else if (ch == cb + 1u) { d.w.cur = hi; d.w.nxt = pf; }
+  else if (ch + 1u == cb) { d.w.cur = lw; d.w.nxt = lo; }                                   // went back (end of a run)
+  else { d.w.cur = d.w.load_chunk(ch, lane); d.w.nxt = d.w.load_chunk(ch + 1u, lane); }
+  d.w.wi = wi; d.bb = 0; d.bl = 0;
+  d.refill(); d.refill();
+  const u32 sk = bitpos & 31u;
+  if (sk) { d.bb <<= sk; d.bl -= (int) sk; }
+}
+
+// how many bits does the token take whose main-tree entry is e (symbol | code length << LZX_MSH, not 0)?
+template <bool ALIGNED>
+__device__ __forceinline__ u32 lzx_adv_from_entry(const LzxShared *sh, const bool length_empty, const u32 e,
+                                                  const u32 w0, const u32 w1, bool &unk)
+{
+  const u32 mlen = e >> LZX_MSH, sym = e & LZX_MMASK;
+  const bool is_match = sym >= 256u;
+  const u32 m = sym - 256u, slot = m >> 3;
+  const bool need_len = is_match && (m & 7u) == 7u;
+  const u32 e2 = sh->len_tab[(w0 << mlen) >> (32 - LZX_LEN_P)];        // the footer's code starts right behind the main code
+  u32 tot = mlen;
+  unk = false;
+  if (need_len) { unk = (e2 == 0u) || length_empty; tot += e2 >> 10; }
+  const int ex_ = (int)(slot >> 1) - 1;
+  const u32 extra = (u32)(ex_ < 0 ? 0 : (ex_ > 17 ? 17 : ex_));
+  const bool expl = is_match && slot >= 3u;
+  if (ALIGNED) {
+    const bool ali = extra >= 3u;
+    const u32 nb = ali ? extra - 3u : extra;
+    const u64 r = ((u64) w0 << 32) | w1;
+    const u32 e3 = sh->ali_tab[(u32)((r << (tot + nb)) >> (64 - LZX_ALI_P))];   // behind the verbatim bits (bit <= 46)
+    if (expl) { tot += nb; if (ali) { tot += e3 >> 10; unk = unk || e3 == 0u; } }
+  }
+  else if (expl) tot += extra;
+  return tot;
+}
+
+#define LZX_TQ2 256u                /* lzx_run_spec2: token queue entries */
+#define LZX_SETS 4                  /* position sets per lane: a round covers 64 * LZX_SETS bit positions */
+
+template <bool ALIGNED>
+__device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 run_end_, const u32 wbase_)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  u8 *const out = d.out;
+  LzxCommit C;
+  C.run_end = rfl(run_end_); C.wbase = rfl(wbase_);
+  C.P = rfl(d.P);
+  C.R0 = rfl(s.R0); C.R1 = rfl(s.R1); C.R2 = rfl(s.R2);
+  C.wsize = rfl(s.wsize); C.offset_written = rfl(s.offset); C.ref_size = rfl(s.ref_size);
+  const bool length_empty = rfl((u32) s.length_empty) != 0u;
+  int rc = LZX_RUN_DONE;
+  // The parser stops `margin` bytes before the end of the input: a round (256 starts + a 53-bit token) plus one
+  // scalar token is at most 46 bytes, a block header read without any symbol decode 17 more and the first symbol
+  // after it 7 -- with 88 the EOF-exact reader still takes over at a symbol boundary well before the reference's
+  // read pointer can reach the end of the input (cf. lzx_run_spec)
+  const u32 bit_limit = spec_bit_limit(d, 88u);
+  if (rfl(d.cons_bits()) >= bit_limit) return LZX_RUN_SWITCH;
+  d.flush_lits();
+  u32 bitpos, cb, pf;
+  spec3_stage(d, bitpos, cb, pf);
+  u32 mlim[16 - LZX_MAIN_P];
+#pragma unroll
+  for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
+  spq_init(sh->spq, C.Q, C.P, lane);
+  u32 *const tq0 = sh->tq0;
+  u32 th = 0, tt = 0;                                   // token queue: committed / parsed (counters)
+  u32 qbase = 0;                                        // start bit of the oldest queued token (valid while tt != th)
+  u32 sw = 0, nside = 0;                                // side slots: written (counter) / pending
+  bool stop = false;
+
+  while (rc == LZX_RUN_DONE && C.P < C.run_end) {
+    // =================================== PARSE ===================================
+    // (not while the oldest queued token would fall out of the LDS window, nor with the side slots nearly full)
+    if (!stop && tt - th < 64u && nside < 12u && (tt == th || ((bitpos + 64u * LZX_SETS + 128u) >> 11) <= (qbase >> 11) + 1u)) {
+      spec3_slide(d, bitpos, cb, pf);
+      const u32 rel = bitpos - ((cb - 1u) << 11) + lane;
+      const u32 k = rel >> 5, sft = rel & 31u;
+      // ---- token lengths at 64 * LZX_SETS positions: lane l looks at bits bitpos + l + 64 j ----
+      u32 vn[LZX_SETS];
+#pragma unroll
+      for (int j = 0; j < LZX_SETS; j++) {
+        const u32 i0 = sh->inbuf[k + 2u * j], i1 = sh->inbuf[k + 2u * j + 1u];
+        const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+        u32 w1 = 0;
+        if (ALIGNED) { const u32 i2 = sh->inbuf[k + 2u * j + 2u]; w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32); }
+        const u32 e = sh->main_tab[w0 >> (32 - LZX_MAIN_P)];
+        bool unk;
+        const u32 tot = lzx_adv_from_entry<ALIGNED>(sh, length_empty, e, w0, w1, unk);
+        // next token start (in bits from bitpos); >= 1024: the scalar decoder must look, >= 2048: a main code longer
+        // than the direct table (resolved below, lane-parallel, if the walk gets there)
+        const u32 pos = lane + 64u * j;
+        vn[j] = e == 0u ? (2048u + pos) : (unk ? (1024u + pos) : (pos + tot));
+      }
+      // ---- follow the real token boundaries through the sets ----
+      u64 chain[LZX_SETS];
+      u32 q = 0, ntok = 0;
+#pragma unroll
+      for (int j = 0; j < LZX_SETS; j++) {
+        chain[j] = 0;
+        if (q < 64u * (j + 1) && ntok <= 64u) {               // (a round queues at most 128 tokens)
+          for (;;) {
+            while (q < 64u * (j + 1)) { chain[j] |= 1ull << (q & 63u); q = rdl(vn[j], q & 63u); }
+            if (q < 2048u) break;
+            // the walk ran into a main code longer than the direct table: resolve this set's long codes (canonical
+            // length = number of per-length limits the 16-bit peek is not below) and go on from there
+            q -= 2048u;
+            const u32 i0 = sh->inbuf[k + 2u * j], i1 = sh->inbuf[k + 2u * j + 1u];
+            const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+            u32 w1 = 0;
+            if (ALIGNED) { const u32 i2 = sh->inbuf[k + 2u * j + 2u]; w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32); }
+            const u32 peek16 = w0 >> 16;
+            u32 ln = LZX_MAIN_P + 1u;
+#pragma unroll
+            for (int l = LZX_MAIN_P + 1; l <= 16; l++) ln += (peek16 >= mlim[l - LZX_MAIN_P - 1]) ? 1u : 0u;
+            const u32 lq = ln <= 16u ? ln : 0u;
+            const u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) d.hr_main.fov);
+            u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
+            if (idx >= LZX_MAIN_SYMS) idx = 0;
+            const u32 e = lq ? ((u32) sh->main_sorted[idx] | (lq << LZX_MSH)) : 0u;
+            bool unk2;
+            const u32 tot2 = lzx_adv_from_entry<ALIGNED>(sh, length_empty, e, w0, w1, unk2);
+            const u32 pos = lane + 64u * j;
+            if (vn[j] >= 2048u) vn[j] = (unk2 || e == 0u) ? (1024u + pos) : (pos + tot2);
+            chain[j] &= ~(1ull << (q & 63u));
+          }
+          ntok += (u32) __popcll(chain[j]);
+        }
+      }
+      bool hit_unknown = false;
+      if (q >= 1024u) {
+        q -= 1024u; hit_unknown = true;
+#pragma unroll
+        for (int j = 0; j < LZX_SETS; j++) if ((q >> 6) == (u32) j) { chain[j] &= ~(1ull << (q & 63u)); ntok--; }
+      }
+      // ---- queue the start bits of the tokens on the chain ----
+      {
+        if (tt == th && ntok) qbase = bitpos;
+        u32 base = tt;
+#pragma unroll
+        for (int j = 0; j < LZX_SETS; j++) {
+          if (chain[j]) {
+            const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain[j] >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain[j], 0u));
+            if ((chain[j] >> lane) & 1ull) tq0[(base + rank) & (LZX_TQ2 - 1u)] = (bitpos + 64u * j + lane) & 0xFFFFu;
+            base += (u32) __popcll(chain[j]);
+          }
+        }
+        tt = base;
+      }
+      d.st_rounds++;
+      if (hit_unknown) {
+        // a token the lane-parallel decoder does not take: the scalar decoder reads it from its 64 bits
+        const u32 tb = bitpos + q;
+        const u32 r2 = tb - ((cb - 1u) << 11);
+        const u32 k2 = r2 >> 5, s2 = r2 & 31u;
+        const u32 a0 = rfl(sh->inbuf[k2]), a1 = rfl(sh->inbuf[k2 + 1u]), a2 = rfl(sh->inbuf[k2 + 2u]);
+        const u64 hi64 = ((u64) a0 << 32) | a1, lo64 = (u64) a2 << 32;
+        const u64 rq = s2 ? ((hi64 << s2) | (lo64 >> (64u - s2))) : hi64;
+        u32 tk_kind = 0, tk_val = 0, tk_off = 0;
+        const u32 tk_tot = lzx_scalar_token<ALIGNED>(d, length_empty, rq, tk_kind, tk_val, tk_off);
+        u32 r0;
+        const u32 r1 = tk_kind == 0u ? tk_val : tk_off;
+        if (tk_tot == 0u) { r0 = LZX_TK_FAIL; stop = true; }
+        else r0 = tk_kind | ((tk_kind == 0u ? 1u : tk_val) << 3);
+        if (lane == 0u) {
+          sh->side0[sw & 15u] = r0; sh->side1[sw & 15u] = r1;
+          tq0[tt & (LZX_TQ2 - 1u)] = (tb & 0xFFFFu) | (((sw & 15u) + 1u) << 16);
+        }
+        if (tt == th) qbase = tb;
+        sw++; nside++; tt++;
+        bitpos = tb + (stop ? 0u : tk_tot);
+      }
+      else bitpos += q;
+      if (bitpos >= bit_limit) stop = true;
+      if (!stop && tt - th < 64u) continue;
+    }
+
+    // =================================== COMMIT ===================================
+    u32 n = tt - th;
+    if (n > 64u) n = 64u;
+    if (n == 0u) { rc = LZX_RUN_SWITCH; break; }         // the input margin was reached and all is committed
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const u32 qe = tq0[(th + lane) & (LZX_TQ2 - 1u)];
+    u32 c0, c1;
+    {
+      // decode the queued tokens' values, one token per lane, from their start bits
+      const u32 sb = qbase + ((qe - qbase) & 0xFFFFu);                 // full start bit
+      const u32 rel = sb - ((cb - 1u) << 11);
+      const u32 k = (lane < n) ? (rel >> 5) : 0u, sft = rel & 31u;
+      const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
+      const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+      const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
+      const SpecTok t = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0, w1);
+      c0 = t.unk ? LZX_TK_FAIL : (t.kind | (t.olen << 3));
+      c1 = t.kind == 0u ? t.sym : t.off;
+      const u32 si = qe >> 16;
+      if (si) { c0 = sh->side0[si - 1u]; c1 = sh->side1[si - 1u]; }
+      c0 |= (qe & 0xFFFFu) << 12;
+    }
+    u32 marker; bool fail_after;
+    const u32 took = lzx_commit_batch(d, C, c0, c1, n, marker, fail_after);
+    nside -= (u32) __popcll(ballot(lane < took && (qe >> 16) != 0u));
+    th += took;
+    if (tt != th) {                                                     // start bit of the token that is the oldest now
+      const u32 nx = rfl(tq0[th & (LZX_TQ2 - 1u)]) & 0xFFFFu;
+      qbase += (nx - qbase) & 0xFFFFu;
+    }
+#ifndef LZX_EXP_NOCOPY
+    if (spq_due(C.Q, C.P)) spq_resolve(sh->spq, C.Q, out, C.P, false, lane);
+#endif
+    if (fail_after || marker == LZX_TK_FAIL) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; }
+  }
+#ifndef LZX_EXP_NOCOPY
+  spq_resolve(sh->spq, C.Q, out, C.P, true, lane);
+#endif
+  // parsed but not committed: the bit position goes back to the first such token
+  if (tt != th) bitpos = qbase;
+  d.P = C.P;
+  s.R0 = C.R0; s.R1 = C.R1; s.R2 = C.R2;
+  spec3_resync(d, bitpos, cb, pf);
+  return rc;
+}
+#endif  /* !LZX_DELTA: lzx_run_spec2 */
 
 #endif  /* !LZX_PARSE_ONLY */
 
@@ -1504,7 +1792,9 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
 #endif
           while (d.P < run_end) {
             if (respec && !d.careful && !d.near_end) {
-#ifndef LZX_NO_SPEC
+#if !defined(LZX_NO_SPEC) && !defined(LZX_DELTA)
+              int rc = aligned ? lzx_run_spec2<true>(d, s, run_end, wbase) : lzx_run_spec2<false>(d, s, run_end, wbase);
+#elif !defined(LZX_NO_SPEC)
               int rc = aligned ? lzx_run_spec<true>(d, s, run_end, wbase) : lzx_run_spec<false>(d, s, run_end, wbase);
 #else
               int rc = aligned ? lzx_run_fast<true>(d, s, run_end, wbase) : lzx_run_fast<false>(d, s, run_end, wbase);
