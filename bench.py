@@ -113,6 +113,7 @@ def cpu_baseline(comp, off, ln, n_units, unit_bytes):
 class DeviceBatch:
     def __init__(self, M, torch, dev, units, comp, out_bytes, kind):
         self.M, self.torch, self.kind = M, torch, kind
+        self.frame_tables = bool((units["flags"] & M.UF_FRAME_TABLE).any())
         self.n = len(units)
         self.units, self.comp_size, self.out_bytes = units, int(comp.size), int(out_bytes)
         self.n_frames = int(M.frames_of(units).sum())
@@ -130,7 +131,7 @@ class DeviceBatch:
     def _args(self):
         return (self.d_units.data_ptr(), self.d_order.data_ptr(), self.n, self.d_in.data_ptr(), self.comp_size,
                 self.d_out.data_ptr(), self.out_bytes, self.d_res.data_ptr(), self.d_fm.data_ptr(), self.n_frames,
-                1 << self.kind, self.stream)
+                (1 << self.kind) | (0x80000000 if self.frame_tables else 0), self.stream)
 
     def step(self):
         rc = self.L.mspack_hip_decode_batch_device(*self._args())

@@ -39,6 +39,8 @@ extern "C" {
                                        4096 bytes below out_off belong to the unit (its window pre-fill).        */
 #define MSPACK_HIP_KIND_KWAJ_LZH 6   /* lzh_decompress (kwajd.c:432-563): KWAJ method 3; same conventions         */
 
+#define MSPACK_HIP_MASK_FRAME_TABLES 0x80000000u   /* mspack_hip_decode_batch_device(kind_mask): see there */
+
 /* result flags */
 #define MSPACK_HIP_F_E8_APPLIED     1u  /* >=1 frame went through the E8 translation (lzxd.c:706-736) */
 #define MSPACK_HIP_F_LOOKAHEAD_READ 2u  /* all bytes produced; the one-frame look-ahead of
@@ -127,7 +129,9 @@ const char *mspack_hip_last_error(void);
  *                work space: per frame the E8 decision, and -- for units with a frame table -- the parse
  *                waves' records and token lists (about 129 KiB per frame slot).  Contents need no
  *                initialisation; may be NULL if the batch has no LZX units (LZX then decodes serially only)
- *   kind_mask  : bit k set = units of kind k may be present (one kernel per codec is launched;
+ *   kind_mask  : bit k set = units of kind k may be present; MSPACK_HIP_MASK_FRAME_TABLES set = LZX units may
+ *                carry frame tables (MSPACK_HIP_UF_FRAME_TABLE): only then are the parse wavefronts launched.
+ *                Was: bit k set = units of kind k may be present (one kernel per codec is launched;
  *                units of other kinds are skipped); 0 = all three codecs
  * MSZIP units need 32768 bytes of slack after out_len in their output region.
  * Returns 0 or a negative hipError_t from the launch. */

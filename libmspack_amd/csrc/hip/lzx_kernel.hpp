@@ -1412,12 +1412,12 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
 // Every 32 KiB frame starts on a 16-bit boundary of the compressed stream (lzxd.c:695-697) at an offset the
 // container states up front -- one CFDATA block per frame in a cabinet (cabd.c:1362-1479), one reset-table
 // entry per frame in a CHM (chmd.c:1146-1149).  The serial chain of a unit is "where does the next token
-// start"; it needs the Huffman tables, not the window and not R0-R2.  So a PARSE wave per frame
-// (mspack_lzx_parse) walks the block headers from the last reset point to its own frame (code lengths are
-// deltas on the previous block's, lzxd.c:138-183), builds the tables, parses the frame's tokens with the same
-// 64-positions-per-round scheme as lzx_run_spec and leaves them in global memory with a record of what it
-// assumed.  It works on the guess that every frame on the way holds exactly ONE verbatim / aligned block that
-// begins where the frame begins -- what encoders do -- and gives up silently otherwise.
+// start"; it needs the Huffman tables, not the window and not R0-R2.  So, per unit, a HEADER wave
+// (mspack_lzx_headers) walks the block headers frame by frame (code lengths are deltas on the previous block's,
+// lzxd.c:138-183: a chain, but a short one) and leaves every frame's code lengths in its record; then a PARSE
+// wave per frame (mspack_lzx_parse) builds the tables, parses the frame's tokens with the 64-positions-per-round
+// scheme and leaves them in global memory.  Both work on the guess that every frame holds exactly ONE verbatim /
+// aligned block that begins where the frame begins -- what encoders do -- and give up silently otherwise.
 // The unit's own wave (mspack_decode_lzx) stays the only judge: frame by frame it checks that its bit
 // position is the one the record was parsed from and that no block is open, adopts the record, and commits
 // the tokens 64 at a time (lzx_run_tokens: positions, literals, R0-R2, the reference's checks, match queue).
@@ -1426,10 +1426,9 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
 // byte counts cannot differ.
 // ---------------------------------------------------------------------------------------------------
 #define LZX_TOK_CAP 16384u          /* tokens a parse wave stores per frame (8 bytes each) */
-#define LZX_CHAIN_MAX 8u            /* headers a parse wave walks in front of its own frame, at most */
 
 struct __align__(16) LzxFrameRec {
-  u32 status;                       /* 1 = parsed */
+  u32 status;                       /* 2 = header known (lzx_walk_headers), 1 = tokens parsed too */
   u32 n_tokens;
   u32 hdr_start_bit;                /* bit positions count from the unit's first compressed byte */
   u32 end_bit;                      /* first bit that was not parsed */
@@ -1498,14 +1497,10 @@ __device__ __forceinline__ void lzx_parse_tokens(LzxDec &d, const bool length_em
   n_tok = tt; end_bit = base_bit + bitpos;
 }
 
-// one parse wave: frame f of unit u
-__device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, LzxFrameRec *rec,
-                                uint2 *tok, LzxShared *sh)
+// common set-up of the header wave and the parse waves: a decoder on the unit's input, nothing read yet
+__device__ __forceinline__ bool lzx_side_setup(LzxDec &d, LzxState &s, const mspack_hip_unit &u, const u8 *in_arena, LzxShared *sh)
 {
-  const u32 lane = threadIdx.x;
-  LzxDec d;
-  LzxState s;
-  d.lane = lane; d.sh = sh; d.err = 0;
+  d.lane = threadIdx.x; d.sh = sh; d.err = 0;
   d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
   d.w.eofs = (u.flags & MSPACK_HIP_UF_HARD_EOF) ? 0u : 2u;
   d.out = nullptr; d.P = 0; d.lit_buf = 0; d.lit_n = 0;
@@ -1519,44 +1514,98 @@ __device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 
   s.offset = 0; s.length = u.out_len;
   s.intel_filesize = 0; s.intel_started = false; s.length_empty = false;
   s.raw_mode = false; s.raw_pos = 0; s.ref_size = 0;
-  {
-    static const u16 slots[11] = { 30, 32, 34, 36, 38, 42, 50, 66, 98, 162, 290 };
-    const u32 wb = u.window_bits;
-    s.num_offsets = (wb >= 15u && wb <= 21u) ? ((u32) slots[wb - 15u] << 3) : 0u;
-  }
-  if (s.num_offsets == 0u) return;
+  s.R0 = s.R1 = s.R2 = 1; s.header_read = false; s.block_remaining = 0; s.block_type = 0; s.block_length = 0;
+  static const u16 slots[11] = { 30, 32, 34, 36, 38, 42, 50, 66, 98, 162, 290 };
+  const u32 wb = u.window_bits;
+  s.num_offsets = (wb >= 15u && wb <= 21u) ? ((u32) slots[wb - 15u] << 3) : 0u;
+  return s.num_offsets != 0u;
+}
+
+// The HEADER wave of a unit (mspack_lzx_headers): code lengths are deltas on the previous block's (lzxd.c:138-183),
+// so the block headers of a unit form a chain.  One wave walks it -- frame by frame it reads the header the frame
+// table points at (lengths only, no decode tables) and leaves the resulting code lengths, the block's type and size
+// and the bit positions in the frame's record -- so that the parse waves can all start at once.  It stops guessing
+// for the rest of a reset interval as soon as a frame is not "one verbatim / aligned block that starts where the
+// frame starts and covers it exactly".
+__device__ void lzx_walk_headers(const mspack_hip_unit &u, const u8 *in_arena, LzxFrameRec *recs, LzxShared *sh)
+{
+  const u32 lane = threadIdx.x;
+  LzxDec d;
+  LzxState s;
+  if (!lzx_side_setup(d, s, u, in_arena, sh)) return;
   const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
   const u32 rf = u.reset_frames;
-  const u32 g0 = rf ? f - f % rf : 0u;
-  if (f - g0 >= LZX_CHAIN_MAX) return;
-  lzx_reset_state(d, s);
-  u32 hdr_start = 0, fsz = 0;
-  for (u32 g = g0; g <= f; g++) {
-    const u32 fo = rfl(ftab[g]);
-    if (fo >= u.in_len || u.in_len - fo <= 64u) return;   // the last bytes of the input belong to the EOF-exact reader
+  const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
+  bool chain = false;
+  for (u32 f = 0; f < nreal; f++) {
+    const bool first = rf ? (f % rf) == 0u : f == 0u;
+    if (first) { lzx_reset_state(d, s); chain = true; }
+    if (!chain) { if (rf == 0u) return; continue; }
+    chain = false;
+    const u32 fo = rfl(ftab[f]);
+    if (fo >= u.in_len || u.in_len - fo <= 64u) continue;      // the last bytes of the input belong to the EOF-exact reader
     d.w.seek(fo, lane);
-    d.bb = 0; d.bl = 0; d.rbl = 0; d.near_end = false; d.careful = false;
-    if (g == g0) {                                        // the interval's (stream's) 1 + 32 header bits, lzxd.c:447-453
+    d.bb = 0; d.bl = 0; d.rbl = 0; d.near_end = false; d.careful = false; d.err = 0;
+    if (first) {                                                // the interval's (stream's) 1 + 32 header bits, lzxd.c:447-453
       u32 v, hi, lo;
-      if (!d.read_bits(1, v)) return;
-      if (v) { if (!d.read_bits(16, hi) || !d.read_bits(16, lo)) return; }
+      if (!d.read_bits(1, v)) continue;
+      if (v) { if (!d.read_bits(16, hi) || !d.read_bits(16, lo)) continue; }
     }
-    hdr_start = fo * 8u + d.cons_bits();
-    if (!lzx_block_header(d, s, g == f)) return;
-    if (d.careful || d.near_end) return;
-    fsz = u.out_len - g * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
-    if ((s.block_type != 1u && s.block_type != 2u) || s.block_length != fsz) return;   // one block per frame, or no guess
+    const u32 hdr_start = fo * 8u + d.cons_bits();
+    s.block_type = 0;
+    if (!lzx_block_header(d, s, false)) continue;
+    if (d.careful || d.near_end) continue;
+    u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
+    if ((s.block_type != 1u && s.block_type != 2u) || s.block_length != fsz) continue;   // one block per frame, or no guess
+    LzxFrameRec *rec = &recs[u.frame_base + f];
+    for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) rec->main_len[i] = sh->main_len[i];
+    for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) rec->len_len[i] = sh->len_len[i];
+    if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
+    if (lane == 0) {
+      rec->n_tokens = 0; rec->hdr_start_bit = hdr_start; rec->end_bit = fo * 8u + d.cons_bits();   // = first token
+      rec->block_type = s.block_type; rec->block_length = s.block_length;
+      rec->flags = (sh->main_len[0xE8] != 0 ? 2u : 0u);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      rec->status = 2u;                                         // header known; tokens not parsed yet
+    }
+    chain = true;
   }
+}
+
+// one PARSE wave: the tokens of frame f of unit u, from the state the header wave left in the record
+__device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, LzxFrameRec *rec,
+                                uint2 *tok, LzxShared *sh)
+{
+  const u32 lane = threadIdx.x;
+  if (rfl(rec->status) != 2u) return;
+  LzxDec d;
+  LzxState s;
+  if (!lzx_side_setup(d, s, u, in_arena, sh)) return;
+  for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) sh->main_len[i] = rec->main_len[i];
+  for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) sh->len_len[i] = rec->len_len[i];
+  if (lane < 8u) sh->ali_len[lane] = rec->ali_len[lane];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  s.block_type = rfl(rec->block_type);
+  if (huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+                                                   sh->cnt, d.hr_main, lane, false)) return;
+  const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, lane, false);
+  if (r == 1) return;
+  s.length_empty = (r == 2);
+  if (s.block_type == 2u && huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false)) return;
+  const u32 start_bit = rfl(rec->end_bit);
+  {                                                             // continue reading at the first token
+    const u32 wbyte = (start_bit >> 4) << 1, sk = start_bit - wbyte * 8u;
+    d.w.seek(wbyte, lane);
+    d.refill(); d.refill();
+    if (sk) { d.bb <<= sk; d.bl -= (int) sk; }
+  }
+  u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
   u32 n_tok = 0, end_bit = 0;
   if (s.block_type == 2u) lzx_parse_tokens<true>(d, s.length_empty, fsz, tok, n_tok, end_bit);
   else lzx_parse_tokens<false>(d, s.length_empty, fsz, tok, n_tok, end_bit);
-  for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) rec->main_len[i] = sh->main_len[i];
-  for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) rec->len_len[i] = sh->len_len[i];
-  if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
   if (lane == 0) {
-    rec->n_tokens = n_tok; rec->hdr_start_bit = hdr_start; rec->end_bit = end_bit;
-    rec->block_type = s.block_type; rec->block_length = s.block_length;
-    rec->flags = (s.length_empty ? 1u : 0u) | (sh->main_len[0xE8] != 0 ? 2u : 0u);
+    rec->n_tokens = n_tok; rec->end_bit = end_bit;
+    rec->flags = rec->flags | (s.length_empty ? 1u : 0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     rec->status = 1u;
   }

@@ -83,7 +83,20 @@ void mspack_lzx_frame_map(const mspack_hip_unit *units, const u32 *order, u32 n_
   }
 }
 
-// one parse wave per frame slot (lzx_kernel.hpp: "Frame-level parse parallelism"; the LZX_PARSE_ONLY build)
+// the header wave of every unit that carries a frame table, then one parse wave per frame slot
+// (lzx_kernel.hpp: "Frame-level parse parallelism"; both from the LZX_PARSE_ONLY build: 5.5 KiB of LDS)
+__global__ __launch_bounds__(64)
+void mspack_lzx_headers(const mspack_hip_unit *units, const u32 *order, u32 n_units, const u8 *in_arena,
+                        lzxn::LzxFrameRec *recs)
+{
+  __shared__ lzxp::LzxShared sh;
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) return;
+  const mspack_hip_unit u = units[ui];
+  if (!(u.flags & MSPACK_HIP_UF_FRAME_TABLE)) return;
+  lzxp::lzx_walk_headers(u, in_arena, (lzxp::LzxFrameRec *) recs, &sh);
+}
+
 __global__ __launch_bounds__(64)
 void mspack_lzx_parse(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
                       const u8 *in_arena, const u32 *frame_unit, const u32 *hdr, lzxn::LzxFrameRec *recs, uint2 *toks)
@@ -223,14 +236,14 @@ static int fail(hipError_t e, const char *what) {
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
 static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
                         const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
-                        size_t slot_lo, size_t n_slots, hipStream_t st)
+                        size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true)
 {
   if (n == 0) return;
   const dim3 grid((unsigned) n), block(64);
   switch (kind) {
   case MSPACK_HIP_KIND_LZX: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total);
-    const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames;
+    const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
     if (frames) {
       static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
       // launches of one batch that run on different streams (host path, several chunks) use different header words;
@@ -239,6 +252,7 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr);
+      hipLaunchKernelGGL(mspack_lzx_headers, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, L.recs);
       hipLaunchKernelGGL(mspack_lzx_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
                          (u32) n_slots, (const u8 *) d_in, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
     }
@@ -288,14 +302,14 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
 {
   (void) in_bytes; (void) out_bytes;
   if (n_units == 0) return 0;
-  if (kind_mask == 0) kind_mask = 0x7E;     // bit k = units of kind k may be present
+  if ((kind_mask & 0x7Eu) == 0) kind_mask |= 0x7Eu;     // bit k = units of kind k may be present
   // the caller's unit table lives on the device, so the kinds cannot be compacted here: every codec in the
   // mask gets the whole grid and blocks of other kinds leave at once.  Callers with mixed batches pass one
   // order list per codec and a one-bit mask (what the host-buffer entry points below do).
   for (unsigned k = 1; k <= 6; k++)
     if (kind_mask & (1u << k))
       launch_kind(k, d_units, d_order, n_units, d_in, d_out, d_results, d_frame_scratch, n_frames_total, 0, n_frames_total,
-                  (hipStream_t) stream);
+                  (hipStream_t) stream, (kind_mask & MSPACK_HIP_MASK_FRAME_TABLES) != 0u);
   CK(hipGetLastError());
   return 0;
 }
@@ -369,6 +383,7 @@ struct Chunk {
   uint64_t in_lo, in_hi, out_lo, out_hi;
   size_t order_off[8], order_n[8];      // per kind: slice of the order array
   size_t fm_lo, fm_n;
+  bool has_ftab;                        // some LZX unit of the chunk carries a frame table
 };
 
 // bytes below out_off that belong to the unit, and the room it may write past out_len
@@ -416,7 +431,8 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     mspack_hip_unit &u = local[i];
     u = units[idx[i]];
     if (u.kind != MSPACK_HIP_KIND_LZX_DELTA) u.ref_len = 0;
-    if (u.kind < 1 || u.kind > 6) { snprintf(errbuf, errcap, "unit %u: unknown kind %u", idx[i], u.kind); return -1; }
+    if (u.kind > 6) { snprintf(errbuf, errcap, "unit %u: unknown kind %u", idx[i], u.kind); return -1; }
+    // kind 0 = "no codec": the unit is carried along, no kernel takes it, its result says MSPACK_ERR_ARGS
     const uint64_t below = unit_below(u);
     if (below > u.out_off) { snprintf(errbuf, errcap, "unit's lower region outside arena"); return -1; }
     const uint64_t lo = u.out_off - below, hi = u.out_off + u.out_len + unit_above(u);
@@ -466,11 +482,12 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     size_t op = 0;
     for (Chunk &c : chunks) {
       c.in_lo = ~0ull; c.in_hi = 0; c.out_lo = ~0ull; c.out_hi = 0;
-      c.fm_lo = local[c.a].frame_base; c.fm_n = 0;
+      c.fm_lo = local[c.a].frame_base; c.fm_n = 0; c.has_ftab = false;
       for (size_t i = c.a; i < c.b; i++) {
         const mspack_hip_unit &u = local[i];
         c.in_lo = std::min<uint64_t>(c.in_lo, u.in_off); c.in_hi = std::max<uint64_t>(c.in_hi, u.in_off + u.in_len);
         if (unit_has_ftab(u)) {
+          c.has_ftab = true;
           c.in_lo = std::min<uint64_t>(c.in_lo, (uint64_t) u.in_chunk * 4u);
           c.in_hi = std::max<uint64_t>(c.in_hi, (uint64_t) u.in_chunk * 4u + unit_ftab_bytes(u));
         }
@@ -529,7 +546,8 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
                                (const char *) host_out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
                                hipMemcpyHostToDevice, st));
       for (unsigned k = 1; k <= 6; k++)
-        launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st);
+        launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
+                    c.has_ftab);
       TRY(hipGetLastError());
       TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
     }
@@ -550,7 +568,10 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     }
     for (int i = 0; i < cx.ns; i++) TRY(hipStreamSynchronize(cx.st[i]));
     hipEventDestroy(ev_tab);
-    for (size_t i = 0; i < n_sel; i++) results[idx[i]] = h_res[i];
+    for (size_t i = 0; i < n_sel; i++) {
+      results[idx[i]] = h_res[i];
+      if (local[i].kind == 0) { memset(&results[idx[i]], 0, sizeof(mspack_hip_result)); results[idx[i]].err = ERR_ARGS; }
+    }
     t3 = tnow();
     if (trace)
       fprintf(stderr, "mspack_hip[dev %d]: %zu units in %zu chunks on %d streams: plan+alloc %.2f ms, issue (H2D %.1f MB) %.2f ms, "

@@ -640,6 +640,9 @@ struct gathered {
   unsigned char *stream; size_t len, cap;      /* codec input: payloads (+0xFF per block for Quantum) */
   unsigned int total;                           /* sum of uncompressed sizes of the blocks read     */
   int read_err; int hard_eof;
+  uint32_t *boff; unsigned int nblk;            /* where every block's payload starts in `stream`; frames_ok: every
+                                                   block but the last holds exactly one 32 KiB frame  */
+  int frames_ok;
 };
 
 /* walk the CFDATA chain of one folder (reference cabd.c:1283-1345 + 1362-1459), following it through
@@ -657,6 +660,8 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
   g->len = 0; g->total = 0; g->read_err = MSPACK_ERR_OK; g->hard_eof = 0;
   g->cap = (size_t) fol->base.num_blocks * 1024 + 65536;
   g->stream = NULL;
+  g->nblk = 0; g->frames_ok = 1;
+  g->boff = (method == MSCAB_COMP_LZX) ? (uint32_t *) sys->alloc(sys, ((size_t) fol->base.num_blocks + 1) * sizeof(uint32_t)) : NULL;
   if ((err = reader_open(self, &r, fol))) {
     if (err != MSPACK_ERR_SEEK) return err;
     /* the reference fails extract() with SEEK before any decoding; keep it as this folder's error */
@@ -675,6 +680,10 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
       unsigned char *n = (unsigned char *) sys->alloc(sys, ncap + 64);
       if (!n) { sys->free(g->stream); g->stream = NULL; reader_close(self, &r); return MSPACK_ERR_NOMEMORY; }
       sys->copy(g->stream, n, g->len); sys->free(g->stream); g->stream = n; g->cap = ncap;
+    }
+    if (g->boff) {
+      if (g->total % CAB_BLOCKMAX) g->frames_ok = 0;          /* an earlier block was not a whole frame */
+      g->boff[g->nblk++] = (uint32_t) g->len;
     }
     sys->copy(r.input, g->stream + g->len, r.i_end);
     g->len += r.i_end;
@@ -724,7 +733,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     used += est;
     n++;
   }
-  if (err) { for (k = 0; k < n; k++) sys->free(gs[k].stream); sys->free(gs); sys->free(units); sys->free(res); return err; }
+  if (err) { for (k = 0; k < n; k++) { sys->free(gs[k].stream); sys->free(gs[k].boff); } sys->free(gs); sys->free(units); sys->free(res); return err; }
 
   /* lay the units out in two arenas */
   memset(units, 0, n * sizeof(*units));
@@ -734,14 +743,24 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     in_bytes = (in_bytes + 15) & ~(size_t) 15;
     units[k].in_off = in_bytes; units[k].in_len = (uint32_t) gs[k].len;
     in_bytes += gs[k].len;
+    /* LZX: every CFDATA block is one frame (cabd.c:1362-1479), so the block sizes are the folder's frame table:
+     * the frames' tokens are parsed by one wavefront each (MSPACK_HIP_UF_FRAME_TABLE) */
+    gs[k].frames_ok = gs[k].frames_ok && method == MSCAB_COMP_LZX && gs[k].boff && !gs[k].hard_eof &&
+                      gs[k].nblk >= 2 && (size_t) gs[k].nblk * CAB_BLOCKMAX >= gs[k].total;
+    if (gs[k].frames_ok) {
+      in_bytes = (in_bytes + 64 + 3) & ~(size_t) 3;          /* (zero bytes behind the stream, as before) */
+      units[k].in_chunk = (uint32_t)(in_bytes / 4);
+      in_bytes += (size_t) gs[k].nblk * 4;
+    }
     units[k].out_off = out_bytes; units[k].out_len = gs[k].total;
     out_bytes += ((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15;
-    units[k].kind = (uint8_t) method;
+    units[k].kind = (uint8_t)((method >= 1 && method <= 3) ? method : 0);   /* 0: no codec (cabd.c:1254), skipped */
     units[k].window_bits = (uint8_t)((fp->base.comp_type >> 8) & 0x1F);
     units[k].reset_frames = 0; units[k].e8_base = 0;
     units[k].flags = (gs[k].hard_eof ? MSPACK_HIP_UF_HARD_EOF : 0) |
-                     ((self->fix_mszip && method == MSCAB_COMP_MSZIP) ? MSPACK_HIP_UF_MSZIP_REPAIR : 0);
-    units[k].in_chunk = (uint32_t)((self->buf_size + 1) & ~1);    /* mszipd.c:348 */
+                     ((self->fix_mszip && method == MSCAB_COMP_MSZIP) ? MSPACK_HIP_UF_MSZIP_REPAIR : 0) |
+                     (gs[k].frames_ok ? MSPACK_HIP_UF_FRAME_TABLE : 0);
+    if (!gs[k].frames_ok) units[k].in_chunk = (uint32_t)((self->buf_size + 1) & ~1);    /* mszipd.c:348 */
   }
   in_arena = (unsigned char *) sys->alloc(sys, in_bytes + 64);
   out_arena = (unsigned char *) sys->alloc(sys, out_bytes + 64);
@@ -749,8 +768,11 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   else {
     size_t nhip = 0;
     memset(in_arena, 0, in_bytes + 64);
-    for (k = 0; k < n; k++) sys->copy(gs[k].stream, in_arena + units[k].in_off, gs[k].len);
-    for (k = 0; k < n; k++) if (units[k].kind >= 1 && units[k].kind <= 3) nhip++;
+    for (k = 0; k < n; k++) {
+      sys->copy(gs[k].stream, in_arena + units[k].in_off, gs[k].len);
+      if (gs[k].frames_ok) memcpy(in_arena + (size_t) units[k].in_chunk * 4, gs[k].boff, (size_t) gs[k].nblk * 4);
+    }
+    for (k = 0; k < n; k++) if (units[k].kind != 0) nhip++;
     memset(res, 0, n * sizeof(*res));
     if (nhip) {
       /* kinds other than 1..3 are answered with MSPACK_ERR_ARGS by the kernels; fix them up below */
@@ -779,7 +801,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
       fp->decoded = 1;
     }
   }
-  for (k = 0; k < n; k++) sys->free(gs[k].stream);
+  for (k = 0; k < n; k++) { sys->free(gs[k].stream); sys->free(gs[k].boff); }
   sys->free(gs); sys->free(units); sys->free(res); sys->free(in_arena); sys->free(out_arena);
   return err;
 }

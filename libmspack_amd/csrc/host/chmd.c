@@ -45,6 +45,9 @@ struct chm_p {
   unsigned char *arena; size_t arena_len;     /* the CHM file from the start of Content to its end  */
   off_t content_start;            /* file offset of the Content stream                              */
   uint64_t *ioff;                 /* reset-table entry (compressed offset) of intervals [0, n_fast)  */
+  size_t ftab_off;                /* arena offset of the per-frame tables (0: none), n_fast * fper uint32: every
+                                     frame's compressed offset from its interval's start (MSPACK_HIP_UF_FRAME_TABLE) */
+  size_t arena_room;              /* bytes of the arena buffer that belong to the batch decoder's input arena */
   mspack_hip_result *ires;        /* stand-alone result per interval                                */
   struct chm_chunk *chunks; unsigned int n_chunks, chunk_int; unsigned long stamp;
   /* the serial span of the virtual decoder (damaged / table-less files) */
@@ -485,8 +488,12 @@ static int decode_intervals(struct chmd_p *self, struct chm_p *c, unsigned int f
     units[k].window_bits = (uint8_t) c->window_bits;
     units[k].reset_frames = (uint16_t) c->fper;
     units[k].e8_base = (int32_t)((off_t)(first + k) * c->interval_bytes - e8_origin);
+    if (c->ftab_off) {
+      units[k].flags |= MSPACK_HIP_UF_FRAME_TABLE;
+      units[k].in_chunk = (uint32_t)((c->ftab_off + (size_t)(first + k) * c->fper * 4) / 4);
+    }
   }
-  rc = hip_batch(units, count, c->arena, c->arena_len + 64, out, (size_t) count * (size_t) c->interval_bytes + 64, res);
+  rc = hip_batch(units, count, c->arena, c->arena_room, out, (size_t) count * (size_t) c->interval_bytes + 64, res);
   sys->free(units);
   if (rc) { sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error()); return MSPACK_ERR_DECRUNCH; }
   return MSPACK_ERR_OK;
@@ -545,8 +552,16 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
     if (mspack_sys_filelen(sys, fh, &flen)) return MSPACK_ERR_SEEK;
     avail = (start >= 0 && flen > start) ? flen - start : 0;
     want = (size_t) avail;
-    if (!(c->arena = (unsigned char *) sys->alloc(sys, want + 128))) return MSPACK_ERR_NOMEMORY;
-    memset(c->arena, 0, want + 128);
+    /* (room behind the stream: 128 zero bytes, then one uint32 per frame the reset table can describe) */
+    {
+      size_t extra = 0;
+      if (!find_sys_file(self, sec, &sec->rtable, rtable_name) && sec->rtable->length >= 0x28 && sec->rtable->length <= 1000000)
+        extra = (size_t) sec->rtable->length;                     /* >= 4 bytes per entry */
+      if (!(c->arena = (unsigned char *) sys->alloc(sys, want + 128 + extra + 16))) return MSPACK_ERR_NOMEMORY;
+      memset(c->arena, 0, want + 128 + extra + 16);
+      c->arena_room = want + 64;
+    }
+    c->ftab_off = 0;
     if (want) {
       if (sys->seek(fh, start, MSPACK_SYS_SEEK_START)) return MSPACK_ERR_SEEK;
       if (sys->read(fh, c->arena, (int) want) != (int) want) return MSPACK_ERR_READ;
@@ -577,6 +592,24 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
         }
         c->n_fast = k;
         c->n_intervals = (unsigned int) ni;
+        /* the frames' offsets inside every interval, for the frame-parallel parse: a hint, never trusted */
+        if (c->fper >= 2 && c->n_fast) {
+          const size_t base = (c->arena_len + 128 + 3) & ~(size_t) 3;
+          uint32_t *tab = (uint32_t *)(c->arena + base);
+          unsigned int j;
+          int ok = 1;
+          for (k = 0; k < c->n_fast && ok; k++)
+            for (j = 0; j < c->fper; j++) {
+              unsigned int entry = k * c->fper + j;
+              unsigned int pos = toff + entry * esz;
+              uint64_t v;
+              if (entry >= nent || (off_t) pos > sec->rtable->length - (off_t) esz) { tab[entry] = 0xFFFFFFFFu; continue; }
+              v = (esz == 4) ? rd_le32(data + pos) : (uint64_t) rd_le64(data + pos);
+              tab[entry] = (v >= c->ioff[k] && v - c->ioff[k] < 0xFFFFFFF0u) ? (uint32_t)(v - c->ioff[k]) : 0xFFFFFFFFu;
+            }
+          c->ftab_off = base;
+          c->arena_room = base + (size_t) c->n_fast * c->fper * 4;
+        }
       }
     }
     sys->free(data);

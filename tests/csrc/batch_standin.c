@@ -36,7 +36,9 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *
     if (u->in_off + u->in_len > in_bytes || u->out_off + u->out_len > out_bytes) {
       snprintf(g_err, sizeof(g_err), "unit outside arena"); return -1;
     }
-    if (u->flags) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
+    /* the frame table is a hint for the GPU's frame-parallel parse; results do not depend on it */
+    if (u->flags & ~MSPACK_HIP_UF_FRAME_TABLE) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
+    if (u->kind == 0) { r->err = 1; continue; }
     switch (u->kind) {
     case MSPACK_HIP_KIND_LZX:
       oracle_lzx_decode(src, u->in_len, dst, u->out_len, u->out_len, u->out_len, u->window_bits, u->reset_frames,
