@@ -1216,7 +1216,10 @@ __device__ __forceinline__ u32 lzx_adv_from_entry(const LzxShared *sh, const boo
 }
 
 #define LZX_TQ2 256u                /* lzx_run_spec2: token queue entries */
-#define LZX_SETS 4                  /* position sets per lane: a round covers 64 * LZX_SETS bit positions */
+#ifndef LZX_SETS
+#define LZX_SETS 6                  /* position sets per lane: a round covers 64 * LZX_SETS bit positions (measured:
+                                       2 sets 4.63 ms, 4 4.57, 6 4.46, 8 4.74 on the headline batch) */
+#endif
 
 template <bool ALIGNED>
 __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 run_end_, const u32 wbase_)
@@ -1235,7 +1238,7 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
   // scalar token is at most 46 bytes, a block header read without any symbol decode 17 more and the first symbol
   // after it 7 -- with 88 the EOF-exact reader still takes over at a symbol boundary well before the reference's
   // read pointer can reach the end of the input (cf. lzx_run_spec)
-  const u32 bit_limit = spec_bit_limit(d, 88u);
+  const u32 bit_limit = spec_bit_limit(d, 56u + 8u * LZX_SETS);
   if (rfl(d.cons_bits()) >= bit_limit) return LZX_RUN_SWITCH;
   d.flush_lits();
   u32 bitpos, cb, pf;
