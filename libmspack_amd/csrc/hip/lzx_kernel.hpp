@@ -72,6 +72,11 @@
 #define HT0() do { } while (0)
 #define HT(k) do { } while (0)
 #endif
+#ifdef LZX_MARKS      /* analysis builds: region markers in the assembly (tools/count_isa.py) */
+#define LZX_MARK(name) asm volatile("; MARK " name)
+#else
+#define LZX_MARK(name) do { } while (0)
+#endif
 #ifdef LZX_EXP_CNT
 #define CNT(k) (d.st_t[k]++)
 #else
@@ -895,7 +900,7 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
 #ifndef LZX_EXP_NOCOPY
     // (3) queue the matches
     if (mm) {
-      bool ism = (mm >> lane) & 1ull;
+      bool ism = lane_in(mm);
       // Offsets no linear copy can serve (0, or beyond the window: only from a stored block's R0-R2;
       // DELTA: beyond the 23 bits the queue holds) take the slow way: resolve the queue, copy this
       // batch's matches one at a time with the reference's ring semantics.
@@ -918,9 +923,9 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
           const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
           if (fit) {
             const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
-            spq_push(sh->spq, C.Q, (fit >> lane) & 1ull, rank, (u32) __popcll(fit), opos, vmoff, olen);
+            spq_push(sh->spq, C.Q, lane_in(fit), rank, (u32) __popcll(fit), opos, vmoff, olen);
             mm &= ~fit;
-            ism = (mm >> lane) & 1ull;
+            ism = lane_in(mm);
           }
           if (!mm) break;
           spq_resolve(sh->spq, C.Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
@@ -1257,6 +1262,7 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
     // =================================== PARSE ===================================
     // (not while the oldest queued token would fall out of the LDS window, nor with the side slots nearly full)
     if (!stop && tt - th < 64u && nside < 12u && (tt == th || ((bitpos + 64u * LZX_SETS + 128u) >> 11) <= (qbase >> 11) + 1u)) {
+      LZX_MARK("parse_begin");
       spec3_slide(d, bitpos, cb, pf);
       const u32 rel = bitpos - ((cb - 1u) << 11) + lane;
       const u32 k = rel >> 5, sft = rel & 31u;
@@ -1276,6 +1282,7 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
         const u32 pos = lane + 64u * j;
         vn[j] = e == 0u ? (2048u + pos) : (unk ? (1024u + pos) : (pos + tot));
       }
+      LZX_MARK("walk_begin");
       // ---- follow the real token boundaries through the sets ----
       u64 chain[LZX_SETS];
       u32 q = 0, ntok = 0;
@@ -1311,6 +1318,7 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
           ntok += (u32) __popcll(chain[j]);
         }
       }
+      LZX_MARK("walk_end");
       bool hit_unknown = false;
       if (q >= 1024u) {
         q -= 1024u; hit_unknown = true;
@@ -1323,15 +1331,14 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
         u32 base = tt;
 #pragma unroll
         for (int j = 0; j < LZX_SETS; j++) {
-          if (chain[j]) {
-            const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain[j] >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain[j], 0u));
-            if ((chain[j] >> lane) & 1ull) tq0[(base + rank) & (LZX_TQ2 - 1u)] = (bitpos + 64u * j + lane) & 0xFFFFu;
-            base += (u32) __popcll(chain[j]);
-          }
+          const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain[j] >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain[j], 0u));
+          if (lane_in(chain[j])) tq0[(base + rank) & (LZX_TQ2 - 1u)] = (bitpos + 64u * j + lane) & 0xFFFFu;
+          base += (u32) __popcll(chain[j]);
         }
         tt = base;
       }
       d.st_rounds++;
+      LZX_MARK("queue_end");
       if (hit_unknown) {
         // a token the lane-parallel decoder does not take: the scalar decoder reads it from its 64 bits
         const u32 tb = bitpos + q;
@@ -1356,10 +1363,12 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
       }
       else bitpos += q;
       if (bitpos >= bit_limit) stop = true;
+      LZX_MARK("parse_end");
       if (!stop && tt - th < 64u) continue;
     }
 
     // =================================== COMMIT ===================================
+    LZX_MARK("commit_begin");
     u32 n = tt - th;
     if (n > 64u) n = 64u;
     if (n == 0u) { rc = LZX_RUN_SWITCH; break; }         // the input margin was reached and all is committed
@@ -1381,17 +1390,21 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
       if (si) { c0 = sh->side0[si - 1u]; c1 = sh->side1[si - 1u]; }
       c0 |= (qe & 0xFFFFu) << 12;
     }
+    LZX_MARK("values_end");
     u32 marker; bool fail_after;
     const u32 took = lzx_commit_batch(d, C, c0, c1, n, marker, fail_after);
+    LZX_MARK("commit_batch_end");
     nside -= (u32) __popcll(ballot(lane < took && (qe >> 16) != 0u));
     th += took;
     if (tt != th) {                                                     // start bit of the token that is the oldest now
       const u32 nx = rfl(tq0[th & (LZX_TQ2 - 1u)]) & 0xFFFFu;
       qbase += (nx - qbase) & 0xFFFFu;
     }
+    LZX_MARK("resolve_begin");
 #ifndef LZX_EXP_NOCOPY
     if (spq_due(C.Q, C.P)) spq_resolve(sh->spq, C.Q, out, C.P, false, lane);
 #endif
+    LZX_MARK("resolve_end");
     if (fail_after || marker == LZX_TK_FAIL) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; }
   }
 #ifndef LZX_EXP_NOCOPY

@@ -35,6 +35,8 @@ __device__ __forceinline__ u32 rdl(u32 v, u32 l) { return (u32) __builtin_amdgcn
 // compare+select is two VALU ops and keeps everything visible to the scheduler)
 #define wrl(old, val, l) ((threadIdx.x == (u32)(l)) ? (u32)(val) : (u32)(old))
 __device__ __forceinline__ u64 ballot(bool p) { return __ballot(p); }
+// is this lane's bit set in a wave-uniform mask?  (the mask goes straight into exec / vcc: no per-lane shift + test)
+__device__ __forceinline__ bool lane_in(u64 uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(uniform_mask); }
 __device__ __forceinline__ u32 lanemask_lt_popc(u64 m, u32 lane) {
   return __popcll(m & ((1ull << lane) - 1ull));
 }
