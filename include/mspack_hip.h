@@ -60,14 +60,16 @@ extern "C" {
 #define MSPACK_HIP_UF_MSZIP_KWAJ    4u  /* MSZIP as KWAJ files frame it (mszipd_decompress_kwaj, mszipd.c:462-495):
                                            16-bit block length (0 ends the stream), 'C','K', one deflate stream;
                                            out_len is the room available, the result's out_len what was produced */
-#define MSPACK_HIP_UF_FRAME_TABLE   8u  /* LZX: the container states where every 32 KiB frame of the unit starts in the
-                                           compressed stream (a cabinet: one CFDATA block per frame, cabd.c:1362-1479;
-                                           a CHM: one reset-table entry per frame, chmd.c:1146-1149).  in_chunk * 4 is the
-                                           byte offset, in the input arena, of a uint32 table with one entry per frame:
-                                           the frame's offset from in_off.  With it the frames' tokens are parsed by one
-                                           wavefront each before the unit's own wavefront commits them; the table is a
-                                           HINT -- a wrong one costs time, never correctness (the unit's wavefront checks
-                                           every frame's bit position and falls back to decoding serially)           */
+#define MSPACK_HIP_UF_FRAME_TABLE   8u  /* LZX / MSZIP: the container states where every 32 KiB frame (LZX) / CFDATA block
+                                           (MSZIP; every block but the last holding 32768 bytes) of the unit starts in
+                                           the compressed stream (a cabinet: the CFDATA sizes, cabd.c:1362-1479; a CHM: one
+                                           reset-table entry per frame, chmd.c:1146-1149).  in_chunk * 4 is the byte
+                                           offset, in the input arena, of a uint32 table with one entry per frame: its
+                                           offset from in_off.  With it the frames' tokens are parsed by one wavefront
+                                           each before the unit's own wavefront commits them; the table is a HINT -- a
+                                           wrong one costs time, never correctness (the unit's wavefront checks every
+                                           frame's bit position and falls back to decoding serially).  Ignored for MSZIP
+                                           units in repair or KWAJ mode (in_chunk has its other meaning there)        */
 #define MSPACK_HIP_UF_HARD_EOF      2u  /* the feeder's read FAILED at in_len (sys->read < 0, e.g. a bad
                                            CFDATA block, cabd.c:1322-1324): ERR_READ at once, without the
                                            two fabricated zero bytes of a clean EOF (readbits.h:194-208) */

@@ -78,9 +78,11 @@ def _check(rc, what):
 
 
 def frames_of(units):
-    """per-unit slots in the LZX per-frame scratch (one spare for the look-ahead frame)"""
-    return np.where((units["kind"] == KIND_LZX) | (units["kind"] == KIND_LZX_DELTA),
-                    units["out_len"] // 32768 + 1, 0).astype(np.int64)
+    """per-unit slots in the work scratch: LZX one per frame + one spare for the look-ahead frame; MSZIP units that
+    carry a frame table (and are not in repair / KWAJ mode) one per CFDATA block"""
+    lzx = (units["kind"] == KIND_LZX) | (units["kind"] == KIND_LZX_DELTA)
+    zipt = (units["kind"] == KIND_MSZIP) & ((units["flags"] & UF_FRAME_TABLE) != 0) & ((units["flags"] & 5) == 0)
+    return np.where(lzx, units["out_len"] // 32768 + 1, np.where(zipt, (units["out_len"].astype(np.int64) + 32767) // 32768, 0)).astype(np.int64)
 
 
 UF_FRAME_TABLE = 8

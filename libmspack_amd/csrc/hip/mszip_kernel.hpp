@@ -25,6 +25,20 @@
 #define ZIP_BL_P 7
 #define ZIP_HIST 8
 
+#define ZIP_TOK_CAP 16384u         /* tokens a parse wave stores per CFDATA block (same slot size as LZX_TOK_CAP) */
+
+// what a parse wave leaves for the unit's wave (same 1152-byte slots as LzxFrameRec; only the head is used)
+struct ZipBlockRec {
+  u32 status;                      /* 1 = the whole CFDATA block was parsed */
+  u32 n_tokens;
+  u32 start_bit;                   /* first bit of the deflate data (behind 'C','K'), from the unit's first byte */
+  u32 end_bit;                     /* first bit behind the last end-of-block symbol */
+  u32 eob_rbl;                     /* the reference's bits_left there */
+  u32 total_out;                   /* bytes the block produces (<= 32768) */
+  u32 pad[282];
+};
+static_assert(sizeof(ZipBlockRec) == 1152, "ZipBlockRec slot size");
+
 struct __align__(16) MszipShared {
   u16 lit_tab[1 << ZIP_LIT_P];
   u16 lit_sorted[288];
@@ -426,6 +440,213 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
   return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Block-level parse parallelism (units that carry a frame table: the CFDATA blocks' offsets in the folder stream).
+// Every CFDATA block of an MSZIP folder is a deflate stream of its own ('C','K' + blocks with their own Huffman
+// tables, mszipd.c:406-418); only its MATCHES may reach into the previous block's bytes (mszipd.c:267-268).  So one
+// PARSE wave per CFDATA block (mspack_mszip_parse) decodes the block's tokens into global memory, and the folder's own
+// wave (mspack_decode_mszip) commits them block after block (zip_run_tokens: positions, literals, match queue) --
+// what stays serial per folder is a quarter of the work.  A parse wave gives up silently on anything unusual (a
+// stored deflate block, an error, the last bytes of the input, more than 32 KiB of output); the folder's wave
+// adopts a record only if it was parsed from exactly its bit position, and decodes everything else as before.
+// ---------------------------------------------------------------------------------------------------
+// the PARSE half of zip_run_spec: tokens to global memory.  Returns 1 when the end-of-block symbol was consumed
+// (bit position and the reference's bits_left behind it are in the decoder), 0 when it stopped in front of a token
+// this path does not take (scalar reader positioned there), -1 when the block cannot be parsed here.
+__device__ __forceinline__ int zip_parse_run(ZipDec &d, uint2 *tok, u32 &tt, u32 &outc)
+{
+  MszipShared *sh = d.sh;
+  const u32 lane = d.lane;
+  const u32 room_bytes = (d.w.in_len > d.w.origin + 56u) ? (d.w.in_len - d.w.origin - 56u) : 0u;
+  const u32 bit_limit = rfl(room_bytes * 8u);
+  u32 bitpos = rfl(d.cons_bits());
+  if (bitpos >= bit_limit) return -1;
+  u32 cb = bitpos >> 11;
+  {
+    u32 lo = d.w.load_chunk(cb, lane), hi = d.w.load_chunk(cb + 1u, lane);
+    sh->inbuf[lane] = lo; sh->inbuf[64u + lane] = hi;
+    if (lane < 4u) sh->inbuf[128u + lane] = 0;
+  }
+  u32 pf = d.w.load_chunk(cb + 2u, lane);
+  u32 llim[16 - ZIP_LIT_P];
+#pragma unroll
+  for (int l = ZIP_LIT_P + 1; l <= 16; l++) llim[l - ZIP_LIT_P - 1] = rdl(d.hr_lit.limv, (u32) l);
+  int rc = 0, eob_rbl = 0;
+  for (;;) {
+    if ((bitpos >> 11) != cb) {                         // slide the LDS window by one chunk
+      u32 up = sh->inbuf[64u + lane];
+      sh->inbuf[lane] = up; sh->inbuf[64u + lane] = pf;
+      cb++;
+      pf = d.w.load_chunk(cb + 2u, lane);
+    }
+    const u32 rel = bitpos - (cb << 11) + lane;
+    const u32 k = rel >> 5, sft = rel & 31u;
+    const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
+    const u64 q01 = ((u64) i1 << 32) | i0, q12 = ((u64) i2 << 32) | i1;
+    const u64 r = (u64)(u32)(q01 >> sft) | ((u64)(u32)(q12 >> sft) << 32);
+    const ZipTok t = zip_spec_token(sh, d.hr_lit.fov, llim, r);
+    const u32 vnext = t.unk ? (128u + lane) : (t.kind == 2u ? (192u + lane) : (lane + t.tot));
+    u64 chain = 0;
+    u32 q = 0;
+    do { chain |= 1ull << q; q = rdl(vnext, q); } while (q < WAVE);
+    bool stop = false;
+    if (q >= 192u) {                                    // the end-of-block symbol: not a token, ends the parse
+      q -= 192u;
+      const u32 st = bitpos + q, tl = rdl(t.tot, q);
+      eob_rbl = (int)(16u + ((0u - st) & 7u) - tl);
+      chain &= ~(1ull << q);
+      q += tl; rc = 1; stop = true;
+    }
+    else if (q >= 128u) { q -= 128u; chain &= ~(1ull << q); stop = true; }
+    const u32 nA = (u32) __popcll(chain);
+    if (tt + nA > ZIP_TOK_CAP) return -1;
+    const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain, 0u));
+    const bool on = lane_in(chain);
+    if (on) tok[tt + rank] = make_uint2(t.kind | (t.olen << 3), t.kind == 0u ? t.sym : t.dist);
+    tt += nA;
+    outc += rdl(wave_incl_scan(on ? t.olen : 0u), 63u);
+    bitpos += q;
+    if (outc > ZIP_FRAME) return -1;
+    if (stop) break;
+    if (bitpos >= bit_limit) return -1;
+  }
+  // hand the exact bit position to the scalar reader
+  {
+    u32 wi = bitpos >> 5, ch = wi >> 6;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    u32 lo = sh->inbuf[lane], hi = sh->inbuf[64u + lane];
+    if (ch == cb) { d.w.cur = lo; d.w.nxt = hi; }
+    else if (ch == cb + 1u) { d.w.cur = hi; d.w.nxt = pf; }
+    else { d.w.cur = d.w.load_chunk(ch, lane); d.w.nxt = d.w.load_chunk(ch + 1u, lane); }
+    d.w.wi = wi; d.bb = 0; d.bl = 0;
+    d.refill(); d.refill();
+    u32 sk = bitpos & 31u;
+    if (sk) { d.bb >>= sk; d.bl -= (int) sk; }
+    d.rbl = rc ? eob_rbl : (int)((0u - bitpos) & 7u);
+  }
+  return rc;
+}
+
+// one parse wave: CFDATA block `b` of unit u
+__device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 *in_arena, ZipBlockRec *rec,
+                                uint2 *tok, MszipShared *sh)
+{
+  const u32 lane = threadIdx.x;
+  ZipDec d;
+  d.lane = lane; d.sh = sh;
+  d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
+  d.w.eofs = (u.flags & MSPACK_HIP_UF_HARD_EOF) ? 0u : 2u;
+  d.out = nullptr; d.B = 0; d.wpos = 0; d.flushed = false; d.hist_n = 0; d.lit_buf = 0; d.lit_n = 0;
+  d.snap_iptr = 0; d.snap_rbl = 0;
+  const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
+  const u32 fo = rfl(ftab[b]);
+  if (fo >= u.in_len || u.in_len - fo <= 64u) return;       // the last bytes of the input belong to the EOF-exact reader
+  d.restart(fo);
+  u32 v, last_block, type;
+  if (!d.read_bits(8, v) || v != 'C' || !d.read_bits(8, v) || v != 'K') return;
+  const u32 start_bit = d.w.origin * 8u + d.cons_bits();
+  u32 tt = 0, outc = 0;
+  do {
+    if (!d.read_bits(1, last_block) || !d.read_bits(2, type)) return;
+    if (type == 1u) {
+      for (u32 k = lane; k < 288u; k += WAVE) sh->lit_len[k] = (u8)(k < 144u ? 8 : (k < 256u ? 9 : (k < 280u ? 7 : 8)));
+      if (lane < 32u) sh->dist_len[lane] = 5;
+    }
+    else if (type == 2u) { if (zip_read_dynamic(d)) return; }
+    else return;                                             // stored (or invalid): the folder's wave does it
+    if (huff_build<ZIP_LIT_P>(sh->lit_len, 288, 9, sh->lit_tab, sh->lit_sorted, sh->cnt, d.hr_lit, lane, true)) return;
+    if (huff_build<ZIP_DIST_P>(sh->dist_len, 32, 6, sh->dist_tab, sh->dist_sorted, sh->cnt, d.hr_dist, lane, true)) return;
+    for (;;) {
+      const int rc = zip_parse_run(d, tok, tt, outc);
+      if (rc < 0) return;
+      if (rc == 1) break;
+      // a token the lane-parallel decoder does not take (a long distance code, ...): one scalar token (mszipd.c:228-303)
+      if (d.bl <= 32) d.refill();
+      const u32 st = d.cons_bits();
+      int sym = d.decode_sym<ZIP_LIT_P>(sh->lit_tab, sh->lit_sorted, d.hr_lit, true);
+      if (sym < 0) return;
+      if (tt + 1u > ZIP_TOK_CAP) return;
+      if (sym < 256) { if (lane == 0) tok[tt] = make_uint2(0u | (1u << 3), (u32) sym); tt++; outc++; continue; }
+      if (sym == 256) {                                      // bits_left behind it: ENSURE_BITS(16) at its first bit, minus its length
+        d.rbl = (int)(16u + ((0u - st) & 7u) - (d.cons_bits() - st));
+        break;
+      }
+      u32 code = (u32) sym - 257u, lbase, lextra, dbase, dextra, ev;
+      if (code >= 29u) return;
+      zip_len_code(code, lbase, lextra);
+      if (!d.read_bits((int) lextra, ev)) return;
+      const u32 length = lbase + ev;
+      if (d.bl <= 32) d.refill();
+      int ds = d.decode_sym<ZIP_DIST_P>(sh->dist_tab, sh->dist_sorted, d.hr_dist, true);
+      if (ds < 0 || ds >= 30) return;
+      zip_dist_code((u32) ds, dbase, dextra);
+      if (!d.read_bits((int) dextra, ev)) return;
+      if (lane == 0) tok[tt] = make_uint2(1u | (length << 3), dbase + ev);
+      tt++; outc += length;
+      if (outc > ZIP_FRAME) return;
+    }
+  } while (!last_block);
+  if (lane == 0) {
+    rec->n_tokens = tt; rec->start_bit = start_bit; rec->end_bit = d.w.origin * 8u + d.cons_bits();
+    rec->eob_rbl = (u32) d.rbl; rec->total_out = outc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    rec->status = 1u;
+  }
+}
+
+// commit a CFDATA block's pre-parsed tokens (the COMMIT half of zip_run_spec).  false: a match needs bytes this path
+// cannot serve (history that is not a full block right below): the caller decodes the block the serial way.
+__device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *tok, const u32 n_tok_)
+{
+  MszipShared *sh = d.sh;
+  const u32 lane = d.lane;
+  u8 *const out = d.out;
+  const u32 B = rfl(d.B), n_tok = rfl(n_tok_);
+  const bool lin_hist = d.hist_n > 0u && rfl(sh->hist_len[0]) == ZIP_FRAME && rfl(sh->hist_B[0]) + ZIP_FRAME == B;
+  u32 P = B;
+  SpecQueue Q;
+  spq_init(sh->spq, Q, P, lane);
+  bool ok = true;
+  uint2 cur = make_uint2(0u, 0u);
+  if (lane < n_tok) cur = tok[lane];
+  for (u32 th = 0; th < n_tok; th += 64u) {
+    const u32 n = n_tok - th < 64u ? n_tok - th : 64u;
+    uint2 nxt = make_uint2(0u, 0u);
+    if (th + 64u + lane < n_tok) nxt = tok[th + 64u + lane];          // in flight while this batch commits
+    const u32 c0 = cur.x, c1 = cur.y;
+    const u32 kind = c0 & 7u;
+    const u32 olen = lane < n ? ((c0 >> 3) & 511u) : 0u;
+    const u32 incl = wave_incl_scan(olen);
+    const u32 opos = P + incl - olen;
+    const u32 newP = P + rdl(incl, 63u);
+    const bool valid = lane < n;
+    if (ballot(valid && kind == 1u && c1 > opos - B && !lin_hist)) { ok = false; break; }
+    if (valid && kind == 0u) out[opos] = (u8) c1;
+    u64 mm = ballot(valid && kind == 1u);
+    if (mm) {
+      bool ism = lane_in(mm);
+      if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
+      for (;;) {
+        const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
+        const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
+        if (fit) {
+          const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+          spq_push(sh->spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, c1, olen);
+          mm &= ~fit;
+          ism = lane_in(mm);
+        }
+        if (!mm) break;
+        spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
+      }
+    }
+    P = newP;
+    if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane);
+    cur = nxt;
+  }
+  spq_resolve(sh->spq, Q, out, P, true, lane);
+  return ok;
+}
+
 // inflate (mszipd.c:154-316): 0 ok, <0 format error, >0 ERR_READ.  *bytes_output as the reference.
 __device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
 {
@@ -517,8 +738,9 @@ __device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
   return 0;
 }
 
+// recs / toks: the parse waves' records and tokens for this launch (NULL: none), indexed by frame slot
 __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
-                                  mspack_hip_result *res, MszipShared *sh)
+                                  mspack_hip_result *res, MszipShared *sh, const ZipBlockRec *recs, const uint2 *toks)
 {
   const u32 lane = threadIdx.x;
   ZipDec d;
@@ -538,6 +760,9 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
   int err = ERR_OK;
   u32 state0 = 0;                 // 'C','K' scanner state carried over a repair restart
   d.snap_iptr = 0; d.snap_rbl = 0;
+  const bool use_recs = recs != nullptr && (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u && !repair && !kwaj;
+  u32 blk = 0;                    // CFDATA blocks started so far (the frame slot of the next one)
+  const u32 nblk = (u.out_len + ZIP_FRAME - 1u) / ZIP_FRAME;
 
   while (remaining > 0u || kwaj) {
     d.byte_align();
@@ -570,7 +795,25 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
     d.wpos = 0; d.flushed = false;
     d.store_bits();                                                              // mszipd.c:419
     u32 bytes_output = 0;
-    int r = zip_inflate(d, bytes_output);
+    int r = 0;
+    bool adopted = false;
+    if (use_recs && blk < nblk) {
+      // a parse wave's record for this block?  adopt it if it was parsed from exactly this bit position
+      const ZipBlockRec *rc_ = &recs[u.frame_base + blk];
+      if (rfl(rc_->status) == 1u && rfl(rc_->start_bit) == d.w.origin * 8u + d.cons_bits() &&
+          zip_run_tokens(d, toks + (size_t)(u.frame_base + blk) * ZIP_TOK_CAP, rc_->n_tokens)) {
+        const u32 eb = rfl(rc_->end_bit), total = rfl(rc_->total_out);
+        d.restart(eb >> 3);
+        { const u32 sk = eb & 7u; if (sk) { d.need((int) sk); d.bb >>= sk; d.bl -= (int) sk; } }
+        d.careful = true; d.rbl = (int) rfl(rc_->eob_rbl);
+        d.flushed = (total == ZIP_FRAME); d.wpos = d.flushed ? 0u : total;
+        bytes_output = total;
+        adopted = true;
+        rflags |= MSPACK_HIP_F_FRAMES_ADOPTED;
+      }
+    }
+    blk++;
+    if (!adopted) r = zip_inflate(d, bytes_output);
     if (r) {
       d.flush_lits();
       if (repair) {                                                              // mszipd.c:422-433

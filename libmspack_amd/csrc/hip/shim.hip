@@ -65,13 +65,15 @@ __host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_fr
 // which frame slots get a parse wave: the real frames of LZX units that carry a frame table
 __global__ __launch_bounds__(64)
 void mspack_lzx_frame_map(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 *frame_unit,
-                          lzxn::LzxFrameRec *recs, u32 *hdr)
+                          lzxn::LzxFrameRec *recs, u32 *hdr, u32 kind)
 {
   u32 ui;
-  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) { if (threadIdx.x == 0 && hdr[1] != 0u) atomicMin(&hdr[1], 0u); return; }
+  if (!pick_unit(units, order, n_units, kind, ui)) { if (threadIdx.x == 0 && hdr[1] != 0u) atomicMin(&hdr[1], 0u); return; }
   const mspack_hip_unit u = units[ui];
-  const u32 nslots = u.out_len / LZX_FRAME + 1u, nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
-  const bool usable = (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u;
+  const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
+  const bool usable = (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u && !(kind == MSPACK_HIP_KIND_MSZIP && (u.flags & (MSPACK_HIP_UF_MSZIP_REPAIR | MSPACK_HIP_UF_MSZIP_KWAJ)));
+  // frame slots of a unit: LZX out_len/32768 + 1 (one spare for the look-ahead frame), MSZIP with a table one per block
+  const u32 nslots = kind == MSPACK_HIP_KIND_LZX ? u.out_len / LZX_FRAME + 1u : (usable ? nreal : 0u);
   if (threadIdx.x == 0) {                   // (a plain look first: 4096 atomics on one word take 0.1 ms)
     const u32 v = usable ? nreal : 0u;
     if (hdr[0] < v) atomicMax(&hdr[0], v);
@@ -175,16 +177,40 @@ void mspack_decode_lzxd(const mspack_hip_unit *units, const u32 *order, u32 n_un
   }
 }
 
+// one parse wave per CFDATA block of the MSZIP units that carry a frame table (mszip_kernel.hpp: "Block-level parse
+// parallelism"); same slot mapping as mspack_lzx_parse
+__global__ __launch_bounds__(64)
+void mspack_mszip_parse(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
+                        const u8 *in_arena, const u32 *frame_unit, const u32 *hdr, lzxn::LzxFrameRec *recs, uint2 *toks)
+{
+  __shared__ MszipShared sh;
+  if (blockIdx.x >= n_slots) return;
+  u32 slot = slot_lo + blockIdx.x;
+  const u32 F = rfl(hdr[0]);
+  if (F != 0u && F == rfl(hdr[1])) {
+    const u32 j = blockIdx.x / F, f = blockIdx.x % F;
+    if (j >= n_units) return;
+    const u32 uj = rfl(order ? order[j] : j);
+    slot = units[uj].frame_base + f;
+  }
+  const u32 ui = rfl(frame_unit[slot]);
+  if (ui == 0xFFFFFFFFu) return;
+  const mspack_hip_unit u = units[ui];
+  zip_parse_block(u, slot - u.frame_base, in_arena, (ZipBlockRec *) &recs[slot], toks + (size_t) slot * ZIP_TOK_CAP, &sh);
+}
+
 __global__ __launch_bounds__(64)
 void mspack_decode_mszip(const mspack_hip_unit *units, const u32 *order, u32 n_units,
-                         const u8 *in_arena, u8 *out_arena, mspack_hip_result *results)
+                         const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
+                         const lzxn::LzxFrameRec *recs, const uint2 *toks)
 {
   __shared__ MszipShared sh;
   u32 ui;
   if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_MSZIP, ui)) return;
   const mspack_hip_unit u = units[ui];
-  mszip_decode_unit(u, in_arena, out_arena, &results[ui], &sh);
+  mszip_decode_unit(u, in_arena, out_arena, &results[ui], &sh, (const ZipBlockRec *) recs, toks);
 }
+static_assert(ZIP_TOK_CAP == LZX_TOK_CAP && sizeof(ZipBlockRec) == sizeof(lzxn::LzxFrameRec), "MSZIP and LZX share the work scratch");
 
 __global__ __launch_bounds__(64)
 void mspack_decode_qtm(const mspack_hip_unit *units, const u32 *order, u32 n_units,
@@ -251,7 +277,8 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       u32 *hdr = L.hdr + 2u * (u32)((slot_lo ^ (slot_lo >> 5) ^ (slot_lo >> 11)) & 31u);
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
-      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr);
+      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
+                         (u32) MSPACK_HIP_KIND_LZX);
       hipLaunchKernelGGL(mspack_lzx_headers, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, L.recs);
       hipLaunchKernelGGL(mspack_lzx_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
                          (u32) n_slots, (const u8 *) d_in, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
@@ -263,9 +290,22 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
   case MSPACK_HIP_KIND_LZX_DELTA:
     hipLaunchKernelGGL(mspack_decode_lzxd, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
                        d_results, (int32_t *) d_fm); break;
-  case MSPACK_HIP_KIND_MSZIP:
+  case MSPACK_HIP_KIND_MSZIP: {
+    LzxScratch L = lzx_scratch(d_fm, n_frames_total);
+    const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
+    if (frames) {
+      static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
+      u32 *hdr = L.hdr + 2u * (u32)(((slot_lo ^ (slot_lo >> 5) ^ (slot_lo >> 11)) + 16u) & 31u);
+      hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
+      hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
+      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
+                         (u32) MSPACK_HIP_KIND_MSZIP);
+      hipLaunchKernelGGL(mspack_mszip_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
+                         (u32) n_slots, (const u8 *) d_in, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
+    }
     hipLaunchKernelGGL(mspack_decode_mszip, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results); break;
+                       d_results, frames ? (const lzxn::LzxFrameRec *) L.recs : nullptr, (const uint2 *) L.toks);
+    break; }
   case MSPACK_HIP_KIND_QUANTUM:
     hipLaunchKernelGGL(mspack_decode_qtm, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
                        d_results); break;
@@ -393,11 +433,15 @@ static inline uint64_t unit_below(const mspack_hip_unit &u) {
 }
 static inline uint64_t unit_above(const mspack_hip_unit &u) { return u.kind == MSPACK_HIP_KIND_MSZIP ? 32768u : 0u; }
 static inline bool unit_has_ftab(const mspack_hip_unit &u) {
-  return u.kind == MSPACK_HIP_KIND_LZX && (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u;
+  if (!(u.flags & MSPACK_HIP_UF_FRAME_TABLE)) return false;
+  if (u.kind == MSPACK_HIP_KIND_LZX) return true;
+  return u.kind == MSPACK_HIP_KIND_MSZIP && !(u.flags & (MSPACK_HIP_UF_MSZIP_REPAIR | MSPACK_HIP_UF_MSZIP_KWAJ));
 }
 static inline uint64_t unit_ftab_bytes(const mspack_hip_unit &u) { return (((uint64_t) u.out_len + 32767u) / 32768u) * 4u; }
 static inline size_t unit_frames(const mspack_hip_unit &u) {
-  return (u.kind == MSPACK_HIP_KIND_LZX || u.kind == MSPACK_HIP_KIND_LZX_DELTA) ? (size_t) u.out_len / 32768u + 1u : 0u;
+  if (u.kind == MSPACK_HIP_KIND_LZX || u.kind == MSPACK_HIP_KIND_LZX_DELTA) return (size_t) u.out_len / 32768u + 1u;
+  if (u.kind == MSPACK_HIP_KIND_MSZIP && unit_has_ftab(u)) return ((size_t) u.out_len + 32767u) / 32768u;   // one per CFDATA block
+  return 0u;
 }
 
 // `sel` lists the unit indices this device handles (NULL = all n_sel units).  host_out != NULL: outputs are

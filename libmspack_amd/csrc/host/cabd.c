@@ -661,7 +661,8 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
   g->cap = (size_t) fol->base.num_blocks * 1024 + 65536;
   g->stream = NULL;
   g->nblk = 0; g->frames_ok = 1;
-  g->boff = (method == MSCAB_COMP_LZX) ? (uint32_t *) sys->alloc(sys, ((size_t) fol->base.num_blocks + 1) * sizeof(uint32_t)) : NULL;
+  g->boff = (method == MSCAB_COMP_LZX || method == MSCAB_COMP_MSZIP)
+          ? (uint32_t *) sys->alloc(sys, ((size_t) fol->base.num_blocks + 1) * sizeof(uint32_t)) : NULL;
   if ((err = reader_open(self, &r, fol))) {
     if (err != MSPACK_ERR_SEEK) return err;
     /* the reference fails extract() with SEEK before any decoding; keep it as this folder's error */
@@ -743,9 +744,11 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     in_bytes = (in_bytes + 15) & ~(size_t) 15;
     units[k].in_off = in_bytes; units[k].in_len = (uint32_t) gs[k].len;
     in_bytes += gs[k].len;
-    /* LZX: every CFDATA block is one frame (cabd.c:1362-1479), so the block sizes are the folder's frame table:
-     * the frames' tokens are parsed by one wavefront each (MSPACK_HIP_UF_FRAME_TABLE) */
-    gs[k].frames_ok = gs[k].frames_ok && method == MSCAB_COMP_LZX && gs[k].boff && !gs[k].hard_eof &&
+    /* LZX: every CFDATA block is one frame (cabd.c:1362-1479); MSZIP: every block is a deflate stream of its own
+     * (mszipd.c:406-418).  The block sizes are the folder's frame table: the blocks' tokens are parsed by one
+     * wavefront each (MSPACK_HIP_UF_FRAME_TABLE) before the folder's wavefront commits them */
+    gs[k].frames_ok = gs[k].frames_ok && gs[k].boff && !gs[k].hard_eof &&
+                      (method == MSCAB_COMP_LZX || (method == MSCAB_COMP_MSZIP && !self->fix_mszip)) &&
                       gs[k].nblk >= 2 && (size_t) gs[k].nblk * CAB_BLOCKMAX >= gs[k].total;
     if (gs[k].frames_ok) {
       in_bytes = (in_bytes + 64 + 3) & ~(size_t) 3;          /* (zero bytes behind the stream, as before) */
