@@ -42,6 +42,7 @@
  * anyway): 5.5 KiB of LDS instead of 9.75, i.e. 7 waves per SIMD instead of 4 -- parse throughput is a matter of
  * how many serial chains a SIMD can interleave */
 #define LZX_MAIN_P 8
+#define LZX_STAGE_WORDS 2048u
 #else
 #define LZX_MAIN_P 10
 #endif
@@ -96,6 +97,9 @@ struct __align__(16) LzxShared {
   u32 cnt[20];
   u8  pre_len[24];
   u32 inbuf[128 + 4];            /* speculative path: two 256-byte input chunks, words pre-swapped */
+#ifdef LZX_PARSE_ONLY
+  u32 stage[LZX_STAGE_WORDS + 64]; /* lzx_parse_lanes: a frame's input (or 8 KiB of it), words pre-swapped */
+#endif
 #else
   /* lzx_run_spec2's token queue (start bits of parsed tokens) shares its room with what only block headers
    * use (pretree tables, the table builder's counters): a header is never decoded while tokens are queued */
@@ -637,6 +641,34 @@ __device__ __forceinline__ SpecTok lzx_spec_token(const LzxShared *sh, const u32
   t.kind = !is_match ? 0u : (expl ? 1u : 2u + slot);
   t.olen = is_match ? mlen : 1u;
   return t;
+}
+
+
+// how many bits does the token take whose main-tree entry is e (symbol | code length << LZX_MSH, not 0)?
+template <bool ALIGNED>
+__device__ __forceinline__ u32 lzx_adv_from_entry(const LzxShared *sh, const bool length_empty, const u32 e,
+                                                  const u32 w0, const u32 w1, bool &unk)
+{
+  const u32 mlen = e >> LZX_MSH, sym = e & LZX_MMASK;
+  const bool is_match = sym >= 256u;
+  const u32 m = sym - 256u, slot = m >> 3;
+  const bool need_len = is_match && (m & 7u) == 7u;
+  const u32 e2 = sh->len_tab[(w0 << mlen) >> (32 - LZX_LEN_P)];        // the footer's code starts right behind the main code
+  u32 tot = mlen;
+  unk = false;
+  if (need_len) { unk = (e2 == 0u) || length_empty; tot += e2 >> 10; }
+  const int ex_ = (int)(slot >> 1) - 1;
+  const u32 extra = (u32)(ex_ < 0 ? 0 : (ex_ > 17 ? 17 : ex_));
+  const bool expl = is_match && slot >= 3u;
+  if (ALIGNED) {
+    const bool ali = extra >= 3u;
+    const u32 nb = ali ? extra - 3u : extra;
+    const u64 r = ((u64) w0 << 32) | w1;
+    const u32 e3 = sh->ali_tab[(u32)((r << (tot + nb)) >> (64 - LZX_ALI_P))];   // behind the verbatim bits (bit <= 46)
+    if (expl) { tot += nb; if (ali) { tot += e3 >> 10; unk = unk || e3 == 0u; } }
+  }
+  else if (expl) tot += extra;
+  return tot;
 }
 
 
@@ -1193,33 +1225,6 @@ __device__ __forceinline__ void spec3_resync(LzxDec &d, const u32 bitpos, const 
   if (sk) { d.bb <<= sk; d.bl -= (int) sk; }
 }
 
-// how many bits does the token take whose main-tree entry is e (symbol | code length << LZX_MSH, not 0)?
-template <bool ALIGNED>
-__device__ __forceinline__ u32 lzx_adv_from_entry(const LzxShared *sh, const bool length_empty, const u32 e,
-                                                  const u32 w0, const u32 w1, bool &unk)
-{
-  const u32 mlen = e >> LZX_MSH, sym = e & LZX_MMASK;
-  const bool is_match = sym >= 256u;
-  const u32 m = sym - 256u, slot = m >> 3;
-  const bool need_len = is_match && (m & 7u) == 7u;
-  const u32 e2 = sh->len_tab[(w0 << mlen) >> (32 - LZX_LEN_P)];        // the footer's code starts right behind the main code
-  u32 tot = mlen;
-  unk = false;
-  if (need_len) { unk = (e2 == 0u) || length_empty; tot += e2 >> 10; }
-  const int ex_ = (int)(slot >> 1) - 1;
-  const u32 extra = (u32)(ex_ < 0 ? 0 : (ex_ > 17 ? 17 : ex_));
-  const bool expl = is_match && slot >= 3u;
-  if (ALIGNED) {
-    const bool ali = extra >= 3u;
-    const u32 nb = ali ? extra - 3u : extra;
-    const u64 r = ((u64) w0 << 32) | w1;
-    const u32 e3 = sh->ali_tab[(u32)((r << (tot + nb)) >> (64 - LZX_ALI_P))];   // behind the verbatim bits (bit <= 46)
-    if (expl) { tot += nb; if (ali) { tot += e3 >> 10; unk = unk || e3 == 0u; } }
-  }
-  else if (expl) tot += extra;
-  return tot;
-}
-
 #define LZX_TQ2 256u                /* lzx_run_spec2: token queue entries */
 #ifndef LZX_SETS
 #define LZX_SETS 6                  /* position sets per lane: a round covers 64 * LZX_SETS bit positions (measured:
@@ -1503,7 +1508,7 @@ __device__ __forceinline__ void lzx_parse_tokens(LzxDec &d, const bool length_em
     if (q >= 256u) { q -= 256u; hit_unknown = true; chain &= ~(1ull << q); }
     const bool on = (chain >> lane) & 1ull;
     const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain, 0u));
-    if (on) tok[tt + rank] = make_uint2(t.kind | (t.olen << 3) | (((base_bit + bitpos + lane) & 0xFFFFu) << 12),
+    if (on) tok[tt + rank] = make_uint2(t.kind | (t.olen << 3) | (((base_bit + bitpos + lane) & 0xFFFFFu) << 12),
                                         t.kind == 0u ? t.sym : t.off);
     tt += (u32) __popcll(chain);
     outc += rdl(wave_incl_scan(on ? t.olen : 0u), 63u);
@@ -1512,6 +1517,156 @@ __device__ __forceinline__ void lzx_parse_tokens(LzxDec &d, const bool length_em
   }
   n_tok = tt; end_bit = base_bit + bitpos;
 }
+
+#ifdef LZX_PARSE_ONLY
+// ---------------------------------------------------------------------------------------------------
+// lzx_parse_lanes -- a frame's tokens, every lane walking its own stretch of the bit stream.
+//
+// The 64-positions-per-round parser above spends its vector instructions on 64 lanes of which the ~5 on the chain
+// matter.  Here the frame's bits [B, E) -- E is what the frame table says, a hint -- are cut into 64 stretches and
+// lane l walks the tokens of stretch l one after the other: length of the token at p, p += length, until p leaves
+// the stretch.  Lane 0 starts at B, a real token start; the others start at their stretch's first bit, which is
+// almost never one.  But a walk that starts in the middle of a token falls into step with the real chain after a
+// few tokens (each landing is a real token start with probability ~1/mean token length), so its EXIT -- the first
+// position beyond the stretch -- is almost always the real chain's.  Round 2: every lane starts again from its
+// left neighbour's exit.  Lane l's walk is the real chain if lane l-1's was and its entry is lane l-1's exit: an
+// induction from lane 0, checked after every round (entry == left exit for all lanes: done, usually after round
+// 2; otherwise only the lanes whose entry moved walk again).  A last walk decodes the token VALUES and stores
+// them: lane l's i-th token at (tokens of lanes < l) + i.  Nothing here depends on E being right: a wrong table
+// only makes the stretches unequal.  What a lane cannot decode (a code the tables do not hold) ends the record
+// there; the unit's own wave judges that token.  The input sits in LDS (8 KiB per pass, halves of every dword
+// swapped: a plain MSB-first bit string); all walks are LDS lookups, one token per lane per step.
+// ---------------------------------------------------------------------------------------------------
+#ifndef LZX_LANE_ROUNDS
+#define LZX_LANE_ROUNDS 5u          /* walks before the consistent prefix is taken as it is */
+#endif
+template <bool ALIGNED>
+__device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_empty, const u32 start_bit,
+                                                const u32 frame_end_bit, uint2 *tok, u32 &n_tok, u32 &end_bit)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  // bit positions count from the unit's first byte; the last 56 bytes of the input belong to the EOF-exact reader
+  const u32 in_limit = d.w.in_len > 56u ? (d.w.in_len - 56u) * 8u : 0u;
+  const u32 Eall = frame_end_bit < in_limit ? frame_end_bit : in_limit;
+  u32 mlim[16 - LZX_MAIN_P];
+#pragma unroll
+  for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
+  const u32 main_fov = d.hr_main.fov;
+  u32 tt = 0, B = rfl(start_bit);
+  bool stop = false;
+
+  while (!stop && B < Eall && tt < LZX_TOK_CAP) {
+    // ---- stage the input from the dword that holds bit B ----
+    const u32 sb_byte = (B >> 5) << 2, sb_bit = sb_byte * 8u;
+    u32 E = sb_bit + LZX_STAGE_WORDS * 32u; if (E > Eall) E = Eall;
+    const u32 b0 = B - sb_bit, e0 = E - sb_bit;
+    d.w.origin = sb_byte;
+    {
+      const u32 nck = (e0 + 128u + 2047u) >> 11;               // a token that starts below e0 ends below e0 + 53
+      for (u32 c = 0; c < nck; c += 4u) {                       // (four loads in flight; chunks beyond nck are inside the pad or harmless)
+        const u32 v0 = d.w.load_chunk(c, lane), v1 = d.w.load_chunk(c + 1u, lane);
+        const u32 v2 = d.w.load_chunk(c + 2u, lane), v3 = d.w.load_chunk(c + 3u, lane);
+        sh->stage[c * 64u + lane] = SWAP16(v0);
+        if (c + 1u < nck) sh->stage[(c + 1u) * 64u + lane] = SWAP16(v1);
+        if (c + 2u < nck) sh->stage[(c + 2u) * 64u + lane] = SWAP16(v2);
+        if (c + 3u < nck) sh->stage[(c + 3u) * 64u + lane] = SWAP16(v3);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    u32 S = (e0 - b0 + 63u) >> 6; if (S < 64u) S = 64u;        // a token is at most 53 bits: it never skips a stretch
+    const u32 nl = (e0 - b0 + S - 1u) / S;                     // lanes that own a stretch
+    const u32 rstart = b0 + lane * S;
+    u32 rend = rstart + S; if (rend > e0) rend = e0;
+    u32 entry = lane == 0u ? b0 : rstart;
+    u32 n = 0, exitp = entry, stop_at = 0;
+    bool dead = false, changed = lane < nl;
+    for (u32 round = 0; ; ) {
+      // ---- the lanes whose entry moved walk their stretch ----
+      u32 p = entry, cnt = 0, sa = 0;
+      bool dd = false;
+      LZX_MARK("lanes_walk_begin");
+      while (ballot(changed && p < rend)) {
+        const bool on = changed && p < rend;
+        const u32 pp = on ? p : 0u;
+        const u32 k = pp >> 5, sft = pp & 31u;
+        const u32 i0 = sh->stage[k], i1 = sh->stage[k + 1u];
+        const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+        u32 w1 = 0;
+        if (ALIGNED) { const u32 i2 = sh->stage[k + 2u]; w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32); }
+        u32 e = sh->main_tab[w0 >> (32 - LZX_MAIN_P)];
+        if (ballot(on && e == 0u)) {                            // main codes beyond the direct table (cf. lzx_spec_token)
+          const u32 peek16 = w0 >> 16;
+          u32 ln = LZX_MAIN_P + 1u;
+#pragma unroll
+          for (int l = LZX_MAIN_P + 1; l <= 16; l++) ln += (peek16 >= mlim[l - LZX_MAIN_P - 1]) ? 1u : 0u;
+          const u32 lq = ln <= 16u ? ln : 0u;
+          const u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) main_fov);
+          u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
+          if (idx >= LZX_MAIN_SYMS) idx = 0;
+          const u32 ls = sh->main_sorted[idx];
+          if (e == 0u && lq != 0u) e = ls | (lq << LZX_MSH);
+        }
+        bool unk;
+        const u32 tot = lzx_adv_from_entry<ALIGNED>(sh, length_empty, e, w0, w1, unk);
+        if (on) {
+          if (unk || e == 0u) { dd = true; sa = p; p = rend; }
+          else { cnt++; p += tot; }
+        }
+      }
+      LZX_MARK("lanes_walk_end");
+      if (changed) { n = cnt; exitp = p; dead = dd; stop_at = sa; }
+      round++;
+      // ---- every lane's entry is its left neighbour's exit ----
+      const u32 pe = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) exitp);
+      const u32 ne = lane == 0u ? b0 : pe;
+      changed = lane < nl && ne != entry;
+      entry = ne;
+      if (!ballot(changed) || round >= LZX_LANE_ROUNDS) break;
+    }
+    // ---- the consistent prefix: lanes < m; it ends early at a lane that met a token it cannot take ----
+    u32 m = nl;
+    { const u64 chm = ballot(changed); if (chm) m = (u32) __ffsll((long long) chm) - 1u; }
+    u32 mm = m, dl = 0;
+    bool hit = false;
+    { const u64 dm = ballot(dead && lane < m); if (dm) { dl = (u32) __ffsll((long long) dm) - 1u; mm = dl + 1u; hit = true; } }
+    const u32 cntv = lane < mm ? n : 0u;
+    const u32 incl = wave_incl_scan(cntv);
+    {
+      const u32 room = LZX_TOK_CAP - tt;
+      const u32 fit = (u32) __popcll(ballot(lane < mm && incl <= room));
+      if (fit < mm) { mm = fit; hit = false; stop = true; }
+    }
+    const u32 base = tt + incl - cntv;
+    // ---- values: every lane walks its stretch once more and stores its tokens ----
+    {
+      const u32 my_n = lane < mm ? n : 0u;
+      u32 p = entry, i = 0;
+      LZX_MARK("lanes_emit_begin");
+      while (ballot(i < my_n)) {
+        const bool on = i < my_n;
+        const u32 pp = on ? p : 0u;
+        const u32 k = pp >> 5, sft = pp & 31u;
+        const u32 i0 = sh->stage[k], i1 = sh->stage[k + 1u], i2 = sh->stage[k + 2u];
+        const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+        const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
+        const SpecTok t = lzx_spec_token<ALIGNED>(sh, main_fov, mlim, length_empty, w0, w1);
+        if (on) {
+          tok[base + i] = make_uint2(t.kind | (t.olen << 3) | (((sb_bit + p) & 0xFFFFFu) << 12), t.kind == 0u ? t.sym : t.off);
+          p += t.tot; i++;
+        }
+      }
+      LZX_MARK("lanes_emit_end");
+    }
+    if (mm) tt += rdl(incl, mm - 1u);
+    if (hit) { B = sb_bit + rdl(stop_at, dl); stop = true; }
+    else if (mm == 0u) stop = true;
+    else B = sb_bit + rdl(exitp, mm - 1u);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the stage is rewritten by the next pass
+  }
+  n_tok = tt; end_bit = B;
+}
+#endif  /* LZX_PARSE_ONLY */
 
 // common set-up of the header wave and the parse waves: a decoder on the unit's input, nothing read yet
 __device__ __forceinline__ bool lzx_side_setup(LzxDec &d, LzxState &s, const mspack_hip_unit &u, const u8 *in_arena, LzxShared *sh)
@@ -1617,8 +1772,21 @@ __device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 
   }
   u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
   u32 n_tok = 0, end_bit = 0;
+#if defined(LZX_PARSE_ONLY) && !defined(LZX_PARSE_ROUNDS64)
+  {
+    // where the frame table says the frame ends (a hint: a wrong one costs time, not correctness)
+    const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
+    const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
+    u32 fe = (f + 1u < nreal) ? rfl(ftab[f + 1u]) : u.in_len;
+    if (fe > u.in_len || fe * 8u <= start_bit) fe = u.in_len;
+    (void) fsz;
+    if (s.block_type == 2u) lzx_parse_lanes<true>(d, s.length_empty, start_bit, fe * 8u, tok, n_tok, end_bit);
+    else lzx_parse_lanes<false>(d, s.length_empty, start_bit, fe * 8u, tok, n_tok, end_bit);
+  }
+#else
   if (s.block_type == 2u) lzx_parse_tokens<true>(d, s.length_empty, fsz, tok, n_tok, end_bit);
   else lzx_parse_tokens<false>(d, s.length_empty, fsz, tok, n_tok, end_bit);
+#endif
   if (lane == 0) {
     rec->n_tokens = n_tok; rec->end_bit = end_bit;
     rec->flags = rec->flags | (s.length_empty ? 1u : 0u);
@@ -1665,29 +1833,55 @@ __device__ __forceinline__ int lzx_run_tokens(LzxDec &d, LzxState &s, const u32 
   d.flush_lits();
   spq_init(sh->spq, C.Q, C.P, lane);
   u32 th = 0;
-  uint2 cur = make_uint2(0u, 0u);
-  if (lane < n_tok) cur = tok[lane];
-  while (C.P < C.run_end && th < n_tok) {
-    u32 n = n_tok - th; if (n > 64u) n = 64u;
-    uint2 nxt = make_uint2(0u, 0u);
-    if (th + 64u + lane < n_tok) nxt = tok[th + 64u + lane];          // in flight while this batch commits
-    u32 marker; bool fail_after;
-    const u32 took = lzx_commit_batch(d, C, cur.x, cur.y, n, marker, fail_after);
-    th += took;
-#ifndef LZX_EXP_NOCOPY
-    if (spq_due(C.Q, C.P)) spq_resolve(sh->spq, C.Q, out, C.P, false, lane);
+  // Tokens come from memory four batches (256 tokens) at a time: the next four loads are issued before the current
+  // four batches are committed, and the registers change hands once per four batches -- a load is only waited for
+  // long after it was issued.  (Handing a single batch's register on every iteration waits for the load that
+  // iteration issued: the whole memory latency, every batch.)
+  uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
+  if (lane < n_tok) cur0 = tok[lane];
+  if (64u + lane < n_tok) cur1 = tok[64u + lane];
+  if (128u + lane < n_tok) cur2 = tok[128u + lane];
+  if (192u + lane < n_tok) cur3 = tok[192u + lane];
+  bool done = false;
+  while (!done && C.P < C.run_end && th < n_tok) {
+    uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
+    const u32 tb = th + 256u + lane;
+    if (tb < n_tok) nx0 = tok[tb];
+    if (tb + 64u < n_tok) nx1 = tok[tb + 64u];
+    if (tb + 128u < n_tok) nx2 = tok[tb + 128u];
+    if (tb + 192u < n_tok) nx3 = tok[tb + 192u];
+#pragma unroll 1
+    for (u32 k = 0; k < 4u; k++) {
+      if (!(C.P < C.run_end && th < n_tok)) { done = true; break; }
+      u32 n = n_tok - th; if (n > 64u) n = 64u;
+      const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
+      u32 marker; bool fail_after;
+#ifdef LZX_PHASE_TIMERS
+      u64 pt_ = __builtin_amdgcn_s_memtime();
 #endif
-    if (fail_after) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; break; }
-    if (took < n) break;                                              // the run ended inside this batch
-    cur = nxt;
+      const u32 took = lzx_commit_batch(d, C, cur.x, cur.y, n, marker, fail_after);
+      th += took;
+#ifdef LZX_PHASE_TIMERS
+      { const u64 n_ = __builtin_amdgcn_s_memtime(); d.st_t[0] += (u32)(n_ - pt_); pt_ = n_; d.st_t[2]++; }
+#endif
+#ifndef LZX_EXP_NOCOPY
+      if (spq_due(C.Q, C.P)) spq_resolve(sh->spq, C.Q, out, C.P, false, lane);
+#endif
+#ifdef LZX_PHASE_TIMERS
+      d.st_t[1] += (u32)(__builtin_amdgcn_s_memtime() - pt_);
+#endif
+      if (fail_after) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; done = true; break; }
+      if (took < n) { done = true; break; }                           // the run ended inside this batch
+    }
+    cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
   }
 #ifndef LZX_EXP_NOCOPY
   spq_resolve(sh->spq, C.Q, out, C.P, true, lane);
 #endif
   next_bit = end_bit;
   if (th < n_tok) {                                                   // parsed beyond the run: back to the first such token
-    const u32 s16 = rfl(tok[th].x) >> 12;
-    next_bit = end_bit - ((end_bit - s16) & 0xFFFFu);
+    const u32 s20 = rfl(tok[th].x) >> 12;                             // (records carry the low 20 bits of their start)
+    next_bit = end_bit - ((end_bit - s20) & 0xFFFFFu);
   }
   d.P = C.P;
   s.R0 = C.R0; s.R1 = C.R1; s.R2 = C.R2;
@@ -1757,6 +1951,9 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
   lzx_reset_state(d, s);
 #ifdef LZX_EXP_STATS
   u64 tstart_ = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef LZX_PHASE_TIMERS
+  const u64 pt_unit_ = __builtin_amdgcn_s_memtime();
 #endif
 
 #ifndef LZX_DELTA
@@ -1843,8 +2040,14 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
 #ifndef LZX_DELTA
           if (adopt) {
             u32 next_bit;
+#ifdef LZX_PHASE_TIMERS
+            const u64 rt_ = __builtin_amdgcn_s_memtime();
+#endif
             const int rc = lzx_run_tokens(d, s, run_end, wbase, toks + (size_t)(u.frame_base + s.frame) * LZX_TOK_CAP,
                                           adopt->n_tokens, adopt->end_bit, next_bit);
+#ifdef LZX_PHASE_TIMERS
+            d.st_t[3] += (u32)(__builtin_amdgcn_s_memtime() - rt_); d.st_t[4] += rfl(adopt->n_tokens);
+#endif
             adopt = nullptr;
             if (rc == LZX_RUN_FAIL) { fail = true; }
             else lzx_seek_bit(d, next_bit);
@@ -1995,6 +2198,11 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
       if (s.frame_posn == s.wsize) s.frame_posn = 0;
     }
   }
+#if defined(LZX_PHASE_TIMERS) && !defined(LZX_DELTA)
+  if (lane == 0 && (blockIdx.x & 1023u) == 0u)
+    printf("lzx unit %u: total %llu clk; run_tokens %u clk (commit_batch %u, resolve %u) in %u batches, %u tokens\n", blockIdx.x,
+           (unsigned long long)(__builtin_amdgcn_s_memtime() - pt_unit_), d.st_t[3], d.st_t[0], d.st_t[1], d.st_t[2], d.st_t[4]);
+#endif
   int err = d.err;
   if (err == 0 && remaining) err = ERR_DECRUNCH;                                  // lzxd.c:758-761
   if (err == ERR_READ && remaining == 0u) flags |= MSPACK_HIP_F_LOOKAHEAD_READ;

@@ -607,43 +607,88 @@ __device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *tok, cons
   SpecQueue Q;
   spq_init(sh->spq, Q, P, lane);
   bool ok = true;
-  uint2 cur = make_uint2(0u, 0u);
-  if (lane < n_tok) cur = tok[lane];
-  for (u32 th = 0; th < n_tok; th += 64u) {
-    const u32 n = n_tok - th < 64u ? n_tok - th : 64u;
-    uint2 nxt = make_uint2(0u, 0u);
-    if (th + 64u + lane < n_tok) nxt = tok[th + 64u + lane];          // in flight while this batch commits
-    const u32 c0 = cur.x, c1 = cur.y;
-    const u32 kind = c0 & 7u;
-    const u32 olen = lane < n ? ((c0 >> 3) & 511u) : 0u;
-    const u32 incl = wave_incl_scan(olen);
-    const u32 opos = P + incl - olen;
-    const u32 newP = P + rdl(incl, 63u);
-    const bool valid = lane < n;
-    if (ballot(valid && kind == 1u && c1 > opos - B && !lin_hist)) { ok = false; break; }
-    if (valid && kind == 0u) out[opos] = (u8) c1;
-    u64 mm = ballot(valid && kind == 1u);
-    if (mm) {
-      bool ism = lane_in(mm);
-      if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
-      for (;;) {
-        const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
-        const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
-        if (fit) {
-          const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
-          spq_push(sh->spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, c1, olen);
-          mm &= ~fit;
-          ism = lane_in(mm);
+#ifdef ZIP_EXP_TOUCH          /* experiment: have the block's output lines in L2 before the partial writes arrive */
+  u32 touch_ = 0;
+  for (u32 i = 0; i < 4u; i++) touch_ ^= *(const volatile u32 *)(out + ((B + (lane + 64u * i) * 128u) & ~3u));
+#endif
+#ifdef ZIP_PHASE_TIMERS       /* analysis builds only (tools/exp_phase_timers.sh) */
+  u64 tm_a = 0, tm_b = 0, tm_t0 = __builtin_amdgcn_s_memtime(), tm_r0 = __builtin_amdgcn_s_memrealtime(), tm_x;
+  u32 tm_calls = 0;
+#define ZT0() tm_x = __builtin_amdgcn_s_memtime()
+#define ZT(acc) do { u64 n_ = __builtin_amdgcn_s_memtime(); acc += n_ - tm_x; tm_x = n_; } while (0)
+#else
+#define ZT0() do { } while (0)
+#define ZT(acc) do { } while (0)
+#endif
+  // Tokens come from memory four batches (256 tokens) at a time: the next four loads are issued before the current
+  // four batches are committed, and the registers change hands once per four batches -- a load is only waited for
+  // long after it was issued (handing one batch's register on per iteration waits for the load just issued)
+  uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
+  if (lane < n_tok) cur0 = tok[lane];
+  if (64u + lane < n_tok) cur1 = tok[64u + lane];
+  if (128u + lane < n_tok) cur2 = tok[128u + lane];
+  if (192u + lane < n_tok) cur3 = tok[192u + lane];
+  bool done = false;
+  u32 th = 0;
+  while (!done && th < n_tok) {
+    uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
+    const u32 tb = th + 256u + lane;
+    if (tb < n_tok) nx0 = tok[tb];
+    if (tb + 64u < n_tok) nx1 = tok[tb + 64u];
+    if (tb + 128u < n_tok) nx2 = tok[tb + 128u];
+    if (tb + 192u < n_tok) nx3 = tok[tb + 192u];
+#pragma unroll 1
+    for (u32 k = 0; k < 4u; k++, th += 64u) {
+      if (th >= n_tok) { done = true; break; }
+      const u32 n = n_tok - th < 64u ? n_tok - th : 64u;
+      ZT0();
+      const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
+      const u32 c0 = cur.x, c1 = cur.y;
+      const u32 kind = c0 & 7u;
+      const u32 olen = lane < n ? ((c0 >> 3) & 511u) : 0u;
+      const u32 incl = wave_incl_scan(olen);
+      const u32 opos = P + incl - olen;
+      const u32 newP = P + rdl(incl, 63u);
+      const bool valid = lane < n;
+      if (ballot(valid && kind == 1u && c1 > opos - B && !lin_hist)) { ok = false; done = true; break; }
+      if (valid && kind == 0u) out[opos] = (u8) c1;
+      u64 mm = ballot(valid && kind == 1u);
+      if (mm) {
+        bool ism = lane_in(mm);
+        if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
+        for (;;) {
+          const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
+          const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
+          if (fit) {
+            const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+            spq_push(sh->spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, c1, olen);
+            mm &= ~fit;
+            ism = lane_in(mm);
+          }
+          if (!mm) break;
+          spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
         }
-        if (!mm) break;
-        spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
       }
+      P = newP;
+      ZT(tm_a);
+#ifdef ZIP_PHASE_TIMERS
+      if (spq_due(Q, P)) tm_calls++;
+#endif
+      if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane);
+      ZT(tm_b);
     }
-    P = newP;
-    if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane);
-    cur = nxt;
+    cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
   }
   spq_resolve(sh->spq, Q, out, P, true, lane);
+#ifdef ZIP_EXP_TOUCH
+  if (touch_ == 0x12345678u && n_tok == 0xFFFFFFFFu) ok = false;
+#endif
+#ifdef ZIP_PHASE_TIMERS
+  if (lane == 0 && blockIdx.x == 0 && B == 3u * ZIP_FRAME)
+    printf("zip_run_tokens: n_tok %u  batch-front %llu clk  resolve %llu clk in %u calls  total %llu clk = %llu x10ns\n", n_tok,
+           (unsigned long long) tm_a, (unsigned long long) tm_b, tm_calls, (unsigned long long)(__builtin_amdgcn_s_memtime() - tm_t0),
+           (unsigned long long)(__builtin_amdgcn_s_memrealtime() - tm_r0));
+#endif
   return ok;
 }
 

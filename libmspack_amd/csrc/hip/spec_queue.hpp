@@ -1,6 +1,6 @@
 // spec_queue.hpp -- deferred LZ77 match resolution shared by the speculative decode paths (LZX, MSZIP).
 //
-// Decode rounds only QUEUE their matches (position, offset<<9 | length) in LDS and raise a flag at the
+// Decode rounds only QUEUE their matches (position, offset<<9 | length) in LDS and raise a flag (one bit) at the
 // match's start position in a small ring; literals go straight to the output.  The queue is resolved in
 // position space, 64 output bytes per pass, one byte per lane: the number of start flags at or below a
 // lane's byte (ballot + mbcnt) is the index of the match that may cover it, and the byte is copied as
@@ -8,8 +8,10 @@
 // special case and every pass is ONE byte gather and ONE coalesced 64-byte store.  A source byte inside
 // the current 64-byte chunk that is itself a match byte is not in memory yet: such lanes follow the
 // source's own pointer (pointer jumping with ds_bpermute, log steps).  Chunks are resolved in address
-// order, so everything below the chunk is final.  The passes are software-pipelined: chunk k's load
-// is in flight while chunk k+1 is set up.
+// order, so everything below the chunk is final.  What a pass costs is the memory round trip of its gather
+// (the sources were stored a moment ago: the load comes back from L2), so SPQ_GROUP chunks are set up together --
+// a source inside an earlier chunk of the group takes over that byte's source -- and their loads are in flight
+// at once, while the next group is being set up.
 //
 // Contract: positions are relative to `out`; matches are pushed in position order, never overlap, and
 // offset <= position (the source lies inside `out`); length <= 511; a round may be pushed only if it
@@ -19,14 +21,15 @@
 #include "wave_common.hpp"
 
 #define SPQ_CAP 160
-#define SPQ_RING 512u
+#define SPQ_RING 2048u            /* positions the start-flag ring covers (one BIT per position) */
 #ifndef SPQ_SPAN
-#define SPQ_SPAN 128u             /* resolve when this many output bytes are pending */
+#define SPQ_SPAN 512u             /* resolve when this many output bytes are pending */
 #endif
+#define SPQ_GROUP 4               /* 64-byte chunks resolved per memory round trip */
 
 struct SpecQueueLds {
   uint2 mlist[SPQ_CAP];           /* queued matches, sorted by position */
-  u8  mflag[SPQ_RING];            /* 1 at (position mod ring) where a queued match starts */
+  u64 mbits[SPQ_RING / 64u];      /* bit (position mod ring) set where a queued match starts */
 };
 struct SpecQueue {
   u32 Pf;                         /* everything below Pf is final in memory */
@@ -36,30 +39,31 @@ struct SpecQueue {
 
 __device__ __forceinline__ void spq_init(SpecQueueLds &l, SpecQueue &q, u32 P, u32 lane) {
   q.Pf = P; q.mcount = 0; q.ja = 0;
-  ((u32 *) l.mflag)[lane] = 0; ((u32 *) l.mflag)[64u + lane] = 0;
+  if (lane < SPQ_RING / 64u) l.mbits[lane] = 0ull;
 }
 __device__ __forceinline__ bool spq_due(const SpecQueue &q, u32 P) {
   return P - q.Pf >= SPQ_SPAN || q.mcount > SPQ_CAP - 64u;
 }
 
-// which match covers byte c + lane, and where does that byte finally come from
+// which match covers byte c + lane, and where does that byte finally come from (sources inside the chunk itself
+// are followed to their own sources: pointer jumping, log steps).  inmask = the lanes whose byte is a match byte.
 __device__ __forceinline__ void spq_cover(SpecQueueLds &l, SpecQueue &q, const u32 c, const u32 lane,
-                                          bool &inm, u32 &ptr, bool &ext)
+                                          u64 &inmask, u32 &ptr, bool &ext)
 {
   const u32 b = c + lane;
-  const u32 fi = b & (SPQ_RING - 1u);
-  const u32 f = l.mflag[fi];
-  l.mflag[fi] = 0;
-  const u64 sm = ballot(f != 0u);
-  const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(sm >> 32), __builtin_amdgcn_mbcnt_lo((u32) sm, 0u)) + (f != 0u ? 1u : 0u);
+  const u32 wq = (c & (SPQ_RING - 1u)) >> 6;
+  const u64 smv = l.mbits[wq];                                           // the chunk's 64 start flags: one word, same for all lanes
+  if (lane == 0u) l.mbits[wq] = 0ull;
+  const u64 sm = ((u64) rfl((u32)(smv >> 32)) << 32) | rfl((u32) smv);
+  const u32 cnt = __builtin_amdgcn_mbcnt_hi((u32)(sm >> 32), __builtin_amdgcn_mbcnt_lo((u32) sm, 0u)) + (lane_in(sm) ? 1u : 0u);
   const int j = (int)(q.ja + cnt) - 1;
   const uint2 mr = l.mlist[j < 0 ? 0 : j];
   const u32 ml = mr.y & 511u;
-  inm = j >= 0 && (b - mr.x) < ml;
+  const bool inm = j >= 0 && (b - mr.x) < ml;
   ptr = b - (mr.y >> 9);
   q.ja += (u32) __popcll(sm);
   ext = (ballot(inm && mr.x + ml > c + 64u) >> 63) != 0ull;      // does the last byte's match run on?
-  const u64 inmask = ballot(inm);
+  inmask = ballot(inm);
   if (ballot(inm && ptr >= c)) {
     for (;;) {
       u32 tl = (ptr - c) & 63u;
@@ -67,6 +71,38 @@ __device__ __forceinline__ void spq_cover(SpecQueueLds &l, SpecQueue &q, const u
       bool follow = inm && ptr >= c && ((inmask >> tl) & 1ull);
       if (!ballot(follow)) break;
       if (follow) ptr = tp;
+    }
+  }
+}
+
+// a group of up to SPQ_GROUP consecutive chunks from c on: afterwards no match byte of the group has its source
+// inside the group's own match bytes (a source in an EARLIER chunk of the group takes over that byte's source,
+// which is final already) -- so all the group's loads can be in flight at once
+struct SpqGroup { u64 inmask[SPQ_GROUP]; u32 ptr[SPQ_GROUP]; u32 c; u32 nch; };
+__device__ __forceinline__ void spq_cover_group(SpecQueueLds &l, SpecQueue &q, const u32 c, const u32 climit,
+                                                const u32 lane, SpqGroup &G, bool &ext)
+{
+  G.c = c;
+  u32 nch = (climit - c + 63u) >> 6; if (nch > SPQ_GROUP) nch = SPQ_GROUP;
+  G.nch = nch;
+#pragma unroll
+  for (int g = 0; g < SPQ_GROUP; g++) {
+    G.inmask[g] = 0ull; G.ptr[g] = 0u;
+    if ((u32) g < nch) {
+      spq_cover(l, q, c + 64u * g, lane, G.inmask[g], G.ptr[g], ext);
+      if (g > 0) {
+        const bool near = lane_in(G.inmask[g]) && G.ptr[g] >= c;
+        if (ballot(near)) {
+          const u32 tl = G.ptr[g] & 63u, jj = (G.ptr[g] - c) >> 6;
+          u32 np = G.ptr[g];
+#pragma unroll
+          for (int j = 0; j < g; j++) {
+            const u32 tp = (u32) __builtin_amdgcn_ds_bpermute((int)(tl << 2), (int) G.ptr[j]);
+            if (near && jj == (u32) j && ((G.inmask[j] >> tl) & 1ull)) np = tp;
+          }
+          G.ptr[g] = np;
+        }
+      }
     }
   }
 }
@@ -79,15 +115,23 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
   u32 c = q.Pf & ~63u;
   const u32 climit = fin ? P : c + ((P - c) & ~63u);
   if (c < climit) {
-    bool inm, ext; u32 ptr;
-    spq_cover(l, q, c, lane, inm, ptr, ext);
+    bool ext = false;
+    SpqGroup G;
+    spq_cover_group(l, q, c, climit, lane, G, ext);
     for (;;) {
-      u32 val = 0; if (inm) val = (u32) out[ptr];
-      const u32 bcur = c + lane; const bool icur = inm;
-      c += 64u;
+      // the group's loads go out together; the next group is set up while they are in flight; then the stores
+      u32 val[SPQ_GROUP];
+#pragma unroll
+      for (int g = 0; g < SPQ_GROUP; g++) { val[g] = 0; if (lane_in(G.inmask[g])) val[g] = (u32) out[G.ptr[g]]; }
+      const SpqGroup cur = G;
+      c += 64u * cur.nch;
       const bool more = c < climit;
-      if (more) spq_cover(l, q, c, lane, inm, ptr, ext);
-      if (icur && bcur < clip) out[bcur] = (u8) val;
+      if (more) spq_cover_group(l, q, c, climit, lane, G, ext);
+#pragma unroll
+      for (int g = 0; g < SPQ_GROUP; g++) {
+        const u32 b = cur.c + 64u * g + lane;
+        if (lane_in(cur.inmask[g]) && b < clip) out[b] = (u8) val[g];
+      }
       if (!more) break;
     }
     if (!fin) {
@@ -113,7 +157,7 @@ __device__ __forceinline__ void spq_push(SpecQueueLds &l, SpecQueue &q, const bo
 {
   if (ism) {
     l.mlist[q.mcount + rank] = make_uint2(pos, (off << 9) | len);
-    l.mflag[pos & (SPQ_RING - 1u)] = 1;
+    atomicOr((unsigned long long *) &l.mbits[(pos & (SPQ_RING - 1u)) >> 6], 1ull << (pos & 63u));
   }
   q.mcount += n;
 }
