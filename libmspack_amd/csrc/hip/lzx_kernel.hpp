@@ -41,7 +41,10 @@
  * queue and no token queue, and a main-tree table of 8 direct bits (codes beyond it are resolved lane-parallel
  * anyway): 5.5 KiB of LDS instead of 9.75, i.e. 7 waves per SIMD instead of 4 -- parse throughput is a matter of
  * how many serial chains a SIMD can interleave */
-#define LZX_MAIN_P 8
+#ifndef LZX_PARSE_MAIN_P
+#define LZX_PARSE_MAIN_P 8
+#endif
+#define LZX_MAIN_P LZX_PARSE_MAIN_P
 #define LZX_STAGE_WORDS 2048u
 #else
 #define LZX_MAIN_P 10
@@ -869,12 +872,21 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
   // tokens are decoded only while the run lasts (lzxd.c:538): the first one that would start at or
   // after run_end, and everything parsed behind it, is not part of this run
   if (newP >= run_end) {
-    const u64 late = ballot(lane < n && opos >= run_end);
+    // (a literal run -- up to four literals in one record, lzx_parse_lanes -- that would cross the end of the run
+    //  is not taken either: it can only come from a record parsed beyond its frame, and the serial path goes on there)
+    const u64 late = ballot(lane < n && (opos >= run_end || (kind == 0u && opos + olen > run_end)));
     if (late) { const u32 j = (u32) __ffsll((long long) late) - 1u; n = j; newP = rdl(opos, j); marker = 0; }
   }
   const bool valid = lane < n;
 #ifndef LZX_EXP_NOLIT
-  if (valid && kind == 0u) out[opos] = (u8) c1;
+  if (valid && kind == 0u) {
+    out[opos] = (u8) c1;
+    if (olen > 1u) {                                        // a literal run: 2..4 bytes, first literal in the low byte
+      out[opos + 1u] = (u8)(c1 >> 8);
+      if (olen > 2u) out[opos + 2u] = (u8)(c1 >> 16);
+      if (olen > 3u) out[opos + 3u] = (u8)(c1 >> 24);
+    }
+  }
 #endif
   const bool ism0 = valid && kind != 0u;
   u64 mm = ballot(ism0);
@@ -1540,6 +1552,9 @@ __device__ __forceinline__ void lzx_parse_tokens(LzxDec &d, const bool length_em
 #ifndef LZX_LANE_ROUNDS
 #define LZX_LANE_ROUNDS 5u          /* walks before the consistent prefix is taken as it is */
 #endif
+#ifndef LZX_LANE_TAIL
+#define LZX_LANE_TAIL 384u
+#endif
 template <bool ALIGNED>
 __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_empty, const u32 start_bit,
                                                 const u32 frame_end_bit, uint2 *tok, u32 &n_tok, u32 &end_bit)
@@ -1555,8 +1570,15 @@ __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_emp
   const u32 main_fov = d.hr_main.fov;
   u32 tt = 0, B = rfl(start_bit);
   bool stop = false;
+#ifdef LZX_PHASE_TIMERS
+  u64 pl_t0 = __builtin_amdgcn_s_memtime(), pl_x = pl_t0; u32 pl_stage = 0, pl_walk = 0, pl_emit = 0, pl_iters = 0, pl_rounds = 0, pl_pass = 0;
+#define PLT(acc) do { const u64 n_ = __builtin_amdgcn_s_memtime(); acc += (u32)(n_ - pl_x); pl_x = n_; } while (0)
+#else
+#define PLT(acc) do { } while (0)
+#endif
 
   while (!stop && B < Eall && tt < LZX_TOK_CAP) {
+    PLT(pl_walk);
     // ---- stage the input from the dword that holds bit B ----
     const u32 sb_byte = (B >> 5) << 2, sb_bit = sb_byte * 8u;
     u32 E = sb_bit + LZX_STAGE_WORDS * 32u; if (E > Eall) E = Eall;
@@ -1574,16 +1596,26 @@ __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_emp
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    PLT(pl_stage);
+#ifdef LZX_PHASE_TIMERS
+    pl_pass++;
+#endif
     u32 S = (e0 - b0 + 63u) >> 6; if (S < 64u) S = 64u;        // a token is at most 53 bits: it never skips a stretch
     const u32 nl = (e0 - b0 + S - 1u) / S;                     // lanes that own a stretch
     const u32 rstart = b0 + lane * S;
     u32 rend = rstart + S; if (rend > e0) rend = e0;
-    u32 entry = lane == 0u ? b0 : rstart;
-    u32 n = 0, exitp = entry, stop_at = 0;
+    // (the first walk only has to find the exit: it starts LZX_LANE_TAIL bits before the stretch's end, far enough to
+    //  fall into step; a wrong exit is caught like any other: the right neighbour's entry moves again)
+    u32 entry = lane == 0u ? b0 : (rend > rstart + LZX_LANE_TAIL ? rend - LZX_LANE_TAIL : rstart);
+    u32 n = 0, nm = 0, exitp = entry, stop_at = 0;      // n: tokens of the stretch, nm: records they make (literal runs merged)
     bool dead = false, changed = lane < nl;
+    // up to four literals in a row become ONE record (kind 0, output length 1..4, the bytes in c1): fewer records to
+    // store and fewer, fuller batches to commit.  A literal that starts in the frame's last 16 bits is never merged:
+    // what follows the frame's last token there is padding, and a record must not mix real tokens with it.
+    const u32 nomerge = frame_end_bit - sb_bit >= 16u ? frame_end_bit - sb_bit - 16u : 0u;
     for (u32 round = 0; ; ) {
       // ---- the lanes whose entry moved walk their stretch ----
-      u32 p = entry, cnt = 0, sa = 0;
+      u32 p = entry, cnt = 0, cntm = 0, run = 0, sa = 0;
       bool dd = false;
       LZX_MARK("lanes_walk_begin");
       while (ballot(changed && p < rend)) {
@@ -1611,11 +1643,23 @@ __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_emp
         const u32 tot = lzx_adv_from_entry<ALIGNED>(sh, length_empty, e, w0, w1, unk);
         if (on) {
           if (unk || e == 0u) { dd = true; sa = p; p = rend; }
-          else { cnt++; p += tot; }
+          else {
+            const bool lit = (e & LZX_MMASK) < 256u;
+            const bool merge = lit && run != 0u && run != 4u && p < nomerge;
+            if (!merge) cntm++;
+            run = lit ? (merge ? run + 1u : 1u) : 0u;
+            cnt++; p += tot;
+          }
         }
+#ifdef LZX_PHASE_TIMERS
+        pl_iters++;
+#endif
       }
+#ifdef LZX_PHASE_TIMERS
+      pl_rounds++;
+#endif
       LZX_MARK("lanes_walk_end");
-      if (changed) { n = cnt; exitp = p; dead = dd; stop_at = sa; }
+      if (changed) { n = cnt; nm = cntm; exitp = p; dead = dd; stop_at = sa; }
       round++;
       // ---- every lane's entry is its left neighbour's exit ----
       const u32 pe = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) exitp);
@@ -1630,7 +1674,7 @@ __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_emp
     u32 mm = m, dl = 0;
     bool hit = false;
     { const u64 dm = ballot(dead && lane < m); if (dm) { dl = (u32) __ffsll((long long) dm) - 1u; mm = dl + 1u; hit = true; } }
-    const u32 cntv = lane < mm ? n : 0u;
+    const u32 cntv = lane < mm ? nm : 0u;
     const u32 incl = wave_incl_scan(cntv);
     {
       const u32 room = LZX_TOK_CAP - tt;
@@ -1638,10 +1682,11 @@ __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_emp
       if (fit < mm) { mm = fit; hit = false; stop = true; }
     }
     const u32 base = tt + incl - cntv;
+    PLT(pl_walk);
     // ---- values: every lane walks its stretch once more and stores its tokens ----
     {
       const u32 my_n = lane < mm ? n : 0u;
-      u32 p = entry, i = 0;
+      u32 p = entry, i = 0, j = base, run = 0, pc0 = 0, pc1 = 0;        // (pc0, pc1): the record being assembled
       LZX_MARK("lanes_emit_begin");
       while (ballot(i < my_n)) {
         const bool on = i < my_n;
@@ -1652,18 +1697,31 @@ __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_emp
         const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
         const SpecTok t = lzx_spec_token<ALIGNED>(sh, main_fov, mlim, length_empty, w0, w1);
         if (on) {
-          tok[base + i] = make_uint2(t.kind | (t.olen << 3) | (((sb_bit + p) & 0xFFFFFu) << 12), t.kind == 0u ? t.sym : t.off);
+          const bool lit = t.kind == 0u;
+          if (lit && run != 0u && run != 4u && p < nomerge) { pc1 |= t.sym << (8u * run); pc0 += 1u << 3; run++; }
+          else {
+            if (i != 0u) { tok[j] = make_uint2(pc0, pc1); j++; }
+            pc0 = t.kind | (t.olen << 3) | (((sb_bit + p) & 0xFFFFFu) << 12); pc1 = lit ? t.sym : t.off;
+            run = lit ? 1u : 0u;
+          }
           p += t.tot; i++;
         }
       }
+      if (my_n != 0u) tok[j] = make_uint2(pc0, pc1);
       LZX_MARK("lanes_emit_end");
     }
+    PLT(pl_emit);
     if (mm) tt += rdl(incl, mm - 1u);
     if (hit) { B = sb_bit + rdl(stop_at, dl); stop = true; }
     else if (mm == 0u) stop = true;
     else B = sb_bit + rdl(exitp, mm - 1u);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the stage is rewritten by the next pass
   }
+#ifdef LZX_PHASE_TIMERS
+  if (lane == 0 && (blockIdx.x % 1000u) == 0u)
+    printf("lzx parse block %u: total %llu clk: stage %u, walks %u (%u iterations, %u rounds, %u passes), values %u; %u tokens\n", blockIdx.x,
+           (unsigned long long)(__builtin_amdgcn_s_memtime() - pl_t0), pl_stage, pl_walk, pl_iters, pl_rounds, pl_pass, pl_emit, tt);
+#endif
   n_tok = tt; end_bit = B;
 }
 #endif  /* LZX_PARSE_ONLY */

@@ -62,14 +62,10 @@ __host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_fr
   return L;
 }
 
-// which frame slots get a parse wave: the real frames of LZX units that carry a frame table
-__global__ __launch_bounds__(64)
-void mspack_lzx_frame_map(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 *frame_unit,
-                          lzxn::LzxFrameRec *recs, u32 *hdr, u32 kind)
+// one unit's frame slots: which of them get a parse wave, and the launch's minimum / maximum frames per unit
+__device__ __forceinline__ void frame_map_unit(const mspack_hip_unit &u, const u32 ui, u32 *frame_unit, lzxn::LzxFrameRec *recs,
+                                               u32 *hdr, const u32 kind)
 {
-  u32 ui;
-  if (!pick_unit(units, order, n_units, kind, ui)) { if (threadIdx.x == 0 && hdr[1] != 0u) atomicMin(&hdr[1], 0u); return; }
-  const mspack_hip_unit u = units[ui];
   const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
   const bool usable = (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u && !(kind == MSPACK_HIP_KIND_MSZIP && (u.flags & (MSPACK_HIP_UF_MSZIP_REPAIR | MSPACK_HIP_UF_MSZIP_KWAJ)));
   // frame slots of a unit: LZX out_len/32768 + 1 (one spare for the look-ahead frame), MSZIP with a table one per block
@@ -85,16 +81,27 @@ void mspack_lzx_frame_map(const mspack_hip_unit *units, const u32 *order, u32 n_
   }
 }
 
+// which frame slots get a parse wave: the real frames of LZX units that carry a frame table
+__global__ __launch_bounds__(64)
+void mspack_lzx_frame_map(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 *frame_unit,
+                          lzxn::LzxFrameRec *recs, u32 *hdr, u32 kind)
+{
+  u32 ui;
+  if (!pick_unit(units, order, n_units, kind, ui)) { if (threadIdx.x == 0 && hdr[1] != 0u) atomicMin(&hdr[1], 0u); return; }
+  frame_map_unit(units[ui], ui, frame_unit, recs, hdr, kind);
+}
+
 // the header wave of every unit that carries a frame table, then one parse wave per frame slot
 // (lzx_kernel.hpp: "Frame-level parse parallelism"; both from the LZX_PARSE_ONLY build: 5.5 KiB of LDS)
 __global__ __launch_bounds__(64)
 void mspack_lzx_headers(const mspack_hip_unit *units, const u32 *order, u32 n_units, const u8 *in_arena,
-                        lzxn::LzxFrameRec *recs)
+                        lzxn::LzxFrameRec *recs, u32 *frame_unit, u32 *hdr)
 {
   __shared__ lzxp::LzxShared sh;
   u32 ui;
-  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) return;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) { if (threadIdx.x == 0 && hdr[1] != 0u) atomicMin(&hdr[1], 0u); return; }
   const mspack_hip_unit u = units[ui];
+  frame_map_unit(u, ui, frame_unit, recs, hdr, MSPACK_HIP_KIND_LZX);       // (LZX: no separate map launch)
   if (!(u.flags & MSPACK_HIP_UF_FRAME_TABLE)) return;
   lzxp::lzx_walk_headers(u, in_arena, (lzxp::LzxFrameRec *) recs, &sh);
 }
@@ -260,7 +267,6 @@ static int fail(hipError_t e, const char *what) {
 // that carry a frame table get their frames parsed by one wave each first (slots [slot_lo, slot_lo + n_slots)
 // of the work scratch belong to this launch).
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
-static const int g_lzx_chunks = getenv("MSPACK_HIP_LZX_CHUNKS") ? atoi(getenv("MSPACK_HIP_LZX_CHUNKS")) : 1;
 static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
                         const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
                         size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true)
@@ -271,45 +277,6 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
   case MSPACK_HIP_KIND_LZX: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
-    if (frames && g_lzx_chunks > 1 && d_order != nullptr && n >= 64u * (size_t) g_lzx_chunks) {
-      // EXPERIMENT (MSPACK_HIP_LZX_CHUNKS=k): the launch in k slices of units, the parse kernels of slice c+1 on one
-      // stream while the unit kernel of slice c runs on another -- the parse kernel is ALU/LDS work, the unit kernel
-      // with adopted records mostly waits for memory
-      static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
-      int dev = 0; hipGetDevice(&dev);
-      static hipStream_t sP[16], sC[16]; static hipEvent_t ev0[16], evP[16][8], evE[16];
-      static bool made[16];
-      if (!made[dev & 15]) {
-        hipStreamCreateWithFlags(&sP[dev & 15], hipStreamNonBlocking); hipStreamCreateWithFlags(&sC[dev & 15], hipStreamNonBlocking);
-        hipEventCreateWithFlags(&ev0[dev & 15], hipEventDisableTiming); hipEventCreateWithFlags(&evE[dev & 15], hipEventDisableTiming);
-        for (int i = 0; i < 8; i++) hipEventCreateWithFlags(&evP[dev & 15][i], hipEventDisableTiming);
-        made[dev & 15] = true;
-      }
-      hipStream_t p_ = sP[dev & 15], c_ = sC[dev & 15];
-      const int K = g_lzx_chunks > 8 ? 8 : g_lzx_chunks;
-      hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
-      hipEventRecord(ev0[dev & 15], st);
-      hipStreamWaitEvent(p_, ev0[dev & 15], 0); hipStreamWaitEvent(c_, ev0[dev & 15], 0);
-      for (int c = 0; c < K; c++) {
-        const size_t lo = n * (size_t) c / K, hi = n * (size_t)(c + 1) / K, nc = hi - lo;
-        u32 *hdr = L.hdr + 2u * (u32)((slot_lo + (size_t) c) & 31u);
-        hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, p_);
-        hipLaunchKernelGGL(mspack_lzx_frame_map, dim3((unsigned) nc), block, 0, p_, d_units, d_order + lo, (u32) nc, L.frame_unit, L.recs, hdr,
-                           (u32) MSPACK_HIP_KIND_LZX);
-        hipLaunchKernelGGL(mspack_lzx_headers, dim3((unsigned) nc), block, 0, p_, d_units, d_order + lo, (u32) nc, (const u8 *) d_in, L.recs);
-        // (slices rely on the launch-order block mapping: every unit of the launch has the same number of frames;
-        //  otherwise a slice's parse kernel also takes the slots earlier slices have mapped -- more work, same result)
-        hipLaunchKernelGGL(mspack_lzx_parse, dim3((unsigned) n_slots), block, 0, p_, d_units, d_order + lo, (u32) nc, (u32) slot_lo,
-                           (u32) n_slots, (const u8 *) d_in, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
-        hipEventRecord(evP[dev & 15][c], p_);
-        hipStreamWaitEvent(c_, evP[dev & 15][c], 0);
-        hipLaunchKernelGGL(mspack_decode_lzx, dim3((unsigned) nc), block, 0, c_, d_units, d_order + lo, (u32) nc, (const u8 *) d_in, (u8 *) d_out,
-                           d_results, L.meta, (const lzxn::LzxFrameRec *) L.recs, (const uint2 *) L.toks);
-      }
-      hipEventRecord(evE[dev & 15], c_);
-      hipStreamWaitEvent(st, evE[dev & 15], 0);
-      break;
-    }
     if (frames) {
       static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
       // launches of one batch that run on different streams (host path, several chunks) use different header words;
@@ -317,9 +284,8 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       u32 *hdr = L.hdr + 2u * (u32)((slot_lo ^ (slot_lo >> 5) ^ (slot_lo >> 11)) & 31u);
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
-      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
-                         (u32) MSPACK_HIP_KIND_LZX);
-      hipLaunchKernelGGL(mspack_lzx_headers, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, L.recs);
+      hipLaunchKernelGGL(mspack_lzx_headers, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, L.recs,
+                         L.frame_unit, hdr);
       hipLaunchKernelGGL(mspack_lzx_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
                          (u32) n_slots, (const u8 *) d_in, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
     }
