@@ -137,3 +137,24 @@ def test_headline_batch_with_tables(built):
     for i in (0, 1, 777, n - 1):
         e, o, r = oracle_lzx(comp[int(off[i]):int(off[i]) + int(ln[i]) + 4].tobytes(), ub, 21, 2)
         assert e == 0 and r.in_next == res["in_next"][i] and (int(res["flags"][i]) & ~ADOPTED) == r.flags
+
+
+FAMILIES = ["TEXT_ENGLISH", "TEXT_RECORDS", "TEXT_BINARY", "TEXT_REPETITIVE", "TEXT_RANDOM"]
+
+
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_frames_other_plaintexts(built, fam):
+    """the lane parser on token statistics unlike the headline corpus's: long matches (few, long tokens: a walk
+    falls into step late), nearly incompressible data (frames larger than one 8 KiB pass of the parse wave's LDS
+    stage, more records than a frame slot holds, stored blocks), a short last frame"""
+    data = M.gen_plaintext(41, getattr(M, fam), 7 * 32768 + 777)
+    streams, params, tabs = [], [], []
+    for wb, reset, kw in [(21, 2, {}), (16, 0, dict(mode=2)), (18, 4, dict(mode=1)), (21, 0, dict(repeats=0, lazy=0))]:
+        comp, fo = M.lzx_encode(data, wb, reset, M.lzx_opts(**kw))
+        fo = fo.astype(np.int64)
+        streams.append(comp.tobytes()); params.append((data.size, wb, reset, 0)); tabs.append(fo[:-1])
+        streams.append(comp.tobytes()); params.append((data.size, wb, reset, 0)); tabs.append(fo[:-1] + 64)   # and a wrong table
+    units, out, res = run(streams, params, tabs)
+    check(streams, params, units, out, res)
+    for i in range(len(streams)):
+        assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
