@@ -45,7 +45,9 @@
 #define LZX_PARSE_MAIN_P 8
 #endif
 #define LZX_MAIN_P LZX_PARSE_MAIN_P
-#define LZX_STAGE_WORDS 2048u
+#ifndef LZX_STAGE_WORDS
+#define LZX_STAGE_WORDS 2048u   /* the parse wave's LDS stage: 8 KiB of the frame's input per pass */
+#endif
 #else
 #define LZX_MAIN_P 10
 #endif
