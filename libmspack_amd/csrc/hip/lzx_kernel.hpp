@@ -1764,6 +1764,7 @@ __device__ void lzx_walk_headers(const mspack_hip_unit &u, const u8 *in_arena, L
   LzxDec d;
   LzxState s;
   if (!lzx_side_setup(d, s, u, in_arena, sh)) return;
+  if (u.in_len >= (1u << 28)) return;                         // bit positions of the records are 32-bit: no guesses beyond 256 MiB
   const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
   const u32 rf = u.reset_frames;
   const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
