@@ -327,6 +327,14 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
 
 extern "C" {
 
+#ifdef SPQ_TIMERS
+/* analysis builds only: read (and clear) the resolve cycle counters of block 0's wave */
+int mspack_hip_debug_counters(unsigned long long *out8) {
+  unsigned long long z[8] = {0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(spq_tm), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(spq_tm), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 const char *mspack_hip_version(void) { return "mspack-hip 0.3 (gfx950; LZX/LZX-DELTA/Quantum/MSZIP batch decode)"; }
 const char *mspack_hip_last_error(void) { return g_err; }
 

@@ -27,6 +27,15 @@
 #endif
 #define SPQ_GROUP 4               /* 64-byte chunks resolved per memory round trip */
 
+#ifdef SPQ_TIMERS       /* analysis builds: where a resolve's cycles go (block 0's wave only; read back by mspack_hip_debug_counters) */
+__device__ unsigned long long spq_tm[8];
+#define SPQ_T0() unsigned long long spq_x_ = __builtin_amdgcn_s_memtime()
+#define SPQ_T(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (blockIdx.x == 0 && threadIdx.x == 0) spq_tm[k] += n_ - spq_x_; spq_x_ = n_; } while (0)
+#else
+#define SPQ_T0() do { } while (0)
+#define SPQ_T(k) do { } while (0)
+#endif
+
 struct SpecQueueLds {
   uint2 mlist[SPQ_CAP];           /* queued matches, sorted by position */
   u64 mbits[SPQ_RING / 64u];      /* bit (position mod ring) set where a queued match starts */
@@ -117,7 +126,9 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
   if (c < climit) {
     bool ext = false;
     SpqGroup G;
+    SPQ_T0();
     spq_cover_group(l, q, c, climit, lane, G, ext);
+    SPQ_T(0);
     for (;;) {
       // the group's loads go out together; the next group is set up while they are in flight; then the stores
       u32 val[SPQ_GROUP];
@@ -126,14 +137,26 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
       const SpqGroup cur = G;
       c += 64u * cur.nch;
       const bool more = c < climit;
+      SPQ_T(1);
       if (more) spq_cover_group(l, q, c, climit, lane, G, ext);
+      SPQ_T(0);
+#ifdef SPQ_TIMERS
+      { u32 acc_ = 0;
+#pragma unroll
+        for (int g = 0; g < SPQ_GROUP; g++) acc_ += val[g];
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(acc_)); }          // (the loads' wait on its own)
+      SPQ_T(2);
+      if (blockIdx.x == 0 && threadIdx.x == 0) { spq_tm[4] += 1; spq_tm[5] += cur.nch; }
+#endif
 #pragma unroll
       for (int g = 0; g < SPQ_GROUP; g++) {
         const u32 b = cur.c + 64u * g + lane;
         if (lane_in(cur.inmask[g]) && b < clip) out[b] = (u8) val[g];
       }
+      SPQ_T(3);
       if (!more) break;
     }
+    SPQ_T(7);
     if (!fin) {
       // keep the match that runs on into the next chunk (if any) and the ones that start above
       q.Pf = c;
@@ -147,6 +170,7 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
       }
       q.mcount = nrem; q.ja = ext ? 1u : 0u;
     }
+    SPQ_T(6);
   }
   if (fin) { q.Pf = P; q.mcount = 0; q.ja = 0; }
 }
