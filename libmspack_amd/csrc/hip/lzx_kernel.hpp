@@ -1188,9 +1188,9 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
 // ---------------------------------------------------------------------------------------------------
 // lzx_run_spec2 -- the speculative run of plain LZX: parse token LENGTHS, decode token VALUES at commit time.
 //
-// Measured on the box (profiles/round2_*): the kernel is bound by how many instructions a SIMD can issue, not by
-// latency -- and three quarters of the vector instructions were the 64-position token decode, executed for 64
-// lanes of which ~7 hold a real token.  What the chain needs from a position is only HOW LONG the token that
+// Measured on the box (profiles/round2_*): a unit's time is its wave's instruction count times the latency of its
+// dependent steps -- and three quarters of the vector instructions were the 64-position token decode, executed
+// for 64 lanes of which ~7 hold a real token.  What the chain needs from a position is only HOW LONG the token that
 // would start there is.  So a round computes just that (main-tree entry -> code length, length footer's code
 // length, number of offset bits, aligned symbol's length) and queues the START BITS of the tokens on the chain;
 // the values (literal, match length, offset) are decoded when 64 queued tokens are committed -- one real token
