@@ -295,13 +295,17 @@ def main():
     ap.add_argument("--text", type=int, default=0, help="plaintext family (0 = mix)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--frame-tables", action="store_true",
-                    help="units carry their frame tables (MSPACK_HIP_UF_FRAME_TABLE): frames are parsed by one wavefront each "
-                         "before the unit's wavefront commits them.  Off by default: on this workload (2 frames per unit, 4096 "
-                         "units = the chip already full) the split costs more instructions than it saves chain length")
+                    help="force the frame-parallel LZX path (MSPACK_HIP_FRAME_PARSE_ALWAYS): frames are parsed by one wavefront "
+                         "each before the unit's wavefront commits them.  Default: the units carry their frame tables (as a CHM's "
+                         "reset table states them) and the LIBRARY decides by the launch's shape -- at 4096 two-frame units, one "
+                         "wave per unit slot of the chip, it keeps the serial kernel (4.40 vs 4.75 ms)")
+    ap.add_argument("--no-frame-tables", action="store_true", help="units without frame tables: serial kernel only")
     ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive and the secondary configs")
     ap.add_argument("--exp", action="store_true", help="kernel experiments: skip the parity gate and the CPU leg (the line is then NOT a valid result)")
     args = ap.parse_args()
 
+    if args.frame_tables:
+        os.environ["MSPACK_HIP_FRAME_PARSE_ALWAYS"] = "1"          # (read when the library is loaded)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 
@@ -336,7 +340,7 @@ def main():
     # every unit carries its frame table (where each 32 KiB frame starts in the compressed stream), as a CHM's
     # reset table states it per frame (chmd.c:1146-1149): the frames' tokens are parsed by one wavefront each
     units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=ub // 32768,
-                                    frame_tabs=tab if args.frame_tables else None)
+                                    frame_tabs=None if args.no_frame_tables else tab)
     batch = DeviceBatch(M, torch, dev, units, comp, out_bytes, M.KIND_LZX)
 
     def barrier():
@@ -395,10 +399,11 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "units_per_gpu": n, "unit_bytes": ub, "bit_exact": all_ok,
-                       "frame_tables": bool(args.frame_tables), "units_on_frame_parallel_path": round(adopted, 4),
+                       "frame_tables": "off" if args.no_frame_tables else ("forced" if args.frame_tables else "auto (library decides by launch shape)"),
+                       "units_on_frame_parallel_path": round(adopted, 4),
                        "corpus_gen_s": round(gen_s, 2), "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
                        "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else ("self-spawned" if world > 1 else "single")},
-            "roofline": roofline(algo_bytes, ms_kernel, "mspack_lzx_parse + mspack_decode_lzx" if args.frame_tables else "mspack_decode_lzx",
+            "roofline": roofline(algo_bytes, ms_kernel, "mspack_lzx_headers + mspack_lzx_parse + mspack_decode_lzx" if adopted > 0.5 else "mspack_decode_lzx",
                                  traffic=traffic, traffic_source=traffic_source),
         }
         extras = world == 1 and not args.exp and not args.no_extras

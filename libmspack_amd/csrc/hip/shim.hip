@@ -267,6 +267,25 @@ static int fail(hipError_t e, const char *what) {
 // that carry a frame table get their frames parsed by one wave each first (slots [slot_lo, slot_lo + n_slots)
 // of the work scratch belong to this launch).
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
+static const bool g_all_frames = getenv("MSPACK_HIP_FRAME_PARSE_ALWAYS") != nullptr;  // experiments: no launch-shape rule
+// Frame-parallel LZX parse or not, for a launch of n units with n_slots frame slots?  Measured on the 2-frames-per-unit
+// headline shape (profiles/round2_batch_sizes.txt): the parse launches win below ~3 500 units (1024 units: 2.98 vs
+// 4.47 ms) and from ~4 700 on (16 384: 12.8 vs 14.5 ms); in between -- about one wave per unit slot of the chip, all
+// resident at once -- the serial kernel does (4096: 4.40 vs 4.75 ms): its parse fills the other waves' stalls and no
+// wave waits for a second round.  Units with more frames always gain (a 512-frame folder: 624 -> 302 ms).
+static bool lzx_frame_parse_pays(size_t n_units, size_t n_slots)
+{
+  if (g_all_frames) return true;
+  static int unit_slots = 0;                                  // waves of the unit kernel the chip holds at once
+  if (!unit_slots) {
+    int dev = 0; hipDeviceProp_t pr;
+    unit_slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess)
+                   ? pr.multiProcessorCount * 16 : 4096;
+  }
+  const double frames_per_unit = (double) n_slots / (double) n_units - 1.0;     // (one spare slot per unit)
+  if (frames_per_unit > 2.5) return true;
+  return !((double) n_units > 0.85 * unit_slots && (double) n_units < 1.13 * unit_slots);
+}
 static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
                         const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
                         size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true)
@@ -276,7 +295,7 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
   switch (kind) {
   case MSPACK_HIP_KIND_LZX: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total);
-    const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
+    const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables && lzx_frame_parse_pays(n, n_slots);
     if (frames) {
       static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
       // launches of one batch that run on different streams (host path, several chunks) use different header words;

@@ -158,3 +158,28 @@ def test_frames_other_plaintexts(built, fam):
     check(streams, params, units, out, res)
     for i in range(len(streams)):
         assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
+
+
+def test_launch_shape_rule(built):
+    """shim.hip: lzx_frame_parse_pays -- around one wave per unit slot of the chip (256 CUs x 16) and few frames per
+    unit the library keeps the serial kernel; smaller and larger launches, and units of many frames, take the
+    frame-parallel path.  Same bytes either way.  (Own process: the rule's override is read when the library loads.)"""
+    import os, subprocess, sys
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, 'tests')
+import libmspack_amd as M
+ADOPTED = M.F_FRAMES_ADOPTED
+def go(n, ub):
+    plain, comp, off, ln, tab = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21, frame_tables=True)
+    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=ub // 32768, frame_tabs=tab)
+    out, res = M.decode_batch(units, comp, out_bytes)
+    assert (res['err'] == 0).all() and np.array_equal(out[:n * ub], plain)
+    return float(((res['flags'] & ADOPTED) != 0).mean())
+print(go(1024, 65536), go(3600, 32768), go(3600, 3 * 32768), go(6144, 32768))
+"""
+    env = dict(os.environ); env.pop("MSPACK_HIP_FRAME_PARSE_ALWAYS", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    assert r.returncode == 0, r.stderr[-2000:]
+    small, full, many_frames, big = [float(x) for x in r.stdout.split()[-4:]]
+    assert small == 1.0 and full == 0.0 and many_frames == 1.0 and big == 1.0, r.stdout
