@@ -1689,6 +1689,8 @@ __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_emp
     {
       const u32 my_n = lane < mm ? n : 0u;
       u32 p = entry, i = 0, j = base, run = 0, pc0 = 0, pc1 = 0;        // (pc0, pc1): the record being assembled
+      u32 h0 = 0, h1 = 0;                                               // a finished record at an even index waits for its
+                                                                        // neighbour: two records leave in one 16-byte store
       LZX_MARK("lanes_emit_begin");
       while (ballot(i < my_n)) {
         const bool on = i < my_n;
@@ -1702,14 +1704,24 @@ __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_emp
           const bool lit = t.kind == 0u;
           if (lit && run != 0u && run != 4u && p < nomerge) { pc1 |= t.sym << (8u * run); pc0 += 1u << 3; run++; }
           else {
-            if (i != 0u) { tok[j] = make_uint2(pc0, pc1); j++; }
+            if (i != 0u) {
+              if (j & 1u) {
+                if (j != base) *(uint4 *)(tok + (j - 1u)) = make_uint4(h0, h1, pc0, pc1);
+                else tok[j] = make_uint2(pc0, pc1);                     // (the lane's first record sits at an odd index)
+              }
+              else { h0 = pc0; h1 = pc1; }
+              j++;
+            }
             pc0 = t.kind | (t.olen << 3) | (((sb_bit + p) & 0xFFFFFu) << 12); pc1 = lit ? t.sym : t.off;
             run = lit ? 1u : 0u;
           }
           p += t.tot; i++;
         }
       }
-      if (my_n != 0u) tok[j] = make_uint2(pc0, pc1);
+      if (my_n != 0u) {
+        if ((j & 1u) && j != base) *(uint4 *)(tok + (j - 1u)) = make_uint4(h0, h1, pc0, pc1);
+        else tok[j] = make_uint2(pc0, pc1);
+      }
       LZX_MARK("lanes_emit_end");
     }
     PLT(pl_emit);
