@@ -251,6 +251,10 @@ __device__ __forceinline__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u3
     }
   }
   HT(1);
+#ifdef LZX_TRACE
+  { u32 h_ = 0; for (u32 x = first; x < last; x++) h_ = h_ * 31u + lens[x];
+    if (d.lane == 0) printf("read_lens [%u,%u) hash %08x cons %u\n", first, last, h_, d.cons_bits()); }
+#endif
   return true;
 }
 
