@@ -1481,6 +1481,30 @@ struct __align__(16) LzxFrameRec {
   u8 pad2[48];
 };
 static_assert(sizeof(LzxFrameRec) == 1152, "LzxFrameRec layout");
+// LzxFrameRec::status.  The separate header / parse launches only use 0, 2, 1.  In the dependency-driven launch
+// (mspack_lzx_pipe, shim.hip) the word is also the hand-off flag between the frame's parse task and the unit's wave:
+//   0 untouched | 5 a parse wave claimed the frame | 2 its code lengths are in the record, tokens still being parsed |
+//   1 tokens parsed (final) | 3 code lengths valid, no tokens (final) | 4 nothing usable (final; the chain of code
+//   lengths is broken for the rest of the reset interval) | 6 the unit's own wave took the frame (decodes it serially)
+#define LZX_ST_NONE 0u
+#define LZX_ST_PARSED 1u
+#define LZX_ST_HEADER 2u
+#define LZX_ST_HDRONLY 3u
+#define LZX_ST_FAILED 4u
+#define LZX_ST_CLAIMED 5u
+#define LZX_ST_TAKEN 6u
+__device__ __forceinline__ u32 lzx_status_load(const u32 *p) {
+  return rfl(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// publish what this wave stored (tokens, record fields), then the status word: agent-scope release, a drained
+// store queue (the compiler may drop the wait behind the write-back: MI355X guide, hand-off recipe), relaxed flag
+__device__ __forceinline__ void lzx_status_publish(u32 *p, const u32 v, const u32 lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#ifndef MSPACK_WAVE_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // continue reading at an absolute bit position (from the unit's first byte)
 __device__ __forceinline__ void lzx_seek_bit(LzxDec &d, const u32 abs_bit)
@@ -1872,6 +1896,104 @@ __device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 
   }
 }
 
+#ifdef LZX_PARSE_ONLY
+// ---------------------------------------------------------------------------------------------------
+// mspack_lzx_pipe's PARSE task: header + tokens of frame f of unit u, by one wave.
+// The block headers of a reset interval are a chain (code lengths are deltas on the previous block's,
+// lzxd.c:138-183): the wave takes the previous frame's lengths from that frame's record as soon as its parse wave
+// has published them (status HEADER or later), reads its own header at the position the frame table states, publishes
+// its lengths, and only then parses its tokens (lzx_parse_lanes) -- so the chain costs one header per link, not one
+// frame.  Same guesses and same give-up rules as lzx_walk_headers + lzx_parse_frame; the unit's own wave stays the judge.
+// Waiting is safe: the task it waits for has an earlier ticket (shim.hip), i.e. a live wave is working on it.
+// ---------------------------------------------------------------------------------------------------
+__device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, LzxFrameRec *urecs,
+                               uint2 *tok, LzxShared *sh)
+{
+  const u32 lane = threadIdx.x;
+  LzxFrameRec *rec = &urecs[f];
+  {
+    u32 st = 0;
+    if (lane == 0) st = atomicCAS(&rec->status, LZX_ST_NONE, LZX_ST_CLAIMED);
+    if (rfl(st) != LZX_ST_NONE) return;                        // the unit's wave was faster: it decodes this frame itself
+  }
+  LzxDec d;
+  LzxState s;
+  if (!lzx_side_setup(d, s, u, in_arena, sh) || u.in_len >= (1u << 28)) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
+  const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
+  const u32 rf = u.reset_frames;
+  const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
+  const bool first = rf ? (f % rf) == 0u : f == 0u;
+  if (first) lzx_reset_state(d, s);
+  else {
+    const LzxFrameRec *pr = rec - 1;
+    u32 ps;
+    for (;;) {
+      ps = lzx_status_load(&pr->status);
+      if (ps != LZX_ST_NONE && ps != LZX_ST_CLAIMED) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (ps == LZX_ST_FAILED || ps == LZX_ST_TAKEN) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) sh->main_len[i] = pr->main_len[i];
+    for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) sh->len_len[i] = pr->len_len[i];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  // ---- the header the frame table points at (cf. lzx_walk_headers) ----
+  const u32 fo = rfl(ftab[f]);
+  bool ok = !(fo >= u.in_len || u.in_len - fo <= 64u);         // the last bytes of the input belong to the EOF-exact reader
+  u32 hdr_start = 0;
+  if (ok) {
+    d.w.seek(fo, lane);
+    d.bb = 0; d.bl = 0; d.rbl = 0; d.near_end = false; d.careful = false; d.err = 0;
+    if (first) {                                                // the interval's (stream's) 1 + 32 header bits, lzxd.c:447-453
+      u32 v, hi, lo;
+      ok = d.read_bits(1, v);
+      if (ok && v) ok = d.read_bits(16, hi) && d.read_bits(16, lo);
+    }
+  }
+  if (ok) {
+    hdr_start = fo * 8u + d.cons_bits();
+    s.block_type = 0;
+    ok = lzx_block_header(d, s, false) && !d.careful && !d.near_end;
+  }
+  u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
+  if (ok) ok = (s.block_type == 1u || s.block_type == 2u) && s.block_length == fsz;    // one block per frame, or no guess
+  if (!ok) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
+  const u32 start_bit = fo * 8u + d.cons_bits();                // the frame's first token
+  for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) rec->main_len[i] = sh->main_len[i];
+  for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) rec->len_len[i] = sh->len_len[i];
+  if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
+  if (lane == 0) {
+    rec->n_tokens = 0; rec->hdr_start_bit = hdr_start; rec->end_bit = start_bit;
+    rec->block_type = s.block_type; rec->block_length = s.block_length;
+    rec->flags = (sh->main_len[0xE8] != 0 ? 2u : 0u);
+  }
+  lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);        // the next frame's wave may go on
+  // ---- tables + tokens (cf. lzx_parse_frame) ----
+  bool tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+                                                              sh->cnt, d.hr_main, lane, false);
+  if (tables) {
+    const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, lane, false);
+    tables = r != 1;
+    s.length_empty = (r == 2);
+  }
+  if (tables && s.block_type == 2u) tables = !huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false);
+  if (!tables) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); return; }
+  u32 n_tok = 0, end_bit = 0;
+  {
+    u32 fe = (f + 1u < nreal) ? rfl(ftab[f + 1u]) : u.in_len;     // where the table says the frame ends (a hint)
+    if (fe > u.in_len || fe * 8u <= start_bit) fe = u.in_len;
+    if (s.block_type == 2u) lzx_parse_lanes<true>(d, s.length_empty, start_bit, fe * 8u, tok, n_tok, end_bit);
+    else lzx_parse_lanes<false>(d, s.length_empty, start_bit, fe * 8u, tok, n_tok, end_bit);
+  }
+  if (lane == 0) {
+    rec->n_tokens = n_tok; rec->end_bit = end_bit;
+    rec->flags = rec->flags | (s.length_empty ? 1u : 0u);
+  }
+  lzx_status_publish(&rec->status, LZX_ST_PARSED, lane);
+}
+#endif  /* LZX_PARSE_ONLY */
+
 #ifndef LZX_PARSE_ONLY
 // an adopted record's code lengths back into LDS (a later block header works on them, lzxd.c:138-183) ...
 __device__ __forceinline__ void lzx_restore_lens(LzxDec &d, const LzxFrameRec *rec)
@@ -1975,9 +2097,11 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
                                 int32_t *frame_meta, mspack_hip_result *res, LzxShared *sh)
 #else
 // recs / toks: the parse waves' records and tokens for this launch (NULL: none), indexed by frame slot
+// pipe: the records are being produced in this same launch (mspack_lzx_pipe): a frame's record is waited for while a
+// parse wave is working on it, and taken over (decoded serially here) when none has started yet
 __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
                                 int32_t *frame_meta, mspack_hip_result *res, LzxShared *sh,
-                                const LzxFrameRec *recs, const uint2 *toks)
+                                const LzxFrameRec *recs, const uint2 *toks, const bool pipe = false)
 #endif
 {
   const u32 lane = threadIdx.x;
@@ -2079,7 +2203,23 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
       const LzxFrameRec *adopt = nullptr;
       if (chain_ok && todo > 0 && s.block_remaining == 0u && !s.raw_mode && !d.careful && !d.near_end) {
         const LzxFrameRec *r = &recs[u.frame_base + s.frame];
-        if (rfl(r->status) == 1u && rfl(r->hdr_start_bit) == rfl(d.w.origin) * 8u + rfl(d.cons_bits()) &&
+        u32 st;
+        if (!pipe) st = rfl(r->status);
+        else {
+          u32 *sp = (u32 *) &r->status;
+          st = lzx_status_load(sp);
+          // (a parse wave that has its ticket needs a moment to claim the frame: look a few times before taking it)
+          for (u32 tries = 0; st == LZX_ST_NONE && tries < 32u; tries++) { __builtin_amdgcn_s_sleep(8); st = lzx_status_load(sp); }
+          if (st == LZX_ST_NONE) {                                   // nobody has started on it: take it
+            u32 old = 0;
+            if (lane == 0) old = atomicCAS(sp, LZX_ST_NONE, LZX_ST_TAKEN);
+            old = rfl(old);
+            st = old == LZX_ST_NONE ? LZX_ST_TAKEN : old;
+          }
+          while (st == LZX_ST_CLAIMED || st == LZX_ST_HEADER) { __builtin_amdgcn_s_sleep(8); st = lzx_status_load(sp); }
+          if (st == LZX_ST_PARSED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (st == LZX_ST_PARSED && rfl(r->hdr_start_bit) == rfl(d.w.origin) * 8u + rfl(d.cons_bits()) &&
             rfl(r->block_length) == frame_size) adopt = r;
       }
       if (adopt) {

@@ -21,6 +21,9 @@ namespace lzxd {
 }
 #undef LZX_DELTA
 #define LZX_PARSE_ONLY 1
+#ifndef LZX_STAGE_WORDS
+#define LZX_STAGE_WORDS 1024u   /* 4 KiB of a frame's input per pass: parse and unit tasks share one 10 KiB LDS block (mspack_lzx_pipe) */
+#endif
 namespace lzxp {
 #include "lzx_kernel.hpp"
 }
@@ -47,12 +50,13 @@ __device__ __forceinline__ bool pick_unit(const mspack_hip_unit *units, const u3
 //   u32    frame_unit[n]  per frame slot: the unit it belongs to when a parse wave should take it, else ~0
 //   LzxFrameRec recs[n]   what the parse wave of that frame assumed and found (lzx_kernel.hpp)
 //   uint2  toks[n][LZX_TOK_CAP]  its tokens
-//   u32    hdr[64]        per launch: [0] = most, [1] = fewest frames of a unit with a frame table
+//   u32    hdr[256]       per launch (up to 32 concurrent ones) 8 words: [0] = most, [1] = fewest frames of a unit with a
+//                         frame table, [2] = ticket counter of mspack_lzx_pipe
 struct LzxScratch { int32_t *meta; u32 *frame_unit; u32 *hdr; lzxn::LzxFrameRec *recs; uint2 *toks; size_t bytes; };
 __host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_frames_total)
 {
   const size_t n = n_frames_total + 1, a = 255;
-  const size_t o_fu = (n * 4 + a) & ~a, o_hdr = o_fu + ((n * 4 + a) & ~a), o_rec = o_hdr + 256,
+  const size_t o_fu = (n * 4 + a) & ~a, o_hdr = o_fu + ((n * 4 + a) & ~a), o_rec = o_hdr + 1024,
                o_tok = o_rec + n * sizeof(lzxn::LzxFrameRec);
   LzxScratch L;
   char *b = (char *) base;
@@ -154,6 +158,106 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
       lzxn::lzx_e8_frame(out_arena + u.out_off + (size_t) f * LZX_FRAME, fsize,
                          (int32_t)((u32) u.e8_base + f * LZX_FRAME), fs, lane);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mspack_lzx_pipe -- headers, parse and commit of a launch's LZX units as ONE dependency-driven launch.
+//
+// Persistent waves pull TICKETS from a counter; a ticket is a task:
+//   P(u, f)  parse frame f of unit u (header chain link + tokens; lzx_pipe_parse)
+//   C(u)     decode unit u: adopt the frames' records as they become ready, commit their tokens, decode whatever no
+//            record covers serially, E8-translate (exactly what mspack_decode_lzx does; lzx_decode_unit)
+// in an order in which every task only waits for tasks with EARLIER tickets:
+//   section 1   every frame but the last of every unit that carries a frame table -- frame-major (all first frames, all
+//               second frames, ...) when all units have the same number of frames, else in frame-slot order;
+//   section 2   per unit, in launch order (longest first):  P(u, last frame), C(u).
+// So a unit's commit starts while its last frame is still being parsed by another wave, finished waves take the next
+// task instead of idling until a kernel boundary, and the launch ends with one task, not with three slowest waves.
+// No co-residency is assumed anywhere: a wave waits only for a task that a LIVE wave holds (a ticket is pulled by a
+// running wave; status CLAIMED / HEADER); a C task that finds a frame nobody has claimed takes it over and decodes it
+// serially.  Hand-off: record + tokens by plain stores, agent-scope release, relaxed status store; the reader polls the
+// status relaxed, then one agent-scope acquire (lzx_kernel.hpp).
+// ---------------------------------------------------------------------------------------------------
+union LzxPipeLds { lzxp::LzxShared p; lzxn::LzxShared n; };
+static_assert(sizeof(LzxPipeLds) <= 10240, "16 waves per CU");
+
+// the two task bodies are real calls: each gets its own register allocation (inlined into the ticket loop they spill)
+__device__ __attribute__((noinline)) void lzx_pipe_task_parse(const mspack_hip_unit *up, const u32 f, const u8 *in_arena,
+                                                              lzxn::LzxFrameRec *recs, uint2 *toks, lzxp::LzxShared *sh)
+{
+  const mspack_hip_unit u = *up;
+  lzxp::lzx_pipe_parse(u, f, in_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], toks + (size_t)(u.frame_base + f) * LZX_TOK_CAP, sh);
+}
+__device__ __attribute__((noinline)) void lzx_pipe_task_unit(const mspack_hip_unit *up, const u8 *in_arena, u8 *out_arena,
+                                                             mspack_hip_result *res, int32_t *frame_meta,
+                                                             const lzxn::LzxFrameRec *recs, const uint2 *toks, lzxn::LzxShared *sh)
+{
+  const mspack_hip_unit u = *up;
+  const u32 lane = threadIdx.x;
+  lzxn::lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, sh, recs, toks, true);
+  if (frame_meta) {                                             // E8 translation, as mspack_decode_lzx does it
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const u32 produced = rfl(res->out_len);
+    const u32 nfr = (produced + LZX_FRAME - 1u) / LZX_FRAME;
+    for (u32 fr = 0; fr < nfr; fr++) {
+      const int32_t fs = (int32_t) rfl((u32) frame_meta[u.frame_base + fr]);
+      if (fs == 0) continue;
+      u32 fsize = u.out_len - fr * LZX_FRAME; if (fsize > LZX_FRAME) fsize = LZX_FRAME;
+      lzxn::lzx_e8_frame(out_arena + u.out_off + (size_t) fr * LZX_FRAME, fsize, (int32_t)((u32) u.e8_base + fr * LZX_FRAME), fs, lane);
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
+                     const u8 *in_arena, u8 *out_arena, mspack_hip_result *results, int32_t *frame_meta,
+                     const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks)
+{
+  __shared__ LzxPipeLds sh;
+  const u32 lane = threadIdx.x;
+  // all units carry a table and have the same number of frames F: section 1 = n_units * (F - 1) tickets, frame-major
+  const u32 Fmax = rfl(ctl[0]), Fmin = rfl(ctl[1]);
+  const u32 F = (Fmax != 0u && Fmax == Fmin) ? Fmax : 0u;
+  const u32 T1 = F ? n_units * (F - 1u) : n_slots, T = T1 + 2u * n_units;
+  for (;;) {
+    u32 t = 0;
+    if (lane == 0) t = atomicAdd(&ctl[2], 1u);
+    t = rfl(t);
+    if (t >= T) break;
+    u32 ui = 0xFFFFFFFFu, f = 0;
+    bool commit = false;
+    if (t < T1) {
+      if (F) { ui = rfl(order ? order[t % n_units] : t % n_units); f = t / n_units; }
+      else {
+        const u32 slot = slot_lo + t;
+        ui = rfl(frame_unit[slot]);
+        if (ui != 0xFFFFFFFFu) {
+          f = slot - rfl(units[ui].frame_base);
+          if (f + 1u == (rfl(units[ui].out_len) + LZX_FRAME - 1u) / LZX_FRAME) ui = 0xFFFFFFFFu;     // the last frame: section 2
+        }
+      }
+    }
+    else {
+      const u32 j = (t - T1) >> 1;
+      ui = rfl(order ? order[j] : j);
+      if ((t - T1) & 1u) commit = true;
+      else {
+        const mspack_hip_unit &uu = units[ui];
+        const u32 nreal = (rfl(uu.out_len) + LZX_FRAME - 1u) / LZX_FRAME;
+        if (rfl((u32) uu.kind) != MSPACK_HIP_KIND_LZX || !(rfl(uu.flags) & MSPACK_HIP_UF_FRAME_TABLE) || nreal == 0u) ui = 0xFFFFFFFFu;
+        else f = nreal - 1u;
+      }
+    }
+    if (ui == 0xFFFFFFFFu) continue;
+    const mspack_hip_unit *up = &units[ui];
+    if (rfl((u32) up->kind) != MSPACK_HIP_KIND_LZX) continue;
+    if (!commit) {
+      if (!(rfl(up->flags) & MSPACK_HIP_UF_FRAME_TABLE)) continue;
+      lzx_pipe_task_parse(up, f, in_arena, recs, toks, &sh.p);
+    }
+    else lzx_pipe_task_unit(up, in_arena, out_arena, &results[ui], frame_meta, recs, toks, &sh.n);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the next task reuses the LDS
   }
 }
 
@@ -267,40 +371,47 @@ static int fail(hipError_t e, const char *what) {
 // that carry a frame table get their frames parsed by one wave each first (slots [slot_lo, slot_lo + n_slots)
 // of the work scratch belong to this launch).
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
-static const bool g_all_frames = getenv("MSPACK_HIP_FRAME_PARSE_ALWAYS") != nullptr;  // experiments: no launch-shape rule
-// Frame-parallel LZX parse or not, for a launch of n units with n_slots frame slots?  Measured on the 2-frames-per-unit
-// headline shape (profiles/round2_batch_sizes.txt): the parse launches win below ~3 500 units (1024 units: 2.98 vs
-// 4.47 ms) and from ~4 700 on (16 384: 12.8 vs 14.5 ms); in between -- about one wave per unit slot of the chip, all
-// resident at once -- the serial kernel does (4096: 4.40 vs 4.75 ms): its parse fills the other waves' stalls and no
-// wave waits for a second round.  Units with more frames always gain (a 512-frame folder: 624 -> 302 ms).
-static bool lzx_frame_parse_pays(size_t n_units, size_t n_slots)
+static const bool g_no_pipe = getenv("MSPACK_HIP_NO_PIPE") != nullptr;               // experiments: header / parse / unit kernels one after the other
+// persistent waves of mspack_lzx_pipe: as many as the device holds at once (nothing depends on that number being right)
+static unsigned lzx_pipe_waves()
 {
-  if (g_all_frames) return true;
-  static int unit_slots = 0;                                  // waves of the unit kernel the chip holds at once
-  if (!unit_slots) {
-    int dev = 0; hipDeviceProp_t pr;
-    unit_slots = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess)
-                   ? pr.multiProcessorCount * 16 : 4096;
+  static unsigned waves = 0;
+  if (!waves) {
+    int dev = 0, per_cu = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 4096u;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_lzx_pipe, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
+    const char *e = getenv("MSPACK_HIP_PIPE_WAVES_PER_CU");
+    if (e && atoi(e) > 0) per_cu = atoi(e);
+    waves = (unsigned) pr.multiProcessorCount * (unsigned) per_cu;
   }
-  const double frames_per_unit = (double) n_slots / (double) n_units - 1.0;     // (one spare slot per unit)
-  if (frames_per_unit > 2.5) return true;
-  return !((double) n_units > 0.85 * unit_slots && (double) n_units < 1.13 * unit_slots);
+  return waves;
 }
 static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
                         const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
-                        size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true)
+                        size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true, unsigned launch_ix = 0)
 {
   if (n == 0) return;
   const dim3 grid((unsigned) n), block(64);
   switch (kind) {
   case MSPACK_HIP_KIND_LZX: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total);
-    const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables && lzx_frame_parse_pays(n, n_slots);
+    const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
+    static const u32 hdr_init[4] = { 0u, 0xFFFFFFFFu, 0u, 0u };
+    // launches of one batch that run on different streams (host path, several chunks) have their own control words
+    u32 *hdr = L.hdr + 8u * (launch_ix & 15u);
+    if (frames && !g_no_pipe) {
+      // one dependency-driven launch: parse tasks and unit tasks from a ticket counter (mspack_lzx_pipe)
+      hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
+      hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
+      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
+                         (u32) MSPACK_HIP_KIND_LZX);
+      const size_t tickets = n_slots + 2u * n;
+      const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
+      hipLaunchKernelGGL(mspack_lzx_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
+                         (const u8 *) d_in, (u8 *) d_out, d_results, L.meta, (const u32 *) L.frame_unit, hdr, L.recs, L.toks);
+      break;
+    }
     if (frames) {
-      static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
-      // launches of one batch that run on different streams (host path, several chunks) use different header words;
-      // a clash would only change the order in which frames are taken, never which tokens a frame yields
-      u32 *hdr = L.hdr + 2u * (u32)((slot_lo ^ (slot_lo >> 5) ^ (slot_lo >> 11)) & 31u);
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_headers, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, L.recs,
@@ -320,7 +431,7 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
     if (frames) {
       static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
-      u32 *hdr = L.hdr + 2u * (u32)(((slot_lo ^ (slot_lo >> 5) ^ (slot_lo >> 11)) + 16u) & 31u);
+      u32 *hdr = L.hdr + 8u * (16u + (launch_ix & 15u));
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
@@ -624,7 +735,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
                                hipMemcpyHostToDevice, st));
       for (unsigned k = 1; k <= 6; k++)
         launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
-                    c.has_ftab);
+                    c.has_ftab, (unsigned) ci);
       TRY(hipGetLastError());
       TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
     }

@@ -146,6 +146,8 @@ hipError_t hipGetDevice(int *d);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d);
 hipError_t hipDeviceSynchronize(void);
+template <typename K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, K, int, size_t) {
+  const char *e = getenv("MSPACK_EMU_OCC"); *n = e ? atoi(e) : 4; return hipSuccess; }
 hipError_t emu_hipMalloc(void **p, size_t n);
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return emu_hipMalloc((void **) p, n); }
 hipError_t hipFree(void *p);
