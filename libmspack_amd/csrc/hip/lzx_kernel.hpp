@@ -1486,6 +1486,14 @@ static_assert(sizeof(LzxFrameRec) == 1152, "LzxFrameRec layout");
 //   0 untouched | 5 a parse wave claimed the frame | 2 its code lengths are in the record, tokens still being parsed |
 //   1 tokens parsed (final) | 3 code lengths valid, no tokens (final) | 4 nothing usable (final; the chain of code
 //   lengths is broken for the rest of the reset interval) | 6 the unit's own wave took the frame (decodes it serially)
+#ifdef LZX_PIPE_TRACE      /* analysis builds: time a unit task spends waiting for parse tasks (shim.hip: g_pipe_wait) */
+__device__ unsigned long long g_pipe_wait[1 << 16];
+#define LZX_PIPE_WAIT_BEGIN() const unsigned long long pw_ = __builtin_amdgcn_s_memrealtime()
+#define LZX_PIPE_WAIT_END() do { if (threadIdx.x == 0) g_pipe_wait[blockIdx.x & 0xFFFFu] += __builtin_amdgcn_s_memrealtime() - pw_; } while (0)
+#else
+#define LZX_PIPE_WAIT_BEGIN() do { } while (0)
+#define LZX_PIPE_WAIT_END() do { } while (0)
+#endif
 #define LZX_ST_NONE 0u
 #define LZX_ST_PARSED 1u
 #define LZX_ST_HEADER 2u
@@ -2208,15 +2216,22 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
         else {
           u32 *sp = (u32 *) &r->status;
           st = lzx_status_load(sp);
-          // (a parse wave that has its ticket needs a moment to claim the frame: look a few times before taking it)
-          for (u32 tries = 0; st == LZX_ST_NONE && tries < 32u; tries++) { __builtin_amdgcn_s_sleep(8); st = lzx_status_load(sp); }
-          if (st == LZX_ST_NONE) {                                   // nobody has started on it: take it
+          // The frame's parse task has an earlier ticket than this unit's task (mspack_lzx_pipe), so a live wave holds it
+          // and the status WILL become final: wait.  The take-over below is a safety net (it keeps a launch whose
+          // tickets were ever handed out in another order from hanging), not a path that is expected to run.
+          LZX_PIPE_WAIT_BEGIN();
+          for (u32 tries = 0; (st == LZX_ST_NONE && tries < (1u << 17)) || st == LZX_ST_CLAIMED || st == LZX_ST_HEADER; tries++) {
+            __builtin_amdgcn_s_sleep(32);
+            st = lzx_status_load(sp);
+          }
+          if (st == LZX_ST_NONE) {
             u32 old = 0;
             if (lane == 0) old = atomicCAS(sp, LZX_ST_NONE, LZX_ST_TAKEN);
             old = rfl(old);
             st = old == LZX_ST_NONE ? LZX_ST_TAKEN : old;
+            while (st == LZX_ST_CLAIMED || st == LZX_ST_HEADER) { __builtin_amdgcn_s_sleep(32); st = lzx_status_load(sp); }
           }
-          while (st == LZX_ST_CLAIMED || st == LZX_ST_HEADER) { __builtin_amdgcn_s_sleep(8); st = lzx_status_load(sp); }
+          LZX_PIPE_WAIT_END();
           if (st == LZX_ST_PARSED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         if (st == LZX_ST_PARSED && rfl(r->hdr_start_bit) == rfl(d.w.origin) * 8u + rfl(d.cons_bits()) &&

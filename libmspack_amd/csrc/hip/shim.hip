@@ -85,6 +85,39 @@ __device__ __forceinline__ void frame_map_unit(const mspack_hip_unit &u, const u
   }
 }
 
+// the same for mspack_lzx_pipe, one unit per LANE (4096 one-wave blocks with two atomics each on the same words took
+// 0.19 ms): frame slots -> unit, record status words cleared, most / fewest frames per unit reduced per wave first
+__global__ __launch_bounds__(64)
+void mspack_lzx_pipe_map(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 *frame_unit,
+                         lzxn::LzxFrameRec *recs, u32 *ctl)
+{
+  const u32 j = blockIdx.x * 64u + threadIdx.x;
+  u32 fr = 0;                                                    // real frames of a unit whose frames get parse tasks
+  bool other = false;
+  if (j < n_units) {
+    const u32 ui = order ? order[j] : j;
+    const mspack_hip_unit u = units[ui];
+    if (u.kind == MSPACK_HIP_KIND_LZX) {
+      const bool usable = (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u;
+      const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME, nslots = u.out_len / LZX_FRAME + 1u;
+      for (u32 f = 0; f < nslots; f++) {
+        frame_unit[u.frame_base + f] = (usable && f < nreal) ? ui : 0xFFFFFFFFu;
+        recs[u.frame_base + f].status = 0u;
+      }
+      fr = usable ? nreal : 0u;
+    }
+    else other = true;
+  }
+  const u32 live = j < n_units ? 1u : 0u;
+  u32 mx = fr, mn = (live && !other) ? fr : (other ? 0u : 0xFFFFFFFFu);
+  for (int o = 32; o >= 1; o >>= 1) {
+    const u32 a = (u32) __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x + (u32) o) & 63u) << 2), (int) mx);
+    const u32 b = (u32) __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x + (u32) o) & 63u) << 2), (int) mn);
+    mx = a > mx ? a : mx; mn = b < mn ? b : mn;
+  }
+  if (threadIdx.x == 0) { atomicMax(&ctl[0], mx); atomicMin(&ctl[1], mn); }
+}
+
 // which frame slots get a parse wave: the real frames of LZX units that carry a frame table
 __global__ __launch_bounds__(64)
 void mspack_lzx_frame_map(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 *frame_unit,
@@ -209,6 +242,9 @@ __device__ __attribute__((noinline)) void lzx_pipe_task_unit(const mspack_hip_un
   }
 }
 
+#ifdef LZX_PIPE_TRACE      /* analysis builds: one line per ticket = start, end (s_memrealtime, 100 MHz), task, time waited */
+__device__ unsigned long long g_pipe_trace[4 << 16];
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
                      const u8 *in_arena, u8 *out_arena, mspack_hip_result *results, int32_t *frame_meta,
@@ -252,11 +288,22 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
     if (ui == 0xFFFFFFFFu) continue;
     const mspack_hip_unit *up = &units[ui];
     if (rfl((u32) up->kind) != MSPACK_HIP_KIND_LZX) continue;
+#ifdef LZX_PIPE_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) lzxn::g_pipe_wait[blockIdx.x & 0xFFFFu] = 0;
+#endif
     if (!commit) {
       if (!(rfl(up->flags) & MSPACK_HIP_UF_FRAME_TABLE)) continue;
       lzx_pipe_task_parse(up, f, in_arena, recs, toks, &sh.p);
     }
     else lzx_pipe_task_unit(up, in_arena, out_arena, &results[ui], frame_meta, recs, toks, &sh.n);
+#ifdef LZX_PIPE_TRACE
+    if (lane == 0 && t < (1u << 16)) {
+      g_pipe_trace[4u * t] = tr0; g_pipe_trace[4u * t + 1u] = __builtin_amdgcn_s_memrealtime();
+      g_pipe_trace[4u * t + 2u] = ((unsigned long long) ui << 32) | (f << 1) | (commit ? 1u : 0u);
+      g_pipe_trace[4u * t + 3u] = lzxn::g_pipe_wait[blockIdx.x & 0xFFFFu] | ((unsigned long long) blockIdx.x << 40);
+    }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the next task reuses the LDS
   }
 }
@@ -403,8 +450,8 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       // one dependency-driven launch: parse tasks and unit tasks from a ticket counter (mspack_lzx_pipe)
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
-      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
-                         (u32) MSPACK_HIP_KIND_LZX);
+      hipLaunchKernelGGL(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, 0, st, d_units, d_order, (u32) n, L.frame_unit,
+                         L.recs, hdr);
       const size_t tickets = n_slots + 2u * n;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
       hipLaunchKernelGGL(mspack_lzx_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
@@ -463,6 +510,11 @@ int mspack_hip_debug_counters(unsigned long long *out8) {
   unsigned long long z[8] = {0};
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(spq_tm), sizeof(z)) != hipSuccess) return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(spq_tm), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef LZX_PIPE_TRACE
+int mspack_hip_debug_pipe_trace(unsigned long long *out, size_t n_words) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pipe_trace), n_words * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 const char *mspack_hip_version(void) { return "mspack-hip 0.3 (gfx950; LZX/LZX-DELTA/Quantum/MSZIP batch decode)"; }

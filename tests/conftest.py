@@ -9,12 +9,6 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
-# The library chooses between the serial LZX kernel and the frame-parallel path by the launch's shape (shim.hip:
-# lzx_frame_parse_pays).  The tests want the frame-parallel path exercised whenever units carry frame tables, whatever
-# the batch size; the rule itself is tested in a subprocess (test_gpu_lzx_frames.py::test_launch_shape_rule).
-os.environ.setdefault("MSPACK_HIP_FRAME_PARSE_ALWAYS", "1")
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -160,26 +160,35 @@ def test_frames_other_plaintexts(built, fam):
         assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
 
 
-def test_launch_shape_rule(built):
-    """shim.hip: lzx_frame_parse_pays -- around one wave per unit slot of the chip (256 CUs x 16) and few frames per
-    unit the library keeps the serial kernel; smaller and larger launches, and units of many frames, take the
-    frame-parallel path.  Same bytes either way.  (Own process: the rule's override is read when the library loads.)"""
+@pytest.mark.parametrize("env", [{}, {"MSPACK_HIP_NO_PIPE": "1"}, {"MSPACK_HIP_NO_FRAME_PARSE": "1"}],
+                         ids=["pipe", "three-kernels", "serial"])
+def test_launch_paths_same_bytes(built, env):
+    """shim.hip launch_kind: the shipped default (mspack_lzx_pipe: one dependency-driven launch), the header / parse /
+    unit kernels one after the other (MSPACK_HIP_NO_PIPE) and the serial kernel alone (MSPACK_HIP_NO_FRAME_PARSE) --
+    same results, on launches smaller than, about and larger than the chip, and on units of three frames.  Every unit
+    carries its table; with the pipe every unit must have had all its frames' records adopted.  (Own process: the
+    switches are read when the library loads.)"""
     import os, subprocess, sys
     code = r"""
 import numpy as np, sys
 sys.path.insert(0, 'tests')
 import libmspack_amd as M
+from helpers import oracle_lzx
 ADOPTED = M.F_FRAMES_ADOPTED
 def go(n, ub):
     plain, comp, off, ln, tab = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21, frame_tables=True)
     units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=ub // 32768, frame_tabs=tab)
     out, res = M.decode_batch(units, comp, out_bytes)
-    assert (res['err'] == 0).all() and np.array_equal(out[:n * ub], plain)
+    assert (res['err'] == 0).all() and (res['out_len'] == ub).all() and np.array_equal(out[:n * ub], plain)
+    for i in (0, n // 2, n - 1):
+        e, o, r = oracle_lzx(comp[int(off[i]):int(off[i]) + int(ln[i]) + 4].tobytes(), ub, 21, ub // 32768)
+        assert e == 0 and r.in_next == res['in_next'][i] and (int(res['flags'][i]) & ~ADOPTED) == r.flags
     return float(((res['flags'] & ADOPTED) != 0).mean())
 print(go(1024, 65536), go(3600, 32768), go(3600, 3 * 32768), go(6144, 32768))
 """
-    env = dict(os.environ); env.pop("MSPACK_HIP_FRAME_PARSE_ALWAYS", None)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    e2 = dict(os.environ); e2.pop("MSPACK_HIP_NO_PIPE", None); e2.pop("MSPACK_HIP_NO_FRAME_PARSE", None); e2.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e2, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stderr[-2000:]
-    small, full, many_frames, big = [float(x) for x in r.stdout.split()[-4:]]
-    assert small == 1.0 and full == 0.0 and many_frames == 1.0 and big == 1.0, r.stdout
+    adopted = [float(x) for x in r.stdout.split()[-4:]]
+    want = 0.0 if "MSPACK_HIP_NO_FRAME_PARSE" in env else 1.0
+    assert all(a == want for a in adopted), r.stdout
