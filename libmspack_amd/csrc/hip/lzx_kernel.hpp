@@ -1478,9 +1478,19 @@ struct __align__(16) LzxFrameRec {
   u8 pad1[8];
   u8 main_len[LZX_MAIN_SYMS + 16];
   u8 len_len[LZX_LEN_SYMS + 70];
+  /* ---- mspack_lzx_pipe (lzx_pipe_parse / lzx_pipe_commit) ---- */
+  u32 frame_start_bit;              /* where the frame begins: in front of a reset interval's 1 + 32 header bits */
+  u32 intel_filesize;               /* the interval header's value when this frame carries it (else 0) */
+  u32 bytes_done;                   /* output bytes the record covers (== the frame's size: a complete frame) */
+  u32 n_edge;                       /* literals kept in edge_lit (the frame's first bytes share a cache line with the
+                                       bytes below them, which another wave may be writing: the commit wave stores them) */
+  u32 edge_mask[4];
+  /* what the unit's commit task leaves for mspack_decode_lzx: where serial decoding resumes (in the unit's FIRST record) */
+  u32 rs_valid, rs_frame, rs_partial, rs_P, rs_next_bit, rs_R0, rs_R1, rs_R2;
+  u8 edge_lit[128];
   u8 pad2[48];
 };
-static_assert(sizeof(LzxFrameRec) == 1152, "LzxFrameRec layout");
+static_assert(sizeof(LzxFrameRec) == 1344, "LzxFrameRec layout");
 // LzxFrameRec::status.  The separate header / parse launches only use 0, 2, 1.  In the dependency-driven launch
 // (mspack_lzx_pipe, shim.hip) the word is also the hand-off flag between the frame's parse task and the unit's wave:
 //   0 untouched | 5 a parse wave claimed the frame | 2 its code lengths are in the record, tokens still being parsed |
@@ -1501,6 +1511,9 @@ __device__ unsigned long long g_pipe_wait[1 << 16];
 #define LZX_ST_FAILED 4u
 #define LZX_ST_CLAIMED 5u
 #define LZX_ST_TAKEN 6u
+#define LZX_ST_EMITTED 7u         /* lzx_pipe_parse: literals stored, match records written (final) */
+/* a match record of lzx_pipe_parse (uint2): x = position in the unit's output, y = offset << 11 | length << 2 | which:
+ * 0 explicit offset, 1..3 repeat of R0 / R1 / R2 (lzxd.c:565-586) */
 __device__ __forceinline__ u32 lzx_status_load(const u32 *p) {
   return rfl(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
@@ -1776,6 +1789,236 @@ __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_emp
 }
 #endif  /* LZX_PARSE_ONLY */
 
+
+#ifdef LZX_PARSE_ONLY
+// ---------------------------------------------------------------------------------------------------
+// lzx_parse_emit -- lzx_parse_lanes taken one step further (mspack_lzx_pipe): the parse wave does not leave TOKENS
+// for the unit's wave, it leaves the frame's LITERALS IN PLACE and a list of MATCH RECORDS.
+//
+// A frame starts at a known output position (f * 32 KiB), so once the lanes' stretches are consistent every lane
+// knows, by a prefix sum over the stretches' output lengths, where its first token's bytes go: in its last walk it
+// stores its literals straight into the output and writes one record per match (position, length, explicit offset or
+// which of R0-R2 it repeats).  What is left for the unit's wave -- the part LZ77 makes serial -- is resolving R0-R2
+// along the record list and copying the matches (lzx_pipe_commit): no token ever travels through memory, and the
+// positions / literal stores of all frames of a unit run in parallel.
+// The frame's first bytes may share a cache line with bytes another wave is writing at that moment (the end of the
+// previous frame, of the previous unit): literals there (`edge_n` positions) are kept in the record and stored by the
+// commit wave.  The walk stops where the frame is full (frame_size bytes), at a token that would cross its end, at a
+// token the tables do not hold and 56 bytes before the end of the input (the EOF-exact reader's): bytes_done / end_bit
+// say how far it got; the rest is decoded serially (mspack_decode_lzx resumes there).
+// ---------------------------------------------------------------------------------------------------
+template <bool ALIGNED>
+__device__ __forceinline__ u32 lzx_adv_olen(const LzxShared *sh, const bool length_empty, const u32 e, const u32 e2,
+                                            const u32 w0, const u32 w1, bool &unk, u32 &olen)
+{
+  const u32 mlen = e >> LZX_MSH, sym = e & LZX_MMASK;
+  const bool is_match = sym >= 256u;
+  const u32 m = sym - 256u, slot = m >> 3;
+  const bool need_len = is_match && (m & 7u) == 7u;
+  u32 tot = mlen;
+  unk = false;
+  olen = is_match ? (m & 7u) + 2u : 1u;
+  if (need_len) { unk = (e2 == 0u) || length_empty; tot += e2 >> 10; olen += e2 & 1023u; }
+  const int ex_ = (int)(slot >> 1) - 1;
+  const u32 extra = (u32)(ex_ < 0 ? 0 : (ex_ > 17 ? 17 : ex_));
+  const bool expl = is_match && slot >= 3u;
+  if (ALIGNED) {
+    const bool ali = extra >= 3u;
+    const u32 nb = ali ? extra - 3u : extra;
+    const u64 r = ((u64) w0 << 32) | w1;
+    const u32 e3 = sh->ali_tab[(u32)((r << (tot + nb)) >> (64 - LZX_ALI_P))];
+    if (expl) { tot += nb; if (ali) { tot += e3 >> 10; unk = unk || e3 == 0u; } }
+  }
+  else if (expl) tot += extra;
+  return tot;
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empty, const u32 start_bit, const u32 frame_end_bit,
+                                               u8 *const fout, const u32 frame_pos, const u32 frame_size, const u32 edge_n,
+                                               LzxFrameRec *rec, uint2 *mrec, u32 &n_rec, u32 &end_bit, u32 &bytes_done)
+{
+  LzxShared *sh = d.sh;
+  const u32 lane = d.lane;
+  const u32 in_limit = d.w.in_len > 56u ? (d.w.in_len - 56u) * 8u : 0u;
+  const u32 Eall = frame_end_bit < in_limit ? frame_end_bit : in_limit;
+  u32 mlim[16 - LZX_MAIN_P], llim[16 - LZX_LEN_P];
+#pragma unroll
+  for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
+#pragma unroll
+  for (int l = LZX_LEN_P + 1; l <= 16; l++) llim[l - LZX_LEN_P - 1] = rdl(d.hr_len.limv, (u32) l);
+  const u32 main_fov = d.hr_main.fov, len_fov = d.hr_len.fov;
+  u32 tt = 0, B = rfl(start_bit), P = 0;                       // records written, next bit, bytes of the frame done
+  bool stop = false;
+  if (lane < 4u) sh->cnt[lane] = 0u;                           // the edge literals' positions (128 bits)
+
+  // main-tree entry at the bits (w0): direct table, codes beyond it resolved for all lanes at once (cf. lzx_spec_token)
+#define EMIT_MAIN_ENTRY(e_, w0_, on_)                                                          \
+  u32 e_ = sh->main_tab[(w0_) >> (32 - LZX_MAIN_P)];                                         \
+  if (ballot((on_) && e_ == 0u)) {                                                             \
+    const u32 pk_ = (w0_) >> 16;                                                               \
+    u32 ln_ = LZX_MAIN_P + 1u;                                                                 \
+    _Pragma("unroll")                                                                          \
+    for (int l = LZX_MAIN_P + 1; l <= 16; l++) ln_ += (pk_ >= mlim[l - LZX_MAIN_P - 1]) ? 1u : 0u; \
+    const u32 lq_ = ln_ <= 16u ? ln_ : 0u;                                                     \
+    const u32 fo_ = (u32) __builtin_amdgcn_ds_bpermute((int)(lq_ << 2), (int) main_fov);       \
+    u32 ix_ = (fo_ >> 16) + ((pk_ >> (16u - lq_)) - (fo_ & 0xFFFFu));                          \
+    if (ix_ >= LZX_MAIN_SYMS) ix_ = 0;                                                         \
+    const u32 ls_ = sh->main_sorted[ix_];                                                      \
+    if (e_ == 0u && lq_ != 0u) e_ = ls_ | (lq_ << LZX_MSH);                                    \
+  }
+  // the length footer's entry behind a main code of mlen_ bits (only looked at when the token has a footer)
+#define EMIT_LEN_ENTRY(e2_, w0_, mlen_, need_)                                                 \
+  u32 e2_ = sh->len_tab[((w0_) << (mlen_)) >> (32 - LZX_LEN_P)];                               \
+  if (ballot((need_) && e2_ == 0u)) {                                                          \
+    const u32 pk_ = ((w0_) << (mlen_)) >> 16;                                                  \
+    u32 ln_ = LZX_LEN_P + 1u;                                                                  \
+    _Pragma("unroll")                                                                          \
+    for (int l = LZX_LEN_P + 1; l <= 16; l++) ln_ += (pk_ >= llim[l - LZX_LEN_P - 1]) ? 1u : 0u; \
+    const u32 lq_ = ln_ <= 16u ? ln_ : 0u;                                                     \
+    const u32 fo_ = (u32) __builtin_amdgcn_ds_bpermute((int)(lq_ << 2), (int) len_fov);        \
+    u32 ix_ = (fo_ >> 16) + ((pk_ >> (16u - lq_)) - (fo_ & 0xFFFFu));                          \
+    if (ix_ >= 256u) ix_ = 0;                                                                  \
+    const u32 ls_ = sh->len_sorted[ix_];                                                       \
+    if (e2_ == 0u && lq_ != 0u && mlen_ + lq_ <= 32u) e2_ = ls_ | (lq_ << 10);                 \
+  }
+
+  while (!stop && B < Eall && P < frame_size) {
+    // ---- stage the input from the dword that holds bit B ----
+    const u32 sb_byte = (B >> 5) << 2, sb_bit = sb_byte * 8u;
+    u32 E = sb_bit + LZX_STAGE_WORDS * 32u; if (E > Eall) E = Eall;
+    const u32 b0 = B - sb_bit, e0 = E - sb_bit;
+    d.w.origin = sb_byte;
+    {
+      const u32 nck = (e0 + 128u + 2047u) >> 11;
+      for (u32 c = 0; c < nck; c += 4u) {
+        const u32 v0 = d.w.load_chunk(c, lane), v1 = d.w.load_chunk(c + 1u, lane);
+        const u32 v2 = d.w.load_chunk(c + 2u, lane), v3 = d.w.load_chunk(c + 3u, lane);
+        sh->stage[c * 64u + lane] = SWAP16(v0);
+        if (c + 1u < nck) sh->stage[(c + 1u) * 64u + lane] = SWAP16(v1);
+        if (c + 2u < nck) sh->stage[(c + 2u) * 64u + lane] = SWAP16(v2);
+        if (c + 3u < nck) sh->stage[(c + 3u) * 64u + lane] = SWAP16(v3);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    u32 S = (e0 - b0 + 63u) >> 6; if (S < 64u) S = 64u;
+    const u32 nl = (e0 - b0 + S - 1u) / S;
+    const u32 rstart = b0 + lane * S;
+    u32 rend = rstart + S; if (rend > e0) rend = e0;
+    u32 entry = lane == 0u ? b0 : (rend > rstart + LZX_LANE_TAIL ? rend - LZX_LANE_TAIL : rstart);
+    u32 n = 0, nb = 0, nmr = 0, exitp = entry, stop_at = 0;      // tokens / output bytes / matches of the stretch
+    bool dead = false, changed = lane < nl;
+    for (u32 round = 0; ; ) {
+      u32 p = entry, cnt = 0, cb = 0, cm = 0, sa = 0;
+      bool dd = false;
+      while (ballot(changed && p < rend)) {
+        const bool on = changed && p < rend;
+        const u32 pp = on ? p : 0u;
+        const u32 k = pp >> 5, sft = pp & 31u;
+        const u32 i0 = sh->stage[k], i1 = sh->stage[k + 1u];
+        const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+        u32 w1 = 0;
+        if (ALIGNED) { const u32 i2 = sh->stage[k + 2u]; w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32); }
+        EMIT_MAIN_ENTRY(e, w0, on)
+        const u32 ml = e >> LZX_MSH, sy = e & LZX_MMASK;
+        const bool nlen = on && e != 0u && sy >= 256u && ((sy - 256u) & 7u) == 7u;
+        EMIT_LEN_ENTRY(e2, w0, ml, nlen)
+        bool unk; u32 ol;
+        const u32 tot = lzx_adv_olen<ALIGNED>(sh, length_empty, e, e2, w0, w1, unk, ol);
+        if (on) {
+          if (unk || e == 0u) { dd = true; sa = p; p = rend; }
+          else { cnt++; cb += ol; cm += sy >= 256u ? 1u : 0u; p += tot; }
+        }
+      }
+      if (changed) { n = cnt; nb = cb; nmr = cm; exitp = p; dead = dd; stop_at = sa; }
+      round++;
+      const u32 pe = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) exitp);
+      const u32 ne = lane == 0u ? b0 : pe;
+      changed = lane < nl && ne != entry;
+      entry = ne;
+      if (!ballot(changed) || round >= LZX_LANE_ROUNDS) break;
+    }
+    // ---- the consistent prefix: lanes < mm ----
+    u32 m = nl;
+    { const u64 chm = ballot(changed); if (chm) m = (u32) __ffsll((long long) chm) - 1u; }
+    u32 mm = m, dl = 0;
+    bool hit = false;
+    { const u64 dm = ballot(dead && lane < m); if (dm) { dl = (u32) __ffsll((long long) dm) - 1u; mm = dl + 1u; hit = true; } }
+    const u32 cvb = lane < mm ? nb : 0u, cvm = lane < mm ? nmr : 0u;
+    const u32 inclb = wave_incl_scan(cvb), inclm = wave_incl_scan(cvm);
+    // ---- last walk: literals into the output, one record per match ----
+    const u32 my_n = lane < mm ? n : 0u;
+    u32 p = entry, i = 0, pos = P + inclb - cvb, j = tt + inclm - cvm;
+    bool cross = false;
+    while (ballot(i < my_n && pos < frame_size && !cross)) {
+      const bool on = i < my_n && pos < frame_size && !cross;
+      const u32 pp = on ? p : 0u;
+      const u32 k = pp >> 5, sft = pp & 31u;
+      const u32 i0 = sh->stage[k], i1 = sh->stage[k + 1u], i2 = sh->stage[k + 2u];
+      const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
+      const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
+      EMIT_MAIN_ENTRY(e, w0, on)
+      const u32 ml = e >> LZX_MSH, sy = e & LZX_MMASK;
+      const bool is_match = sy >= 256u;
+      const u32 mq = sy - 256u, slot = mq >> 3, lh = mq & 7u;
+      const bool nlen = on && is_match && lh == 7u;
+      EMIT_LEN_ENTRY(e2, w0, ml, nlen)
+      u64 r = (((u64) w0 << 32) | w1) << ml;
+      u32 tot = ml;
+      u32 mlen = lh + 2u;
+      if (is_match && lh == 7u) { const u32 l2 = e2 >> 10; r <<= l2; tot += l2; mlen += e2 & 1023u; }
+      const int ex_ = (int)(slot >> 1) - 1;
+      const u32 extra = (u32)(ex_ < 0 ? 0 : (ex_ > 17 ? 17 : ex_));
+      u32 off = (((slot < 36u) ? 2u + (slot & 1u) : slot - 34u) << extra) - 2u;
+      const bool expl = is_match && slot >= 3u;
+      if (ALIGNED) {
+        const bool ali = extra >= 3u;
+        const u32 nbx = ali ? extra - 3u : extra;
+        const u32 vb = nbx ? (u32)(r >> (64u - nbx)) : 0u;
+        const u64 r2 = r << nbx;
+        const u32 e3 = sh->ali_tab[(u32)(r2 >> (64 - LZX_ALI_P))];
+        if (expl) { tot += nbx; if (ali) { off += (vb << 3) + (e3 & 1023u); tot += e3 >> 10; } else off += vb; }
+      }
+      else {
+        const u32 vb = extra ? (u32)(r >> (64u - extra)) : 0u;
+        if (expl) { off += vb; tot += extra; }
+      }
+      if (on) {
+        if (!is_match) {
+          if (pos >= edge_n) fout[pos] = (u8) sy;
+          else { rec->edge_lit[pos] = (u8) sy; atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
+          pos++; p += tot; i++;
+        }
+        else if (pos + mlen > frame_size) cross = true;          // lzxd.c:678-693: the serial path reports it
+        else {
+          // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
+          mrec[j] = make_uint2(frame_pos + pos, (expl ? ((off < (1u << 21) ? off : 0u) << 11) : 0u) | (mlen << 2) | (expl ? 0u : slot + 1u));
+          j++; pos += mlen; p += tot; i++;
+        }
+      }
+    }
+    // ---- where did this pass get to?  the first lane that did not emit its whole stretch ends the frame ----
+    const u64 tm = ballot(lane < mm && (i < my_n || cross));
+    if (tm) {
+      const u32 kq = (u32) __ffsll((long long) tm) - 1u;
+      P = rdl(pos, kq); tt = rdl(j, kq); B = sb_bit + rdl(p, kq); stop = true;
+    }
+    else {
+      if (mm) { P += rdl(inclb, mm - 1u); tt += rdl(inclm, mm - 1u); }
+      if (hit) { B = sb_bit + rdl(stop_at, dl); stop = true; }
+      else if (mm == 0u) stop = true;
+      else B = sb_bit + rdl(exitp, mm - 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the stage is rewritten by the next pass
+  }
+#undef EMIT_MAIN_ENTRY
+#undef EMIT_LEN_ENTRY
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  if (lane < 4u) rec->edge_mask[lane] = sh->cnt[lane];
+  n_rec = tt; end_bit = B; bytes_done = P;
+}
+#endif  /* LZX_PARSE_ONLY */
+
 // common set-up of the header wave and the parse waves: a decoder on the unit's input, nothing read yet
 __device__ __forceinline__ bool lzx_side_setup(LzxDec &d, LzxState &s, const mspack_hip_unit &u, const u8 *in_arena, LzxShared *sh)
 {
@@ -1914,7 +2157,7 @@ __device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 
 // frame.  Same guesses and same give-up rules as lzx_walk_headers + lzx_parse_frame; the unit's own wave stays the judge.
 // Waiting is safe: the task it waits for has an earlier ticket (shim.hip), i.e. a live wave is working on it.
 // ---------------------------------------------------------------------------------------------------
-__device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, LzxFrameRec *urecs,
+__device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, u8 *out_arena, LzxFrameRec *urecs,
                                uint2 *tok, LzxShared *sh)
 {
   const u32 lane = threadIdx.x;
@@ -1949,14 +2192,15 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   // ---- the header the frame table points at (cf. lzx_walk_headers) ----
   const u32 fo = rfl(ftab[f]);
   bool ok = !(fo >= u.in_len || u.in_len - fo <= 64u);         // the last bytes of the input belong to the EOF-exact reader
-  u32 hdr_start = 0;
+  u32 hdr_start = 0, intel = 0;
   if (ok) {
     d.w.seek(fo, lane);
     d.bb = 0; d.bl = 0; d.rbl = 0; d.near_end = false; d.careful = false; d.err = 0;
     if (first) {                                                // the interval's (stream's) 1 + 32 header bits, lzxd.c:447-453
-      u32 v, hi, lo;
+      u32 v, hi = 0, lo = 0;
       ok = d.read_bits(1, v);
       if (ok && v) ok = d.read_bits(16, hi) && d.read_bits(16, lo);
+      intel = (hi << 16) | lo;
     }
   }
   if (ok) {
@@ -1975,6 +2219,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     rec->n_tokens = 0; rec->hdr_start_bit = hdr_start; rec->end_bit = start_bit;
     rec->block_type = s.block_type; rec->block_length = s.block_length;
     rec->flags = (sh->main_len[0xE8] != 0 ? 2u : 0u);
+    rec->frame_start_bit = fo * 8u; rec->intel_filesize = intel; rec->bytes_done = 0; rec->n_edge = 0;
   }
   lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);        // the next frame's wave may go on
   // ---- tables + tokens (cf. lzx_parse_frame) ----
@@ -1987,18 +2232,22 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   }
   if (tables && s.block_type == 2u) tables = !huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false);
   if (!tables) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); return; }
-  u32 n_tok = 0, end_bit = 0;
+  u32 n_rec = 0, end_bit = 0, bytes_done = 0;
   {
     u32 fe = (f + 1u < nreal) ? rfl(ftab[f + 1u]) : u.in_len;     // where the table says the frame ends (a hint)
     if (fe > u.in_len || fe * 8u <= start_bit) fe = u.in_len;
-    if (s.block_type == 2u) lzx_parse_lanes<true>(d, s.length_empty, start_bit, fe * 8u, tok, n_tok, end_bit);
-    else lzx_parse_lanes<false>(d, s.length_empty, start_bit, fe * 8u, tok, n_tok, end_bit);
+    u8 *const fout = out_arena + u.out_off + (size_t) f * LZX_FRAME;
+    // the frame's first bytes up to the next 128-byte line: another wave may be writing that line (see lzx_parse_emit)
+    const u32 edge_n = (128u - (u32)((size_t) fout & 127u)) & 127u;
+    if (s.block_type == 2u) lzx_parse_emit<true>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done);
+    else lzx_parse_emit<false>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done);
+    if (lane == 0) rec->n_edge = edge_n < fsz ? edge_n : fsz;
   }
   if (lane == 0) {
-    rec->n_tokens = n_tok; rec->end_bit = end_bit;
+    rec->n_tokens = n_rec; rec->end_bit = end_bit; rec->bytes_done = bytes_done;
     rec->flags = rec->flags | (s.length_empty ? 1u : 0u);
   }
-  lzx_status_publish(&rec->status, LZX_ST_PARSED, lane);
+  lzx_status_publish(&rec->status, LZX_ST_EMITTED, lane);
 }
 #endif  /* LZX_PARSE_ONLY */
 
@@ -2094,6 +2343,160 @@ __device__ __forceinline__ int lzx_run_tokens(LzxDec &d, LzxState &s, const u32 
   s.R0 = C.R0; s.R1 = C.R1; s.R2 = C.R2;
   return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// lzx_pipe_commit -- mspack_lzx_pipe's COMMIT task: the serial rest of a unit whose frames were parsed by
+// lzx_pipe_parse.  Frame by frame, in order: wait for the frame's record, check that it continues the unit exactly
+// where the previous frame ended (bit position, one block of the frame's size), store the few literals the parse wave
+// left in the record, then run down the match records 64 at a time: R0-R2 resolved along the list (lzxd.c:565-586;
+// the same prefix-scan as lzx_commit_batch), the reference's source checks (lzxd.c:613-634), the copies through the
+// position-space resolver (spec_queue.hpp).  It stops at the first frame that is not a complete regular one and
+// leaves, in the unit's first record, where serial decoding has to resume (frame, output position, bit position,
+// R0-R2): mspack_decode_lzx (launched behind the pipe) skips what is done, finishes the rest -- at least the last bytes of
+// the input, which always belong to the EOF-exact reader -- and reports.  A failed check discards the frame: the
+// serial path decodes it again from its first bit and reports the error with the reference's code and byte count.
+// ---------------------------------------------------------------------------------------------------
+__device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFrameRec *urecs, const uint2 *utoks, SpecQueueLds *spq)
+{
+  const u32 lane = threadIdx.x;
+  u8 *const out = out_arena + u.out_off;
+  const u32 rf = u.reset_frames;
+  const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
+  const u32 wsize = 1u << u.window_bits;
+  u32 R0 = 1, R1 = 1, R2 = 1;
+  u32 rs_frame = 0, rs_partial = 0, rs_P = 0, rs_next = 0;
+  u32 prev_end = 0;                                              // where the next frame has to begin (bits)
+  for (u32 f = 0; f < nreal; f++) {
+    const bool first = rf ? (f % rf) == 0u : f == 0u;
+    if (first) { R0 = R1 = R2 = 1; }                             // lzxd.c:257-270
+    LzxFrameRec *rec = &urecs[f];
+    u32 st = lzx_status_load(&rec->status);
+    LZX_PIPE_WAIT_BEGIN();
+    // (the frame's parse task has an earlier ticket than this task: a live wave holds it, the status becomes final)
+    for (u32 tries = 0; (st == LZX_ST_NONE || st == LZX_ST_CLAIMED || st == LZX_ST_HEADER) && tries < (1u << 22); tries++) {
+      __builtin_amdgcn_s_sleep(32);
+      st = lzx_status_load(&rec->status);
+    }
+    LZX_PIPE_WAIT_END();
+    if (st != LZX_ST_EMITTED) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
+    if (rfl(rec->frame_start_bit) != prev_end || rfl(rec->block_length) != fsz) break;
+    const u32 frame_pos = f * LZX_FRAME;
+    const u32 n_rec = rfl(rec->n_tokens), bytes = rfl(rec->bytes_done), end_bit = rfl(rec->end_bit);
+    if (bytes > fsz || n_rec > LZX_TOK_CAP) break;
+    // ---- the literals of the frame's first cache line ----
+    {
+      const u32 ne = rfl(rec->n_edge);
+      for (u32 i = lane; i < ne; i += WAVE)
+        if ((rec->edge_mask[i >> 5] >> (i & 31u)) & 1u) out[frame_pos + i] = rec->edge_lit[i];
+    }
+    // ---- the match records ----
+    const u32 eR0 = R0, eR1 = R1, eR2 = R2;
+    const uint2 *mrec = utoks + (size_t) f * LZX_TOK_CAP;
+    const u32 wbase = frame_pos & ~(wsize - 1u);                 // linear position of window index 0 in this pass
+    SpecQueue Q;
+    spq_init(*spq, Q, frame_pos, lane);
+    bool bad = false;
+    uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
+    if (lane < n_rec) cur0 = mrec[lane];
+    if (64u + lane < n_rec) cur1 = mrec[64u + lane];
+    if (128u + lane < n_rec) cur2 = mrec[128u + lane];
+    if (192u + lane < n_rec) cur3 = mrec[192u + lane];
+    for (u32 th = 0; th < n_rec && !bad; ) {
+      uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
+      const u32 tb = th + 256u + lane;
+      if (tb < n_rec) nx0 = mrec[tb];
+      if (tb + 64u < n_rec) nx1 = mrec[tb + 64u];
+      if (tb + 128u < n_rec) nx2 = mrec[tb + 128u];
+      if (tb + 192u < n_rec) nx3 = mrec[tb + 192u];
+#pragma unroll 1
+      for (u32 k = 0; k < 4u && th < n_rec && !bad; k++) {
+        u32 n = n_rec - th; if (n > 64u) n = 64u;
+        const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
+        const bool ism = lane < n;
+        const u32 opos = cur.x, olen = (cur.y >> 2) & 511u, which = cur.y & 3u, c1 = cur.y >> 11;
+        const u64 mm = ballot(ism);
+        // (1) every match's offset through the R0-R2 LRU (cf. lzx_commit_batch)
+        const u32 sR0 = R0, sR1 = R1, sR2 = R2;
+        u32 vmoff = c1;
+        const u64 k1 = ballot(ism && which == 0u);
+        if (!ballot(ism && which >= 2u)) {
+          const u64 below = k1 & ((1ull << lane) - 1ull);
+          const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
+          const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
+          if (which == 1u) vmoff = below ? pv : sR0;
+          if (k1) {
+            u64 m = k1;
+            const u32 j0 = 63u - (u32) __clzll((long long) m);
+            u32 nbv = sR0, ncv = sR1;
+            m &= ~(1ull << j0);
+            if (m) {
+              const u32 j1 = 63u - (u32) __clzll((long long) m);
+              nbv = rdl(c1, j1); ncv = sR0;
+              m &= ~(1ull << j1);
+              if (m) ncv = rdl(c1, 63u - (u32) __clzll((long long) m));
+            }
+            R0 = rdl(c1, j0); R1 = nbv; R2 = ncv;
+          }
+        }
+        else {
+          u32 x = LRU_ID;
+          if (ism) x = which == 0u ? (0x010080u | lane) : (which == 2u ? 0x020001u : (which == 3u ? 0x000102u : LRU_ID));
+          const u32 Cm = lru_scan(x);
+          const u32 e0 = Cm & 0xFFu;
+          const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
+          vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
+          const u32 Cl = rdl(Cm, 63u);
+          const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
+          R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
+          R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
+          R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
+        }
+        // (2) the reference's checks (lzxd.c:613-634); offsets no linear copy serves (0, beyond the window) end the fast path too
+        {
+          const u32 wp = opos - wbase;
+          const bool b = ism && (wp + olen > wsize || LZX_BAD_SOURCE(vmoff, wp, frame_pos, 0u, wsize) ||
+                                 vmoff == 0u || vmoff > wsize || vmoff > opos);
+          if (ballot(b)) { bad = true; break; }
+        }
+        // (3) queue the copies (cf. lzx_commit_batch)
+        {
+          const u32 newP = rdl(opos + olen, n - 1u);
+          u64 mq = mm;
+          if (Q.mcount + (u32) __popcll(mq) > SPQ_CAP) spq_resolve(*spq, Q, out, rdl(opos, 0u), true, lane);
+          bool im = ism;
+          for (;;) {
+            const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
+            const u64 fit = newP <= limit ? mq : ballot(im && opos + olen <= limit);
+            if (fit) {
+              const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+              spq_push(*spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, vmoff, olen);
+              mq &= ~fit;
+              im = lane_in(mq);
+            }
+            if (!mq) break;
+            spq_resolve(*spq, Q, out, rdl(opos, (u32) __ffsll((long long) mq) - 1u), true, lane);
+          }
+          if (spq_due(Q, newP)) spq_resolve(*spq, Q, out, newP, false, lane);
+        }
+        th += n;
+      }
+      cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
+    }
+    if (bad) { R0 = eR0; R1 = eR1; R2 = eR2; break; }            // the serial path decodes this frame from its first bit
+    spq_resolve(*spq, Q, out, frame_pos + bytes, true, lane);
+    if (bytes < fsz) { rs_partial = 1; rs_P = frame_pos + bytes; rs_next = end_bit; break; }
+    prev_end = (end_bit + 15u) & ~15u;
+    rs_frame = f + 1u;
+  }
+  if (!rs_partial) { rs_P = rs_frame * LZX_FRAME; rs_next = prev_end; }
+  if (lane == 0) {
+    LzxFrameRec *r0 = &urecs[0];
+    r0->rs_frame = rs_frame; r0->rs_partial = rs_partial; r0->rs_P = rs_P; r0->rs_next_bit = rs_next;
+    r0->rs_R0 = R0; r0->rs_R1 = R1; r0->rs_R2 = R2; r0->rs_valid = 1u;
+  }
+}
 #endif  /* !LZX_PARSE_ONLY */
 #endif  /* !LZX_DELTA */
 
@@ -2105,11 +2508,12 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
                                 int32_t *frame_meta, mspack_hip_result *res, LzxShared *sh)
 #else
 // recs / toks: the parse waves' records and tokens for this launch (NULL: none), indexed by frame slot
-// pipe: the records are being produced in this same launch (mspack_lzx_pipe): a frame's record is waited for while a
-// parse wave is working on it, and taken over (decoded serially here) when none has started yet
+// resume: the launch ran mspack_lzx_pipe first -- the unit's first record says how far its commit task got (rs_*: so many
+// complete frames, possibly part of the next one).  Those frames are not decoded again: only their bookkeeping (interval
+// header, E8 decision, offsets, in_next) is replayed from their records, and decoding goes on serially where the pipe stopped
 __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
                                 int32_t *frame_meta, mspack_hip_result *res, LzxShared *sh,
-                                const LzxFrameRec *recs, const uint2 *toks, const bool pipe = false)
+                                const LzxFrameRec *recs, const uint2 *toks, const bool resume = false)
 #endif
 {
   const u32 lane = threadIdx.x;
@@ -2170,6 +2574,17 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
   bool chain_ok = use_recs;                 // every frame since the last reset point was adopted
   const LzxFrameRec *stale = nullptr;       // adopted record whose code lengths / tables are not in LDS (yet)
   bool stale_tables = false;
+  // where mspack_lzx_pipe's commit task stopped (resume): rs_frame complete frames, then possibly part of frame rs_frame
+  bool rs_on = false, rs_partial = false, rs_inject = false, positioned = true;
+  u32 rs_frame = 0, rs_P = 0, rs_next = 0, rs_R0 = 1, rs_R1 = 1, rs_R2 = 1, ff_end = 0;
+  if (resume && use_recs) {
+    const LzxFrameRec *r0 = &recs[u.frame_base];
+    if (rfl(r0->rs_valid) == 1u) {
+      rs_on = true; positioned = false;
+      rs_frame = rfl(r0->rs_frame); rs_partial = rfl(r0->rs_partial) != 0u; rs_P = rfl(r0->rs_P); rs_next = rfl(r0->rs_next_bit);
+      rs_R0 = rfl(r0->rs_R0); rs_R1 = rfl(r0->rs_R1); rs_R2 = rfl(r0->rs_R2);
+    }
+  }
 #endif
   if (out_bytes != 0u) {
     const u32 end_frame = out_bytes / LZX_FRAME + 1u;                      // lzxd.c:419
@@ -2181,6 +2596,18 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
         chain_ok = use_recs; stale = nullptr; stale_tables = false;
 #endif
       }
+#ifndef LZX_DELTA
+      const bool ff = rs_on && s.frame < rs_frame;                   // done by the pipe: bookkeeping only
+      const bool pf = rs_on && s.frame == rs_frame && rs_partial;    // partly done: go on behind its last record
+      const LzxFrameRec *frec = (ff || pf) ? &recs[u.frame_base + s.frame] : nullptr;
+      if (rs_on && s.frame == rs_frame && !rs_partial) {
+        // serial decoding starts with this frame: the state the pipe left at its first bit
+        lzx_seek_bit(d, rs_next);
+        d.P = rs_P; s.R0 = rs_R0; s.R1 = rs_R1; s.R2 = rs_R2;
+        if (rs_frame != 0u && !(s.reset_frames && (s.frame % s.reset_frames) == 0u)) stale = &recs[u.frame_base + rs_frame - 1u];
+        rs_on = false; positioned = true;
+      }
+#endif
 #ifdef LZX_DELTA
       {                                                               // chunk size (lzxd.c:440-444)
         u32 cs;
@@ -2194,9 +2621,15 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
 #endif
       if (!s.header_read) {
         u32 v, hi = 0, lo = 0;
-        lzx_leave_raw(d, s);
-        if (!d.read_bits(1, v)) break;
-        if (v) { if (!d.read_bits(16, hi) || !d.read_bits(16, lo)) break; }
+#ifndef LZX_DELTA
+        if (frec) { const u32 iv = rfl(frec->intel_filesize); hi = iv >> 16; lo = iv & 0xFFFFu; }   // (its parse wave read the bits)
+        else
+#endif
+        {
+          lzx_leave_raw(d, s);
+          if (!d.read_bits(1, v)) break;
+          if (v) { if (!d.read_bits(16, hi) || !d.read_bits(16, lo)) break; }
+        }
         s.intel_filesize = (int32_t)((hi << 16) | lo);
         if (s.intel_filesize) flags |= MSPACK_HIP_F_INTEL_HEADER;
         s.header_read = true;
@@ -2207,33 +2640,32 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
       int todo = (int)(s.frame_posn + frame_size - s.wpos);
       bool fail = false;
 #ifndef LZX_DELTA
+      if (ff) {
+        // a frame the pipe finished: one block of the frame's size, decoded and in place
+        s.block_type = rfl(frec->block_type); s.block_length = frame_size; s.block_remaining = 0;
+        const u32 rfl_ = rfl(frec->flags);
+        s.length_empty = (rfl_ & 1u) != 0u;
+        if (rfl_ & 2u) s.intel_started = true;
+        flags |= MSPACK_HIP_F_FRAMES_ADOPTED;
+        d.P += frame_size; s.wpos += frame_size;
+        ff_end = (rfl(frec->end_bit) + 15u) & ~15u;                  // behind the 16-bit realignment (lzxd.c:695-697)
+        todo = 0;
+      }
       // ---- a parse wave's record for this frame?  adopt it if it was parsed from exactly this state ----
       const LzxFrameRec *adopt = nullptr;
-      if (chain_ok && todo > 0 && s.block_remaining == 0u && !s.raw_mode && !d.careful && !d.near_end) {
+      if (pf) {
+        s.block_type = rfl(frec->block_type);
+        s.block_length = s.block_remaining = rfl(frec->block_length);
+        const u32 rfl_ = rfl(frec->flags);
+        s.length_empty = (rfl_ & 1u) != 0u;
+        if (rfl_ & 2u) s.intel_started = true;
+        stale = frec; stale_tables = true;
+        flags |= MSPACK_HIP_F_FRAMES_ADOPTED;
+        rs_inject = true; rs_on = false; chain_ok = false;
+      }
+      else if (chain_ok && todo > 0 && s.block_remaining == 0u && !s.raw_mode && !d.careful && !d.near_end) {
         const LzxFrameRec *r = &recs[u.frame_base + s.frame];
-        u32 st;
-        if (!pipe) st = rfl(r->status);
-        else {
-          u32 *sp = (u32 *) &r->status;
-          st = lzx_status_load(sp);
-          // The frame's parse task has an earlier ticket than this unit's task (mspack_lzx_pipe), so a live wave holds it
-          // and the status WILL become final: wait.  The take-over below is a safety net (it keeps a launch whose
-          // tickets were ever handed out in another order from hanging), not a path that is expected to run.
-          LZX_PIPE_WAIT_BEGIN();
-          for (u32 tries = 0; (st == LZX_ST_NONE && tries < (1u << 17)) || st == LZX_ST_CLAIMED || st == LZX_ST_HEADER; tries++) {
-            __builtin_amdgcn_s_sleep(32);
-            st = lzx_status_load(sp);
-          }
-          if (st == LZX_ST_NONE) {
-            u32 old = 0;
-            if (lane == 0) old = atomicCAS(sp, LZX_ST_NONE, LZX_ST_TAKEN);
-            old = rfl(old);
-            st = old == LZX_ST_NONE ? LZX_ST_TAKEN : old;
-            while (st == LZX_ST_CLAIMED || st == LZX_ST_HEADER) { __builtin_amdgcn_s_sleep(32); st = lzx_status_load(sp); }
-          }
-          LZX_PIPE_WAIT_END();
-          if (st == LZX_ST_PARSED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
+        const u32 st = rfl(r->status);
         if (st == LZX_ST_PARSED && rfl(r->hdr_start_bit) == rfl(d.w.origin) * 8u + rfl(d.cons_bits()) &&
             rfl(r->block_length) == frame_size) adopt = r;
       }
@@ -2283,6 +2715,13 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
             adopt = nullptr;
             if (rc == LZX_RUN_FAIL) { fail = true; }
             else lzx_seek_bit(d, next_bit);
+          }
+          else if (rs_inject) {
+            // the pipe committed this frame's records up to rs_P: go on from the bit behind the last of them
+            rs_inject = false; positioned = true;
+            d.flush_lits();
+            d.P = rs_P; s.R0 = rs_R0; s.R1 = rs_R1; s.R2 = rs_R2;
+            lzx_seek_bit(d, rs_next);
           }
           if (!fail && d.P < run_end && stale_tables) {      // the record did not reach the end of the run
             if (stale) { lzx_restore_lens(d, stale); stale = nullptr; }
@@ -2402,15 +2841,24 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
       if ((s.wpos - s.frame_posn) != frame_size) { d.err = ERR_DECRUNCH; break; }  // lzxd.c:689
 
       // re-align the bitstream to 16 bits (lzxd.c:695-697)
-      if (!s.raw_mode) {
-        if (d.careful) { if (d.rbl > 0 && !d.ref_ensure(16)) break; }
-        int n = d.bl & 15;
-        if (d.bl < n) d.refill();
-        if (n) d.drop(n);
+#ifndef LZX_DELTA
+      if (ff) {                    // (a frame the pipe finished: its record says where the stream goes on)
+        in_next = ff_end >> 3;
+        flags &= ~MSPACK_HIP_F_BLOCK_OPEN;
       }
-      if (frame_size) {            // for callers that chain units (CHM reset intervals): where the next frame starts
-        in_next = s.raw_mode ? s.raw_pos : d.w.origin + (d.cons_bits() >> 3);
-        flags = s.block_remaining ? (flags | MSPACK_HIP_F_BLOCK_OPEN) : (flags & ~MSPACK_HIP_F_BLOCK_OPEN);
+      else
+#endif
+      {
+        if (!s.raw_mode) {
+          if (d.careful) { if (d.rbl > 0 && !d.ref_ensure(16)) break; }
+          int n = d.bl & 15;
+          if (d.bl < n) d.refill();
+          if (n) d.drop(n);
+        }
+        if (frame_size) {            // for callers that chain units (CHM reset intervals): where the next frame starts
+          in_next = s.raw_mode ? s.raw_pos : d.w.origin + (d.cons_bits() >> 3);
+          flags = s.block_remaining ? (flags | MSPACK_HIP_F_BLOCK_OPEN) : (flags & ~MSPACK_HIP_F_BLOCK_OPEN);
+        }
       }
 
       // E8: record what the translation pass must do for this frame (lzxd.c:707-708)
@@ -2430,6 +2878,9 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
       if (s.frame_posn == s.wsize) s.frame_posn = 0;
     }
   }
+#ifndef LZX_DELTA
+  if (!positioned && d.err == 0) lzx_seek_bit(d, ff_end);          // every frame came from the pipe: the reader stands behind the last one
+#endif
 #if defined(LZX_PHASE_TIMERS) && !defined(LZX_DELTA)
   if (lane == 0 && (blockIdx.x & 1023u) == 0u)
     printf("lzx unit %u: total %llu clk; run_tokens %u clk (commit_batch %u, resolve %u) in %u batches, %u tokens\n", blockIdx.x,

@@ -27,7 +27,7 @@
 
 #define ZIP_TOK_CAP 16384u         /* tokens a parse wave stores per CFDATA block (same slot size as LZX_TOK_CAP) */
 
-// what a parse wave leaves for the unit's wave (same 1152-byte slots as LzxFrameRec; only the head is used)
+// what a parse wave leaves for the unit's wave (same 1344-byte slots as LzxFrameRec; only the head is used)
 struct ZipBlockRec {
   u32 status;                      /* 1 = the whole CFDATA block was parsed */
   u32 n_tokens;
@@ -35,9 +35,9 @@ struct ZipBlockRec {
   u32 end_bit;                     /* first bit behind the last end-of-block symbol */
   u32 eob_rbl;                     /* the reference's bits_left there */
   u32 total_out;                   /* bytes the block produces (<= 32768) */
-  u32 pad[282];
+  u32 pad[330];
 };
-static_assert(sizeof(ZipBlockRec) == 1152, "ZipBlockRec slot size");
+static_assert(sizeof(ZipBlockRec) == 1344, "ZipBlockRec slot size");
 
 struct __align__(16) MszipShared {
   u16 lit_tab[1 << ZIP_LIT_P];

@@ -104,6 +104,7 @@ void mspack_lzx_pipe_map(const mspack_hip_unit *units, const u32 *order, u32 n_u
         frame_unit[u.frame_base + f] = (usable && f < nreal) ? ui : 0xFFFFFFFFu;
         recs[u.frame_base + f].status = 0u;
       }
+      recs[u.frame_base].rs_valid = 0u;
       fr = usable ? nreal : 0u;
     }
     else other = true;
@@ -169,7 +170,7 @@ void mspack_lzx_parse(const mspack_hip_unit *units, const u32 *order, u32 n_unit
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_units,
                        const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
-                       int32_t *frame_meta, const lzxn::LzxFrameRec *recs, const uint2 *toks)
+                       int32_t *frame_meta, const lzxn::LzxFrameRec *recs, const uint2 *toks, u32 resume)
 {
   __shared__ lzxn::LzxShared sh;
   u32 ui;
@@ -177,7 +178,7 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
   const mspack_hip_unit u = units[ui];
   mspack_hip_result *res = &results[ui];
   const u32 lane = threadIdx.x;
-  lzxn::lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, &sh, recs, toks);
+  lzxn::lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, &sh, recs, toks, resume != 0u);
   // E8 translation, frame by frame, once the unit no longer needs its window (lzxd.c:706-736)
   if (frame_meta) {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -212,34 +213,21 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
 // serially.  Hand-off: record + tokens by plain stores, agent-scope release, relaxed status store; the reader polls the
 // status relaxed, then one agent-scope acquire (lzx_kernel.hpp).
 // ---------------------------------------------------------------------------------------------------
-union LzxPipeLds { lzxp::LzxShared p; lzxn::LzxShared n; };
+union LzxPipeLds { lzxp::LzxShared p; SpecQueueLds q; };
 static_assert(sizeof(LzxPipeLds) <= 10240, "16 waves per CU");
 
 // the two task bodies are real calls: each gets its own register allocation (inlined into the ticket loop they spill)
-__device__ __attribute__((noinline)) void lzx_pipe_task_parse(const mspack_hip_unit *up, const u32 f, const u8 *in_arena,
+__device__ __attribute__((noinline)) void lzx_pipe_task_parse(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
                                                               lzxn::LzxFrameRec *recs, uint2 *toks, lzxp::LzxShared *sh)
 {
   const mspack_hip_unit u = *up;
-  lzxp::lzx_pipe_parse(u, f, in_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], toks + (size_t)(u.frame_base + f) * LZX_TOK_CAP, sh);
+  lzxp::lzx_pipe_parse(u, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], toks + (size_t)(u.frame_base + f) * LZX_TOK_CAP, sh);
 }
-__device__ __attribute__((noinline)) void lzx_pipe_task_unit(const mspack_hip_unit *up, const u8 *in_arena, u8 *out_arena,
-                                                             mspack_hip_result *res, int32_t *frame_meta,
-                                                             const lzxn::LzxFrameRec *recs, const uint2 *toks, lzxn::LzxShared *sh)
+__device__ __attribute__((noinline)) void lzx_pipe_task_commit(const mspack_hip_unit *up, u8 *out_arena, lzxn::LzxFrameRec *recs,
+                                                               const uint2 *toks, SpecQueueLds *spq)
 {
   const mspack_hip_unit u = *up;
-  const u32 lane = threadIdx.x;
-  lzxn::lzx_decode_unit(u, in_arena, out_arena, frame_meta, res, sh, recs, toks, true);
-  if (frame_meta) {                                             // E8 translation, as mspack_decode_lzx does it
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const u32 produced = rfl(res->out_len);
-    const u32 nfr = (produced + LZX_FRAME - 1u) / LZX_FRAME;
-    for (u32 fr = 0; fr < nfr; fr++) {
-      const int32_t fs = (int32_t) rfl((u32) frame_meta[u.frame_base + fr]);
-      if (fs == 0) continue;
-      u32 fsize = u.out_len - fr * LZX_FRAME; if (fsize > LZX_FRAME) fsize = LZX_FRAME;
-      lzxn::lzx_e8_frame(out_arena + u.out_off + (size_t) fr * LZX_FRAME, fsize, (int32_t)((u32) u.e8_base + fr * LZX_FRAME), fs, lane);
-    }
-  }
+  lzxn::lzx_pipe_commit(u, out_arena, &recs[u.frame_base], toks + (size_t) u.frame_base * LZX_TOK_CAP, spq);
 }
 
 #ifdef LZX_PIPE_TRACE      /* analysis builds: one line per ticket = start, end (s_memrealtime, 100 MHz), task, time waited */
@@ -294,9 +282,12 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
 #endif
     if (!commit) {
       if (!(rfl(up->flags) & MSPACK_HIP_UF_FRAME_TABLE)) continue;
-      lzx_pipe_task_parse(up, f, in_arena, recs, toks, &sh.p);
+      lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &sh.p);
     }
-    else lzx_pipe_task_unit(up, in_arena, out_arena, &results[ui], frame_meta, recs, toks, &sh.n);
+    else {
+      if (!(rfl(up->flags) & MSPACK_HIP_UF_FRAME_TABLE)) continue;       // (no records: mspack_decode_lzx decodes it serially)
+      lzx_pipe_task_commit(up, out_arena, recs, toks, &sh.q);
+    }
 #ifdef LZX_PIPE_TRACE
     if (lane == 0 && t < (1u << 16)) {
       g_pipe_trace[4u * t] = tr0; g_pipe_trace[4u * t + 1u] = __builtin_amdgcn_s_memrealtime();
@@ -456,6 +447,10 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
       hipLaunchKernelGGL(mspack_lzx_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
                          (const u8 *) d_in, (u8 *) d_out, d_results, L.meta, (const u32 *) L.frame_unit, hdr, L.recs, L.toks);
+      // what the pipe leaves: the last bytes of every unit's input (the EOF-exact reader's), the look-ahead frame, frames
+      // that are not one regular block, errors, E8, the results -- the unit kernel, resuming where each unit's commit task stopped
+      hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
+                         d_results, L.meta, (const lzxn::LzxFrameRec *) L.recs, (const uint2 *) L.toks, 1u);
       break;
     }
     if (frames) {
@@ -468,7 +463,7 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
     }
     hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
                        d_results, d_fm ? L.meta : nullptr, frames ? (const lzxn::LzxFrameRec *) L.recs : nullptr,
-                       (const uint2 *) L.toks);
+                       (const uint2 *) L.toks, 0u);
     break; }
   case MSPACK_HIP_KIND_LZX_DELTA:
     hipLaunchKernelGGL(mspack_decode_lzxd, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
