@@ -1498,6 +1498,23 @@ static_assert(sizeof(LzxFrameRec) == 1344, "LzxFrameRec layout");
 //   lengths is broken for the rest of the reset interval) | 6 the unit's own wave took the frame (decodes it serially)
 #ifdef LZX_PIPE_TRACE      /* analysis builds: time a unit task spends waiting for parse tasks (shim.hip: g_pipe_wait) */
 __device__ unsigned long long g_pipe_wait[1 << 16];
+__device__ unsigned long long g_pipe_phase[16];     /* summed over all waves: s_memrealtime ticks per phase (PH below) */
+/* (accumulated in registers, added to the global sums once per task: an atomic per stamp would serialise the waves) */
+#define PHDECL() u32 pha_[12] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u }
+#define PH0() unsigned long long ph_ = __builtin_amdgcn_s_memrealtime()
+#define PH(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); pha_[k] += (u32)(n_ - ph_); ph_ = n_; } while (0)
+#define PHE0() unsigned long long phe_ = __builtin_amdgcn_s_memrealtime()
+#define PHE(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); d.st_t[k] += (u32)(n_ - phe_); phe_ = n_; } while (0)
+#define PHFLUSH() do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 12; k_++) if (pha_[k_]) atomicAdd(&g_pipe_phase[k_], (unsigned long long) pha_[k_]); } while (0)
+#else
+#define PHDECL() do { } while (0)
+#define PHE0() do { } while (0)
+#define PHE(k) do { } while (0)
+#define PH0() do { } while (0)
+#define PH(k) do { } while (0)
+#define PHFLUSH() do { } while (0)
+#endif
+#ifdef LZX_PIPE_TRACE
 #define LZX_PIPE_WAIT_BEGIN() const unsigned long long pw_ = __builtin_amdgcn_s_memrealtime()
 #define LZX_PIPE_WAIT_END() do { if (threadIdx.x == 0) g_pipe_wait[blockIdx.x & 0xFFFFu] += __builtin_amdgcn_s_memrealtime() - pw_; } while (0)
 #else
@@ -1884,23 +1901,24 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
   }
 
   while (!stop && B < Eall && P < frame_size) {
+    PHE0();
     // ---- stage the input from the dword that holds bit B ----
     const u32 sb_byte = (B >> 5) << 2, sb_bit = sb_byte * 8u;
     u32 E = sb_bit + LZX_STAGE_WORDS * 32u; if (E > Eall) E = Eall;
     const u32 b0 = B - sb_bit, e0 = E - sb_bit;
     d.w.origin = sb_byte;
     {
-      const u32 nck = (e0 + 128u + 2047u) >> 11;
-      for (u32 c = 0; c < nck; c += 4u) {
-        const u32 v0 = d.w.load_chunk(c, lane), v1 = d.w.load_chunk(c + 1u, lane);
-        const u32 v2 = d.w.load_chunk(c + 2u, lane), v3 = d.w.load_chunk(c + 3u, lane);
-        sh->stage[c * 64u + lane] = SWAP16(v0);
-        if (c + 1u < nck) sh->stage[(c + 1u) * 64u + lane] = SWAP16(v1);
-        if (c + 2u < nck) sh->stage[(c + 2u) * 64u + lane] = SWAP16(v2);
-        if (c + 3u < nck) sh->stage[(c + 3u) * 64u + lane] = SWAP16(v3);
-      }
+      // every chunk of the pass is requested before the first one is waited for: one memory round trip per pass
+      const u32 nck = (e0 + 128u + 2047u) >> 11;               // a token that starts below e0 ends below e0 + 53
+      constexpr int NCH = (int)(LZX_STAGE_WORDS / 64u) + 1;
+      u32 sv[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) sv[c] = (u32) c < nck ? d.w.load_chunk((u32) c, lane) : 0u;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) if ((u32) c < nck) sh->stage[(u32) c * 64u + lane] = SWAP16(sv[c]);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    PHE(6);
     u32 S = (e0 - b0 + 63u) >> 6; if (S < 64u) S = 64u;
     const u32 nl = (e0 - b0 + S - 1u) / S;
     const u32 rstart = b0 + lane * S;
@@ -1946,6 +1964,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     { const u64 dm = ballot(dead && lane < m); if (dm) { dl = (u32) __ffsll((long long) dm) - 1u; mm = dl + 1u; hit = true; } }
     const u32 cvb = lane < mm ? nb : 0u, cvm = lane < mm ? nmr : 0u;
     const u32 inclb = wave_incl_scan(cvb), inclm = wave_incl_scan(cvm);
+    PHE(7);
     // ---- last walk: literals into the output, one record per match ----
     const u32 my_n = lane < mm ? n : 0u;
     u32 p = entry, i = 0, pos = P + inclb - cvb, j = tt + inclm - cvm;
@@ -1997,6 +2016,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
         }
       }
     }
+    PHE(8);
     // ---- where did this pass get to?  the first lane that did not emit its whole stretch ends the frame ----
     const u64 tm = ballot(lane < mm && (i < my_n || cross));
     if (tm) {
@@ -2174,6 +2194,8 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   const u32 rf = u.reset_frames;
   const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
   const bool first = rf ? (f % rf) == 0u : f == 0u;
+  PHDECL();
+  PH0();
   if (first) lzx_reset_state(d, s);
   else {
     const LzxFrameRec *pr = rec - 1;
@@ -2189,6 +2211,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) sh->len_len[i] = pr->len_len[i];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
+  PH(0);
   // ---- the header the frame table points at (cf. lzx_walk_headers) ----
   const u32 fo = rfl(ftab[f]);
   bool ok = !(fo >= u.in_len || u.in_len - fo <= 64u);         // the last bytes of the input belong to the EOF-exact reader
@@ -2212,6 +2235,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   if (ok) ok = (s.block_type == 1u || s.block_type == 2u) && s.block_length == fsz;    // one block per frame, or no guess
   if (!ok) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
   const u32 start_bit = fo * 8u + d.cons_bits();                // the frame's first token
+  PH(1);
   for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) rec->main_len[i] = sh->main_len[i];
   for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) rec->len_len[i] = sh->len_len[i];
   if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
@@ -2222,6 +2246,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     rec->frame_start_bit = fo * 8u; rec->intel_filesize = intel; rec->bytes_done = 0; rec->n_edge = 0;
   }
   lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);        // the next frame's wave may go on
+  PH(2);
   // ---- tables + tokens (cf. lzx_parse_frame) ----
   bool tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
                                                               sh->cnt, d.hr_main, lane, false);
@@ -2232,6 +2257,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   }
   if (tables && s.block_type == 2u) tables = !huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false);
   if (!tables) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); return; }
+  PH(3);
   u32 n_rec = 0, end_bit = 0, bytes_done = 0;
   {
     u32 fe = (f + 1u < nreal) ? rfl(ftab[f + 1u]) : u.in_len;     // where the table says the frame ends (a hint)
@@ -2247,7 +2273,13 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     rec->n_tokens = n_rec; rec->end_bit = end_bit; rec->bytes_done = bytes_done;
     rec->flags = rec->flags | (s.length_empty ? 1u : 0u);
   }
+  PH(4);
   lzx_status_publish(&rec->status, LZX_ST_EMITTED, lane);
+  PH(5);
+#ifdef LZX_PIPE_TRACE
+  pha_[6] = d.st_t[6]; pha_[7] = d.st_t[7]; pha_[8] = d.st_t[8];
+#endif
+  PHFLUSH();
 }
 #endif  /* LZX_PARSE_ONLY */
 
@@ -2366,6 +2398,7 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
   u32 R0 = 1, R1 = 1, R2 = 1;
   u32 rs_frame = 0, rs_partial = 0, rs_P = 0, rs_next = 0;
   u32 prev_end = 0;                                              // where the next frame has to begin (bits)
+  PHDECL();
   for (u32 f = 0; f < nreal; f++) {
     const bool first = rf ? (f % rf) == 0u : f == 0u;
     if (first) { R0 = R1 = R2 = 1; }                             // lzxd.c:257-270
@@ -2379,6 +2412,7 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
     }
     LZX_PIPE_WAIT_END();
     if (st != LZX_ST_EMITTED) break;
+    PH0();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
     if (rfl(rec->frame_start_bit) != prev_end || rfl(rec->block_length) != fsz) break;
@@ -2460,6 +2494,7 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
                                  vmoff == 0u || vmoff > wsize || vmoff > opos);
           if (ballot(b)) { bad = true; break; }
         }
+        PH(9);
         // (3) queue the copies (cf. lzx_commit_batch)
         {
           const u32 newP = rdl(opos + olen, n - 1u);
@@ -2478,7 +2513,9 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
             if (!mq) break;
             spq_resolve(*spq, Q, out, rdl(opos, (u32) __ffsll((long long) mq) - 1u), true, lane);
           }
+          PH(10);
           if (spq_due(Q, newP)) spq_resolve(*spq, Q, out, newP, false, lane);
+          PH(11);
         }
         th += n;
       }
@@ -2496,6 +2533,7 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
     r0->rs_frame = rs_frame; r0->rs_partial = rs_partial; r0->rs_P = rs_P; r0->rs_next_bit = rs_next;
     r0->rs_R0 = R0; r0->rs_R1 = R1; r0->rs_R2 = R2; r0->rs_valid = 1u;
   }
+  PHFLUSH();
 }
 #endif  /* !LZX_PARSE_ONLY */
 #endif  /* !LZX_DELTA */

@@ -233,7 +233,10 @@ __device__ __attribute__((noinline)) void lzx_pipe_task_commit(const mspack_hip_
 #ifdef LZX_PIPE_TRACE      /* analysis builds: one line per ticket = start, end (s_memrealtime, 100 MHz), task, time waited */
 __device__ unsigned long long g_pipe_trace[4 << 16];
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+#ifndef LZX_PIPE_WAVES_PER_EU
+#define LZX_PIPE_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZX_PIPE_WAVES_PER_EU)))
 void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
                      const u8 *in_arena, u8 *out_arena, mspack_hip_result *results, int32_t *frame_meta,
                      const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks)
@@ -243,7 +246,11 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
   // all units carry a table and have the same number of frames F: section 1 = n_units * (F - 1) tickets, frame-major
   const u32 Fmax = rfl(ctl[0]), Fmin = rfl(ctl[1]);
   const u32 F = (Fmax != 0u && Fmax == Fmin) ? Fmax : 0u;
-  const u32 T1 = F ? n_units * (F - 1u) : n_slots, T = T1 + 2u * n_units;
+  // section 2: the last frames' parse tasks run K units ahead of the units' commit tasks, so that a commit task finds
+  // its last frame parsed when it has committed the frames before it (measured: without the lead a unit task waited
+  // 0.18 ms on average, and the launch ended with units whose last frame was still being parsed)
+  const u32 K = n_units < 4u ? n_units : n_units / 4u;
+  const u32 T1 = F ? n_units * (F - 1u) : n_slots, T = T1 + K + 2u * n_units;
   for (;;) {
     u32 t = 0;
     if (lane == 0) t = atomicAdd(&ctl[2], 1u);
@@ -263,10 +270,16 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
       }
     }
     else {
-      const u32 j = (t - T1) >> 1;
-      ui = rfl(order ? order[j] : j);
-      if ((t - T1) & 1u) commit = true;
+      u32 j;
+      if (t - T1 < K) j = t - T1;                                 // P(j)
       else {
+        const u32 r = t - T1 - K;
+        j = r >> 1;
+        if (!(r & 1u)) commit = true;                             // C(j), then P(j + K)
+        else { j += K; if (j >= n_units) continue; }
+      }
+      ui = rfl(order ? order[j] : j);
+      if (!commit) {
         const mspack_hip_unit &uu = units[ui];
         const u32 nreal = (rfl(uu.out_len) + LZX_FRAME - 1u) / LZX_FRAME;
         if (rfl((u32) uu.kind) != MSPACK_HIP_KIND_LZX || !(rfl(uu.flags) & MSPACK_HIP_UF_FRAME_TABLE) || nreal == 0u) ui = 0xFFFFFFFFu;
@@ -443,7 +456,7 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, 0, st, d_units, d_order, (u32) n, L.frame_unit,
                          L.recs, hdr);
-      const size_t tickets = n_slots + 2u * n;
+      const size_t tickets = n_slots + 3u * n;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
       hipLaunchKernelGGL(mspack_lzx_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
                          (const u8 *) d_in, (u8 *) d_out, d_results, L.meta, (const u32 *) L.frame_unit, hdr, L.recs, L.toks);
@@ -510,6 +523,14 @@ int mspack_hip_debug_counters(unsigned long long *out8) {
 #ifdef LZX_PIPE_TRACE
 int mspack_hip_debug_pipe_trace(unsigned long long *out, size_t n_words) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pipe_trace), n_words * 8) == hipSuccess ? 0 : -1;
+}
+/* ticks (100 MHz) per phase summed over all waves: lzxp:: phases 0-8 (parse task), lzxn:: phases 9-11 (commit task); cleared on read */
+int mspack_hip_debug_pipe_phases(unsigned long long *out32) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(lzxp::g_pipe_phase), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out32 + 16, HIP_SYMBOL(lzxn::g_pipe_phase), sizeof(z)) != hipSuccess) return -1;
+  hipMemcpyToSymbol(HIP_SYMBOL(lzxp::g_pipe_phase), z, sizeof(z));
+  return hipMemcpyToSymbol(HIP_SYMBOL(lzxn::g_pipe_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
 const char *mspack_hip_version(void) { return "mspack-hip 0.3 (gfx950; LZX/LZX-DELTA/Quantum/MSZIP batch decode)"; }

@@ -10,8 +10,22 @@ ub = 65536
 plain, comp, off, ln, tab = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21, frame_tables=True)
 units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=2, frame_tabs=tab)
 L = M.lib()
-for _ in range(3):
+ph = np.zeros(32, dtype=np.uint64)
+if hasattr(L, "mspack_hip_debug_pipe_phases"):
+    L.mspack_hip_debug_pipe_phases.argtypes = [ctypes.c_void_p]
+for it in range(3):
+    if it == 2 and hasattr(L, "mspack_hip_debug_pipe_phases"):
+        L.mspack_hip_debug_pipe_phases(ph.ctypes.data)          # clear: the phases of the last launch only
     out, res = M.decode_batch(units, comp, out_bytes)
+if hasattr(L, "mspack_hip_debug_pipe_phases"):
+    L.mspack_hip_debug_pipe_phases(ph.ctypes.data)
+    names = ["P wait prev header", "P header decode", "P record + publish", "P table builds", "P parse_emit total", "P final publish",
+             "  emit: staging", "  emit: sync + count rounds", "  emit: last walk (values, literals, records)"]
+    print("parse tasks, us per frame (%d frames):" % (2 * n))
+    for k, nm in enumerate(names):
+        print("  %-46s %8.1f" % (nm, ph[k] / 100.0 / (2 * n)))
+    print("commit tasks, us per unit: front (load, R0-R2, checks) %.1f  push %.1f  resolve %.1f" %
+          (ph[16 + 9] / 100.0 / n, ph[16 + 10] / 100.0 / n, ph[16 + 11] / 100.0 / n))
 assert (res["err"] == 0).all() and np.array_equal(out[:n * ub], plain)
 T = min(3 * n + 2 * n, 1 << 16)
 a = np.zeros(4 * T, dtype=np.uint64)
