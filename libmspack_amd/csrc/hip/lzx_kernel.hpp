@@ -194,7 +194,7 @@ struct LzxDec {
 
   __device__ __forceinline__ void flush_lits() {
     if (lit_n) {
-      if (lane < lit_n) out[P - lit_n + lane] = (u8) lit_buf;
+      if (lane < lit_n) gst(out + P - lit_n + lane, (u8) lit_buf);
       lit_n = 0;
     }
   }
@@ -382,7 +382,7 @@ __device__ __forceinline__ void lzx_copy_match(u8 *out, u32 P, u32 off, u32 len,
   const u8 *src = dst - off;
   if (off >= len || off >= WAVE) {
     // every 64-byte step only reads bytes that are already complete (earlier steps/tokens)
-    for (u32 i = lane; i < len; i += WAVE) dst[i] = src[i];
+    for (u32 i = lane; i < len; i += WAVE) gst(dst + i, gld(src + i));
   }
   else {
     // overlapping copy, period `off` < 64: lane i takes pattern byte (i mod off)
@@ -393,7 +393,7 @@ __device__ __forceinline__ void lzx_copy_match(u8 *out, u32 P, u32 off, u32 len,
 #pragma unroll
     for (int k = 0; k < 6; k++) { u32 t = step - ss; step = t < step ? t : step; ss >>= 1; }  // 64 mod off
     for (u32 i = lane; i < len; i += WAVE) {
-      dst[i] = src[r];
+      gst(dst + i, gld(src + r));
       r += step; if (r >= off) r -= off;
     }
   }
@@ -886,11 +886,11 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
   const bool valid = lane < n;
 #ifndef LZX_EXP_NOLIT
   if (valid && kind == 0u) {
-    out[opos] = (u8) c1;
+    gst(out + opos, (u8) c1);
     if (olen > 1u) {                                        // a literal run: 2..4 bytes, first literal in the low byte
-      out[opos + 1u] = (u8)(c1 >> 8);
-      if (olen > 2u) out[opos + 2u] = (u8)(c1 >> 16);
-      if (olen > 3u) out[opos + 3u] = (u8)(c1 >> 24);
+      gst(out + opos + 1u, (u8)(c1 >> 8));
+      if (olen > 2u) gst(out + opos + 2u, (u8)(c1 >> 16));
+      if (olen > 3u) gst(out + opos + 3u, (u8)(c1 >> 24));
     }
   }
 #endif
@@ -1850,6 +1850,88 @@ __device__ __forceinline__ u32 lzx_adv_olen(const LzxShared *sh, const bool leng
   return tot;
 }
 
+// 32 bits of the staged input (sh->stage: dwords of an MSB-first bit string) from bit p on, and the 32 behind them.
+// The window is taken one bit early -- dwords ((p + 31) >> 5) - 1 and the next, shifted right by 31 - ((p + 31) & 31)
+// -- so that the shift is always 0..31: one v_alignbit_b32 per word, no 64-bit shift and no special case for p % 32 == 0
+// (for p == 0 the dword in front of the stage is read and shifted out entirely).
+#define STAGE_BITS(p_, w0_, w1_, WANT1)                                                        \
+  u32 w0_, w1_ = 0u;                                                                           \
+  {                                                                                            \
+    const u32 t_ = (p_) + 31u, a_ = ~t_ & 31u;                                                 \
+    const u32 *q_ = sh->stage + (t_ >> 5);                                                     \
+    const u32 x0_ = q_[-1], x1_ = q_[0];                                                       \
+    w0_ = (u32) __builtin_amdgcn_alignbit(x0_, x1_, a_);                                       \
+    if (WANT1) { const u32 x2_ = q_[1]; w1_ = (u32) __builtin_amdgcn_alignbit(x1_, x2_, a_); } \
+  }
+
+// One token at the bits (w0, w1), every lane its own: main-tree entry (codes beyond the direct table resolved for all
+// lanes at once when any lane has one), length footer, offset bits, aligned-offset symbol.  Everything is computed for
+// every lane and selected -- no divergent branches in the walks' loop bodies.  unk: the tables do not hold this token.
+struct EmitTok { u32 tot, olen, sym, slot, off; bool is_match, expl, unk; };
+template <bool ALIGNED, bool VALUES>
+__device__ __forceinline__ EmitTok lzx_emit_token(const LzxShared *sh, const bool act, const bool length_empty,
+                                                  const u32 *mlim, const u32 *llim, const u32 main_fov, const u32 len_fov,
+                                                  const u32 w0, const u32 w1)
+{
+  EmitTok t;
+  u32 e = sh->main_tab[w0 >> (32 - LZX_MAIN_P)];
+  if (ballot(act && e == 0u)) {
+    const u32 pk = w0 >> 16;
+    u32 ln = LZX_MAIN_P + 1u;
+#pragma unroll
+    for (int l = LZX_MAIN_P + 1; l <= 16; l++) ln += (pk >= mlim[l - LZX_MAIN_P - 1]) ? 1u : 0u;
+    const u32 lq = ln <= 16u ? ln : 0u;
+    const u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) main_fov);
+    u32 ix = (fo >> 16) + ((pk >> (16u - lq)) - (fo & 0xFFFFu));
+    ix = ix < LZX_MAIN_SYMS ? ix : 0u;
+    const u32 el = (u32) sh->main_sorted[ix] | (lq << LZX_MSH);
+    e = (e == 0u && lq != 0u) ? el : e;
+  }
+  const u32 ml = e >> LZX_MSH, sy = e & LZX_MMASK;
+  const bool is_match = sy >= 256u;
+  const u32 mq = sy - 256u, slot = mq >> 3, lh = mq & 7u;
+  const bool foot = is_match && lh == 7u;
+  const u32 wl = w0 << ml;
+  u32 e2 = sh->len_tab[wl >> (32 - LZX_LEN_P)];
+  if (ballot(act && foot && e2 == 0u)) {
+    const u32 pk = wl >> 16;
+    u32 ln = LZX_LEN_P + 1u;
+#pragma unroll
+    for (int l = LZX_LEN_P + 1; l <= 16; l++) ln += (pk >= llim[l - LZX_LEN_P - 1]) ? 1u : 0u;
+    const u32 lq = ln <= 16u ? ln : 0u;
+    const u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) len_fov);
+    u32 ix = (fo >> 16) + ((pk >> (16u - lq)) - (fo & 0xFFFFu));
+    ix = ix < 256u ? ix : 0u;
+    const u32 el = (u32) sh->len_sorted[ix] | (lq << 10);
+    e2 = (e2 == 0u && lq != 0u) ? el : e2;
+  }
+  u32 tot = ml + (foot ? e2 >> 10 : 0u);
+  t.olen = is_match ? lh + 2u + (foot ? e2 & 1023u : 0u) : 1u;
+  bool unk = e == 0u || (foot && (e2 == 0u || length_empty));
+  const int ex_ = (int)(slot >> 1) - 1;
+  const u32 extra = (u32)(ex_ < 0 ? 0 : (ex_ > 17 ? 17 : ex_));
+  const bool expl = is_match && slot >= 3u;
+  u32 off = 0;
+  if (VALUES) off = (((slot < 36u) ? 2u + (slot & 1u) : slot - 34u) << extra) - 2u;
+  // the 32 bits behind the codes read so far (tot <= 32; a shift of 32 - tot == 0 hands back w1: right for tot == 32)
+  const u32 v = (u32) __builtin_amdgcn_alignbit(w0, w1, 32u - tot);
+  if (ALIGNED) {
+    const bool ali = extra >= 3u;
+    const u32 nb = ali ? extra - 3u : extra;
+    const u32 vb = nb ? v >> (32u - nb) : 0u;
+    const u32 e3 = sh->ali_tab[(v << nb) >> (32 - LZX_ALI_P)];
+    tot += expl ? nb + (ali ? e3 >> 10 : 0u) : 0u;
+    unk = unk || (expl && ali && e3 == 0u);
+    if (VALUES) off += ali ? (vb << 3) + (e3 & 1023u) : vb;
+  }
+  else {
+    if (VALUES) off += extra ? v >> (32u - extra) : 0u;
+    tot += expl ? extra : 0u;
+  }
+  t.tot = tot; t.sym = sy; t.slot = slot; t.off = off; t.is_match = is_match; t.expl = expl; t.unk = unk;
+  return t;
+}
+
 template <bool ALIGNED>
 __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empty, const u32 start_bit, const u32 frame_end_bit,
                                                u8 *const fout, const u32 frame_pos, const u32 frame_size, const u32 edge_n,
@@ -1869,37 +1951,6 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
   bool stop = false;
   if (lane < 4u) sh->cnt[lane] = 0u;                           // the edge literals' positions (128 bits)
 
-  // main-tree entry at the bits (w0): direct table, codes beyond it resolved for all lanes at once (cf. lzx_spec_token)
-#define EMIT_MAIN_ENTRY(e_, w0_, on_)                                                          \
-  u32 e_ = sh->main_tab[(w0_) >> (32 - LZX_MAIN_P)];                                         \
-  if (ballot((on_) && e_ == 0u)) {                                                             \
-    const u32 pk_ = (w0_) >> 16;                                                               \
-    u32 ln_ = LZX_MAIN_P + 1u;                                                                 \
-    _Pragma("unroll")                                                                          \
-    for (int l = LZX_MAIN_P + 1; l <= 16; l++) ln_ += (pk_ >= mlim[l - LZX_MAIN_P - 1]) ? 1u : 0u; \
-    const u32 lq_ = ln_ <= 16u ? ln_ : 0u;                                                     \
-    const u32 fo_ = (u32) __builtin_amdgcn_ds_bpermute((int)(lq_ << 2), (int) main_fov);       \
-    u32 ix_ = (fo_ >> 16) + ((pk_ >> (16u - lq_)) - (fo_ & 0xFFFFu));                          \
-    if (ix_ >= LZX_MAIN_SYMS) ix_ = 0;                                                         \
-    const u32 ls_ = sh->main_sorted[ix_];                                                      \
-    if (e_ == 0u && lq_ != 0u) e_ = ls_ | (lq_ << LZX_MSH);                                    \
-  }
-  // the length footer's entry behind a main code of mlen_ bits (only looked at when the token has a footer)
-#define EMIT_LEN_ENTRY(e2_, w0_, mlen_, need_)                                                 \
-  u32 e2_ = sh->len_tab[((w0_) << (mlen_)) >> (32 - LZX_LEN_P)];                               \
-  if (ballot((need_) && e2_ == 0u)) {                                                          \
-    const u32 pk_ = ((w0_) << (mlen_)) >> 16;                                                  \
-    u32 ln_ = LZX_LEN_P + 1u;                                                                  \
-    _Pragma("unroll")                                                                          \
-    for (int l = LZX_LEN_P + 1; l <= 16; l++) ln_ += (pk_ >= llim[l - LZX_LEN_P - 1]) ? 1u : 0u; \
-    const u32 lq_ = ln_ <= 16u ? ln_ : 0u;                                                     \
-    const u32 fo_ = (u32) __builtin_amdgcn_ds_bpermute((int)(lq_ << 2), (int) len_fov);        \
-    u32 ix_ = (fo_ >> 16) + ((pk_ >> (16u - lq_)) - (fo_ & 0xFFFFu));                          \
-    if (ix_ >= 256u) ix_ = 0;                                                                  \
-    const u32 ls_ = sh->len_sorted[ix_];                                                       \
-    if (e2_ == 0u && lq_ != 0u && mlen_ + lq_ <= 32u) e2_ = ls_ | (lq_ << 10);                 \
-  }
-
   while (!stop && B < Eall && P < frame_size) {
     PHE0();
     // ---- stage the input from the dword that holds bit B ----
@@ -1912,10 +1963,29 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       const u32 nck = (e0 + 128u + 2047u) >> 11;               // a token that starts below e0 ends below e0 + 53
       constexpr int NCH = (int)(LZX_STAGE_WORDS / 64u) + 1;
       u32 sv[NCH];
+      if ((((size_t) d.w.unit) & 3u) == 0u) {
+        // dword-aligned input (sb_byte is a multiple of 4): plain loads from clamped addresses, nothing between them
+        // that waits -- the chunks' loads are all in flight before the first LDS store
 #pragma unroll
-      for (int c = 0; c < NCH; c++) sv[c] = (u32) c < nck ? d.w.load_chunk((u32) c, lane) : 0u;
+        for (int c = 0; c < NCH; c++) {
+          const u32 o = sb_byte + (u32) c * 256u + lane * 4u;
+          sv[c] = gld((const u32 *)(d.w.unit + (((u32) c < nck && o < d.w.in_len) ? o : 0u)));
+        }
 #pragma unroll
-      for (int c = 0; c < NCH; c++) if ((u32) c < nck) sh->stage[(u32) c * 64u + lane] = SWAP16(sv[c]);
+        for (int c = 0; c < NCH; c++) {
+          const u32 o = sb_byte + (u32) c * 256u + lane * 4u;
+          u32 v = o < d.w.in_len ? sv[c] : 0u;
+          const u32 rem = d.w.in_len - o;
+          v = (o < d.w.in_len && rem < 4u) ? v & ((1u << (8u * rem)) - 1u) : v;
+          if ((u32) c < nck) sh->stage[(u32) c * 64u + lane] = SWAP16(v);
+        }
+      }
+      else {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) sv[c] = (u32) c < nck ? d.w.load_chunk((u32) c, lane) : 0u;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) if ((u32) c < nck) sh->stage[(u32) c * 64u + lane] = SWAP16(sv[c]);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     PHE(6);
@@ -1927,26 +1997,18 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     u32 n = 0, nb = 0, nmr = 0, exitp = entry, stop_at = 0;      // tokens / output bytes / matches of the stretch
     bool dead = false, changed = lane < nl;
     for (u32 round = 0; ; ) {
+      // ---- the lanes whose entry moved walk their stretch: token lengths, output lengths ----
       u32 p = entry, cnt = 0, cb = 0, cm = 0, sa = 0;
       bool dd = false;
-      while (ballot(changed && p < rend)) {
-        const bool on = changed && p < rend;
-        const u32 pp = on ? p : 0u;
-        const u32 k = pp >> 5, sft = pp & 31u;
-        const u32 i0 = sh->stage[k], i1 = sh->stage[k + 1u];
-        const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
-        u32 w1 = 0;
-        if (ALIGNED) { const u32 i2 = sh->stage[k + 2u]; w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32); }
-        EMIT_MAIN_ENTRY(e, w0, on)
-        const u32 ml = e >> LZX_MSH, sy = e & LZX_MMASK;
-        const bool nlen = on && e != 0u && sy >= 256u && ((sy - 256u) & 7u) == 7u;
-        EMIT_LEN_ENTRY(e2, w0, ml, nlen)
-        bool unk; u32 ol;
-        const u32 tot = lzx_adv_olen<ALIGNED>(sh, length_empty, e, e2, w0, w1, unk, ol);
-        if (on) {
-          if (unk || e == 0u) { dd = true; sa = p; p = rend; }
-          else { cnt++; cb += ol; cm += sy >= 256u ? 1u : 0u; p += tot; }
-        }
+      for (;;) {
+        const bool act = changed && p < rend;
+        if (!ballot(act)) break;
+        STAGE_BITS(act ? p : 0u, w0, w1, ALIGNED)
+        const EmitTok t = lzx_emit_token<ALIGNED, false>(sh, act, length_empty, mlim, llim, main_fov, len_fov, w0, w1);
+        const bool ok = act && !t.unk, die = act && t.unk;
+        dd = dd || die; sa = die ? p : sa;
+        cnt += ok ? 1u : 0u; cb += ok ? t.olen : 0u; cm += (ok && t.is_match) ? 1u : 0u;
+        p = die ? rend : p + (ok ? t.tot : 0u);
       }
       if (changed) { n = cnt; nb = cb; nmr = cm; exitp = p; dead = dd; stop_at = sa; }
       round++;
@@ -1969,52 +2031,25 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     const u32 my_n = lane < mm ? n : 0u;
     u32 p = entry, i = 0, pos = P + inclb - cvb, j = tt + inclm - cvm;
     bool cross = false;
-    while (ballot(i < my_n && pos < frame_size && !cross)) {
+    for (;;) {
       const bool on = i < my_n && pos < frame_size && !cross;
-      const u32 pp = on ? p : 0u;
-      const u32 k = pp >> 5, sft = pp & 31u;
-      const u32 i0 = sh->stage[k], i1 = sh->stage[k + 1u], i2 = sh->stage[k + 2u];
-      const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
-      const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
-      EMIT_MAIN_ENTRY(e, w0, on)
-      const u32 ml = e >> LZX_MSH, sy = e & LZX_MMASK;
-      const bool is_match = sy >= 256u;
-      const u32 mq = sy - 256u, slot = mq >> 3, lh = mq & 7u;
-      const bool nlen = on && is_match && lh == 7u;
-      EMIT_LEN_ENTRY(e2, w0, ml, nlen)
-      u64 r = (((u64) w0 << 32) | w1) << ml;
-      u32 tot = ml;
-      u32 mlen = lh + 2u;
-      if (is_match && lh == 7u) { const u32 l2 = e2 >> 10; r <<= l2; tot += l2; mlen += e2 & 1023u; }
-      const int ex_ = (int)(slot >> 1) - 1;
-      const u32 extra = (u32)(ex_ < 0 ? 0 : (ex_ > 17 ? 17 : ex_));
-      u32 off = (((slot < 36u) ? 2u + (slot & 1u) : slot - 34u) << extra) - 2u;
-      const bool expl = is_match && slot >= 3u;
-      if (ALIGNED) {
-        const bool ali = extra >= 3u;
-        const u32 nbx = ali ? extra - 3u : extra;
-        const u32 vb = nbx ? (u32)(r >> (64u - nbx)) : 0u;
-        const u64 r2 = r << nbx;
-        const u32 e3 = sh->ali_tab[(u32)(r2 >> (64 - LZX_ALI_P))];
-        if (expl) { tot += nbx; if (ali) { off += (vb << 3) + (e3 & 1023u); tot += e3 >> 10; } else off += vb; }
+      if (!ballot(on)) break;
+      STAGE_BITS(on ? p : 0u, w0, w1, true)
+      const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1);
+      const bool lit = on && !t.is_match;
+      const bool crs = on && t.is_match && pos + t.olen > frame_size;   // lzxd.c:678-693: the serial path reports it
+      const bool mt = on && t.is_match && !crs;
+      if (lit) {
+        if (pos >= edge_n) gst(fout + pos, (u8) t.sym);
+        else { gst(&rec->edge_lit[pos], (u8) t.sym); atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
       }
-      else {
-        const u32 vb = extra ? (u32)(r >> (64u - extra)) : 0u;
-        if (expl) { off += vb; tot += extra; }
-      }
-      if (on) {
-        if (!is_match) {
-          if (pos >= edge_n) fout[pos] = (u8) sy;
-          else { rec->edge_lit[pos] = (u8) sy; atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
-          pos++; p += tot; i++;
-        }
-        else if (pos + mlen > frame_size) cross = true;          // lzxd.c:678-693: the serial path reports it
-        else {
-          // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
-          mrec[j] = make_uint2(frame_pos + pos, (expl ? ((off < (1u << 21) ? off : 0u) << 11) : 0u) | (mlen << 2) | (expl ? 0u : slot + 1u));
-          j++; pos += mlen; p += tot; i++;
-        }
-      }
+      // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
+      if (mt) gst(mrec + j, make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
+                                                       (t.expl ? 0u : t.slot + 1u)));
+      cross = cross || crs;
+      const bool adv = lit || mt;
+      pos += lit ? 1u : (mt ? t.olen : 0u); j += mt ? 1u : 0u;
+      p += adv ? t.tot : 0u; i += adv ? 1u : 0u;
     }
     PHE(8);
     // ---- where did this pass get to?  the first lane that did not emit its whole stretch ends the frame ----
@@ -2031,8 +2066,6 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the stage is rewritten by the next pass
   }
-#undef EMIT_MAIN_ENTRY
-#undef EMIT_LEN_ENTRY
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   if (lane < 4u) rec->edge_mask[lane] = sh->cnt[lane];
   n_rec = tt; end_bit = B; bytes_done = P;
@@ -2207,8 +2240,9 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     }
     if (ps == LZX_ST_FAILED || ps == LZX_ST_TAKEN) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) sh->main_len[i] = pr->main_len[i];
-    for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) sh->len_len[i] = pr->len_len[i];
+    // (1056 bytes, a dword per lane and step)
+    for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) ((u32 *) sh->main_len)[i] = gld((const u32 *) pr->main_len + i);
+    for (u32 i = lane; i < (LZX_LEN_SYMS + 70) / 4u; i += WAVE) ((u32 *) sh->len_len)[i] = gld((const u32 *) pr->len_len + i);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
   PH(0);
@@ -2236,8 +2270,8 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   if (!ok) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
   const u32 start_bit = fo * 8u + d.cons_bits();                // the frame's first token
   PH(1);
-  for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) rec->main_len[i] = sh->main_len[i];
-  for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) rec->len_len[i] = sh->len_len[i];
+  for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) gst((u32 *) rec->main_len + i, ((const u32 *) sh->main_len)[i]);
+  for (u32 i = lane; i < (LZX_LEN_SYMS + 70) / 4u; i += WAVE) gst((u32 *) rec->len_len + i, ((const u32 *) sh->len_len)[i]);
   if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
   if (lane == 0) {
     rec->n_tokens = 0; rec->hdr_start_bit = hdr_start; rec->end_bit = start_bit;
@@ -2423,7 +2457,7 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
     {
       const u32 ne = rfl(rec->n_edge);
       for (u32 i = lane; i < ne; i += WAVE)
-        if ((rec->edge_mask[i >> 5] >> (i & 31u)) & 1u) out[frame_pos + i] = rec->edge_lit[i];
+        if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
     }
     // ---- the match records ----
     const u32 eR0 = R0, eR1 = R1, eR2 = R2;
@@ -2433,17 +2467,17 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
     spq_init(*spq, Q, frame_pos, lane);
     bool bad = false;
     uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
-    if (lane < n_rec) cur0 = mrec[lane];
-    if (64u + lane < n_rec) cur1 = mrec[64u + lane];
-    if (128u + lane < n_rec) cur2 = mrec[128u + lane];
-    if (192u + lane < n_rec) cur3 = mrec[192u + lane];
+    if (lane < n_rec) cur0 = gld(mrec + lane);
+    if (64u + lane < n_rec) cur1 = gld(mrec + 64u + lane);
+    if (128u + lane < n_rec) cur2 = gld(mrec + 128u + lane);
+    if (192u + lane < n_rec) cur3 = gld(mrec + 192u + lane);
     for (u32 th = 0; th < n_rec && !bad; ) {
       uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
       const u32 tb = th + 256u + lane;
-      if (tb < n_rec) nx0 = mrec[tb];
-      if (tb + 64u < n_rec) nx1 = mrec[tb + 64u];
-      if (tb + 128u < n_rec) nx2 = mrec[tb + 128u];
-      if (tb + 192u < n_rec) nx3 = mrec[tb + 192u];
+      if (tb < n_rec) nx0 = gld(mrec + tb);
+      if (tb + 64u < n_rec) nx1 = gld(mrec + tb + 64u);
+      if (tb + 128u < n_rec) nx2 = gld(mrec + tb + 128u);
+      if (tb + 192u < n_rec) nx3 = gld(mrec + tb + 192u);
 #pragma unroll 1
       for (u32 k = 0; k < 4u && th < n_rec && !bad; k++) {
         u32 n = n_rec - th; if (n > 64u) n = 64u;

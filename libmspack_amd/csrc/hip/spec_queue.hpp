@@ -133,7 +133,7 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
       // the group's loads go out together; the next group is set up while they are in flight; then the stores
       u32 val[SPQ_GROUP];
 #pragma unroll
-      for (int g = 0; g < SPQ_GROUP; g++) { val[g] = 0; if (lane_in(G.inmask[g])) val[g] = (u32) out[G.ptr[g]]; }
+      for (int g = 0; g < SPQ_GROUP; g++) { val[g] = 0; if (lane_in(G.inmask[g])) val[g] = (u32) gld(out + G.ptr[g]); }
       const SpqGroup cur = G;
       c += 64u * cur.nch;
       const bool more = c < climit;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
 #pragma unroll
       for (int g = 0; g < SPQ_GROUP; g++) {
         const u32 b = cur.c + 64u * g + lane;
-        if (lane_in(cur.inmask[g]) && b < clip) out[b] = (u8) val[g];
+        if (lane_in(cur.inmask[g]) && b < clip) gst(out + b, (u8) val[g]);
       }
       SPQ_T(3);
       if (!more) break;

@@ -29,6 +29,21 @@ typedef uint64_t u64;
 
 #define WAVE 64
 
+// Accesses to the arenas and the work scratch on the hot paths go through gld / gst.  Pointers that live in structs or
+// reach a real (non-inlined) device function have lost their address space, so these are FLAT instructions.  Casting them
+// to address space 1 (global_load / global_store) was measured on the headline launch (round 3, same box, same session):
+// 3.38 ms flat vs 3.49 ms global, 6.43 vs 6.77 ms at 8192 units -- the explicit form is SLOWER here, so it is off.
+#if !defined(MSPACK_GLOBAL_ACCESS) || defined(MSPACK_WAVE_EMU)
+template <typename T> __device__ __forceinline__ T gld(const T *p) { return *p; }
+template <typename T> __device__ __forceinline__ void gst(T *p, T v) { *p = v; }
+#else
+template <typename T> __device__ __forceinline__ T gld(const T *p) { return *(const __attribute__((address_space(1))) T *) p; }
+template <typename T> __device__ __forceinline__ void gst(T *p, T v) { *(__attribute__((address_space(1))) T *) p = v; }
+typedef unsigned int gv2u_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 gld(const uint2 *p) { const gv2u_ t = *(const __attribute__((address_space(1))) gv2u_ *) p; return make_uint2(t.x, t.y); }
+__device__ __forceinline__ void gst(uint2 *p, uint2 v) { gv2u_ t; t.x = v.x; t.y = v.y; *(__attribute__((address_space(1))) gv2u_ *) p = t; }
+#endif
+
 __device__ __forceinline__ u32 rfl(u32 v) { return (u32) __builtin_amdgcn_readfirstlane((int) v); }
 __device__ __forceinline__ u32 rdl(u32 v, u32 l) { return (u32) __builtin_amdgcn_readlane((int) v, (int) l); }
 // write `val` into lane `l` of a per-lane register (this clang has no writelane builtin; the
@@ -63,8 +78,8 @@ struct InWindow {
       u64 a = (u64) p;
       u32 sh = (u32)(a & 3u);
       const u32 *q = (const u32 *)(a & ~3ull);
-      u32 lo = q[0];
-      u32 hi = q[1];
+      u32 lo = gld(q);
+      u32 hi = gld(q + 1);
       v = __builtin_amdgcn_alignbyte(hi, lo, sh);
       u32 rem = in_len - o;
       if (rem < 4u) v &= (1u << (8u * rem)) - 1u;
@@ -83,7 +98,7 @@ struct InWindow {
     return d;
   }
   // single byte at absolute unit offset (zero beyond in_len); per-lane
-  __device__ __forceinline__ u32 byte_at(u32 pos) const { return pos < in_len ? unit[pos] : 0u; }
+  __device__ __forceinline__ u32 byte_at(u32 pos) const { return pos < in_len ? gld(unit + pos) : 0u; }
 };
 
 // ---------------------------------------------------------------------------------------------------

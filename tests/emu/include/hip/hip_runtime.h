@@ -97,6 +97,8 @@ static inline unsigned emu_perm_(unsigned s0, unsigned s1, unsigned sel) {      
 #define __builtin_amdgcn_s_memrealtime() emu_clock()
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
 #define __builtin_amdgcn_s_setprio(n) do { } while (0)
+#define __builtin_amdgcn_is_shared(p) false
+#define __builtin_amdgcn_is_private(p) false
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }

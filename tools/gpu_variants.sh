@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/variants; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
 B="python bench.py --exp --no-cpu --no-extras --steps 15 --warmup 4"
-for v in base $VARIANTS; do
+for rep in 1 ${REPS:+2}; do for v in base $VARIANTS; do
   so=$R/build/variants/libmspack_hip_$v.so; [ $v = base ] && so=$R/libmspack_amd/libmspack_hip.so
   for u in ${UNITS:-4096 8192}; do
     ( MSPACK_HIP_SO=$so timeout 200 $B --units $u 2>&1 | tail -1 | python -c "
@@ -13,7 +13,7 @@ try:
 except Exception as e: print('$v units $u: FAILED', e)
 " ) >> $OUT/bench_${TAG:-x}.txt 2>&1
   done
-done
+done; done
 if [ -n "$TRACE" ]; then
   echo "== trace, 4096 units" > $OUT/trace_${TAG:-x}.txt
   MSPACK_HIP_SO=$R/build/variants/libmspack_hip_trace.so timeout 200 python tools/pipe_trace.py 4096 >> $OUT/trace_${TAG:-x}.txt 2>&1
