@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+LZX_KERNELS = "mspack_lzx_pipe_map + mspack_lzx_pipe + mspack_decode_lzx (resume)"
 METRIC = "decompressed MB/s (whole node), LZX 21-bit window, 4096-interval batch"
 
 
@@ -109,6 +110,41 @@ def cpu_baseline(comp, off, ln, n_units, unit_bytes):
             "sample": "first %d units, single thread, oracle/liboracle.so (NOT the reference)" % sample}
 
 
+def ref_cpu_secondary(kind, comp, off, ln, out_lens, window_bits, reset_frames, budget_s=8.0):
+    """the real reference codec (oracle/_ref: kind 0 lzxd, 1 mszipd, 2 qtmd) over the same units on the usable host cores,
+    a bounded number of passes; None when the reference library did not travel"""
+    import ctypes as C
+    import helpers
+    if not helpers.have_ref():
+        return None
+    try:
+        R = helpers.ref()
+        cores = usable_cpus()
+        n = len(off)
+        off64 = np.ascontiguousarray(off, dtype=np.uint64)
+        ilen = np.ascontiguousarray(ln, dtype=np.uint32)
+        olen = np.ascontiguousarray(out_lens, dtype=np.uint32)
+
+        def run(units, threads, reps):
+            b = C.c_ulonglong(0); e = C.c_int(0)
+            t = R.refh_bench(kind, comp.ctypes.data, off64.ctypes.data, ilen.ctypes.data, olen.ctypes.data, units,
+                             window_bits, reset_frames, threads, reps, C.byref(b), C.byref(e))
+            if e.value:
+                raise RuntimeError("reference failed on %d units" % e.value)
+            return b.value / t / 1e6, t
+        probe = max(1, min(n, cores))                                # one unit per core: the per-core rate
+        rate1, t1 = run(probe, probe, 1)
+        est_pass = float(olen.sum()) / (rate1 * 1e6)
+        reps = max(1, min(64, int(budget_s / max(est_pass, 1e-3))))
+        units = n if est_pass <= budget_s else max(cores, int(n * budget_s / est_pass))
+        v, t = run(units, cores, reps)
+        return {"value": round(v, 1), "unit": "MB/s", "cores": cores, "kind": "reference",
+                "sample": "%d pass(es) over %d of the %d units on %d threads in %.2f s (libmspack's own codec, memory to memory)" %
+                          (reps, units, n, cores, t)}
+    except Exception as ex:          # pragma: no cover
+        return {"value": None, "kind": "reference", "error": str(ex)}
+
+
 # ---- device-resident batch: upload once, time launches with HIP events on the launch stream ----------------
 class DeviceBatch:
     def __init__(self, M, torch, dev, units, comp, out_bytes, kind):
@@ -161,7 +197,7 @@ def roofline(algo_bytes, ms, kernel, **extra):
     return d
 
 
-def secondary_mszip(M, torch, dev, n=4096, ub=32768, iters=10):
+def secondary_mszip(M, torch, dev, n=4096, ub=32768, iters=10, cpu=True):
     """BASELINE config 2: n independent MSZIP CFDATA blocks ('CK' + raw deflate, zlib level 6), one per unit"""
     import zlib
     plain = M.gen_plaintext(0xC0FFEE, 0, n * ub)
@@ -183,10 +219,11 @@ def secondary_mszip(M, torch, dev, n=4096, ub=32768, iters=10):
     return {"config": "BASELINE config 2: %d independent MSZIP CFDATA blocks of %d KiB (zlib level 6), ratio %.3f" %
                       (n, ub // 1024, float(ln.sum()) / (n * ub)),
             "value": round(n * ub / ms / 1e3, 1), "unit": "MB/s", "kernel_ms": round(ms, 4), "bit_exact": ok,
-            "roofline": roofline(float(ln.sum()) + n * ub, ms, "mspack_decode_mszip")}
+            "roofline": roofline(float(ln.sum()) + n * ub, ms, "mspack_decode_mszip"),
+            "cpu_baseline": ref_cpu_secondary(1, comp, off, ln, np.full(n, ub), 0, 0) if cpu else None}
 
 
-def secondary_qtm(M, torch, dev, n=512, frames=32, window_bits=21, iters=2):
+def secondary_qtm(M, torch, dev, n=512, frames=32, window_bits=21, iters=2, cpu=True):
     """BASELINE config 4 as SURVEY 8(d) specifies it: comp_type 0x1572 -- Quantum, window 2^21 -- n folders of
     `frames` 32 KiB blocks each (the folder stream as cabd feeds it: every block followed by the 0xFF trailer)"""
     from concurrent.futures import ThreadPoolExecutor
@@ -214,7 +251,23 @@ def secondary_qtm(M, torch, dev, n=512, frames=32, window_bits=21, iters=2):
     return {"config": "BASELINE config 4: %d Quantum folders (comp_type 0x1572: window 2^%d), %d blocks = %d KiB each, ratio %.3f" %
                       (n, window_bits, frames, ub // 1024, float(ln.sum()) / (n * ub)),
             "value": round(n * ub / ms / 1e3, 1), "unit": "MB/s", "kernel_ms": round(ms, 4), "bit_exact": ok,
-            "roofline": roofline(float(ln.sum()) + n * ub, ms, "mspack_decode_qtm")}
+            "roofline": roofline(float(ln.sum()) + n * ub, ms, "mspack_decode_qtm"),
+            "cpu_baseline": ref_cpu_secondary(2, comp, off, ln, np.full(n, ub), window_bits, 0) if cpu else None}
+
+
+def secondary_lzx(M, torch, dev, what, n, ub, seed, first_unit=0, iters=10, threads=1):
+    """another LZX launch shape (BASELINE configs 3 and 5): n CHM-style reset intervals of ub bytes, window 2^21, frame tables"""
+    plain, comp, off, ln, tab = M.corpus_lzx_units(seed, 0, n, ub, 21, n_threads=threads, first_unit=first_unit, frame_tables=True)
+    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=ub // 32768, frame_tabs=tab)
+    b = DeviceBatch(M, torch, dev, units, comp, out_bytes, M.KIND_LZX)
+    b.step(); torch.cuda.synchronize()
+    ms = b.kernel_ms(iters)
+    res, out = b.results(), b.output()[:n * ub]
+    ok = bool((res["err"] == 0).all() and (res["out_len"] == ub).all() and np.array_equal(out, plain))
+    return {"config": what + ", ratio %.3f" % (float(ln.sum()) / (n * ub)),
+            "value": round(n * ub / ms / 1e3, 1), "unit": "MB/s", "kernel_ms": round(ms, 4), "bit_exact": ok,
+            "units_on_frame_parallel_path": round(float(((res["flags"] & M.F_FRAMES_ADOPTED) != 0).mean()), 4),
+            "roofline": roofline(float(ln.sum()) + n * ub, ms, LZX_KERNELS)}
 
 
 def host_inclusive(M, torch, dev, units, comp, out_bytes, plain, n, ub, reps=5):
@@ -294,18 +347,14 @@ def main():
     ap.add_argument("--unit-kib", type=int, default=64)
     ap.add_argument("--text", type=int, default=0, help="plaintext family (0 = mix)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--frame-tables", action="store_true",
-                    help="force the frame-parallel LZX path (MSPACK_HIP_FRAME_PARSE_ALWAYS): frames are parsed by one wavefront "
-                         "each before the unit's wavefront commits them.  Default: the units carry their frame tables (as a CHM's "
-                         "reset table states them) and the LIBRARY decides by the launch's shape -- at 4096 two-frame units, one "
-                         "wave per unit slot of the chip, it keeps the serial kernel (4.40 vs 4.75 ms)")
-    ap.add_argument("--no-frame-tables", action="store_true", help="units without frame tables: serial kernel only")
+    ap.add_argument("--no-frame-tables", action="store_true",
+                    help="units without frame tables: the serial kernel only.  Default: every unit carries its frame table (as a "
+                         "CHM's reset table states it per frame) and the launch is mspack_lzx_pipe: parse tasks and commit tasks "
+                         "from one ticket counter, then the unit kernel for the last bytes of every unit")
     ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive and the secondary configs")
     ap.add_argument("--exp", action="store_true", help="kernel experiments: skip the parity gate and the CPU leg (the line is then NOT a valid result)")
     args = ap.parse_args()
 
-    if args.frame_tables:
-        os.environ["MSPACK_HIP_FRAME_PARSE_ALWAYS"] = "1"          # (read when the library is loaded)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
 
@@ -360,6 +409,8 @@ def main():
     per_rank_ms = D.gather_scalar(dist, dev, my_elapsed / args.steps * 1e3)
 
     ms_kernel = batch.kernel_ms(max(3, min(args.steps, 10)))       # roofline numerator: HIP events on the launch stream
+    singles = sorted(batch.kernel_ms(1) for _ in range(7))          # spread of single launches (outside the timed region)
+    step_spread = [round(singles[0], 4), round(singles[len(singles) // 2], 4), round(singles[-1], 4)]
 
     # ---- parity: every unit, every byte, outside the timed region ----
     res = batch.results()
@@ -399,11 +450,13 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "units_per_gpu": n, "unit_bytes": ub, "bit_exact": all_ok,
-                       "frame_tables": "off" if args.no_frame_tables else ("forced" if args.frame_tables else "auto (library decides by launch shape)"),
+                       "frame_tables": "off (serial kernel)" if args.no_frame_tables else "on (mspack_lzx_pipe)",
+                       "residency": "value: compressed units and decoded bytes resident in HBM; host_inclusive: the same batch from host memory",
                        "units_on_frame_parallel_path": round(adopted, 4),
                        "corpus_gen_s": round(gen_s, 2), "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+                       "step_ms_min_median_max": step_spread,
                        "launcher": "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else ("self-spawned" if world > 1 else "single")},
-            "roofline": roofline(algo_bytes, ms_kernel, "mspack_lzx_headers + mspack_lzx_parse + mspack_decode_lzx" if adopted > 0.5 else "mspack_decode_lzx",
+            "roofline": roofline(algo_bytes, ms_kernel, LZX_KERNELS if adopted > 0.5 else "mspack_decode_lzx",
                                  traffic=traffic, traffic_source=traffic_source),
         }
         extras = world == 1 and not args.exp and not args.no_extras
@@ -411,10 +464,23 @@ def main():
             line["host_inclusive"] = host_inclusive(M, torch, dev, units, comp, out_bytes, plain, n, ub)
         del batch
         torch.cuda.empty_cache()
+        cpu = world == 1 and not args.no_cpu and not args.exp
         if extras:
-            line["secondary"] = [secondary_mszip(M, torch, dev), secondary_qtm(M, torch, dev)]
-        if world == 1 and not args.no_cpu and not args.exp:
+            lo5, hi5 = D.shard_range(65536, 0, 8)
+            line["secondary"] = [
+                secondary_lzx(M, torch, dev, "BASELINE config 3's launch shape: 1024 LZX reset intervals of 64 KiB (window 2^21)", 1024, ub,
+                              0xBA5E11, threads=threads),
+                secondary_lzx(M, torch, dev, "BASELINE config 5, rank 0's shard of 8: %d of 65536 LZX reset intervals of 64 KiB in one "
+                              "launch (strong-scaling seeding)" % (hi5 - lo5), hi5 - lo5, ub, 0xC0F165, first_unit=lo5, threads=threads),
+                secondary_mszip(M, torch, dev, cpu=cpu), secondary_qtm(M, torch, dev, cpu=cpu)]
+        if cpu:
             line["cpu_baseline"] = cpu_baseline(comp, off, ln, n, ub)
+            cb = line["cpu_baseline"]
+            if cb and cb.get("value"):
+                line["vs_cpu_baseline"] = {"device_resident": round(line["value"] / cb["value"], 2),
+                                           "host_to_device": round(line["host_inclusive"]["MBps"] / cb["value"], 2) if extras else None,
+                                           "host_to_host": round(line["host_inclusive"]["to_host_MBps"] / cb["value"], 2) if extras else None,
+                                           "note": "against %d host threads (the container's CPU quota), not a whole socket" % cb["cores"]}
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -53,10 +53,13 @@ __device__ __forceinline__ bool pick_unit(const mspack_hip_unit *units, const u3
 //   u32    hdr[256]       per launch (up to 32 concurrent ones) 8 words: [0] = most, [1] = fewest frames of a unit with a
 //                         frame table, [2] = ticket counter of mspack_lzx_pipe
 struct LzxScratch { int32_t *meta; u32 *frame_unit; u32 *hdr; lzxn::LzxFrameRec *recs; uint2 *toks; size_t bytes; };
-__host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_frames_total)
+// n_rec_slots: frame slots that can hold a record + tokens -- all of them for a caller's own scratch (the size
+// mspack_hip_frame_scratch_bytes states); the host path numbers the units that carry a table first and gives only those
+// the 130 KiB per slot (a batch of OAB blocks or of folders without tables needs the 4-byte meta words only)
+__host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_frames_total, size_t n_rec_slots)
 {
-  const size_t n = n_frames_total + 1, a = 255;
-  const size_t o_fu = (n * 4 + a) & ~a, o_hdr = o_fu + ((n * 4 + a) & ~a), o_rec = o_hdr + 1024,
+  const size_t n0 = n_frames_total + 1, n = n_rec_slots + 1, a = 255;
+  const size_t o_fu = (n0 * 4 + a) & ~a, o_hdr = o_fu + ((n * 4 + a) & ~a), o_rec = o_hdr + 1024,
                o_tok = o_rec + n * sizeof(lzxn::LzxFrameRec);
   LzxScratch L;
   char *b = (char *) base;
@@ -439,13 +442,15 @@ static unsigned lzx_pipe_waves()
 }
 static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
                         const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
-                        size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true, unsigned launch_ix = 0)
+                        size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true, unsigned launch_ix = 0,
+                        size_t n_rec_slots = (size_t) -1)
 {
+  if (n_rec_slots == (size_t) -1) n_rec_slots = n_frames_total;
   if (n == 0) return;
   const dim3 grid((unsigned) n), block(64);
   switch (kind) {
   case MSPACK_HIP_KIND_LZX: {
-    LzxScratch L = lzx_scratch(d_fm, n_frames_total);
+    LzxScratch L = lzx_scratch(d_fm, n_frames_total, n_rec_slots);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
     static const u32 hdr_init[4] = { 0u, 0xFFFFFFFFu, 0u, 0u };
     // launches of one batch that run on different streams (host path, several chunks) have their own control words
@@ -482,7 +487,7 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
     hipLaunchKernelGGL(mspack_decode_lzxd, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
                        d_results, (int32_t *) d_fm); break;
   case MSPACK_HIP_KIND_MSZIP: {
-    LzxScratch L = lzx_scratch(d_fm, n_frames_total);
+    LzxScratch L = lzx_scratch(d_fm, n_frames_total, n_rec_slots);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
     if (frames) {
       static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
@@ -544,7 +549,7 @@ int mspack_hip_device_count(void) {
 }
 int mspack_hip_set_device(int device) { CK(hipSetDevice(device)); return 0; }
 
-size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total) { return lzx_scratch(nullptr, n_frames_total).bytes; }
+size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total) { return lzx_scratch(nullptr, n_frames_total, n_frames_total).bytes; }
 
 int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_t *d_order,
                                    size_t n_units, const void *d_in, size_t in_bytes,
@@ -658,9 +663,11 @@ static inline size_t unit_frames(const mspack_hip_unit &u) {
 
 // `sel` lists the unit indices this device handles (NULL = all n_sel units).  host_out != NULL: outputs are
 // copied back into it; dev_out != NULL: the caller's DEVICE buffer receives them (out_off relative to it).
+// per_unit_back: copy the outputs back unit by unit (a sharded call whose shards' output spans interleave)
 static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uint32_t *sel, size_t n_sel,
                                       const void *in, size_t in_bytes, void *host_out, void *dev_out,
-                                      size_t out_bytes, mspack_hip_result *results, char *errbuf, size_t errcap)
+                                      size_t out_bytes, mspack_hip_result *results, char *errbuf, size_t errcap,
+                                      bool per_unit_back = false)
 {
   if (n_sel == 0) return 0;
   if (dev < 0 || dev >= MSPK_MAX_DEV) { snprintf(errbuf, errcap, "device index %d out of range", dev); return -1; }
@@ -680,9 +687,9 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
   for (size_t i = 0; i < n_sel; i++) idx[i] = sel ? sel[i] : (uint32_t) i;
   std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return units[x].in_off < units[y].in_off; });
   std::vector<mspack_hip_unit> local(n_sel);
-  bool monotone = true;
+  bool monotone = !per_unit_back;
   uint64_t in_lo = ~0ull, in_hi = 0, out_lo = ~0ull, out_hi = 0, prev_hi = 0, in_sum = 0;
-  size_t n_frames = 0;
+  size_t n_frames = 0, n_rec_slots = 0;
   for (size_t i = 0; i < n_sel; i++) {
     mspack_hip_unit &u = local[i];
     u = units[idx[i]];
@@ -703,8 +710,16 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     }
     out_lo = std::min(out_lo, lo); out_hi = std::max(out_hi, hi);
     in_sum += u.in_len;
-    u.frame_base = (uint32_t) n_frames; units[idx[i]].frame_base = (uint32_t) n_frames;
-    n_frames += unit_frames(u);
+  }
+  // frame slots: the units that carry a usable frame / block table first -- only their slots hold records and tokens
+  for (int pass = 0; pass < 2; pass++) {
+    for (size_t i = 0; i < n_sel; i++) {
+      mspack_hip_unit &u = local[i];
+      if ((pass == 0) != unit_has_ftab(u)) continue;
+      u.frame_base = (uint32_t) n_frames; units[idx[i]].frame_base = (uint32_t) n_frames;
+      n_frames += unit_frames(u);
+    }
+    if (pass == 0) n_rec_slots = n_frames;
   }
   in_lo &= ~15ull;                                     // keep the units' alignment
   if (dev_out) out_lo = 0;                             // the caller's device buffer is addressed as is
@@ -738,7 +753,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     size_t op = 0;
     for (Chunk &c : chunks) {
       c.in_lo = ~0ull; c.in_hi = 0; c.out_lo = ~0ull; c.out_hi = 0;
-      c.fm_lo = local[c.a].frame_base; c.fm_n = 0; c.has_ftab = false;
+      c.fm_lo = ~(size_t) 0; c.fm_n = 0; c.has_ftab = false;
       for (size_t i = c.a; i < c.b; i++) {
         const mspack_hip_unit &u = local[i];
         c.in_lo = std::min<uint64_t>(c.in_lo, u.in_off); c.in_hi = std::max<uint64_t>(c.in_hi, u.in_off + u.in_len);
@@ -746,11 +761,13 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
           c.has_ftab = true;
           c.in_lo = std::min<uint64_t>(c.in_lo, (uint64_t) u.in_chunk * 4u);
           c.in_hi = std::max<uint64_t>(c.in_hi, (uint64_t) u.in_chunk * 4u + unit_ftab_bytes(u));
+          c.fm_lo = std::min<size_t>(c.fm_lo, u.frame_base);          // (the chunk's table units' slots are contiguous)
+          c.fm_n += unit_frames(u);
         }
         c.out_lo = std::min<uint64_t>(c.out_lo, u.out_off - unit_below(u));
         c.out_hi = std::max<uint64_t>(c.out_hi, u.out_off + u.out_len + unit_above(u));
-        c.fm_n += unit_frames(u);
       }
+      if (c.fm_lo == ~(size_t) 0) c.fm_lo = 0;
       c.in_lo &= ~15ull;
       for (unsigned k = 1; k <= 6; k++) {
         c.order_off[k] = op;
@@ -771,7 +788,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     TRY(grow(cx.d_units, n_sel * sizeof(mspack_hip_unit), false));
     TRY(grow(cx.d_order, n_sel * sizeof(uint32_t), false));
     TRY(grow(cx.d_res, n_sel * sizeof(mspack_hip_result), false));
-    TRY(grow(cx.d_fm, mspack_hip_frame_scratch_bytes(n_frames), false));
+    TRY(grow(cx.d_fm, lzx_scratch(nullptr, n_frames, n_rec_slots).bytes, false));
     TRY(grow(cx.h_stage, n_sel * sizeof(mspack_hip_result), true));
     u8 *const d_in = (u8 *) cx.d_in.p;
     u8 *const d_out = dev_out ? (u8 *) dev_out : (u8 *) cx.d_out.p;
@@ -803,7 +820,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
                                hipMemcpyHostToDevice, st));
       for (unsigned k = 1; k <= 6; k++)
         launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
-                    c.has_ftab, (unsigned) ci);
+                    c.has_ftab, (unsigned) ci, n_rec_slots);
       TRY(hipGetLastError());
       TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
     }
@@ -886,6 +903,18 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
       if (s + 1 < n_shards && acc * n_shards >= total * (uint64_t)(s + 1)) s++;
     }
   }
+  // every shard copies its whole output span back with one copy -- valid only if the spans do not interleave, i.e. if
+  // the outputs ascend with the inputs over the WHOLE batch; otherwise the shards copy back unit by unit
+  bool ascending = true;
+  {
+    uint64_t prev_hi = 0;
+    for (size_t i = 0; i < n_units && ascending; i++) {
+      const mspack_hip_unit &u = units[idx[i]];
+      const uint64_t lo = u.out_off - std::min<uint64_t>(u.out_off, unit_below(u)), hi = u.out_off + u.out_len + unit_above(u);
+      if (i && lo < prev_hi) ascending = false;
+      prev_hi = std::max(prev_hi, hi);
+    }
+  }
   std::vector<int> rcs(n_shards, 0);
   std::vector<std::array<char, 256>> errs(n_shards);
   std::vector<std::thread> th;
@@ -896,7 +925,7 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
       hipError_t e = hipSetDevice(dv);
       if (e != hipSuccess) { snprintf(errs[sh].data(), 256, "hipSetDevice(%d): %s", dv, hipGetErrorString(e)); rcs[sh] = -(int) e; return; }
       rcs[sh] = pipeline_on_current_device(dv, units, shard[sh].data(), shard[sh].size(), in, in_bytes, out, nullptr,
-                                           out_bytes, results, errs[sh].data(), 256);
+                                           out_bytes, results, errs[sh].data(), 256, !ascending);
     });
   }
   for (auto &t : th) t.join();

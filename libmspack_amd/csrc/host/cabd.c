@@ -664,14 +664,16 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
   g->boff = (method == MSCAB_COMP_LZX || method == MSCAB_COMP_MSZIP)
           ? (uint32_t *) sys->alloc(sys, ((size_t) fol->base.num_blocks + 1) * sizeof(uint32_t)) : NULL;
   if ((err = reader_open(self, &r, fol))) {
-    if (err != MSPACK_ERR_SEEK) return err;
+    if (err != MSPACK_ERR_SEEK) { if (g->boff) { sys->free(g->boff); g->boff = NULL; } return err; }
     /* the reference fails extract() with SEEK before any decoding; keep it as this folder's error */
-    if (!(g->stream = (unsigned char *) sys->alloc(sys, 64))) return MSPACK_ERR_NOMEMORY;
+    if (!(g->stream = (unsigned char *) sys->alloc(sys, 64))) { if (g->boff) { sys->free(g->boff); g->boff = NULL; } return MSPACK_ERR_NOMEMORY; }
     memset(g->stream, 0, 64);
     g->read_err = MSPACK_ERR_SEEK; g->hard_eof = 1;
     return MSPACK_ERR_OK;
   }
-  if (!(g->stream = (unsigned char *) sys->alloc(sys, g->cap + 64))) { reader_close(self, &r); return MSPACK_ERR_NOMEMORY; }
+  if (!(g->stream = (unsigned char *) sys->alloc(sys, g->cap + 64))) {
+    reader_close(self, &r); if (g->boff) { sys->free(g->boff); g->boff = NULL; } return MSPACK_ERR_NOMEMORY;
+  }
   while (r.block < fol->base.num_blocks) {
     unsigned int ulen = 0;
     r.block++;
@@ -679,7 +681,7 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
     if (g->len + r.i_end + 1 > g->cap) {
       size_t ncap = (g->cap + r.i_end + 1) * 2;
       unsigned char *n = (unsigned char *) sys->alloc(sys, ncap + 64);
-      if (!n) { sys->free(g->stream); g->stream = NULL; reader_close(self, &r); return MSPACK_ERR_NOMEMORY; }
+      if (!n) { sys->free(g->stream); g->stream = NULL; if (g->boff) { sys->free(g->boff); g->boff = NULL; } reader_close(self, &r); return MSPACK_ERR_NOMEMORY; }
       sys->copy(g->stream, n, g->len); sys->free(g->stream); g->stream = n; g->cap = ncap;
     }
     if (g->boff) {

@@ -517,6 +517,7 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
   int err = MSPACK_ERR_OK;
   unsigned int version, wsize;
   off_t reset_interval;
+  size_t arena_alloc = 0;            /* bytes behind c->arena */
 
   if ((err = find_sys_file(self, sec, &sec->content, content_name))) return err;
   if ((err = find_sys_file(self, sec, &sec->control, control_name))) return err;
@@ -554,11 +555,14 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
     want = (size_t) avail;
     /* (room behind the stream: 128 zero bytes, then one uint32 per frame the reset table can describe) */
     {
+      /* the frame table below holds n_fast * fper entries, n_fast <= table bytes / (fper * entry size) + 1 intervals:
+       * at most one uint32 per 4 table bytes plus one interval's worth (fper comes from ControlData: up to 65535) */
       size_t extra = 0;
       if (!find_sys_file(self, sec, &sec->rtable, rtable_name) && sec->rtable->length >= 0x28 && sec->rtable->length <= 1000000)
-        extra = (size_t) sec->rtable->length;                     /* >= 4 bytes per entry */
-      if (!(c->arena = (unsigned char *) sys->alloc(sys, want + 128 + extra + 16))) return MSPACK_ERR_NOMEMORY;
-      memset(c->arena, 0, want + 128 + extra + 16);
+        extra = (size_t) sec->rtable->length + (size_t) c->fper * 4u;
+      arena_alloc = want + 128 + extra + 16;
+      if (!(c->arena = (unsigned char *) sys->alloc(sys, arena_alloc))) return MSPACK_ERR_NOMEMORY;
+      memset(c->arena, 0, arena_alloc);
       c->arena_room = want + 64;
     }
     c->ftab_off = 0;
@@ -593,7 +597,8 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
         c->n_fast = k;
         c->n_intervals = (unsigned int) ni;
         /* the frames' offsets inside every interval, for the frame-parallel parse: a hint, never trusted */
-        if (c->fper >= 2 && c->n_fast) {
+        if (c->fper >= 2 && c->n_fast &&
+            ((c->arena_len + 128 + 3) & ~(size_t) 3) + (size_t) c->n_fast * c->fper * 4u <= arena_alloc) {   /* (never without room) */
           const size_t base = (c->arena_len + 128 + 3) & ~(size_t) 3;
           uint32_t *tab = (uint32_t *)(c->arena + base);
           unsigned int j;

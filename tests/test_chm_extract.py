@@ -49,3 +49,26 @@ def test_chm_extract_vs_reference_gpu(built, v):
                          ids=[v["tag"] for v in VECS if v["case"]["n_bytes"] <= (8 << 20)])
 def test_chm_extract_host_logic_cpu(built, hostlogic, v):
     replay(v, L=hostlogic)
+
+
+def test_chm_big_reset_interval_small_table(built, hostlogic):
+    """ADVICE round 2 (chmd.c setup_sec1): ControlData may state a reset interval of up to 65535 frames while the reset
+    table has a handful of entries; the per-frame offset table the driver builds behind the compressed stream then
+    holds one interval's worth of entries and must have room for them.  Same answers as the real chmd (where the
+    reference is built), no crash anywhere."""
+    import helpers
+    base = dict(seed=77, text=0, n_bytes=200000, window_bits=16, reset_frames=2, files=R.spread_files(200000, 5, 3, 65536))
+    for frames in (1024, 60000, 65535):
+        case = dict(base, mutations=[["control_u32", 0x0C, frames]])      # version 2: counted in 32 KiB frames
+        chm, _d, files = R.build(case)
+        want = None
+        if helpers.have_ref():
+            rc, want = helpers.ref_chm_extract(chm, list(range(len(files))))
+            want = None if rc else want
+        with api.Chm(chm, mem=True, L=hostlogic) as c:
+            if c.open_error:
+                continue
+            for i in range(len(files)):
+                err, data = c.extract(i)
+                if want is not None:
+                    assert err == want[i][0] and (err or data == want[i][1]), (frames, i, err, want[i][0])

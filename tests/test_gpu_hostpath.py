@@ -182,3 +182,61 @@ def test_headline_batch_host_entry_points(built):
     M.lib().mspack_hip_release()
     out, res = M.decode_batch(units[:64], comp, out_bytes)                 # contexts come back after a release
     assert (res["err"] == 0).all() and np.array_equal(out[:64 * ub], plain[:64 * ub])
+
+
+BIG_WORKER = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import numpy as np
+import libmspack_amd as M
+from helpers import oracle_lzx
+mode = sys.argv[1]
+rng = np.random.default_rng(5)
+if mode == "shard8":
+    # BASELINE config 5's per-GPU shape and beyond: 16 384 CHM-style intervals of mixed length (1..3 frames), every one
+    # with its frame table, cut into 8 shards (mspack_hip_decode_batch_multi; MSPACK_HIP_FORCE_SHARDS=8 on one device)
+    parts = []
+    for ub, n in ((65536, 8192), (32768, 4096), (98304, 4096)):
+        plain, comp, off, ln, tab = M.corpus_lzx_units(0xC0F165 + ub, 0, n, ub, 21, frame_tables=True)
+        parts.append((ub, n, plain, comp, off, ln, tab))
+    arena = np.concatenate([p[3] for p in parts] + [np.zeros(64, np.uint8)])
+    base = np.cumsum([0] + [p[3].size for p in parts])
+    offs = np.concatenate([p[4].astype(np.int64) + base[i] for i, p in enumerate(parts)])
+    lens = np.concatenate([p[5].astype(np.int64) + 4 for p in parts])
+    tabs = np.concatenate([p[6].astype(np.int64) + base[i] for i, p in enumerate(parts)])
+    outl = np.concatenate([np.full(p[1], p[0]) for p in parts])
+    rf = np.concatenate([np.full(p[1], p[0] // 32768) for p in parts])
+    perm = rng.permutation(len(offs))                 # (the unit table in any order; outputs follow the table)
+    units, out_bytes = M.make_units(M.KIND_LZX, offs[perm], lens[perm], outl[perm], window_bits=21, reset_frames=rf[perm], frame_tabs=tabs[perm])
+    out, res = M.decode_batch(units, arena, out_bytes, n_devices=8)
+    assert (res["err"] == 0).all() and (res["out_len"] == outl[perm]).all()
+    plain_all = np.concatenate([p[2] for p in parts]); pbase = np.cumsum([0] + [p[0] * p[1] for p in parts])
+    src = np.concatenate([pbase[i] + np.arange(p[1], dtype=np.int64) * p[0] for i, p in enumerate(parts)])[perm]
+    oo = units["out_off"].astype(np.int64)
+    for k in range(len(perm)):
+        assert np.array_equal(out[oo[k]:oo[k] + outl[perm][k]], plain_all[src[k]:src[k] + outl[perm][k]]), k
+    assert ((res["flags"] & M.F_FRAMES_ADOPTED) != 0).all()
+elif mode == "n8192":
+    # one launch of 8192 intervals (config 5: 65 536 intervals over 8 GPUs): every byte against the plaintext, a sample
+    # of units against the oracle's flags / in_next
+    n, ub = 8192, 65536
+    plain, comp, off, ln, tab = M.corpus_lzx_units(0xC0F165, 0, n, ub, 21, frame_tables=True)
+    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=2, frame_tabs=tab)
+    out, res = M.decode_batch(units, comp, out_bytes)
+    assert (res["err"] == 0).all() and (res["out_len"] == ub).all() and np.array_equal(out[:n * ub], plain)
+    for i in (0, 1, 4095, 4096, n - 1):
+        e, o, r = oracle_lzx(comp[int(off[i]):int(off[i]) + int(ln[i]) + 4].tobytes(), ub, 21, 2)
+        assert e == 0 and r.in_next == res["in_next"][i] and (int(res["flags"][i]) & ~M.F_FRAMES_ADOPTED) == r.flags
+print("BIG_OK")
+'''
+
+
+@pytest.mark.parametrize("mode,env", [("n8192", {}), ("shard8", {"MSPACK_HIP_FORCE_SHARDS": "8"})])
+def test_config5_shapes(built, mode, env, tmp_path):
+    """BASELINE config 5's per-GPU shard (8192 intervals in one launch) and the sharded entry point over 16 384 mixed
+    units whose outputs do NOT ascend with their inputs (the shards then copy back unit by unit)."""
+    script = tmp_path / "w.py"
+    script.write_text(BIG_WORKER % (ROOT, ROOT))
+    p = subprocess.run([sys.executable, str(script), mode], env=dict(os.environ, **env), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=1500)
+    assert p.returncode == 0 and b"BIG_OK" in p.stdout, p.stdout.decode()[-3000:]
