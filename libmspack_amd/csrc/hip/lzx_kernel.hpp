@@ -2040,11 +2040,11 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       const bool crs = on && t.is_match && pos + t.olen > frame_size;   // lzxd.c:678-693: the serial path reports it
       const bool mt = on && t.is_match && !crs;
       if (lit) {
-        if (pos >= edge_n) gst(fout + pos, (u8) t.sym);
+        if (pos >= edge_n) gst_stream(fout + pos, (u8) t.sym);
         else { gst(&rec->edge_lit[pos], (u8) t.sym); atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
       }
       // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
-      if (mt) gst(mrec + j, make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
+      if (mt) gst_stream(mrec + j, make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
                                                        (t.expl ? 0u : t.slot + 1u)));
       cross = cross || crs;
       const bool adv = lit || mt;

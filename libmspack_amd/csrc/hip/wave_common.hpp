@@ -33,6 +33,13 @@ typedef uint64_t u64;
 // reach a real (non-inlined) device function have lost their address space, so these are FLAT instructions.  Casting them
 // to address space 1 (global_load / global_store) was measured on the headline launch (round 3, same box, same session):
 // 3.38 ms flat vs 3.49 ms global, 6.43 vs 6.77 ms at 8192 units -- the explicit form is SLOWER here, so it is off.
+// streaming stores of the parse waves (literals, match records): analysis builds can mark them non-temporal
+#if defined(MSPACK_NT_STORES) && !defined(MSPACK_WAVE_EMU)
+template <typename T> __device__ __forceinline__ void gst_stream(T *p, T v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void gst_stream(uint2 *p, uint2 v) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); }
+#else
+#define gst_stream gst
+#endif
 #if !defined(MSPACK_GLOBAL_ACCESS) || defined(MSPACK_WAVE_EMU)
 template <typename T> __device__ __forceinline__ T gld(const T *p) { return *p; }
 template <typename T> __device__ __forceinline__ void gst(T *p, T v) { *p = v; }
