@@ -1623,6 +1623,9 @@ __device__ __forceinline__ void lzx_parse_tokens(LzxDec &d, const bool length_em
 #ifndef LZX_LANE_TAIL
 #define LZX_LANE_TAIL 384u
 #endif
+#ifndef LZX_SEG
+#define LZX_SEG 16u                 /* lzx_parse_emit: tokens per segment of the balanced last walk (a power of two) */
+#endif
 template <bool ALIGNED>
 __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_empty, const u32 start_bit,
                                                 const u32 frame_end_bit, uint2 *tok, u32 &n_tok, u32 &end_bit)
@@ -1996,13 +1999,30 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     u32 entry = lane == 0u ? b0 : (rend > rstart + LZX_LANE_TAIL ? rend - LZX_LANE_TAIL : rstart);
     u32 n = 0, nb = 0, nmr = 0, exitp = entry, stop_at = 0;      // tokens / output bytes / matches of the stretch
     bool dead = false, changed = lane < nl;
+#ifndef LZX_EMIT_LANES
+    // checkpoints of the lane's walk, one per LZX_SEG tokens: bit position | output bytes so far << 16, and matches so far
+    // (a byte each).  All walking lanes take a token per step, so the capture is a wave-uniform branch every LZX_SEG steps.
+    u32 ckA1 = 0, ckA2 = 0, ckA3 = 0, ckA4 = 0, ckA5 = 0, ckA6 = 0, ckA7 = 0, ckM0 = 0, ckM1 = 0;
+#endif
     for (u32 round = 0; ; ) {
       // ---- the lanes whose entry moved walk their stretch: token lengths, output lengths ----
       u32 p = entry, cnt = 0, cb = 0, cm = 0, sa = 0;
       bool dd = false;
-      for (;;) {
+      for (u32 it = 0; ; it++) {
         const bool act = changed && p < rend;
         if (!ballot(act)) break;
+#ifndef LZX_EMIT_LANES
+        if ((it & (LZX_SEG - 1u)) == 0u && it != 0u && it < 8u * LZX_SEG) {
+          // (a lane that has stopped keeps cnt < it: its checkpoints beyond its last token are never used)
+          const u32 a = p | (cb << 16), k = it / LZX_SEG;
+          if (changed) {
+            if (k == 1u) ckA1 = a; else if (k == 2u) ckA2 = a; else if (k == 3u) ckA3 = a; else if (k == 4u) ckA4 = a;
+            else if (k == 5u) ckA5 = a; else if (k == 6u) ckA6 = a; else ckA7 = a;
+            if (k <= 4u) ckM0 = (ckM0 & ~(0xFFu << (8u * (k - 1u)))) | (cm << (8u * (k - 1u)));
+            else ckM1 = (ckM1 & ~(0xFFu << (8u * (k - 5u)))) | (cm << (8u * (k - 5u)));
+          }
+        }
+#endif
         STAGE_BITS(act ? p : 0u, w0, w1, ALIGNED)
         const EmitTok t = lzx_emit_token<ALIGNED, false>(sh, act, length_empty, mlim, llim, main_fov, len_fov, w0, w1);
         const bool ok = act && !t.unk, die = act && t.unk;
@@ -2027,6 +2047,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     const u32 cvb = lane < mm ? nb : 0u, cvm = lane < mm ? nmr : 0u;
     const u32 inclb = wave_incl_scan(cvb), inclm = wave_incl_scan(cvm);
     PHE(7);
+#ifdef LZX_EMIT_LANES
     // ---- last walk: literals into the output, one record per match ----
     const u32 my_n = lane < mm ? n : 0u;
     u32 p = entry, i = 0, pos = P + inclb - cvb, j = tt + inclm - cvm;
@@ -2064,6 +2085,82 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       else if (mm == 0u) stop = true;
       else B = sb_bit + rdl(exitp, mm - 1u);
     }
+#else
+    // ---- last walk, BALANCED: the pass's tokens are cut into segments of LZX_SEG tokens (the lanes' checkpoints) and
+    // segment r * 64 + l goes to lane l in round r.  Every lane then decodes the same number of tokens per round (the
+    // stretches are equal in bits, not in tokens: the longest one used to set the pace), and the 64 segments of a round
+    // are NEIGHBOURS in the output and in the record list: a round writes ~2 KiB of adjacent literals and ~3 KiB of
+    // adjacent records whose cache lines are complete when the round ends, instead of 64 lines per store that the
+    // XCD's L2 has dropped again before the lane's next store to them arrives (traffic).
+    u32 segc = lane < mm ? (n + LZX_SEG - 1u) / LZX_SEG : 0u;
+    if (segc > 8u) segc = 8u;                                     // (a stretch of more than 8 segments: the last one is long)
+    const u32 seginc = wave_incl_scan(segc);
+    const u32 T = rdl(seginc, 63u);
+    u8 *const owner = sh->main_len;                               // (the code lengths are in the record; 512 bytes of scratch)
+    for (u32 q = 0; q < segc; q++) owner[seginc - segc + q] = (u8) lane;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const u32 info0 = entry | (n << 16), info1 = P + inclb - cvb, info2 = tt + inclm - cvm, info3 = (seginc - segc) | (segc << 16);
+    bool have_bad = false;
+    u32 bad_s = 0xFFFFu, bad_pos = 0, bad_j = 0, bad_p = 0;
+    for (u32 r = 0; r * 64u < T; r++) {
+      const u32 sg = r * 64u + lane;
+      const bool sact = sg < T;
+      const u32 o = sact ? (u32) owner[sg] : 0u, oa = o << 2;
+      const u32 i0_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) info0), i1_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) info1);
+      const u32 i2_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) info2), i3_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) info3);
+      const u32 k = sg - (i3_ & 0xFFFFu), osegc = i3_ >> 16, on_ = i0_ >> 16;
+      const u32 a1 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA1), a2 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA2);
+      const u32 a3 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA3), a4 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA4);
+      const u32 a5 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA5), a6 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA6);
+      const u32 a7 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA7);
+      const u32 m0_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckM0), m1_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckM1);
+      const u32 ca = k == 0u ? (i0_ & 0xFFFFu) : (k == 1u ? a1 : (k == 2u ? a2 : (k == 3u ? a3 : (k == 4u ? a4 : (k == 5u ? a5 : (k == 6u ? a6 : a7))))));
+      const u32 cmk = k == 0u ? 0u : (k <= 4u ? (m0_ >> (8u * (k - 1u))) & 0xFFu : (m1_ >> (8u * (k - 5u))) & 0xFFu);
+      const u32 ntok = sact ? (k + 1u == osegc ? on_ - k * LZX_SEG : LZX_SEG) : 0u;
+      u32 p = ca & 0xFFFFu, i = 0, pos = i1_ + (k == 0u ? 0u : ca >> 16), j = i2_ + cmk;
+      bool cross = false;
+      for (;;) {
+        const bool on = i < ntok && pos < frame_size && !cross;
+        if (!ballot(on)) break;
+        STAGE_BITS(on ? p : 0u, w0, w1, true)
+        const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1);
+        const bool lit = on && !t.is_match;
+        const bool crs = on && t.is_match && pos + t.olen > frame_size;   // lzxd.c:678-693: the serial path reports it
+        const bool mt = on && t.is_match && !crs;
+        if (lit) {
+          if (pos >= edge_n) gst_stream(fout + pos, (u8) t.sym);
+          else { gst(&rec->edge_lit[pos], (u8) t.sym); atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
+        }
+        // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
+        if (mt) gst_stream(mrec + j, make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
+                                                         (t.expl ? 0u : t.slot + 1u)));
+        cross = cross || crs;
+        const bool adv = lit || mt;
+        pos += lit ? 1u : (mt ? t.olen : 0u); j += mt ? 1u : 0u;
+        p += adv ? t.tot : 0u; i += adv ? 1u : 0u;
+      }
+      if (sact && !have_bad && (i < ntok || cross)) { have_bad = true; bad_s = sg; bad_pos = pos; bad_j = j; bad_p = p; }
+    }
+    PHE(8);
+    // ---- where did this pass get to?  the first segment that was not emitted completely ends the frame ----
+    u32 smin = have_bad ? bad_s : 0xFFFFu;
+#pragma unroll
+    for (u32 dlt = 1; dlt < WAVE; dlt <<= 1) {
+      const u32 ot = (u32) __builtin_amdgcn_ds_bpermute((int)((lane ^ dlt) << 2), (int) smin);
+      smin = ot < smin ? ot : smin;
+    }
+    smin = rfl(smin);
+    if (smin != 0xFFFFu) {
+      const u32 kq = smin & 63u;
+      P = rdl(bad_pos, kq); tt = rdl(bad_j, kq); B = sb_bit + rdl(bad_p, kq); stop = true;
+    }
+    else {
+      if (mm) { P += rdl(inclb, mm - 1u); tt += rdl(inclm, mm - 1u); }
+      if (hit) { B = sb_bit + rdl(stop_at, dl); stop = true; }
+      else if (mm == 0u) stop = true;
+      else B = sb_bit + rdl(exitp, mm - 1u);
+    }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the stage is rewritten by the next pass
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
