@@ -1992,10 +1992,18 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     PHE(6);
-    u32 S = (e0 - b0 + 63u) >> 6; if (S < 64u) S = 64u;
-    const u32 nl = (e0 - b0 + S - 1u) / S;
-    const u32 rstart = b0 + lane * S;
-    u32 rend = rstart + S; if (rend > e0) rend = e0;
+    // Stretches: equal in bits, but lane 0's is only as long as the others' FIRST walk (their last LZX_LANE_TAIL bits):
+    // lane 0 starts at a real token and walks its whole stretch in the first round, while the others find their exits --
+    // with equal stretches that round lasted as long as a full walk.
+    const u32 Lb = e0 - b0;
+    u32 S = (Lb + 63u) >> 6; if (S < 64u) S = 64u;
+    u32 S0 = S;
+#ifndef LZX_EQUAL_STRETCHES
+    if (S > LZX_LANE_TAIL + 64u) { S0 = LZX_LANE_TAIL; S = (Lb - S0 + 62u) / 63u; }
+#endif
+    const u32 nl = Lb <= S0 ? 1u : 1u + (Lb - S0 + S - 1u) / S;
+    const u32 rstart = lane == 0u ? b0 : b0 + S0 + (lane - 1u) * S;
+    u32 rend = rstart + (lane == 0u ? S0 : S); if (rend > e0) rend = e0;
     u32 entry = lane == 0u ? b0 : (rend > rstart + LZX_LANE_TAIL ? rend - LZX_LANE_TAIL : rstart);
     u32 n = 0, nb = 0, nmr = 0, exitp = entry, stop_at = 0;      // tokens / output bytes / matches of the stretch
     bool dead = false, changed = lane < nl;

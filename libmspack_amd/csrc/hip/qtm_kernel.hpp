@@ -151,14 +151,14 @@ __device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, in
   u32 range2 = (u32)((int) H - (int) L + 1);
   // H = L + (cf[i-1]*range)/tot - 1 ; L = L + (cf[i]*range)/tot : both quotients from ONE division
   u32 num = (lane == 0u) ? (e_im1 & 0xFFFFu) * range2 : cf_i * range2;
-  // exact 32-bit / 16-bit division through one double-precision reciprocal (a generic integer
-  // division is ~25 dependent instructions): the estimate is off by at most one either way
+  // exact 32-bit / 16-bit division through one single-precision reciprocal (a generic integer division is ~25
+  // dependent instructions; round 2 used a double-precision reciprocal + a Newton step: four slow instructions on the
+  // chain).  num < 2^32 and the quotient is at most 65536: float(num) is off by 2^-24, v_rcp_f32 by one ulp, the product
+  // by 2^-24 -- relative 2^-22, i.e. less than 0.02 on the quotient: the truncated estimate is off by at most one.
   u32 quo;
   {
-    const double td = (double) tot;
-    double rc = __builtin_amdgcn_rcp(td);
-    rc = __builtin_fma(__builtin_fma(-td, rc, 1.0), rc, rc);           // one Newton step: full precision
-    quo = (u32)((double) num * rc);
+    const float rc = __builtin_amdgcn_rcpf((float) tot);
+    quo = (u32)((float) num * rc);
     u32 rem = num - quo * tot;
     if ((int) rem < 0) quo--;
     else if (rem >= tot) quo++;
@@ -294,12 +294,21 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   // dependent load -> store round trip per match; literals are stored directly
   SpecQueue Q;
   spq_init(sh->spq, Q, 0u, lane);
+  // literals wait in two registers, lane i holding the i-th pending one and its position, and leave 64 at a time in one
+  // store instruction (round 2 stored every literal on its own from lane 0: 12 M store instructions per launch of
+  // config 4); they go out before anything reads the output (a resolve, a direct copy)
+  u32 lit_buf = 0, lit_pos = 0, lit_n = 0;
+#define QTM_FLUSH()                                                                           \
+  do {                                                                                        \
+    if (lit_n) { if (lane < lit_n && lit_pos < out_len) out[lit_pos] = (u8) lit_buf; lit_n = 0; } \
+  } while (0)
 #define QTM_COPY(P_, off_, len_)                                                              \
   do {                                                                                        \
     if ((off_) <= (P_) && (P_) + (len_) - (Q.Pf & ~63u) <= SPQ_RING && Q.mcount < SPQ_CAP) {   \
       spq_push(sh->spq, Q, lane == 0u, 0u, 1u, (P_), (off_), (len_));                         \
     }                                                                                         \
     else {                                                                                    \
+      QTM_FLUSH();                                                                            \
       spq_resolve(sh->spq, Q, out, (P_), true, lane, out_len);                                \
       qtm_copy(out, (P_), (off_), (len_), out_len, lane);                                     \
       Q.Pf = (P_) + (len_);                                                                   \
@@ -331,7 +340,8 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
         if (sel == 0) { m0 = mm; s0 = ss; } else if (sel == 1) { m1 = mm; s1 = ss; }
         else if (sel == 2) { m2 = mm; s2 = ss; } else { m3 = mm; s3 = ss; }
         if (sym < 0) { err = ERR_READ; stop = true; break; }
-        if (lane == 0 && P < out_len) out[P] = (u8) sym;
+        lit_buf = wrl(lit_buf, (u32) sym, lit_n); lit_pos = wrl(lit_pos, P, lit_n);
+        if (++lit_n == WAVE) QTM_FLUSH();
         P++; wpos++; frame_todo--;
         continue;
       }
@@ -378,7 +388,7 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
       if (moff > wpos && (moff - wpos) > wsize) { err = ERR_DECRUNCH; stop = true; break; }   // qtmd.c:399
       QTM_COPY(P, moff, mlen);
       P += mlen; wpos += mlen;
-      if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane, out_len);
+      if (spq_due(Q, P)) { QTM_FLUSH(); spq_resolve(sh->spq, Q, out, P, false, lane, out_len); }
     }
     if (stop) break;
     o_end = wpos;
@@ -401,6 +411,7 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
       written += i; need -= i; o_ptr = 0; o_end = 0; wpos = 0;
     }
   }
+  QTM_FLUSH();
   // whatever is still queued lies below the highest position any token reached
   {
     u32 top = Q.Pf;
@@ -409,6 +420,7 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
     spq_resolve(sh->spq, Q, out, top, true, lane, out_len);
   }
 #undef QTM_COPY
+#undef QTM_FLUSH
   if (err == ERR_OK && need) { written += (u32) need; }
   if (err == ERR_OK) good = written;
   if (lane == 0) {

@@ -96,6 +96,7 @@ static inline unsigned emu_perm_(unsigned s0, unsigned s1, unsigned sel) {      
 #define __builtin_amdgcn_s_memtime() emu_clock()
 #define __builtin_amdgcn_s_memrealtime() emu_clock()
 #define __builtin_amdgcn_rcp(x) (1.0 / (x))
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_setprio(n) do { } while (0)
 #define __builtin_amdgcn_is_shared(p) false
 #define __builtin_amdgcn_is_private(p) false
