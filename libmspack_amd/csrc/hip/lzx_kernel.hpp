@@ -101,9 +101,21 @@ struct __align__(16) LzxShared {
   u16 pre_sorted[24];
   u32 cnt[20];
   u8  pre_len[24];
+#ifndef LZX_PARSE_ONLY
   u32 inbuf[128 + 4];            /* speculative path: two 256-byte input chunks, words pre-swapped */
-#ifdef LZX_PARSE_ONLY
-  u32 stage[LZX_STAGE_WORDS + 64]; /* lzx_parse_lanes: a frame's input (or 8 KiB of it), words pre-swapped */
+#else
+  u32 stage[LZX_STAGE_WORDS + 64]; /* lzx_parse_lanes / lzx_parse_emit: 4 KiB (or 8) of a frame's input, words pre-swapped */
+  /* what only the block header needs -- its input window and the code lengths -- shares its room with the main tree's
+   * second-level table (lzx_build_sub), which is built when the header is done and the lengths are in the frame's record */
+  union {
+    struct {
+      u32 inbuf[128 + 4];
+      u8  main_len[LZX_MAIN_SYMS + 16];
+      u8  len_len[LZX_LEN_SYMS + 70];
+      u8  ali_len[8];
+    };
+    u16 sub_tab[(528 + LZX_MAIN_SYMS + 16 + LZX_LEN_SYMS + 70 + 8) / 2];
+  };
 #endif
 #else
   /* lzx_run_spec2's token queue (start bits of parsed tokens) shares its room with what only block headers
@@ -115,10 +127,10 @@ struct __align__(16) LzxShared {
   u32 inbuf[192 + 4];            /* lzx_run_spec2: three chunks (the one behind the parse position too: queued
                                     tokens are decoded from their start bit at commit time) */
 #endif
+#ifndef LZX_PARSE_ONLY
   u8  main_len[LZX_MAIN_SYMS + 16];
   u8  len_len[LZX_LEN_SYMS + 70];
   u8  ali_len[8];
-#ifndef LZX_PARSE_ONLY
   SpecQueueLds spq;              /* speculative path: queued matches + start flags (spec_queue.hpp) */
 #ifdef LZX_DELTA
   u32 tq0[128], tq1[128];        /* lzx_run_spec keeps whole tokens (kind/length, value) */
@@ -1853,6 +1865,83 @@ __device__ __forceinline__ u32 lzx_adv_olen(const LzxShared *sh, const bool leng
   return tot;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// lzx_build_sub -- second level of the parse waves' main-tree table.
+// The direct table has 2^8 entries (LDS), and a main tree of 656 symbols has many codes of 9..16 bits: in nearly every
+// step of a walk SOME lane meets one, and the lane-parallel resolve of codes beyond the table (eight limit compares, a
+// ds_bpermute, a sorted-symbol lookup: ~35 instructions) ran for the whole wave.  With a second level -- per 8-bit
+// prefix that starts longer codes, a sub-table indexed by the next Lmax(prefix) - 8 bits -- a long code costs one more
+// LDS read and no branch.  Canonical codes: symbol i of the sorted list (length L, i-th of its length) has the code
+// first(L) + (i - offs(L)); hr.fov holds first | offs << 16 per length.  Returns false (tables untouched) when the
+// sub-tables do not fit LZX_SUB_CAP entries: the walks then resolve long codes the old way.
+// Level-1 entry of such a prefix: 0x8000 | (sub-table bits - 1) << 11 | sub-table base.
+// ---------------------------------------------------------------------------------------------------
+#define LZX_SUB_CAP ((528u + LZX_MAIN_SYMS + 16u + LZX_LEN_SYMS + 70u + 8u) / 2u)
+__device__ __forceinline__ bool lzx_build_sub(LzxShared *sh, const HuffRegs &hr, const u32 nsorted, const u32 lane)
+{
+  static_assert(LZX_MAIN_P == 8, "lzx_build_sub: 8 direct bits");
+  u32 *const lmax = sh->stage;                                  // 256 words of scratch (the stage is filled later)
+  for (u32 x = lane; x < 256u; x += WAVE) lmax[x] = 0u;
+  u32 first[8], offs[9];                                        // lengths 9..16
+#pragma unroll
+  for (int l = 9; l <= 16; l++) { const u32 fo = rdl(hr.fov, (u32) l); first[l - 9] = fo & 0xFFFFu; offs[l - 9] = fo >> 16; }
+  offs[8] = nsorted;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const u32 lo = offs[0];
+  if (lo >= nsorted) return true;                               // no code is longer than the direct table
+  // ---- the longest code under every prefix ----
+  for (u32 i = lo + lane; i < nsorted; i += WAVE) {
+    u32 L = 9u;
+#pragma unroll
+    for (int l = 10; l <= 16; l++) L += (i >= offs[l - 9]) ? 1u : 0u;
+    u32 fc = first[0], of = offs[0];
+#pragma unroll
+    for (int l = 10; l <= 16; l++) if (L == (u32) l) { fc = first[l - 9]; of = offs[l - 9]; }
+    const u32 code16 = (fc + (i - of)) << (16u - L);
+    atomicMax(&lmax[(code16 >> 8) & 255u], L);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  // ---- sub-table sizes -> bases; level-1 entries ----
+  u32 total = 0;
+  u32 bases[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const u32 x = (u32) r * 64u + lane;
+    const u32 lm = lmax[x];
+    const u32 sz = lm ? 1u << (lm - 8u) : 0u;
+    const u32 inc = wave_incl_scan(sz);
+    bases[r] = total + inc - sz;
+    total += rdl(inc, 63u);
+  }
+  if (total > LZX_SUB_CAP) return false;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const u32 x = (u32) r * 64u + lane;
+    const u32 lm = lmax[x];
+    if (lm) { sh->main_tab[x] = (LZX_MTAB_T)(0x8000u | ((lm - 9u) << 11) | bases[r]); lmax[x] = lm | (bases[r] << 8); }
+  }
+  for (u32 q = lane; q < total; q += WAVE) sh->sub_tab[q] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  // ---- every long symbol fills its share of its prefix's sub-table ----
+  for (u32 i = lo + lane; i < nsorted; i += WAVE) {
+    u32 L = 9u;
+#pragma unroll
+    for (int l = 10; l <= 16; l++) L += (i >= offs[l - 9]) ? 1u : 0u;
+    u32 fc = first[0], of = offs[0];
+#pragma unroll
+    for (int l = 10; l <= 16; l++) if (L == (u32) l) { fc = first[l - 9]; of = offs[l - 9]; }
+    const u32 code16 = (fc + (i - of)) << (16u - L);
+    const u32 lb = lmax[(code16 >> 8) & 255u];
+    const u32 lm = lb & 255u, base = lb >> 8, sb = lm - 8u;
+    const u32 start = (code16 & 255u) >> (8u - sb), cnt = 1u << (lm - L);
+    const u32 ent = (u32) sh->main_sorted[i] | (L << 10);
+    for (u32 r = 0; r < cnt; r++) sh->sub_tab[base + start + r] = (u16) ent;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  return true;
+}
+
 // 32 bits of the staged input (sh->stage: dwords of an MSB-first bit string) from bit p on, and the 32 behind them.
 // The window is taken one bit early -- dwords ((p + 31) >> 5) - 1 and the next, shifted right by 31 - ((p + 31) & 31)
 // -- so that the shift is always 0..31: one v_alignbit_b32 per word, no 64-bit shift and no special case for p % 32 == 0
@@ -1874,11 +1963,19 @@ struct EmitTok { u32 tot, olen, sym, slot, off; bool is_match, expl, unk; };
 template <bool ALIGNED, bool VALUES>
 __device__ __forceinline__ EmitTok lzx_emit_token(const LzxShared *sh, const bool act, const bool length_empty,
                                                   const u32 *mlim, const u32 *llim, const u32 main_fov, const u32 len_fov,
-                                                  const u32 w0, const u32 w1)
+                                                  const u32 w0, const u32 w1, const bool two_level)
 {
   EmitTok t;
   u32 e = sh->main_tab[w0 >> (32 - LZX_MAIN_P)];
-  if (ballot(act && e == 0u)) {
+  if (two_level) {
+    // (second level: always read, selected -- no branch; a direct entry's fields index some harmless slot)
+    const u32 sb = ((e >> 11) & 7u) + 1u;
+    u32 ix = (e & 0x7FFu) + (((w0 >> 16) & 255u) >> (8u - sb));
+    ix = ix < LZX_SUB_CAP ? ix : 0u;
+    const u32 e2_ = sh->sub_tab[ix];
+    e = (e & 0x8000u) ? e2_ : e;
+  }
+  else if (ballot(act && e == 0u)) {
     const u32 pk = w0 >> 16;
     u32 ln = LZX_MAIN_P + 1u;
 #pragma unroll
@@ -1938,7 +2035,8 @@ __device__ __forceinline__ EmitTok lzx_emit_token(const LzxShared *sh, const boo
 template <bool ALIGNED>
 __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empty, const u32 start_bit, const u32 frame_end_bit,
                                                u8 *const fout, const u32 frame_pos, const u32 frame_size, const u32 edge_n,
-                                               LzxFrameRec *rec, uint2 *mrec, u32 &n_rec, u32 &end_bit, u32 &bytes_done)
+                                               LzxFrameRec *rec, uint2 *mrec, u32 &n_rec, u32 &end_bit, u32 &bytes_done,
+                                               const bool two_level)
 {
   LzxShared *sh = d.sh;
   const u32 lane = d.lane;
@@ -2032,7 +2130,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
         }
 #endif
         STAGE_BITS(act ? p : 0u, w0, w1, ALIGNED)
-        const EmitTok t = lzx_emit_token<ALIGNED, false>(sh, act, length_empty, mlim, llim, main_fov, len_fov, w0, w1);
+        const EmitTok t = lzx_emit_token<ALIGNED, false>(sh, act, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
         const bool ok = act && !t.unk, die = act && t.unk;
         dd = dd || die; sa = die ? p : sa;
         cnt += ok ? 1u : 0u; cb += ok ? t.olen : 0u; cm += (ok && t.is_match) ? 1u : 0u;
@@ -2064,7 +2162,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       const bool on = i < my_n && pos < frame_size && !cross;
       if (!ballot(on)) break;
       STAGE_BITS(on ? p : 0u, w0, w1, true)
-      const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1);
+      const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
       const bool lit = on && !t.is_match;
       const bool crs = on && t.is_match && pos + t.olen > frame_size;   // lzxd.c:678-693: the serial path reports it
       const bool mt = on && t.is_match && !crs;
@@ -2104,7 +2202,8 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     if (segc > 8u) segc = 8u;                                     // (a stretch of more than 8 segments: the last one is long)
     const u32 seginc = wave_incl_scan(segc);
     const u32 T = rdl(seginc, 63u);
-    u8 *const owner = sh->main_len;                               // (the code lengths are in the record; 512 bytes of scratch)
+    // (512 bytes of scratch: the sorted symbols are not needed once the second-level table stands; else the code lengths' room)
+    u8 *const owner = two_level ? (u8 *) sh->main_sorted : sh->main_len;
     for (u32 q = 0; q < segc; q++) owner[seginc - segc + q] = (u8) lane;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const u32 info0 = entry | (n << 16), info1 = P + inclb - cvb, info2 = tt + inclm - cvm, info3 = (seginc - segc) | (segc << 16);
@@ -2131,7 +2230,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
         const bool on = i < ntok && pos < frame_size && !cross;
         if (!ballot(on)) break;
         STAGE_BITS(on ? p : 0u, w0, w1, true)
-        const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1);
+        const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
         const bool lit = on && !t.is_match;
         const bool crs = on && t.is_match && pos + t.olen > frame_size;   // lzxd.c:678-693: the serial path reports it
         const bool mt = on && t.is_match && !crs;
@@ -2386,15 +2485,23 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   }
   lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);        // the next frame's wave may go on
   PH(2);
-  // ---- tables + tokens (cf. lzx_parse_frame) ----
-  bool tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
-                                                              sh->cnt, d.hr_main, lane, false);
-  if (tables) {
+  // ---- tables + tokens (cf. lzx_parse_frame): length and aligned trees first, the main tree last -- its second level
+  // takes the room of the code lengths ----
+  bool tables = true, two_level = false;
+  {
     const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, lane, false);
     tables = r != 1;
     s.length_empty = (r == 2);
   }
   if (tables && s.block_type == 2u) tables = !huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false);
+  if (tables) {
+    u32 nsorted = 0;
+    tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+                                                          sh->cnt, d.hr_main, lane, false, &nsorted);
+#ifndef LZX_NO_SUB_TABLE
+    if (tables) two_level = lzx_build_sub(sh, d.hr_main, nsorted, lane);
+#endif
+  }
   if (!tables) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); return; }
   PH(3);
   u32 n_rec = 0, end_bit = 0, bytes_done = 0;
@@ -2404,8 +2511,8 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     u8 *const fout = out_arena + u.out_off + (size_t) f * LZX_FRAME;
     // the frame's first bytes up to the next 128-byte line: another wave may be writing that line (see lzx_parse_emit)
     const u32 edge_n = (128u - (u32)((size_t) fout & 127u)) & 127u;
-    if (s.block_type == 2u) lzx_parse_emit<true>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done);
-    else lzx_parse_emit<false>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done);
+    if (s.block_type == 2u) lzx_parse_emit<true>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done, two_level);
+    else lzx_parse_emit<false>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done, two_level);
     if (lane == 0) rec->n_edge = edge_n < fsz ? edge_n : fsz;
   }
   if (lane == 0) {

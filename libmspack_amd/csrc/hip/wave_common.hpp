@@ -127,7 +127,7 @@ struct HuffRegs { u32 limv; u32 fov; };
 // above 1023 symbols (LZX DELTA main tree: 12 bits of symbol in u32 entries).
 template <int P, int SH = 10, typename TabT = u16>
 __device__ __forceinline__ int huff_build(const u8 *lens, int nsyms, int ref_tablebits, TabT *tab, u16 *sorted,
-                          u32 *cnt_scratch /* >= 20 u32 in LDS */, HuffRegs &hr, u32 lane, bool lsb)
+                          u32 *cnt_scratch /* >= 20 u32 in LDS */, HuffRegs &hr, u32 lane, bool lsb, u32 *n_sorted = nullptr)
 {
   // 1. histogram of code lengths
   if (lane < 20u) cnt_scratch[lane] = 0;
@@ -162,6 +162,7 @@ __device__ __forceinline__ int huff_build(const u8 *lens, int nsyms, int ref_tab
     code <<= 1;
   }
   hr.limv = limv; hr.fov = fov;
+  if (n_sorted) *n_sorted = n;                           // symbols that have a code (the sorted list's length)
 
   // 3. counting sort by (length, symbol): ballot-ranked, 64 symbols per step
   for (int base = 0; base < nsyms; base += WAVE) {
