@@ -2499,7 +2499,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
                                                           sh->cnt, d.hr_main, lane, false, &nsorted);
 #ifndef LZX_NO_SUB_TABLE
-    if (tables) two_level = lzx_build_sub(sh, d.hr_main, nsorted, lane);
+    if (tables) two_level = rfl(lzx_build_sub(sh, d.hr_main, nsorted, lane) ? 1u : 0u) != 0u;
 #endif
   }
   if (!tables) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); return; }
@@ -2634,6 +2634,9 @@ __device__ __forceinline__ int lzx_run_tokens(LzxDec &d, LzxState &s, const u32 
 // the input, which always belong to the EOF-exact reader -- and reports.  A failed check discards the frame: the
 // serial path decodes it again from its first bit and reports the error with the reference's code and byte count.
 // ---------------------------------------------------------------------------------------------------
+#ifdef LZX_COMMIT_STATS
+__device__ u32 g_commit_stats[8];
+#endif
 __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFrameRec *urecs, const uint2 *utoks, SpecQueueLds *spq)
 {
   const u32 lane = threadIdx.x;
@@ -2740,6 +2743,15 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
                                  vmoff == 0u || vmoff > wsize || vmoff > opos);
           if (ballot(b)) { bad = true; break; }
         }
+#ifdef LZX_COMMIT_STATS      /* emulator runs: how many matches read bytes of their own batch's output region, by length */
+        {
+          const u32 bs = rdl(opos, 0u);
+          const u64 nearm = ballot(ism && opos - vmoff + olen > bs), longm = ballot(ism && olen > 16u), near2 = ballot(ism && vmoff < 512u);
+          if (lane == 0) { atomicAdd(&g_commit_stats[0], (u32) __popcll(mm)); atomicAdd(&g_commit_stats[1], (u32) __popcll(nearm));
+                           atomicAdd(&g_commit_stats[2], (u32) __popcll(longm)); atomicAdd(&g_commit_stats[3], (u32) __popcll(near2));
+                           atomicAdd(&g_commit_stats[4], (u32) __popcll(nearm | longm)); }
+        }
+#endif
         PH(9);
         // (3) queue the copies (cf. lzx_commit_batch)
         {
@@ -2778,6 +2790,10 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
     LzxFrameRec *r0 = &urecs[0];
     r0->rs_frame = rs_frame; r0->rs_partial = rs_partial; r0->rs_P = rs_P; r0->rs_next_bit = rs_next;
     r0->rs_R0 = R0; r0->rs_R1 = R1; r0->rs_R2 = R2; r0->rs_valid = 1u;
+#ifdef LZX_COMMIT_STATS
+    printf("commit stats so far: matches %u, source inside own batch %u, longer than 16 %u, offset < 512 %u, either of the first two %u\n",
+           g_commit_stats[0], g_commit_stats[1], g_commit_stats[2], g_commit_stats[3], g_commit_stats[4]);
+#endif
   }
   PHFLUSH();
 }

@@ -1,0 +1,70 @@
+"""The real kernel sources on the wavefront emulator (tests/emu/): kernel LOGIC checked without a GPU.
+
+tests/emu/build_emu.sh compiles libmspack_amd/csrc/hip/shim.hip -- unchanged -- for the host CPU (64 fibers per wavefront,
+SIMT lock step through instrumentation hooks, cross-lane builtins as collectives) into
+tests/_build/libmspack_emu.so.  A fresh process (the ctypes mirror reads MSPACK_HIP_SO when it is imported) decodes small
+batches through the C ABI and compares them with the oracle: LZX units with frame tables through mspack_lzx_pipe (parse
+tasks, commit tasks, hand-offs between concurrently running workgroups, the resuming unit kernel), a damaged one and one
+with a wrong table, an MSZIP folder and a Quantum folder.  Test infrastructure only: the product library never contains or
+loads the emulator, and nothing here is a fallback for it."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+SO = os.path.join(ROOT, "tests", "_build", "libmspack_emu.so")
+
+WORKER = r'''
+import sys, zlib
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import numpy as np
+import libmspack_amd as M
+import test_gpu_lzx_frames as T
+assert "emu" in M.HIP_SO
+# ---- LZX with frame tables -> mspack_lzx_pipe: right table, wrong table, damaged and cut streams ----
+data = M.gen_plaintext(17, M.TEXT_MIX, 4 * 32768 + 1234)
+comp, fo = M.lzx_encode(data, 21, 2)
+fo = fo.astype(np.int64)[:-1]
+c = comp.tobytes()
+bad = bytearray(c); bad[int(fo[1]) + 900] ^= 0x10
+streams = [c, c, bytes(bad), c[:int(fo[2]) + 1], c[int(fo[2]):]]
+params = [(data.size, 21, 2, 0)] * 4 + [(data.size - 65536, 21, 2, 65536)]
+tabs = [fo, fo + 2, fo, fo, fo[2:] - fo[2]]
+units, out, res = T.run(streams, params, tabs)
+T.check(streams, params, units, out, res, compare_bytes=False)
+for i in (0, 1):
+    assert res["err"][i] == 0 or res["out_len"][i] == data.size
+    assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
+assert res["flags"][0] & T.ADOPTED and res["flags"][4] & T.ADOPTED
+# ---- MSZIP: one folder of two blocks with history; Quantum: one folder ----
+d = M.gen_plaintext(9, 0, 50000).tobytes()
+co = zlib.compressobj(6, zlib.DEFLATED, -15); b0 = b"CK" + co.compress(d[:32768]) + co.flush()
+co = zlib.compressobj(6, zlib.DEFLATED, -15, zdict=d[:32768]); b1 = b"CK" + co.compress(d[32768:]) + co.flush()
+zs = b0 + b1
+qs = bytes(M.qtm_encode(np.frombuffer(d[:40000], dtype=np.uint8), 16)[0])
+qo = (len(zs) + 15) & ~15
+arena = np.zeros(qo + len(qs) + 96, dtype=np.uint8)
+arena[:len(zs)] = np.frombuffer(zs, dtype=np.uint8); arena[qo:qo + len(qs)] = np.frombuffer(qs, dtype=np.uint8)
+units, out_bytes = M.make_units([M.KIND_MSZIP, M.KIND_QUANTUM], [0, qo], [len(zs), len(qs)], [len(d), 40000], window_bits=[0, 16], out_slack=32768)
+out, res = M.decode_batch(units, arena, out_bytes)
+assert res["err"][0] == 0 and out[units["out_off"][0]:units["out_off"][0] + len(d)].tobytes() == d, res[0]
+assert res["err"][1] == 0 and out[units["out_off"][1]:units["out_off"][1] + 40000].tobytes() == d[:40000], res[1]
+print("EMU_OK")
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="the emulator build needs ROCm's clang++")
+def test_kernels_on_the_wavefront_emulator(built, tmp_path):
+    srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("emu_runtime.cpp", "build_emu.sh", "include/hip/hip_runtime.h")]
+    hip = os.path.join(ROOT, "libmspack_amd", "csrc", "hip")
+    srcs += [os.path.join(hip, f) for f in os.listdir(hip) if f.endswith((".hpp", ".hip"))]
+    if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
+        subprocess.check_call(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MSPACK_HIP_SO=SO)
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert p.returncode == 0 and b"EMU_OK" in p.stdout, p.stdout.decode()[-3000:]
