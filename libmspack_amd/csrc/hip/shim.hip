@@ -605,21 +605,28 @@ double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32
 
 // ---------------------------------------------------------------------------------------------------
 // Host-buffer path: a persistent context per device (device arenas and pinned staging grown on demand,
-// never freed per call; MSPACK_HIP_NSTREAMS streams) and a chunked pipeline.  The batch is cut into chunks of
-// units that are contiguous in the caller's arenas; chunk c lives on stream c mod NS:
-//     H2D of the chunk's input span -> one launch per codec over the chunk's compact unit lists -> D2H.
-// Chunks on different streams run concurrently, so the copy of chunk c+1 overlaps the decode of chunk c and
-// the copy-back of chunk c overlaps the decode of chunk c+1 -- and, because one unit is one wavefront's
-// serial chain, all chunks' kernels are resident together once their input has landed.
+// never freed per call; four streams) and a chunked pipeline.  The batch is cut into up to MSPACK_HIP_NCHUNKS
+// chunks of units that are contiguous in the caller's arenas:
+//     copy-in stream :  H2D chunk 0, H2D chunk 1, ...                      (one after the other: the link's rate)
+//     two compute streams, chunk c on stream c mod 2: wait for chunk c's H2D -> one launch per codec over the
+//                       chunk's compact unit lists (a launch's waves leave as its queue runs dry, the next chunk's
+//                       launch -- on the other stream -- fills the slots they free: no tail between chunks)
+//     copy-out stream:  wait for chunk c's launches -> D2H chunk c          (PCIe is full duplex)
+// so the copy of chunk c+1 overlaps the decode of chunk c and the copy-back of chunk c the decode of chunk c+1.
+// (Four streams = four hardware queues: with more, two streams share a queue and a copy waits behind another
+// chunk's kernel -- what profiles/round2_hostpath_streams.txt shows for its third chunk.)
 // ---------------------------------------------------------------------------------------------------
 #define MSPK_MAX_DEV 16
 #define MSPK_MAX_STREAMS 8
+#define MSPK_MAX_CHUNKS 8
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 struct DevCtx {
   std::mutex mu;
   bool ready = false;
   int ns = 0;
-  hipStream_t st[MSPK_MAX_STREAMS];
+  hipStream_t st[MSPK_MAX_STREAMS];      // [0] copy-in (and everything of a one-chunk call), [1] copy-out, [2] [3] compute
+  hipEvent_t ev_in[MSPK_MAX_CHUNKS], ev_done[MSPK_MAX_CHUNKS];
+  int max_chunks = 1, n_compute = 2;
   DevBuf d_in, d_out, d_units, d_order, d_res, d_fm;
   DevBuf h_stage;                       // pinned: results + (optionally) the output on its way to pageable memory
 };
@@ -733,26 +740,38 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
   const size_t in_span = (size_t)(in_hi - in_lo), out_span = (size_t)(out_hi - out_lo);
 
   if (!cx.ready) {
-    // Default: ONE chunk.  Measured on the box (profiles/round2_hostpath_streams.txt): a chunk's launch lasts as
-    // long as its slowest unit whatever its size (one unit = one wavefront's serial chain), so the last
-    // chunk still ends at H2D_total + 4.7 ms; and hipMemcpyAsync from PAGEABLE memory on a third stream does
-    // not start before an earlier chunk's kernel has finished.  More streams (MSPACK_HIP_NSTREAMS=2..8) only
-    // pay once units are short against the copies.
-    cx.ns = env_int("MSPACK_HIP_NSTREAMS", 1, 1, MSPK_MAX_STREAMS);
+    cx.n_compute = env_int("MSPACK_HIP_NCOMPUTE", 2, 1, MSPK_MAX_STREAMS - 2);
+    cx.ns = 2 + cx.n_compute;
+    cx.max_chunks = env_int("MSPACK_HIP_NCHUNKS", 4, 1, MSPK_MAX_CHUNKS);
     for (int i = 0; i < cx.ns; i++) TRY(hipStreamCreateWithFlags(&cx.st[i], hipStreamNonBlocking));
+    for (int i = 0; i < MSPK_MAX_CHUNKS; i++) {
+      TRY(hipEventCreateWithFlags(&cx.ev_in[i], hipEventDisableTiming));
+      TRY(hipEventCreateWithFlags(&cx.ev_done[i], hipEventDisableTiming));
+    }
     cx.ready = true;
   }
   {
     // chunks: arena-contiguous runs of units; enough of them to overlap the copies with the decode, each
     // big enough to be worth a launch.  Outputs that interleave (not monotone) are copied back unit by unit.
-    size_t want = monotone ? std::min<size_t>((size_t) cx.ns, std::max<size_t>(1, in_sum >> 22)) : 1;
-    want = std::min(want, std::max<size_t>(1, n_sel / 64));
+    // (a chunk: >= 8 MiB of input -- a copy of >= 150 us -- and >= 256 units)
+    static const size_t chunk_bytes = (size_t) env_int("MSPACK_HIP_CHUNK_BYTES", 8 << 20, 1, 1 << 30);
+    static const size_t chunk_units = (size_t) env_int("MSPACK_HIP_CHUNK_UNITS", 256, 1, 1 << 30);
+    size_t want = monotone ? std::min<size_t>((size_t) cx.max_chunks, std::max<size_t>(1, in_sum / chunk_bytes)) : 1;
+    want = std::min(want, std::max<size_t>(1, n_sel / chunk_units));
     std::vector<Chunk> chunks;
     {
-      size_t a = 0; uint64_t acc = 0; const uint64_t per = in_sum / want + 1;
+      // equal shares of the input bytes.  (MSPACK_HIP_CHUNK_SHAPE=1: 1 : 1 : 2 : 4 ... -- an early first copy-back and a
+      // large last launch; measured at the headline: to the device 4.55 ms against 4.74, to the host 8.06 against 7.62)
+      static const bool geometric = env_int("MSPACK_HIP_CHUNK_SHAPE", 0, 0, 1) != 0;
+      uint64_t wsum = 0, w[MSPK_MAX_CHUNKS];
+      for (size_t k = 0; k < want; k++) { w[k] = geometric && k >= 2 ? (uint64_t) 1 << (k - 1) : 1; wsum += w[k]; }
+      size_t a = 0; uint64_t acc = 0, upto = 0;
       for (size_t i = 0; i < n_sel; i++) {
         acc += local[i].in_len;
-        if (i + 1 == n_sel || (acc >= per && chunks.size() + 1 < want)) { Chunk c; c.a = a; c.b = i + 1; chunks.push_back(c); a = i + 1; acc = 0; }
+        const uint64_t goal = (uint64_t)((double) in_sum * (double)(upto + w[chunks.size()]) / (double) wsum);
+        if (i + 1 == n_sel || (acc >= goal && chunks.size() + 1 < want)) {
+          Chunk c; c.a = a; c.b = i + 1; upto += w[chunks.size()]; chunks.push_back(c); a = i + 1;
+        }
       }
     }
     // per chunk: spans, per-kind launch lists (longest compressed unit first: the slowest chain starts first)
@@ -805,58 +824,106 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     mspack_hip_result *const h_res = (mspack_hip_result *) cx.h_stage.p;
     t1 = tnow();
 
-    // ---- issue: tables on stream 0, then every chunk on its own stream ----
-    hipEvent_t ev_tab;
-    TRY(hipEventCreateWithFlags(&ev_tab, hipEventDisableTiming));
-    TRY(hipMemcpyAsync(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice, cx.st[0]));
-    TRY(hipMemcpyAsync(d_order, order.data(), n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, cx.st[0]));
-    TRY(hipMemsetAsync(cx.d_fm.p, 0, (n_frames + 1) * sizeof(int32_t), cx.st[0]));
-    TRY(hipMemsetAsync(d_in + in_span, 0, 64, cx.st[0]));
-    TRY(hipEventRecord(ev_tab, cx.st[0]));
+    // ---- issue: tables, then every chunk's copy on the copy-in stream and its launches on a compute stream ----
+    const bool one = chunks.size() == 1;                 // one chunk: everything in order on one stream, no events
+    hipStream_t st_in = cx.st[0], st_out = one ? cx.st[0] : cx.st[1];
+    TRY(hipMemcpyAsync(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice, st_in));
+    TRY(hipMemcpyAsync(d_order, order.data(), n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, st_in));
+    TRY(hipMemsetAsync(cx.d_fm.p, 0, (n_frames + 1) * sizeof(int32_t), st_in));
+    TRY(hipMemsetAsync(d_in + in_span, 0, 64, st_in));
+    // The copies back are issued by a second thread.  A copy into PAGEABLE memory holds its calling thread and (measured,
+    // profiles/round3_hostpath.txt) does not start before every stream of the device has drained, so this thread first
+    // page-locks each chunk's part of the caller's buffer (hipHostRegister -- while the main thread is inside the H2D
+    // copies and the first launches run), after which chunk c's D2H is a plain DMA that starts the moment chunk c's
+    // launches have ended, next to the H2D of later chunks (PCIe is full duplex).  The pages are released before the
+    // call returns.  A buffer that cannot be registered (already pinned by its owner, or the runtime refuses) is
+    // copied the ordinary way.
+    std::atomic<size_t> issued{0};                       // chunks whose ev_done has been recorded
+    std::atomic<bool> stop{false};
+    hipError_t back_err = hipSuccess;
+    double pin_ms = 0.0, unpin_ms = 0.0;
+    std::thread back;
+    struct Pins {                                          // page-locked ranges of the caller's buffer
+      char *p[MSPK_MAX_CHUNKS]; int n = 0;
+      void release() { for (int i = 0; i < n; i++) hipHostUnregister(p[i]); n = 0; }
+      ~Pins() { if (n) { hipDeviceSynchronize(); release(); } }      // (an error path: nothing may still be writing them)
+    } pins;
+    struct Joiner { std::thread &t; std::atomic<bool> &stop; ~Joiner() { if (t.joinable()) { stop.store(true); t.join(); } } } joiner{back, stop};
+    static const bool pin_out = env_int("MSPACK_HIP_PIN_OUT", 1, 0, 1) != 0;
+    if (host_out && !one)
+      back = std::thread([&]() {
+        hipError_t be = hipSetDevice(dev);
+        const uintptr_t PG = 4096u, base = (uintptr_t) host_out;
+        for (size_t ci = 0; ci < chunks.size() && be == hipSuccess; ci++) {
+          const Chunk &c = chunks[ci];
+          // chunk ci's pages: from the first page boundary inside it (chunk 0: the page its first byte is in) to the
+          // first page boundary at or after its end -- disjoint from its neighbours' ranges
+          uintptr_t ra = base + c.out_lo, rb = base + c.out_hi;
+          ra = ci == 0 ? (ra & ~(PG - 1u)) : ((ra + PG - 1u) & ~(PG - 1u));
+          rb = (rb + PG - 1u) & ~(PG - 1u);
+          auto r0 = tnow();
+          if (pin_out && rb > ra && hipHostRegister((void *) ra, rb - ra, hipHostRegisterDefault) == hipSuccess)
+            pins.p[pins.n++] = (char *) ra;
+          else
+            (void) hipGetLastError();
+          pin_ms += tms(r0, tnow());
+          while (issued.load(std::memory_order_acquire) <= ci) { if (stop.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
+          be = hipStreamWaitEvent(st_out, cx.ev_done[ci], 0);
+          // (the bytes of chunk ci below its first page boundary lie in the previous chunk's range: a copy of their own)
+          uintptr_t lo = base + c.out_lo, hi = base + c.out_hi, cut = std::min(std::max(lo, ra), hi);
+          if (be == hipSuccess && cut > lo)
+            be = hipMemcpyAsync((void *) lo, d_out + (c.out_lo - out_lo), cut - lo, hipMemcpyDeviceToHost, st_out);
+          if (be == hipSuccess && hi > cut)
+            be = hipMemcpyAsync((void *) cut, d_out + (c.out_lo - out_lo) + (cut - lo), hi - cut, hipMemcpyDeviceToHost, st_out);
+        }
+        back_err = be;
+      });
     for (size_t ci = 0; ci < chunks.size(); ci++) {
       const Chunk &c = chunks[ci];
-      hipStream_t st = cx.st[ci % cx.ns];
-      if (ci != 0) TRY(hipStreamWaitEvent(st, ev_tab, 0));
+      hipStream_t st = one ? cx.st[0] : cx.st[2 + ci % (size_t) cx.n_compute];
       TRY(hipMemcpyAsync(d_in + (c.in_lo - in_lo), (const char *) in + c.in_lo, (size_t)(c.in_hi - c.in_lo),
-                         hipMemcpyHostToDevice, st));
+                         hipMemcpyHostToDevice, st_in));
       if (host_out)
         for (size_t i = c.a; i < c.b; i++)               // LZX DELTA reference data sits below the unit's output
           if (local[i].ref_len)
             TRY(hipMemcpyAsync(d_out + local[i].out_off - local[i].ref_len,
                                (const char *) host_out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
-                               hipMemcpyHostToDevice, st));
+                               hipMemcpyHostToDevice, st_in));
+      if (!one) { TRY(hipEventRecord(cx.ev_in[ci], st_in)); TRY(hipStreamWaitEvent(st, cx.ev_in[ci], 0)); }
       for (unsigned k = 1; k <= 6; k++)
         launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
                     c.has_ftab, (unsigned) ci, n_rec_slots);
       TRY(hipGetLastError());
       TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
+      if (!one) { TRY(hipEventRecord(cx.ev_done[ci], st)); issued.store(ci + 1, std::memory_order_release); }
     }
     t2 = tnow();
-    // ---- copy-back, chunk by chunk (each call waits for its own chunk only) ----
-    if (host_out) {
-      for (size_t ci = 0; ci < chunks.size(); ci++) {
-        const Chunk &c = chunks[ci];
-        hipStream_t st = cx.st[ci % cx.ns];
-        if (monotone)
-          TRY(hipMemcpyAsync((char *) host_out + c.out_lo, d_out + (c.out_lo - out_lo), (size_t)(c.out_hi - c.out_lo),
-                             hipMemcpyDeviceToHost, st));
-        else
-          for (size_t i = c.a; i < c.b; i++)
-            TRY(hipMemcpyAsync((char *) host_out + out_lo + local[i].out_off, d_out + local[i].out_off, local[i].out_len,
-                               hipMemcpyDeviceToHost, st));
-      }
+    // ---- copy-back, chunk by chunk on the copy-out stream (each copy waits for its own chunk's launches only) ----
+    if (host_out && one) {
+      const Chunk &c = chunks[0];
+      if (monotone)
+        TRY(hipMemcpyAsync((char *) host_out + c.out_lo, d_out + (c.out_lo - out_lo), (size_t)(c.out_hi - c.out_lo),
+                           hipMemcpyDeviceToHost, st_out));
+      else
+        for (size_t i = c.a; i < c.b; i++)
+          TRY(hipMemcpyAsync((char *) host_out + out_lo + local[i].out_off, d_out + local[i].out_off, local[i].out_len,
+                             hipMemcpyDeviceToHost, st_out));
+    }
+    if (back.joinable()) {
+      back.join();
+      if (back_err != hipSuccess) TRY(back_err);
     }
     for (int i = 0; i < cx.ns; i++) TRY(hipStreamSynchronize(cx.st[i]));
-    hipEventDestroy(ev_tab);
+    { auto r0 = tnow(); pins.release(); unpin_ms = tms(r0, tnow()); }
     for (size_t i = 0; i < n_sel; i++) {
       results[idx[i]] = h_res[i];
       if (local[i].kind == 0) { memset(&results[idx[i]], 0, sizeof(mspack_hip_result)); results[idx[i]].err = ERR_ARGS; }
     }
     t3 = tnow();
     if (trace)
-      fprintf(stderr, "mspack_hip[dev %d]: %zu units in %zu chunks on %d streams: plan+alloc %.2f ms, issue (H2D %.1f MB) %.2f ms, "
-              "drain (D2H %.1f MB) %.2f ms\n", dev, n_sel, chunks.size(), cx.ns, tms(t0, t1), in_span / 1e6, tms(t1, t2),
-              host_out ? out_span / 1e6 : 0.0, tms(t2, t3));
+      fprintf(stderr, "mspack_hip[dev %d]: %zu units in %zu chunks (%d streams): plan+alloc %.2f ms, issue (H2D %.1f MB) %.2f ms, "
+              "drain (D2H %.1f MB) %.2f ms (page-locking %.2f ms beside the issue, release %.2f ms)\n", dev, n_sel, chunks.size(), cx.ns,
+              tms(t0, t1), in_span / 1e6, tms(t1, t2), host_out ? out_span / 1e6 : 0.0, tms(t2, t3), pin_ms, unpin_ms);
   }
 done:
   if (rc) for (int i = 0; i < cx.ns; i++) hipStreamSynchronize(cx.st[i]);
@@ -953,7 +1020,10 @@ void mspack_hip_release(void)
     hipDeviceSynchronize();
     for (DevBuf *b : { &cx.d_in, &cx.d_out, &cx.d_units, &cx.d_order, &cx.d_res, &cx.d_fm }) { if (b->p) hipFree(b->p); b->p = nullptr; b->cap = 0; }
     if (cx.h_stage.p) { hipHostFree(cx.h_stage.p); cx.h_stage.p = nullptr; cx.h_stage.cap = 0; }
-    if (cx.ready) for (int i = 0; i < cx.ns; i++) hipStreamDestroy(cx.st[i]);
+    if (cx.ready) {
+      for (int i = 0; i < cx.ns; i++) hipStreamDestroy(cx.st[i]);
+      for (int i = 0; i < MSPK_MAX_CHUNKS; i++) { hipEventDestroy(cx.ev_in[i]); hipEventDestroy(cx.ev_done[i]); }
+    }
     cx.ready = false;
   }
   hipSetDevice(keep);

@@ -157,6 +157,9 @@ hipError_t hipFree(void *p);
 hipError_t emu_hipHostMalloc(void **p, size_t n);
 template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned flags = 0) { (void) flags; return emu_hipHostMalloc((void **) p, n); }
 hipError_t hipHostFree(void *p);
+#define hipHostRegisterDefault 0
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s = 0);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s = 0);

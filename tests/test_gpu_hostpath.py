@@ -165,6 +165,39 @@ def test_multi_sharded_path(built, shards, tmp_path):
     assert p.returncode == 0 and b"SHARDS_OK" in p.stdout, p.stdout.decode()[-3000:]
 
 
+CHUNK_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import libmspack_amd as M
+import test_gpu_hostpath as T
+units, arena, out_bytes, items = T.mixed_batch(n_each=int(sys.argv[1]), seed=21)
+for _ in range(2):                                   # (the second call reuses streams, events and arenas)
+    out, res = M.decode_batch(units, arena, out_bytes)
+    T.check(units, out, res, items)
+d_out = T.DevBuf(out_bytes + 64)
+res = np.zeros(len(units), dtype=M.RESULT_DTYPE)
+u = np.ascontiguousarray(units)
+rc = M.lib().mspack_hip_decode_batch_to_device(u.ctypes.data, len(u), arena.ctypes.data, arena.size, d_out.ptr, out_bytes + 64, res.ctypes.data)
+assert rc == 0
+T.check(units, d_out.to_host(), res, items)
+print("CHUNKS_OK")
+'''
+
+
+@pytest.mark.parametrize("nchunks", [2, 5, 8])
+def test_chunked_pipeline_small_chunks(built, nchunks, tmp_path):
+    """the copy-in / compute / copy-out streams with many small chunks of a mixed batch (thresholds lowered through
+    the environment: every chunk holds LZX, MSZIP and Quantum units, concurrent LZX launches use their own control
+    words and slot ranges)"""
+    script = tmp_path / "w.py"
+    script.write_text(CHUNK_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MSPACK_HIP_NCHUNKS=str(nchunks), MSPACK_HIP_CHUNK_BYTES="4096", MSPACK_HIP_CHUNK_UNITS="4", MSPACK_HIP_TRACE="1")
+    p = subprocess.run([sys.executable, str(script), "24"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0 and b"CHUNKS_OK" in p.stdout, p.stdout.decode()[-3000:]
+    assert (b"in %d chunks" % nchunks) in p.stdout, p.stdout.decode()[-3000:]
+
+
 def test_headline_batch_host_entry_points(built):
     """the 4096-interval headline batch through both host entry points (what bench.py's host_inclusive times)"""
     n, ub = 4096, 65536
