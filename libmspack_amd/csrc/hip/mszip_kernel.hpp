@@ -25,6 +25,10 @@
 #define ZIP_BL_P 7
 #define ZIP_HIST 8
 
+#define ZIP_STAGE_WORDS 1024u      /* zip_parse_lanes: 4 KiB of a CFDATA block's input per pass */
+#define ZIP_LANE_TAIL 384u         /* bits a lane walks in front of its stretch's end to find its exit */
+#define ZIP_LANE_ROUNDS 5u         /* walks before the consistent prefix is taken as it is */
+
 #define ZIP_TOK_CAP 16384u         /* tokens a parse wave stores per CFDATA block (same slot size as LZX_TOK_CAP) */
 
 // what a parse wave leaves for the unit's wave (same 1344-byte slots as LzxFrameRec; only the head is used)
@@ -52,9 +56,14 @@ struct __align__(16) MszipShared {
   u8  dist_len[32];
   u8  bl_len[20];
   u8  lens[324];
-  u32 inbuf[128 + 4];            /* speculative path: two 256-byte input chunks */
-  SpecQueueLds spq;              /* speculative path: queued matches + start flags (spec_queue.hpp) */
-  u32 tq0[128], tq1[128];        /* speculative path: parsed tokens waiting for their commit (zip_run_spec) */
+  union {
+    struct {
+      u32 inbuf[128 + 4];        /* speculative path: two 256-byte input chunks */
+      SpecQueueLds spq;          /* speculative path: queued matches + start flags (spec_queue.hpp) */
+      u32 tq0[128], tq1[128];    /* speculative path: parsed tokens waiting for their commit (zip_run_spec) */
+    };
+    u32 stage[ZIP_STAGE_WORDS + 64u + 4u];   /* parse waves (zip_parse_lanes): the input of one pass, stream order */
+  };
 };
 
 // inflate() failure classes: <0 = format error (-> MSPACK_ERR_DECRUNCH), >0 = MSPACK_ERR_READ
@@ -240,7 +249,8 @@ __device__ __forceinline__ int zip_read_dynamic(ZipDec &d)
 // ---------------------------------------------------------------------------------------------------
 struct ZipTok { u32 tot, sym, kind, olen, dist; bool unk; };      // kind 0 literal, 1 match, 2 end of block
 
-__device__ __forceinline__ ZipTok zip_spec_token(const MszipShared *sh, const u32 lit_fov, const u32 *llim, u64 r)
+__device__ __forceinline__ ZipTok zip_spec_token(const MszipShared *sh, const u32 lit_fov, const u32 *llim, u64 r,
+                                                 const u32 *dlim = nullptr, const u32 dist_fov = 0u)
 {
   ZipTok t;
   const u32 lo = (u32) r;
@@ -269,7 +279,19 @@ __device__ __forceinline__ ZipTok zip_spec_token(const MszipShared *sh, const u3
   zip_len_code(code < 29u ? code : 0u, lbase, lextra);
   const u32 lev = (u32) r & ((1u << lextra) - 1u);
   r >>= lextra;
-  const u32 e2 = sh->dist_tab[(u32) r & ((1u << ZIP_DIST_P) - 1u)];
+  u32 e2 = sh->dist_tab[(u32) r & ((1u << ZIP_DIST_P) - 1u)];
+  if (dlim && ballot(is_match && e2 == 0u)) {                     // a distance code beyond the direct table (rare)
+    const u32 pk = __brev((u32) r) >> 16;
+    u32 ln = ZIP_DIST_P + 1u;
+#pragma unroll
+    for (int l = ZIP_DIST_P + 1; l <= 16; l++) ln += (pk >= dlim[l - ZIP_DIST_P - 1]) ? 1u : 0u;
+    const u32 lq = ln <= 16u ? ln : 0u;
+    const u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) dist_fov);
+    u32 idx = (fo >> 16) + ((pk >> (16u - lq)) - (fo & 0xFFFFu));
+    if (idx >= 32u) idx = 0;
+    const u32 dsr = sh->dist_sorted[idx];
+    if (e2 == 0u && lq != 0u) e2 = dsr | (lq << 10);
+  }
   const u32 ds = e2 & 1023u;
   zip_dist_code(ds < 30u ? ds : 0u, dbase, dextra);
   r >>= (e2 >> 10);
@@ -450,77 +472,151 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
 // stored deflate block, an error, the last bytes of the input, more than 32 KiB of output); the folder's wave
 // adopts a record only if it was parsed from exactly its bit position, and decodes everything else as before.
 // ---------------------------------------------------------------------------------------------------
-// the PARSE half of zip_run_spec: tokens to global memory.  Returns 1 when the end-of-block symbol was consumed
-// (bit position and the reference's bits_left behind it are in the decoder), 0 when it stopped in front of a token
-// this path does not take (scalar reader positioned there), -1 when the block cannot be parsed here.
-__device__ __forceinline__ int zip_parse_run(ZipDec &d, uint2 *tok, u32 &tt, u32 &outc)
+// ---------------------------------------------------------------------------------------------------
+// zip_parse_lanes -- the lane-stretch parser of the LZX path (lzx_kernel.hpp, lzx_parse_emit) for deflate: same
+// tokens of the current deflate block from the reader's bit position on; returns 1 = the end-of-block symbol was
+// consumed (bit position and the reference's bits_left behind it are in the decoder), 0 = stopped in front of a token
+// this path does not take (scalar reader positioned there), -1 = the block cannot be parsed here.  A pass covers up to
+// 4 KiB of input (round 2's parse: 64 bit positions per round, the chain of real tokens followed):
+//   * the pass's input is staged in LDS; its bits are cut into 64 stretches, one per lane (lane 0's is short: it
+//     starts at a real token and walks its stretch while the others look for their exits);
+//   * round 0: every other lane walks the last ZIP_LANE_TAIL bits in front of its stretch's end from an arbitrary
+//     bit -- Huffman-coded token streams fall into step after a few tokens -- and hands the bit at which it leaves
+//     its stretch to the next lane as that lane's entry; next rounds: lanes whose entry moved walk their stretch from
+//     it, until no entry moves (a lane's tokens are then exactly the tokens of the serial decoder: its entry is the
+//     exit of a lane for which that holds, down to lane 0);
+//   * the end-of-block symbol and a token this path does not take (an invalid code, a distance code longer than the
+//     direct table) end a lane's walk; the first such lane in chain order ends the pass;
+//   * prefix sums of the lanes' output bytes and match counts give every lane its place in the block's output and in
+//     the record list; a last walk stores the LITERALS straight into the output (`fout` = where the block's bytes go if
+//     every earlier block of the folder is a full one -- the folder's wave checks that before it adopts the record)
+//     and one record per MATCH: (position in the block, distance << 9 | length), what zip_run_tokens queues.
+// mszipd.c:228-303 (the token loop), readhuff.h:144-172 (the codes).
+// ---------------------------------------------------------------------------------------------------
+#define ZIP_STAGE_R(p_, r_)                                                                      \
+  u64 r_;                                                                                        \
+  {                                                                                              \
+    const u32 k_ = (p_) >> 5, s_ = (p_) & 31u;                                                   \
+    const u32 x0_ = sh->stage[k_], x1_ = sh->stage[k_ + 1u], x2_ = sh->stage[k_ + 2u];          \
+    r_ = (u64)(u32) __builtin_amdgcn_alignbit(x1_, x0_, s_) | ((u64)(u32) __builtin_amdgcn_alignbit(x2_, x1_, s_) << 32); \
+  }
+
+__device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, uint2 *tok, u32 &tt, u32 &outc)
 {
   MszipShared *sh = d.sh;
   const u32 lane = d.lane;
-  const u32 room_bytes = (d.w.in_len > d.w.origin + 56u) ? (d.w.in_len - d.w.origin - 56u) : 0u;
-  const u32 bit_limit = rfl(room_bytes * 8u);
-  u32 bitpos = rfl(d.cons_bits());
+  // Tokens may start anywhere below the end of the input (the bytes behind it are staged as zeros, which is what the
+  // reference's reader fabricates there, readbits.h:194); whether the reference got as far without MSPACK_ERR_READ is
+  // decided once, at the end-of-block symbol (below).
+  const u32 bit_limit = rfl(d.w.in_len > d.w.origin ? (d.w.in_len - d.w.origin) * 8u : 0u);
+  u32 bitpos = rfl(d.cons_bits());                       // relative to d.w.origin, like everything below
   if (bitpos >= bit_limit) return -1;
-  u32 cb = bitpos >> 11;
-  {
-    u32 lo = d.w.load_chunk(cb, lane), hi = d.w.load_chunk(cb + 1u, lane);
-    sh->inbuf[lane] = lo; sh->inbuf[64u + lane] = hi;
-    if (lane < 4u) sh->inbuf[128u + lane] = 0;
-  }
-  u32 pf = d.w.load_chunk(cb + 2u, lane);
   u32 llim[16 - ZIP_LIT_P];
 #pragma unroll
   for (int l = ZIP_LIT_P + 1; l <= 16; l++) llim[l - ZIP_LIT_P - 1] = rdl(d.hr_lit.limv, (u32) l);
+  u32 dlim[16 - ZIP_DIST_P];
+#pragma unroll
+  for (int l = ZIP_DIST_P + 1; l <= 16; l++) dlim[l - ZIP_DIST_P - 1] = rdl(d.hr_dist.limv, (u32) l);
+  const u32 lit_fov = d.hr_lit.fov, dist_fov = d.hr_dist.fov;
   int rc = 0, eob_rbl = 0;
   for (;;) {
-    if ((bitpos >> 11) != cb) {                         // slide the LDS window by one chunk
-      u32 up = sh->inbuf[64u + lane];
-      sh->inbuf[lane] = up; sh->inbuf[64u + lane] = pf;
-      cb++;
-      pf = d.w.load_chunk(cb + 2u, lane);
+    // ---- stage the input from the dword that holds bit `bitpos` ----
+    const u32 sw = bitpos >> 5, sb_bit = sw << 5;
+    const u32 b0 = bitpos - sb_bit;
+    u32 e0 = ZIP_STAGE_WORDS * 32u; if (e0 > bit_limit - sb_bit) e0 = bit_limit - sb_bit;
+    {
+      InWindow ws = d.w; ws.origin = d.w.origin + sw * 4u;
+      const u32 nck = (e0 + 128u + 2047u) >> 11;         // a token that starts below e0 ends below e0 + 48
+      constexpr int NCH = (int)(ZIP_STAGE_WORDS / 64u) + 1;
+      u32 sv[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) sv[c] = (u32) c < nck ? ws.load_chunk((u32) c, lane) : 0u;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) if ((u32) c < nck) sh->stage[(u32) c * 64u + lane] = sv[c];
+      if (lane < 4u) sh->stage[nck * 64u + lane] = 0u;
     }
-    const u32 rel = bitpos - (cb << 11) + lane;
-    const u32 k = rel >> 5, sft = rel & 31u;
-    const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
-    const u64 q01 = ((u64) i1 << 32) | i0, q12 = ((u64) i2 << 32) | i1;
-    const u64 r = (u64)(u32)(q01 >> sft) | ((u64)(u32)(q12 >> sft) << 32);
-    const ZipTok t = zip_spec_token(sh, d.hr_lit.fov, llim, r);
-    const u32 vnext = t.unk ? (128u + lane) : (t.kind == 2u ? (192u + lane) : (lane + t.tot));
-    u64 chain = 0;
-    u32 q = 0;
-    do { chain |= 1ull << q; q = rdl(vnext, q); } while (q < WAVE);
-    bool stop = false;
-    if (q >= 192u) {                                    // the end-of-block symbol: not a token, ends the parse
-      q -= 192u;
-      const u32 st = bitpos + q, tl = rdl(t.tot, q);
-      eob_rbl = (int)(16u + ((0u - st) & 7u) - tl);
-      chain &= ~(1ull << q);
-      q += tl; rc = 1; stop = true;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // ---- stretches ----
+    const u32 Lb = e0 - b0;
+    u32 S = (Lb + 63u) >> 6; if (S < 64u) S = 64u;
+    u32 S0 = S;
+    if (S > ZIP_LANE_TAIL + 64u) { S0 = ZIP_LANE_TAIL; S = (Lb - S0 + 62u) / 63u; }
+    const u32 nl = Lb <= S0 ? 1u : 1u + (Lb - S0 + S - 1u) / S;
+    const u32 rstart = lane == 0u ? b0 : b0 + S0 + (lane - 1u) * S;
+    u32 rend = rstart + (lane == 0u ? S0 : S); if (rend > e0) rend = e0;
+    u32 entry = lane == 0u ? b0 : (rend > rstart + ZIP_LANE_TAIL ? rend - ZIP_LANE_TAIL : rstart);
+    u32 n = 0, nb = 0, nmr = 0, exitp = entry, stop_at = 0, stop_tot = 0, ended = 0;     // ended: 1 end of block, 2 a token not taken
+    bool changed = lane < nl;
+    for (u32 round = 0; ; ) {
+      u32 p = entry, cnt = 0, cb = 0, cm = 0, sa = 0, st = 0, en = 0;
+      for (;;) {
+        const bool act = changed && p < rend;
+        if (!ballot(act)) break;
+        ZIP_STAGE_R(act ? p : 0u, r)
+        const ZipTok t = zip_spec_token(sh, lit_fov, llim, r, dlim, dist_fov);
+        const bool die = act && t.unk, eob = act && !t.unk && t.kind == 2u, ok = act && !die && !eob;
+        if (die || eob) { en = die ? 2u : 1u; sa = p; st = t.tot; }
+        cnt += ok ? 1u : 0u; cb += ok ? t.olen : 0u; cm += (ok && t.kind == 1u) ? 1u : 0u;
+        p = (die || eob) ? rend : p + (ok ? t.tot : 0u);
+      }
+      if (changed) { n = cnt; nb = cb; nmr = cm; exitp = p; ended = en; stop_at = sa; stop_tot = st; }
+      round++;
+      const u32 pe = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) exitp);
+      const u32 ne = lane == 0u ? b0 : pe;
+      changed = lane < nl && ne != entry;
+      entry = ne;
+      if (!ballot(changed) || round >= ZIP_LANE_ROUNDS) break;
     }
-    else if (q >= 128u) { q -= 128u; chain &= ~(1ull << q); stop = true; }
-    const u32 nA = (u32) __popcll(chain);
-    if (tt + nA > ZIP_TOK_CAP) return -1;
-    const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain, 0u));
-    const bool on = lane_in(chain);
-    if (on) tok[tt + rank] = make_uint2(t.kind | (t.olen << 3), t.kind == 0u ? t.sym : t.dist);
-    tt += nA;
-    outc += rdl(wave_incl_scan(on ? t.olen : 0u), 63u);
-    bitpos += q;
-    if (outc > ZIP_FRAME) return -1;
-    if (stop) break;
+    // ---- the consistent prefix: lanes < mm ----
+    u32 m = nl;
+    { const u64 chm = ballot(changed); if (chm) m = (u32) __ffsll((long long) chm) - 1u; }
+    u32 mm = m, dl = 0;
+    bool hit = false;
+    { const u64 dm = ballot(ended != 0u && lane < m); if (dm) { dl = (u32) __ffsll((long long) dm) - 1u; mm = dl + 1u; hit = true; } }
+    if (mm == 0u) return -1;
+    const u32 cvn = lane < mm ? n : 0u, cvb = lane < mm ? nb : 0u, cvm = lane < mm ? nmr : 0u;
+    const u32 inclb = wave_incl_scan(cvb), inclm = wave_incl_scan(cvm);
+    const u32 tot_m = rdl(inclm, 63u), tot_b = rdl(inclb, 63u);
+    if (tt + tot_m > ZIP_TOK_CAP || outc + tot_b > ZIP_FRAME) return -1;
+    // ---- last walk: literals into the output, one record per match ----
+    {
+      u32 p = entry, i = 0, pos = outc + inclb - cvb, j = tt + inclm - cvm;
+      for (;;) {
+        const bool on = i < cvn;
+        if (!ballot(on)) break;
+        ZIP_STAGE_R(on ? p : 0u, r)
+        const ZipTok t = zip_spec_token(sh, lit_fov, llim, r, dlim, dist_fov);
+        if (on && t.kind == 0u) gst_stream(fout + pos, (u8) t.sym);
+        if (on && t.kind == 1u) gst_stream(tok + j, make_uint2(pos, (t.dist << 9) | t.olen));
+        p += on ? t.tot : 0u; i += on ? 1u : 0u;
+        pos += on ? t.olen : 0u; j += (on && t.kind == 1u) ? 1u : 0u;
+      }
+    }
+    tt += tot_m; outc += tot_b;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the stage is rewritten by the next pass
+    if (hit) {
+      const u32 sa = sb_bit + rdl(stop_at, dl);
+      if (rdl(ended, dl) == 1u) {                                 // the end-of-block symbol: not a token, ends the parse
+        // ENSURE_BITS(16) in front of it (mszipd.c:229 via readhuff.h:44) is the farthest the reference reads in this
+        // block: byte (sa + 15) >> 3 of the stream must exist or be one of the bytes fabricated at the end of the input
+        if (((sa + 15u) >> 3) >= d.w.in_len - d.w.origin + d.w.eofs) return -1;
+        const u32 tl = rdl(stop_tot, dl);
+        eob_rbl = (int)(16u + ((0u - sa) & 7u) - tl);
+        bitpos = sa + tl; rc = 1;
+      }
+      else bitpos = sa;
+      break;
+    }
+    bitpos = sb_bit + rdl(exitp, mm - 1u);
     if (bitpos >= bit_limit) return -1;
   }
   // hand the exact bit position to the scalar reader
   {
-    u32 wi = bitpos >> 5, ch = wi >> 6;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    u32 lo = sh->inbuf[lane], hi = sh->inbuf[64u + lane];
-    if (ch == cb) { d.w.cur = lo; d.w.nxt = hi; }
-    else if (ch == cb + 1u) { d.w.cur = hi; d.w.nxt = pf; }
-    else { d.w.cur = d.w.load_chunk(ch, lane); d.w.nxt = d.w.load_chunk(ch + 1u, lane); }
+    const u32 wi = bitpos >> 5, ch = wi >> 6;
+    d.w.cur = d.w.load_chunk(ch, lane); d.w.nxt = d.w.load_chunk(ch + 1u, lane);
     d.w.wi = wi; d.bb = 0; d.bl = 0;
     d.refill(); d.refill();
-    u32 sk = bitpos & 31u;
+    const u32 sk = bitpos & 31u;
     if (sk) { d.bb >>= sk; d.bl -= (int) sk; }
     d.rbl = rc ? eob_rbl : (int)((0u - bitpos) & 7u);
   }
@@ -528,9 +624,10 @@ __device__ __forceinline__ int zip_parse_run(ZipDec &d, uint2 *tok, u32 &tt, u32
 }
 
 // one parse wave: CFDATA block `b` of unit u
-__device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 *in_arena, ZipBlockRec *rec,
+__device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 *in_arena, u8 *out_arena, ZipBlockRec *rec,
                                 uint2 *tok, MszipShared *sh)
 {
+  u8 *const fout = out_arena + u.out_off + (size_t) b * ZIP_FRAME;      // (inside the unit's region: b < ceil(out_len / 32768), 32 KiB of slack)
   const u32 lane = threadIdx.x;
   ZipDec d;
   d.lane = lane; d.sh = sh;
@@ -557,7 +654,7 @@ __device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 
     if (huff_build<ZIP_LIT_P>(sh->lit_len, 288, 9, sh->lit_tab, sh->lit_sorted, sh->cnt, d.hr_lit, lane, true)) return;
     if (huff_build<ZIP_DIST_P>(sh->dist_len, 32, 6, sh->dist_tab, sh->dist_sorted, sh->cnt, d.hr_dist, lane, true)) return;
     for (;;) {
-      const int rc = zip_parse_run(d, tok, tt, outc);
+      const int rc = zip_parse_lanes(d, fout, tok, tt, outc);
       if (rc < 0) return;
       if (rc == 1) break;
       // a token the lane-parallel decoder does not take (a long distance code, ...): one scalar token (mszipd.c:228-303)
@@ -565,8 +662,8 @@ __device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 
       const u32 st = d.cons_bits();
       int sym = d.decode_sym<ZIP_LIT_P>(sh->lit_tab, sh->lit_sorted, d.hr_lit, true);
       if (sym < 0) return;
-      if (tt + 1u > ZIP_TOK_CAP) return;
-      if (sym < 256) { if (lane == 0) tok[tt] = make_uint2(0u | (1u << 3), (u32) sym); tt++; outc++; continue; }
+      if (tt + 1u > ZIP_TOK_CAP || outc >= ZIP_FRAME) return;
+      if (sym < 256) { if (lane == 0) fout[outc] = (u8) sym; outc++; continue; }
       if (sym == 256) {                                      // bits_left behind it: ENSURE_BITS(16) at its first bit, minus its length
         d.rbl = (int)(16u + ((0u - st) & 7u) - (d.cons_bits() - st));
         break;
@@ -581,9 +678,9 @@ __device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 
       if (ds < 0 || ds >= 30) return;
       zip_dist_code((u32) ds, dbase, dextra);
       if (!d.read_bits((int) dextra, ev)) return;
-      if (lane == 0) tok[tt] = make_uint2(1u | (length << 3), dbase + ev);
+      if (outc + length > ZIP_FRAME) return;
+      if (lane == 0) tok[tt] = make_uint2(outc, ((dbase + ev) << 9) | length);
       tt++; outc += length;
-      if (outc > ZIP_FRAME) return;
     }
   } while (!last_block);
   if (lane == 0) {
@@ -594,35 +691,25 @@ __device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 
   }
 }
 
-// commit a CFDATA block's pre-parsed tokens (the COMMIT half of zip_run_spec).  false: a match needs bytes this path
-// cannot serve (history that is not a full block right below): the caller decodes the block the serial way.
-__device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *tok, const u32 n_tok_)
+// commit a CFDATA block a parse wave has taken apart: its literals are in the output already, its matches are records
+// (position in the block, distance << 9 | length) in position order; they are queued and resolved in position space
+// (spec_queue.hpp).  false: a match needs bytes this path cannot serve (history that is not a full block right
+// below) or a record is not what a parse wave writes: the caller decodes the block the serial way.
+__device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *tok, const u32 n_tok_, const u32 total_)
 {
   MszipShared *sh = d.sh;
   const u32 lane = d.lane;
   u8 *const out = d.out;
-  const u32 B = rfl(d.B), n_tok = rfl(n_tok_);
+  const u32 B = rfl(d.B), n_tok = rfl(n_tok_), total = rfl(total_);
   const bool lin_hist = d.hist_n > 0u && rfl(sh->hist_len[0]) == ZIP_FRAME && rfl(sh->hist_B[0]) + ZIP_FRAME == B;
+  if (n_tok > ZIP_TOK_CAP || total > ZIP_FRAME) return false;
   u32 P = B;
   SpecQueue Q;
   spq_init(sh->spq, Q, P, lane);
   bool ok = true;
-#ifdef ZIP_EXP_TOUCH          /* experiment: have the block's output lines in L2 before the partial writes arrive */
-  u32 touch_ = 0;
-  for (u32 i = 0; i < 4u; i++) touch_ ^= *(const volatile u32 *)(out + ((B + (lane + 64u * i) * 128u) & ~3u));
-#endif
-#ifdef ZIP_PHASE_TIMERS       /* analysis builds only (tools/exp_phase_timers.sh) */
-  u64 tm_a = 0, tm_b = 0, tm_t0 = __builtin_amdgcn_s_memtime(), tm_r0 = __builtin_amdgcn_s_memrealtime(), tm_x;
-  u32 tm_calls = 0;
-#define ZT0() tm_x = __builtin_amdgcn_s_memtime()
-#define ZT(acc) do { u64 n_ = __builtin_amdgcn_s_memtime(); acc += n_ - tm_x; tm_x = n_; } while (0)
-#else
-#define ZT0() do { } while (0)
-#define ZT(acc) do { } while (0)
-#endif
-  // Tokens come from memory four batches (256 tokens) at a time: the next four loads are issued before the current
-  // four batches are committed, and the registers change hands once per four batches -- a load is only waited for
-  // long after it was issued (handing one batch's register on per iteration waits for the load just issued)
+  // Records come from memory four batches (256 records) at a time: the next four loads are issued before the current
+  // four batches are queued, and the registers change hands once per four batches -- a load is only waited for
+  // long after it was issued
   uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
   if (lane < n_tok) cur0 = tok[lane];
   if (64u + lane < n_tok) cur1 = tok[64u + lane];
@@ -641,54 +728,38 @@ __device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *tok, cons
     for (u32 k = 0; k < 4u; k++, th += 64u) {
       if (th >= n_tok) { done = true; break; }
       const u32 n = n_tok - th < 64u ? n_tok - th : 64u;
-      ZT0();
       const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
-      const u32 c0 = cur.x, c1 = cur.y;
-      const u32 kind = c0 & 7u;
-      const u32 olen = lane < n ? ((c0 >> 3) & 511u) : 0u;
-      const u32 incl = wave_incl_scan(olen);
-      const u32 opos = P + incl - olen;
-      const u32 newP = P + rdl(incl, 63u);
       const bool valid = lane < n;
-      if (ballot(valid && kind == 1u && c1 > opos - B && !lin_hist)) { ok = false; done = true; break; }
-      if (valid && kind == 0u) out[opos] = (u8) c1;
-      u64 mm = ballot(valid && kind == 1u);
-      if (mm) {
-        bool ism = lane_in(mm);
-        if (Q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
-        for (;;) {
-          const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
-          const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
-          if (fit) {
-            const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
-            spq_push(sh->spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, c1, olen);
-            mm &= ~fit;
-            ism = lane_in(mm);
-          }
-          if (!mm) break;
-          spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
+      const u32 rpos = cur.x, olen = valid ? (cur.y & 511u) : 0u, dist = cur.y >> 9;
+      const u32 opos = B + rpos;
+      // in order, inside the block, at or above everything queued so far; a source below the block only with the
+      // previous block right below it
+      const u32 prev_end = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int)(opos + olen));
+      const bool bad = valid && (olen < 3u || dist == 0u || rpos + olen > total || opos < (lane == 0u ? P : prev_end) ||
+                                 (dist > rpos && (!lin_hist || dist > rpos + ZIP_FRAME)));
+      if (ballot(bad)) { ok = false; done = true; break; }
+      const u32 newP = rdl(opos + olen, n - 1u);
+      u64 mm = ballot(valid);
+      bool ism = valid;
+      if (Q.mcount + n > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
+      for (;;) {
+        const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
+        const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
+        if (fit) {
+          const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+          spq_push(sh->spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, dist, olen);
+          mm &= ~fit;
+          ism = lane_in(mm);
         }
+        if (!mm) break;
+        spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
       }
       P = newP;
-      ZT(tm_a);
-#ifdef ZIP_PHASE_TIMERS
-      if (spq_due(Q, P)) tm_calls++;
-#endif
       if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane);
-      ZT(tm_b);
     }
     cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
   }
   spq_resolve(sh->spq, Q, out, P, true, lane);
-#ifdef ZIP_EXP_TOUCH
-  if (touch_ == 0x12345678u && n_tok == 0xFFFFFFFFu) ok = false;
-#endif
-#ifdef ZIP_PHASE_TIMERS
-  if (lane == 0 && blockIdx.x == 0 && B == 3u * ZIP_FRAME)
-    printf("zip_run_tokens: n_tok %u  batch-front %llu clk  resolve %llu clk in %u calls  total %llu clk = %llu x10ns\n", n_tok,
-           (unsigned long long) tm_a, (unsigned long long) tm_b, tm_calls, (unsigned long long)(__builtin_amdgcn_s_memtime() - tm_t0),
-           (unsigned long long)(__builtin_amdgcn_s_memrealtime() - tm_r0));
-#endif
   return ok;
 }
 
@@ -845,8 +916,9 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
     if (use_recs && blk < nblk) {
       // a parse wave's record for this block?  adopt it if it was parsed from exactly this bit position
       const ZipBlockRec *rc_ = &recs[u.frame_base + blk];
-      if (rfl(rc_->status) == 1u && rfl(rc_->start_bit) == d.w.origin * 8u + d.cons_bits() &&
-          zip_run_tokens(d, toks + (size_t)(u.frame_base + blk) * ZIP_TOK_CAP, rc_->n_tokens)) {
+      // (and only where the parse wave put the literals: every earlier block of the folder a full one)
+      if (rfl(rc_->status) == 1u && rfl(rc_->start_bit) == d.w.origin * 8u + d.cons_bits() && d.B == blk * ZIP_FRAME &&
+          zip_run_tokens(d, toks + (size_t)(u.frame_base + blk) * ZIP_TOK_CAP, rc_->n_tokens, rc_->total_out)) {
         const u32 eb = rfl(rc_->end_bit), total = rfl(rc_->total_out);
         d.restart(eb >> 3);
         { const u32 sk = eb & 7u; if (sk) { d.need((int) sk); d.bb >>= sk; d.bl -= (int) sk; } }

@@ -353,7 +353,7 @@ void mspack_decode_lzxd(const mspack_hip_unit *units, const u32 *order, u32 n_un
 // parallelism"); same slot mapping as mspack_lzx_parse
 __global__ __launch_bounds__(64)
 void mspack_mszip_parse(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
-                        const u8 *in_arena, const u32 *frame_unit, const u32 *hdr, lzxn::LzxFrameRec *recs, uint2 *toks)
+                        const u8 *in_arena, u8 *out_arena, const u32 *frame_unit, const u32 *hdr, lzxn::LzxFrameRec *recs, uint2 *toks)
 {
   __shared__ MszipShared sh;
   if (blockIdx.x >= n_slots) return;
@@ -368,7 +368,7 @@ void mspack_mszip_parse(const mspack_hip_unit *units, const u32 *order, u32 n_un
   const u32 ui = rfl(frame_unit[slot]);
   if (ui == 0xFFFFFFFFu) return;
   const mspack_hip_unit u = units[ui];
-  zip_parse_block(u, slot - u.frame_base, in_arena, (ZipBlockRec *) &recs[slot], toks + (size_t) slot * ZIP_TOK_CAP, &sh);
+  zip_parse_block(u, slot - u.frame_base, in_arena, out_arena, (ZipBlockRec *) &recs[slot], toks + (size_t) slot * ZIP_TOK_CAP, &sh);
 }
 
 __global__ __launch_bounds__(64)
@@ -504,7 +504,7 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
                          (u32) MSPACK_HIP_KIND_MSZIP);
       hipLaunchKernelGGL(mspack_mszip_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
-                         (u32) n_slots, (const u8 *) d_in, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
+                         (u32) n_slots, (const u8 *) d_in, (u8 *) d_out, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
     }
     hipLaunchKernelGGL(mspack_decode_mszip, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
                        d_results, frames ? (const lzxn::LzxFrameRec *) L.recs : nullptr, (const uint2 *) L.toks);
