@@ -209,17 +209,27 @@ def secondary_mszip(M, torch, dev, n=4096, ub=32768, iters=10, cpu=True):
         offs.append(pos); lens.append(len(blob)); parts.append(blob + b"\0" * pad); pos += len(blob) + pad
     comp = np.frombuffer(b"".join(parts) + b"\0" * 64, dtype=np.uint8).copy()
     off = np.array(offs, dtype=np.uint64); ln = np.array(lens, dtype=np.uint32)
-    units, out_bytes = M.make_units(M.KIND_MSZIP, off, ln, np.full(n, ub), out_slack=32768)
+    # every unit carries its block table -- where its CFDATA blocks start, which a cabinet states (cabd.c:1362-1479) --
+    # here one entry, 0: all units share one zero dword behind the arena's last block
+    ztab = np.full(n, (pos + 15) & ~15, dtype=np.uint64)
+    units, out_bytes = M.make_units(M.KIND_MSZIP, off, ln, np.full(n, ub), out_slack=32768, frame_tabs=ztab)
     b = DeviceBatch(M, torch, dev, units, comp, out_bytes, M.KIND_MSZIP)
     b.step(); torch.cuda.synchronize()
     ms = b.kernel_ms(iters)
     res, out = b.results(), b.output()
     oo = units["out_off"].astype(np.int64)
     ok = bool((res["err"] == 0).all()) and all(np.array_equal(out[oo[i]:oo[i] + ub], plain[i * ub:(i + 1) * ub]) for i in range(n))
+    adopted = float(((res["flags"] & M.F_FRAMES_ADOPTED) != 0).mean())
+    # the same units without tables: one wavefront per unit does everything (round 2's launch)
+    u0, _ = M.make_units(M.KIND_MSZIP, off, ln, np.full(n, ub), out_slack=32768)
+    b0 = DeviceBatch(M, torch, dev, u0, comp, out_bytes, M.KIND_MSZIP)
+    b0.step(); torch.cuda.synchronize()
+    ms0 = b0.kernel_ms(iters)
     return {"config": "BASELINE config 2: %d independent MSZIP CFDATA blocks of %d KiB (zlib level 6), ratio %.3f" %
                       (n, ub // 1024, float(ln.sum()) / (n * ub)),
             "value": round(n * ub / ms / 1e3, 1), "unit": "MB/s", "kernel_ms": round(ms, 4), "bit_exact": ok,
-            "roofline": roofline(float(ln.sum()) + n * ub, ms, "mspack_decode_mszip"),
+            "units_on_block_parallel_path": adopted, "kernel_ms_without_block_tables": round(ms0, 4),
+            "roofline": roofline(float(ln.sum()) + n * ub, ms, "mspack_lzx_frame_map + mspack_mszip_parse + mspack_decode_mszip"),
             "cpu_baseline": ref_cpu_secondary(1, comp, off, ln, np.full(n, ub), 0, 0) if cpu else None}
 
 

@@ -33,7 +33,7 @@
 
 // what a parse wave leaves for the unit's wave (same 1344-byte slots as LzxFrameRec; only the head is used)
 struct ZipBlockRec {
-  u32 status;                      /* 1 = the whole CFDATA block was parsed */
+  u32 status;                      /* 0 = not yet, 1 = the whole CFDATA block was parsed, 2 = the parse wave gave up */
   u32 n_tokens;
   u32 start_bit;                   /* first bit of the deflate data (behind 'C','K'), from the unit's first byte */
   u32 end_bit;                     /* first bit behind the last end-of-block symbol */
@@ -623,8 +623,23 @@ __device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, uint2 
   return rc;
 }
 
-// one parse wave: CFDATA block `b` of unit u
-__device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 *in_arena, u8 *out_arena, ZipBlockRec *rec,
+// Hand-off of a block record between waves of ONE launch (mspack_mszip_pipe): what the parse wave stored (literals in the
+// output, match records, record fields) is published with an agent-scope release, a drained store queue and a relaxed
+// status store; the folder's wave polls the status relaxed and then takes one agent-scope acquire (the recipe of the
+// LZX path, lzx_kernel.hpp).  Status: 0 = not yet, 1 = the whole CFDATA block was parsed, 2 = the parse wave gave up.
+__device__ __forceinline__ u32 zip_status_load(const u32 *p) {
+  return rfl(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void zip_status_publish(u32 *p, const u32 v, const u32 lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#ifndef MSPACK_WAVE_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  if (lane == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one parse wave: CFDATA block `b` of unit u; true = the record is complete
+__device__ __forceinline__ bool zip_parse_block_body(const mspack_hip_unit &u, const u32 b, const u8 *in_arena, u8 *out_arena, ZipBlockRec *rec,
                                 uint2 *tok, MszipShared *sh)
 {
   u8 *const fout = out_arena + u.out_off + (size_t) b * ZIP_FRAME;      // (inside the unit's region: b < ceil(out_len / 32768), 32 KiB of slack)
@@ -637,48 +652,48 @@ __device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 
   d.snap_iptr = 0; d.snap_rbl = 0;
   const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
   const u32 fo = rfl(ftab[b]);
-  if (fo >= u.in_len || u.in_len - fo <= 64u) return;       // the last bytes of the input belong to the EOF-exact reader
+  if (fo >= u.in_len || u.in_len - fo <= 64u) return false;       // the last bytes of the input belong to the EOF-exact reader
   d.restart(fo);
   u32 v, last_block, type;
-  if (!d.read_bits(8, v) || v != 'C' || !d.read_bits(8, v) || v != 'K') return;
+  if (!d.read_bits(8, v) || v != 'C' || !d.read_bits(8, v) || v != 'K') return false;
   const u32 start_bit = d.w.origin * 8u + d.cons_bits();
   u32 tt = 0, outc = 0;
   do {
-    if (!d.read_bits(1, last_block) || !d.read_bits(2, type)) return;
+    if (!d.read_bits(1, last_block) || !d.read_bits(2, type)) return false;
     if (type == 1u) {
       for (u32 k = lane; k < 288u; k += WAVE) sh->lit_len[k] = (u8)(k < 144u ? 8 : (k < 256u ? 9 : (k < 280u ? 7 : 8)));
       if (lane < 32u) sh->dist_len[lane] = 5;
     }
-    else if (type == 2u) { if (zip_read_dynamic(d)) return; }
-    else return;                                             // stored (or invalid): the folder's wave does it
-    if (huff_build<ZIP_LIT_P>(sh->lit_len, 288, 9, sh->lit_tab, sh->lit_sorted, sh->cnt, d.hr_lit, lane, true)) return;
-    if (huff_build<ZIP_DIST_P>(sh->dist_len, 32, 6, sh->dist_tab, sh->dist_sorted, sh->cnt, d.hr_dist, lane, true)) return;
+    else if (type == 2u) { if (zip_read_dynamic(d)) return false; }
+    else return false;                                             // stored (or invalid): the folder's wave does it
+    if (huff_build<ZIP_LIT_P>(sh->lit_len, 288, 9, sh->lit_tab, sh->lit_sorted, sh->cnt, d.hr_lit, lane, true)) return false;
+    if (huff_build<ZIP_DIST_P>(sh->dist_len, 32, 6, sh->dist_tab, sh->dist_sorted, sh->cnt, d.hr_dist, lane, true)) return false;
     for (;;) {
       const int rc = zip_parse_lanes(d, fout, tok, tt, outc);
-      if (rc < 0) return;
+      if (rc < 0) return false;
       if (rc == 1) break;
       // a token the lane-parallel decoder does not take (a long distance code, ...): one scalar token (mszipd.c:228-303)
       if (d.bl <= 32) d.refill();
       const u32 st = d.cons_bits();
       int sym = d.decode_sym<ZIP_LIT_P>(sh->lit_tab, sh->lit_sorted, d.hr_lit, true);
-      if (sym < 0) return;
-      if (tt + 1u > ZIP_TOK_CAP || outc >= ZIP_FRAME) return;
+      if (sym < 0) return false;
+      if (tt + 1u > ZIP_TOK_CAP || outc >= ZIP_FRAME) return false;
       if (sym < 256) { if (lane == 0) fout[outc] = (u8) sym; outc++; continue; }
       if (sym == 256) {                                      // bits_left behind it: ENSURE_BITS(16) at its first bit, minus its length
         d.rbl = (int)(16u + ((0u - st) & 7u) - (d.cons_bits() - st));
         break;
       }
       u32 code = (u32) sym - 257u, lbase, lextra, dbase, dextra, ev;
-      if (code >= 29u) return;
+      if (code >= 29u) return false;
       zip_len_code(code, lbase, lextra);
-      if (!d.read_bits((int) lextra, ev)) return;
+      if (!d.read_bits((int) lextra, ev)) return false;
       const u32 length = lbase + ev;
       if (d.bl <= 32) d.refill();
       int ds = d.decode_sym<ZIP_DIST_P>(sh->dist_tab, sh->dist_sorted, d.hr_dist, true);
-      if (ds < 0 || ds >= 30) return;
+      if (ds < 0 || ds >= 30) return false;
       zip_dist_code((u32) ds, dbase, dextra);
-      if (!d.read_bits((int) dextra, ev)) return;
-      if (outc + length > ZIP_FRAME) return;
+      if (!d.read_bits((int) dextra, ev)) return false;
+      if (outc + length > ZIP_FRAME) return false;
       if (lane == 0) tok[tt] = make_uint2(outc, ((dbase + ev) << 9) | length);
       tt++; outc += length;
     }
@@ -686,9 +701,14 @@ __device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 
   if (lane == 0) {
     rec->n_tokens = tt; rec->start_bit = start_bit; rec->end_bit = d.w.origin * 8u + d.cons_bits();
     rec->eob_rbl = (u32) d.rbl; rec->total_out = outc;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    rec->status = 1u;
   }
+  return true;
+}
+__device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 *in_arena, u8 *out_arena, ZipBlockRec *rec,
+                                uint2 *tok, MszipShared *sh)
+{
+  const bool ok = zip_parse_block_body(u, b, in_arena, out_arena, rec, tok, sh);
+  zip_status_publish(&rec->status, ok ? 1u : 2u, threadIdx.x);
 }
 
 // commit a CFDATA block a parse wave has taken apart: its literals are in the output already, its matches are records
@@ -856,7 +876,8 @@ __device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
 
 // recs / toks: the parse waves' records and tokens for this launch (NULL: none), indexed by frame slot
 __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
-                                  mspack_hip_result *res, MszipShared *sh, const ZipBlockRec *recs, const uint2 *toks)
+                                  mspack_hip_result *res, MszipShared *sh, const ZipBlockRec *recs, const uint2 *toks,
+                                  const bool wait_recs = false)
 {
   const u32 lane = threadIdx.x;
   ZipDec d;
@@ -916,8 +937,15 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
     if (use_recs && blk < nblk) {
       // a parse wave's record for this block?  adopt it if it was parsed from exactly this bit position
       const ZipBlockRec *rc_ = &recs[u.frame_base + blk];
+      u32 st_ = 0;
+      if (wait_recs) {
+        // (mspack_mszip_pipe: the block's parse task has an earlier ticket, so a live wave holds it or it is done)
+        while ((st_ = zip_status_load(&rc_->status)) == 0u) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      else st_ = rfl(rc_->status);
       // (and only where the parse wave put the literals: every earlier block of the folder a full one)
-      if (rfl(rc_->status) == 1u && rfl(rc_->start_bit) == d.w.origin * 8u + d.cons_bits() && d.B == blk * ZIP_FRAME &&
+      if (st_ == 1u && rfl(rc_->start_bit) == d.w.origin * 8u + d.cons_bits() && d.B == blk * ZIP_FRAME &&
           zip_run_tokens(d, toks + (size_t)(u.frame_base + blk) * ZIP_TOK_CAP, rc_->n_tokens, rc_->total_out)) {
         const u32 eb = rfl(rc_->end_bit), total = rfl(rc_->total_out);
         d.restart(eb >> 3);

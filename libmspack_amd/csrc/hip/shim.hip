@@ -382,6 +382,66 @@ void mspack_decode_mszip(const mspack_hip_unit *units, const u32 *order, u32 n_u
   const mspack_hip_unit u = units[ui];
   mszip_decode_unit(u, in_arena, out_arena, &results[ui], &sh, (const ZipBlockRec *) recs, toks);
 }
+// ---------------------------------------------------------------------------------------------------
+// mspack_mszip_pipe -- block parse tasks and folder tasks of a launch's MSZIP units from ONE ticket counter (the scheme of
+// mspack_lzx_pipe): tickets [0, n_slots) are P(block slot) -- block-major (all first blocks, all second blocks, ...) when
+// every unit has the same number of blocks, else in slot order --, tickets [n_slots, n_slots + n_units) are F(unit) in
+// launch order: mszip_decode_unit, which waits for each block's record (its parse task has an earlier ticket, so a live
+// wave holds it or it is done), commits it, and decodes whatever no record covers the serial way.  A folder's first
+// blocks are committed while its later ones are still being parsed; no kernel boundary between parse and commit.
+// Where the folder's wave decodes serially it writes only output that belongs to blocks whose records it has already
+// waited for (a block's bytes lie at or below its index * 32 KiB), so no parse wave's literals can arrive afterwards.
+// ---------------------------------------------------------------------------------------------------
+__device__ __attribute__((noinline)) void mszip_pipe_task_parse(const mspack_hip_unit *up, const u32 b, const u8 *in_arena, u8 *out_arena,
+                                                                lzxn::LzxFrameRec *recs, uint2 *toks, MszipShared *sh)
+{
+  const mspack_hip_unit u = *up;
+  zip_parse_block(u, b, in_arena, out_arena, (ZipBlockRec *) &recs[u.frame_base + b], toks + (size_t)(u.frame_base + b) * ZIP_TOK_CAP, sh);
+}
+__device__ __attribute__((noinline)) void mszip_pipe_task_folder(const mspack_hip_unit *up, const u8 *in_arena, u8 *out_arena,
+                                                                 mspack_hip_result *res, const lzxn::LzxFrameRec *recs, const uint2 *toks,
+                                                                 MszipShared *sh)
+{
+  const mspack_hip_unit u = *up;
+  mszip_decode_unit(u, in_arena, out_arena, res, sh, (const ZipBlockRec *) recs, toks, true);
+}
+static_assert(sizeof(MszipShared) <= 10240, "16 waves per CU");
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void mspack_mszip_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
+                       const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
+                       const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks)
+{
+  __shared__ MszipShared sh;
+  const u32 lane = threadIdx.x;
+  const u32 Fmax = rfl(ctl[0]), Fmin = rfl(ctl[1]);
+  const u32 F = (Fmax != 0u && Fmax == Fmin && n_units * Fmax == n_slots) ? Fmax : 0u;
+  const u32 T = n_slots + n_units;
+  for (;;) {
+    u32 t = 0;
+    if (lane == 0) t = atomicAdd(&ctl[2], 1u);
+    t = rfl(t);
+    if (t >= T) break;
+    if (t < n_slots) {
+      u32 ui, b;
+      if (F) { ui = rfl(order ? order[t % n_units] : t % n_units); b = t / n_units; }
+      else {
+        const u32 slot = slot_lo + t;
+        ui = rfl(frame_unit[slot]);
+        if (ui == 0xFFFFFFFFu) continue;
+        b = slot - rfl(units[ui].frame_base);
+      }
+      mszip_pipe_task_parse(&units[ui], b, in_arena, out_arena, recs, toks, &sh);
+    }
+    else {
+      const u32 j = t - n_slots;
+      const u32 ui = rfl(order ? order[j] : j);
+      if (rfl((u32) units[ui].kind) != MSPACK_HIP_KIND_MSZIP) continue;
+      mszip_pipe_task_folder(&units[ui], in_arena, out_arena, &results[ui], recs, toks, &sh);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the next task reuses the LDS
+  }
+}
 static_assert(ZIP_TOK_CAP == LZX_TOK_CAP && sizeof(ZipBlockRec) == sizeof(lzxn::LzxFrameRec), "MSZIP and LZX share the work scratch");
 
 __global__ __launch_bounds__(64)
@@ -432,6 +492,7 @@ static int fail(hipError_t e, const char *what) {
 // that carry a frame table get their frames parsed by one wave each first (slots [slot_lo, slot_lo + n_slots)
 // of the work scratch belong to this launch).
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
+static const bool g_mszip_pipe = getenv("MSPACK_HIP_MSZIP_PIPE") != nullptr;         // experiments: mspack_mszip_pipe instead of parse + folder kernels
 static const bool g_no_pipe = getenv("MSPACK_HIP_NO_PIPE") != nullptr;               // experiments: header / parse / unit kernels one after the other
 // persistent waves of mspack_lzx_pipe: as many as the device holds at once (nothing depends on that number being right)
 static unsigned lzx_pipe_waves()
@@ -443,6 +504,17 @@ static unsigned lzx_pipe_waves()
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_lzx_pipe, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
     const char *e = getenv("MSPACK_HIP_PIPE_WAVES_PER_CU");
     if (e && atoi(e) > 0) per_cu = atoi(e);
+    waves = (unsigned) pr.multiProcessorCount * (unsigned) per_cu;
+  }
+  return waves;
+}
+static unsigned mszip_pipe_waves()
+{
+  static unsigned waves = 0;
+  if (!waves) {
+    int dev = 0, per_cu = 0; hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 4096u;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_mszip_pipe, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
     waves = (unsigned) pr.multiProcessorCount * (unsigned) per_cu;
   }
   return waves;
@@ -497,12 +569,24 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
     LzxScratch L = lzx_scratch(d_fm, n_frames_total, n_rec_slots);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
     if (frames) {
-      static const u32 hdr_init[2] = { 0u, 0xFFFFFFFFu };
+      static const u32 hdr_init[4] = { 0u, 0xFFFFFFFFu, 0u, 0u };
       u32 *hdr = L.hdr + 8u * (16u + (launch_ix & 15u));
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
                          (u32) MSPACK_HIP_KIND_MSZIP);
+      if (g_mszip_pipe) {
+        // (experiment, MSPACK_HIP_MSZIP_PIPE=1) one dependency-driven launch: block parse tasks and folder tasks from a
+        // ticket counter.  Measured slower than the two kernels below: 4096 one-block units 2.10 ms against 1.79,
+        // 512 x 8 blocks 3.63 against 3.52 (profiles/round3_mszip.txt) -- the blocks' parse tasks do not depend on each
+        // other, so the kernel boundary costs one tail only, while the hand-off costs a release per block and the two
+        // roles share one register budget (parse alone: 62 VGPRs; in the pipe kernel 120)
+        const size_t tickets = n_slots + n;
+        const unsigned waves = (unsigned) std::min<size_t>(tickets, mszip_pipe_waves());
+        hipLaunchKernelGGL(mspack_mszip_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
+                           (const u8 *) d_in, (u8 *) d_out, d_results, (const u32 *) L.frame_unit, hdr, L.recs, L.toks);
+        break;
+      }
       hipLaunchKernelGGL(mspack_mszip_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
                          (u32) n_slots, (const u8 *) d_in, (u8 *) d_out, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
     }

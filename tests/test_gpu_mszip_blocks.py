@@ -138,3 +138,16 @@ def test_repair_mode_ignores_tables(built):
     for i, st in enumerate([bytes(b), s]):
         e, o, r, _bl = oracle_mszip(st, len(d), repair=1)
         assert res["err"][i] == e and res["out_len"][i] == r.out_len and not (res["flags"][i] & ADOPTED)
+
+
+def test_pipe_launch_same_results(built):
+    """MSPACK_HIP_MSZIP_PIPE=1: block parse tasks and folder tasks in ONE launch (mspack_mszip_pipe: hand-off through
+    status words between running waves; measured slower than the default parse kernel + folder kernel, kept as an
+    experiment) -- the same checks in a fresh process"""
+    import os, subprocess, sys
+    env = dict(os.environ, MSPACK_HIP_MSZIP_PIPE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "folders_with_tables or wrong_tables or damaged"], env=env, cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=1800)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
