@@ -2129,12 +2129,14 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
           }
         }
 #endif
+        LZX_MARK("emit_count_step_begin");
         STAGE_BITS(act ? p : 0u, w0, w1, ALIGNED)
         const EmitTok t = lzx_emit_token<ALIGNED, false>(sh, act, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
         const bool ok = act && !t.unk, die = act && t.unk;
         dd = dd || die; sa = die ? p : sa;
         cnt += ok ? 1u : 0u; cb += ok ? t.olen : 0u; cm += (ok && t.is_match) ? 1u : 0u;
         p = die ? rend : p + (ok ? t.tot : 0u);
+        LZX_MARK("emit_count_step_end");
       }
       if (changed) { n = cnt; nb = cb; nmr = cm; exitp = p; dead = dd; stop_at = sa; }
       round++;
@@ -2229,6 +2231,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       for (;;) {
         const bool on = i < ntok && pos < frame_size && !cross;
         if (!ballot(on)) break;
+        LZX_MARK("emit_last_step_begin");
         STAGE_BITS(on ? p : 0u, w0, w1, true)
         const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
         const bool lit = on && !t.is_match;
@@ -2245,6 +2248,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
         const bool adv = lit || mt;
         pos += lit ? 1u : (mt ? t.olen : 0u); j += mt ? 1u : 0u;
         p += adv ? t.tot : 0u; i += adv ? 1u : 0u;
+        LZX_MARK("emit_last_step_end");
       }
       if (sact && !have_bad && (i < ntok || cross)) { have_bad = true; bad_s = sg; bad_pos = pos; bad_j = j; bad_p = p; }
     }

@@ -27,6 +27,11 @@
 #endif
 #define SPQ_GROUP 4               /* 64-byte chunks resolved per memory round trip */
 
+#ifdef LZX_MARKS        /* analysis builds: static instruction counts between marks (tools/count_isa.py) */
+#define SPQ_MARK(name) asm volatile("; MARK " name)
+#else
+#define SPQ_MARK(name) do { } while (0)
+#endif
 #ifdef SPQ_TIMERS       /* analysis builds: where a resolve's cycles go (block 0's wave only; read back by mspack_hip_debug_counters) */
 __device__ unsigned long long spq_tm[8];
 #define SPQ_T0() unsigned long long spq_x_ = __builtin_amdgcn_s_memtime()
@@ -130,6 +135,7 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
     spq_cover_group(l, q, c, climit, lane, G, ext);
     SPQ_T(0);
     for (;;) {
+      SPQ_MARK("spq_group_begin");
       // the group's loads go out together; the next group is set up while they are in flight; then the stores
       u32 val[SPQ_GROUP];
 #pragma unroll
@@ -154,6 +160,7 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
         if (lane_in(cur.inmask[g]) && b < clip) gst(out + b, (u8) val[g]);
       }
       SPQ_T(3);
+      SPQ_MARK("spq_group_end");
       if (!more) break;
     }
     SPQ_T(7);
