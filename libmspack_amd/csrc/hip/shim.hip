@@ -824,10 +824,21 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
   const size_t in_span = (size_t)(in_hi - in_lo), out_span = (size_t)(out_hi - out_lo);
 
   if (!cx.ready) {
-    cx.n_compute = env_int("MSPACK_HIP_NCOMPUTE", 2, 1, MSPK_MAX_STREAMS - 2);
+    cx.n_compute = env_int("MSPACK_HIP_NCOMPUTE", 4, 1, MSPK_MAX_STREAMS - 2);
     cx.ns = 2 + cx.n_compute;
     cx.max_chunks = env_int("MSPACK_HIP_NCHUNKS", 4, 1, MSPK_MAX_CHUNKS);
-    for (int i = 0; i < cx.ns; i++) TRY(hipStreamCreateWithFlags(&cx.st[i], hipStreamNonBlocking));
+    // The runtime maps a process's streams onto a few hardware queues PER PRIORITY LEVEL (four by default), and streams that
+    // share a queue run one after the other -- whichever library created them: inside a process that has streams of its own
+    // (bench.py: torch's) the copy-in stream landed on a compute stream's queue and every chunk's copy waited for the chunk
+    // before it (to the device 8.2 ms instead of 4.7, profiles/round3_hostpath.txt).  So the three roles live on three
+    // priority levels, i.e. in three queue pools: compute streams high (a pool of their own: the chunks' launches run side
+    // by side), copy-in normal, copy-out low.
+    int prio_lo = 0, prio_hi = 0;
+    TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));           // (least, greatest): numerically high = low priority
+    for (int i = 0; i < cx.ns; i++) {
+      const int pr = i == 0 ? (prio_lo + prio_hi) / 2 : (i == 1 ? prio_lo : prio_hi);
+      TRY(hipStreamCreateWithPriority(&cx.st[i], hipStreamNonBlocking, pr));
+    }
     for (int i = 0; i < MSPK_MAX_CHUNKS; i++) {
       TRY(hipEventCreateWithFlags(&cx.ev_in[i], hipEventDisableTiming));
       TRY(hipEventCreateWithFlags(&cx.ev_done[i], hipEventDisableTiming));
@@ -910,6 +921,10 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
 
     // ---- issue: tables, then every chunk's copy on the copy-in stream and its launches on a compute stream ----
     const bool one = chunks.size() == 1;                 // one chunk: everything in order on one stream, no events
+    // compute streams in use: all of them when the output stays on the device (the chunks' launches side by side: the
+    // last one ends earliest), two when it goes back to the host (the chunks then finish one after the other and the
+    // copy-back, the longest leg, starts early) -- measured, profiles/round3_hostpath.txt
+    const size_t n_comp = host_out ? std::min<size_t>(2, (size_t) cx.n_compute) : (size_t) cx.n_compute;
     hipStream_t st_in = cx.st[0], st_out = one ? cx.st[0] : cx.st[1];
     TRY(hipMemcpyAsync(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice, st_in));
     TRY(hipMemcpyAsync(d_order, order.data(), n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, st_in));
@@ -964,7 +979,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       });
     for (size_t ci = 0; ci < chunks.size(); ci++) {
       const Chunk &c = chunks[ci];
-      hipStream_t st = one ? cx.st[0] : cx.st[2 + ci % (size_t) cx.n_compute];
+      hipStream_t st = one ? cx.st[0] : cx.st[2 + ci % n_comp];
       TRY(hipMemcpyAsync(d_in + (c.in_lo - in_lo), (const char *) in + c.in_lo, (size_t)(c.in_hi - c.in_lo),
                          hipMemcpyHostToDevice, st_in));
       if (host_out)

@@ -164,6 +164,8 @@ hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k,
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s = 0);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 1; *greatest = -1; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);

@@ -8,6 +8,9 @@ if "EXP_HOSTPATH_WORKER" not in os.environ:
         subprocess.call([sys.executable, __file__] + sys.argv[1:3], env=dict(os.environ, EXP_HOSTPATH_WORKER="1", MSPACK_HIP_NCHUNKS=nc))
     sys.exit(0)
 import numpy as np
+if os.environ.get("EXP_TORCH"):              # a process that has streams of its own (as bench.py has)
+    import torch
+    _t = torch.zeros(1 << 20, device="cuda"); _s = [torch.cuda.Stream() for _ in range(int(os.environ["EXP_TORCH"]))]; torch.cuda.synchronize()
 sys.path.insert(0, ROOT + '/tests'); sys.path.insert(0, ROOT)
 import libmspack_amd as M
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
