@@ -146,14 +146,14 @@ size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total);
 
 /* ---- host-buffer entry points (what the C drivers in mspack.h use) -------------------------------------
  * Same semantics with HOST pointers.  Each device keeps a persistent context (device arenas, pinned staging,
- * four streams and their events, grown or created on demand, never freed per call).  The batch is cut into up to
+ * its streams and their events, grown or created on demand, never freed per call).  The batch is cut into up to
  * MSPACK_HIP_NCHUNKS (default 4) chunks of arena-contiguous units (each >= 8 MiB of input and >= 256 units); chunk c's
  * input is copied on the copy-in stream, its launches (one per codec over a compact list of that codec's units) run on
  * a compute stream (four of them when the output stays on the device, two when it goes back to the host), its decoded
  * span goes back on the copy-out stream -- so copies overlap decode in both directions; the three roles' streams have
- * three different priorities, i.e. hardware queues of their own.  While that runs, mspack_hip_decode_batch page-locks the caller's output buffer chunk by chunk
- * (hipHostRegister; released before it returns) so that the copy-back is a DMA that need not wait for the other
- * streams; a buffer that cannot be registered is copied the ordinary way (MSPACK_HIP_PIN_OUT=0: always).
+ * three different priorities, i.e. hardware queues of their own.  While that runs, mspack_hip_decode_batch page-locks
+ * the caller's output buffer chunk by chunk (hipHostRegister; released before it returns) so that the copy-back is a
+ * DMA that need not wait for the other streams; a buffer that cannot be registered is copied the ordinary way (MSPACK_HIP_PIN_OUT=0: always).
  * `units[i].frame_base` is filled in by the call.  Synchronous.  Bytes of the output arena
  * BETWEEN units that lie inside a copied span (alignment padding, the MSZIP slack) are unspecified afterwards.
  * Thread-safe; calls that target the same device are serialised. */
