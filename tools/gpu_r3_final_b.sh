@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r3f; mkdir -p $OUT; cd /tmp; exp
 for f in $(find $OUT/stats -name "*kernel_stats.csv"); do cp $f $OUT/bench_kernel_stats.csv; done
 ( cd $R && timeout 400 bash tools/gpu_traffic.sh > $OUT/traffic_lzx.txt 2>&1; cp gpurun_out/traffic/traffic.json $OUT/traffic_lzx.json )
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/mz_$c -o pmc -- python $R/tools/bench_mszip_folder.py 4096 1 > $OUT/mz_$c.log 2>&1
+  ( cd $R && timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/mz_$c -o pmc -- python tools/bench_mszip_folder.py 4096 1 > $OUT/mz_$c.log 2>&1 )
 done
 python - <<PY > $OUT/traffic_mszip.txt 2>&1
 import csv, glob, collections
