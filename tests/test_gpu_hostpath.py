@@ -181,18 +181,35 @@ u = np.ascontiguousarray(units)
 rc = M.lib().mspack_hip_decode_batch_to_device(u.ctypes.data, len(u), arena.ctypes.data, arena.size, d_out.ptr, out_bytes + 64, res.ctypes.data)
 assert rc == 0
 T.check(units, d_out.to_host(), res, items)
+# an output buffer the caller has pinned itself (hipHostMalloc): registering it is refused, the copies back are DMA anyway
+import ctypes as C
+hip = d_out.hip
+hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+hip.hipHostFree.argtypes = [C.c_void_p]
+hp = C.c_void_p()
+assert hip.hipHostMalloc(C.byref(hp), out_bytes + 64, 0) == 0
+pinned = np.frombuffer((C.c_ubyte * (out_bytes + 64)).from_address(hp.value), dtype=np.uint8)
+pinned[:] = 0
+res = np.zeros(len(units), dtype=M.RESULT_DTYPE)
+rc = M.lib().mspack_hip_decode_batch(u.ctypes.data, len(u), arena.ctypes.data, arena.size, hp.value, out_bytes + 64, res.ctypes.data)
+assert rc == 0
+T.check(units, pinned, res, items)
+del pinned
+hip.hipHostFree(hp)
 print("CHUNKS_OK")
 '''
 
 
-@pytest.mark.parametrize("nchunks", [2, 5, 8])
-def test_chunked_pipeline_small_chunks(built, nchunks, tmp_path):
+@pytest.mark.parametrize("nchunks,pin", [(2, "1"), (5, "1"), (8, "1"), (4, "0")])
+def test_chunked_pipeline_small_chunks(built, nchunks, pin, tmp_path):
     """the copy-in / compute / copy-out streams with many small chunks of a mixed batch (thresholds lowered through
     the environment: every chunk holds LZX, MSZIP and Quantum units, concurrent LZX launches use their own control
-    words and slot ranges)"""
+    words and slot ranges); output into pageable memory that the call page-locks chunk by chunk, into pageable memory it
+    must leave alone, into a buffer the caller pinned itself, and into device memory"""
     script = tmp_path / "w.py"
     script.write_text(CHUNK_WORKER % (ROOT, ROOT))
-    env = dict(os.environ, MSPACK_HIP_NCHUNKS=str(nchunks), MSPACK_HIP_CHUNK_BYTES="4096", MSPACK_HIP_CHUNK_UNITS="4", MSPACK_HIP_TRACE="1")
+    env = dict(os.environ, MSPACK_HIP_NCHUNKS=str(nchunks), MSPACK_HIP_CHUNK_BYTES="4096", MSPACK_HIP_CHUNK_UNITS="4", MSPACK_HIP_TRACE="1",
+               MSPACK_HIP_PIN_OUT=pin)            # "0": the caller's buffer is never page-locked (plain pageable copies back)
     p = subprocess.run([sys.executable, str(script), "24"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert p.returncode == 0 and b"CHUNKS_OK" in p.stdout, p.stdout.decode()[-3000:]
     assert (b"in %d chunks" % nchunks) in p.stdout, p.stdout.decode()[-3000:]
