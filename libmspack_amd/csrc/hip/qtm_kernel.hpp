@@ -23,6 +23,11 @@
 #include "spec_queue.hpp"
 
 #define QTM_FRAME 32768u
+#ifdef LZX_MARKS        /* analysis builds: static instruction counts between marks (tools/count_isa.py) */
+#define QTM_MARK(name) asm volatile("; MARK " name)
+#else
+#define QTM_MARK(name) do { } while (0)
+#endif
 
 struct QtmShared { SpecQueueLds spq; };
 
@@ -132,6 +137,7 @@ __device__ void qtm_update_model(u32 &m, u32 entries, int &shiftsleft, u32 lane)
 __device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, int &shiftsleft)
 {
   const u32 lane = d.lane;
+  QTM_MARK("qtm_sym_begin");
   u32 H = d.H, L = d.L, C = d.C;
   const u32 cf = m & 0xFFFFu;
   const u32 tot = rdl(cf, 0);
@@ -167,7 +173,9 @@ __device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, in
   L = (L + rdl(quo, 1)) & 0xFFFFu;
   // cumfreq[0..i-1] += 8; rescale when the total passes 3800
   if (lane < i) m += 8u;
+  QTM_MARK("qtm_sym_interval_done");
   if (tot + 8u > 3800u) qtm_update_model(m, entries, shiftsleft, lane);
+  QTM_MARK("qtm_sym_renorm_begin");
   // Renormalisation (qtmd.c:107-122) in closed form.  The reference's bit-at-a-time loop is always
   // n shifts while the top bits of L and H agree, then m "underflow" steps while L = 01.., H = 10..
   // (each drops bit 14 and keeps the top bits 0 / 1), then it stops: n = leading equal bits,
@@ -205,6 +213,7 @@ __device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, in
     }
   }
   d.H = H; d.L = L; d.C = C;
+  QTM_MARK("qtm_sym_end");
   return sym;
 }
 
