@@ -1485,7 +1485,8 @@ struct __align__(16) LzxFrameRec {
   u32 end_bit;                      /* first bit that was not parsed */
   u32 block_type, block_length;
   u32 flags;                        /* 1: the length tree is empty, 2: literal 0xE8 has a code */
-  u32 pad0;
+  u32 prog;                         /* mspack_lzx_pipe, while status is 2: match records | output bytes << 15 that are in memory
+                                       already (published after every pass of lzx_parse_emit but the last) */
   u8 ali_len[8];
   u8 pad1[8];
   u8 main_len[LZX_MAIN_SYMS + 16];
@@ -2036,7 +2037,7 @@ template <bool ALIGNED>
 __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empty, const u32 start_bit, const u32 frame_end_bit,
                                                u8 *const fout, const u32 frame_pos, const u32 frame_size, const u32 edge_n,
                                                LzxFrameRec *rec, uint2 *mrec, u32 &n_rec, u32 &end_bit, u32 &bytes_done,
-                                               const bool two_level)
+                                               const bool two_level, const bool stream)
 {
   LzxShared *sh = d.sh;
   const u32 lane = d.lane;
@@ -2273,6 +2274,17 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     }
 #endif
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the stage is rewritten by the next pass
+    // Another pass follows (and the launch has wave slots to spare, `stream`): what this one stored -- literals below P,
+    // match records below tt -- is published now, so that the unit's commit task works on this frame while its later passes
+    // are still being parsed (lzx_pipe_commit).  The edge literals all lie in the first 128 bytes: their mask is complete
+    // once P has passed them.
+    if (stream && !stop && B < Eall && P < frame_size && P >= 128u && tt <= 0x7FFFu) {
+      if (lane < 4u) rec->edge_mask[lane] = sh->cnt[lane];
+      lzx_status_publish(&rec->prog, tt | (P << 15), lane);
+#ifdef MSPACK_WAVE_EMU
+      if (lane == 0) emu_test_delay();                             // (emulator test hook: lets the commit task see partial progress)
+#endif
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   if (lane < 4u) rec->edge_mask[lane] = sh->cnt[lane];
@@ -2419,7 +2431,7 @@ __device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 
 // Waiting is safe: the task it waits for has an earlier ticket (shim.hip), i.e. a live wave is working on it.
 // ---------------------------------------------------------------------------------------------------
 __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, u8 *out_arena, LzxFrameRec *urecs,
-                               uint2 *tok, LzxShared *sh)
+                               uint2 *tok, LzxShared *sh, const bool stream)
 {
   const u32 lane = threadIdx.x;
   LzxFrameRec *rec = &urecs[f];
@@ -2485,7 +2497,10 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     rec->n_tokens = 0; rec->hdr_start_bit = hdr_start; rec->end_bit = start_bit;
     rec->block_type = s.block_type; rec->block_length = s.block_length;
     rec->flags = (sh->main_len[0xE8] != 0 ? 2u : 0u);
-    rec->frame_start_bit = fo * 8u; rec->intel_filesize = intel; rec->bytes_done = 0; rec->n_edge = 0;
+    rec->frame_start_bit = fo * 8u; rec->intel_filesize = intel; rec->bytes_done = 0; rec->prog = 0;
+    // the frame's first bytes up to the next 128-byte line: another wave may be writing that line (see lzx_parse_emit)
+    const u32 en_ = (128u - (u32)((size_t)(out_arena + u.out_off + (size_t) f * LZX_FRAME) & 127u)) & 127u;
+    rec->n_edge = en_ < fsz ? en_ : fsz;
   }
   lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);        // the next frame's wave may go on
   PH(2);
@@ -2515,9 +2530,8 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     u8 *const fout = out_arena + u.out_off + (size_t) f * LZX_FRAME;
     // the frame's first bytes up to the next 128-byte line: another wave may be writing that line (see lzx_parse_emit)
     const u32 edge_n = (128u - (u32)((size_t) fout & 127u)) & 127u;
-    if (s.block_type == 2u) lzx_parse_emit<true>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done, two_level);
-    else lzx_parse_emit<false>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done, two_level);
-    if (lane == 0) rec->n_edge = edge_n < fsz ? edge_n : fsz;
+    if (s.block_type == 2u) lzx_parse_emit<true>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done, two_level, stream);
+    else lzx_parse_emit<false>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done, two_level, stream);
   }
   if (lane == 0) {
     rec->n_tokens = n_rec; rec->end_bit = end_bit; rec->bytes_done = bytes_done;
@@ -2641,7 +2655,8 @@ __device__ __forceinline__ int lzx_run_tokens(LzxDec &d, LzxState &s, const u32 
 #ifdef LZX_COMMIT_STATS
 __device__ u32 g_commit_stats[8];
 #endif
-__device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFrameRec *urecs, const uint2 *utoks, SpecQueueLds *spq)
+__device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFrameRec *urecs, const uint2 *utoks, SpecQueueLds *spq,
+                                const bool stream)
 {
   const u32 lane = threadIdx.x;
   u8 *const out = out_arena + u.out_off;
@@ -2659,25 +2674,19 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
     u32 st = lzx_status_load(&rec->status);
     LZX_PIPE_WAIT_BEGIN();
     // (the frame's parse task has an earlier ticket than this task: a live wave holds it, the status becomes final)
-    for (u32 tries = 0; (st == LZX_ST_NONE || st == LZX_ST_CLAIMED || st == LZX_ST_HEADER) && tries < (1u << 22); tries++) {
+    // (`stream`: the launch has wave slots to spare -- a frame whose header is known is taken up as its passes arrive; else
+    // this wave would hold its slot waiting inside the frame while parse tasks queue for slots: wait for the whole frame)
+    for (u32 tries = 0; (st == LZX_ST_NONE || st == LZX_ST_CLAIMED || (!stream && st == LZX_ST_HEADER)) && tries < (1u << 22); tries++) {
       __builtin_amdgcn_s_sleep(32);
       st = lzx_status_load(&rec->status);
     }
     LZX_PIPE_WAIT_END();
-    if (st != LZX_ST_EMITTED) break;
+    if (st != LZX_ST_EMITTED && st != LZX_ST_HEADER) break;
     PH0();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
     if (rfl(rec->frame_start_bit) != prev_end || rfl(rec->block_length) != fsz) break;
     const u32 frame_pos = f * LZX_FRAME;
-    const u32 n_rec = rfl(rec->n_tokens), bytes = rfl(rec->bytes_done), end_bit = rfl(rec->end_bit);
-    if (bytes > fsz || n_rec > LZX_TOK_CAP) break;
-    // ---- the literals of the frame's first cache line ----
-    {
-      const u32 ne = rfl(rec->n_edge);
-      for (u32 i = lane; i < ne; i += WAVE)
-        if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
-    }
     // ---- the match records ----
     const u32 eR0 = R0, eR1 = R1, eR2 = R2;
     const uint2 *mrec = utoks + (size_t) f * LZX_TOK_CAP;
@@ -2685,103 +2694,145 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
     SpecQueue Q;
     spq_init(*spq, Q, frame_pos, lane);
     bool bad = false;
-    uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
-    if (lane < n_rec) cur0 = gld(mrec + lane);
-    if (64u + lane < n_rec) cur1 = gld(mrec + 64u + lane);
-    if (128u + lane < n_rec) cur2 = gld(mrec + 128u + lane);
-    if (192u + lane < n_rec) cur3 = gld(mrec + 192u + lane);
-    for (u32 th = 0; th < n_rec && !bad; ) {
-      uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
-      const u32 tb = th + 256u + lane;
-      if (tb < n_rec) nx0 = gld(mrec + tb);
-      if (tb + 64u < n_rec) nx1 = gld(mrec + tb + 64u);
-      if (tb + 128u < n_rec) nx2 = gld(mrec + tb + 128u);
-      if (tb + 192u < n_rec) nx3 = gld(mrec + tb + 192u);
-#pragma unroll 1
-      for (u32 k = 0; k < 4u && th < n_rec && !bad; k++) {
-        u32 n = n_rec - th; if (n > 64u) n = 64u;
-        const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
-        const bool ism = lane < n;
-        const u32 opos = cur.x, olen = (cur.y >> 2) & 511u, which = cur.y & 3u, c1 = cur.y >> 11;
-        const u64 mm = ballot(ism);
-        // (1) every match's offset through the R0-R2 LRU (cf. lzx_commit_batch)
-        const u32 sR0 = R0, sR1 = R1, sR2 = R2;
-        u32 vmoff = c1;
-        const u64 k1 = ballot(ism && which == 0u);
-        if (!ballot(ism && which >= 2u)) {
-          const u64 below = k1 & ((1ull << lane) - 1ull);
-          const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
-          const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
-          if (which == 1u) vmoff = below ? pv : sR0;
-          if (k1) {
-            u64 m = k1;
-            const u32 j0 = 63u - (u32) __clzll((long long) m);
-            u32 nbv = sR0, ncv = sR1;
-            m &= ~(1ull << j0);
-            if (m) {
-              const u32 j1 = 63u - (u32) __clzll((long long) m);
-              nbv = rdl(c1, j1); ncv = sR0;
-              m &= ~(1ull << j1);
-              if (m) ncv = rdl(c1, 63u - (u32) __clzll((long long) m));
-            }
-            R0 = rdl(c1, j0); R1 = nbv; R2 = ncv;
+    // The frame's records arrive pass by pass (lzx_parse_emit publishes `prog` behind every pass but the last, then the final
+    // status): each event below takes what is in memory so far -- literals below `bytes`, match records below `n_rec` -- so
+    // the commit of a frame's first kilobytes runs while a parse wave is still working on its last ones, and a unit's chain
+    // is the longer of its parse and its commit, not their sum.
+    u32 th = 0, n_rec = 0, bytes = 0, end_bit = 0;
+    bool final = false, edge_done = false;
+    for (u32 tries = 0; ; ) {
+      {
+        const u32 st2 = lzx_status_load(&rec->status), pg = lzx_status_load(&rec->prog);
+        if (st2 == LZX_ST_EMITTED) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          final = true;
+          n_rec = rfl(rec->n_tokens); bytes = rfl(rec->bytes_done); end_bit = rfl(rec->end_bit);
+          if (bytes > fsz || n_rec > LZX_TOK_CAP || n_rec < th) { bad = true; break; }
+        }
+        else if (st2 == LZX_ST_HEADER) {
+          const u32 na = pg & 0x7FFFu, nb = pg >> 15;
+          if (na <= n_rec && nb <= bytes) {                      // nothing new yet
+            if (++tries >= (1u << 22)) { bad = true; break; }
+            LZX_PIPE_WAIT_BEGIN();
+            __builtin_amdgcn_s_sleep(32);
+            LZX_PIPE_WAIT_END();
+            continue;
           }
-        }
-        else {
-          u32 x = LRU_ID;
-          if (ism) x = which == 0u ? (0x010080u | lane) : (which == 2u ? 0x020001u : (which == 3u ? 0x000102u : LRU_ID));
-          const u32 Cm = lru_scan(x);
-          const u32 e0 = Cm & 0xFFu;
-          const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
-          vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
-          const u32 Cl = rdl(Cm, 63u);
-          const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
-          R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
-          R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
-          R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
-        }
-        // (2) the reference's checks (lzxd.c:613-634); offsets no linear copy serves (0, beyond the window) end the fast path too
-        {
-          const u32 wp = opos - wbase;
-          const bool b = ism && (wp + olen > wsize || LZX_BAD_SOURCE(vmoff, wp, frame_pos, 0u, wsize) ||
-                                 vmoff == 0u || vmoff > wsize || vmoff > opos);
-          if (ballot(b)) { bad = true; break; }
-        }
-#ifdef LZX_COMMIT_STATS      /* emulator runs: how many matches read bytes of their own batch's output region, by length */
-        {
-          const u32 bs = rdl(opos, 0u);
-          const u64 nearm = ballot(ism && opos - vmoff + olen > bs), longm = ballot(ism && olen > 16u), near2 = ballot(ism && vmoff < 512u);
-          if (lane == 0) { atomicAdd(&g_commit_stats[0], (u32) __popcll(mm)); atomicAdd(&g_commit_stats[1], (u32) __popcll(nearm));
-                           atomicAdd(&g_commit_stats[2], (u32) __popcll(longm)); atomicAdd(&g_commit_stats[3], (u32) __popcll(near2));
-                           atomicAdd(&g_commit_stats[4], (u32) __popcll(nearm | longm)); }
-        }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          if (nb > fsz || na > LZX_TOK_CAP) { bad = true; break; }
+          n_rec = na; bytes = nb;
+#ifdef LZX_COMMIT_STATS
+          if (lane == 0) atomicAdd(&g_commit_stats[5], 1u);      // events that took records of a frame still being parsed
 #endif
-        PH(9);
-        // (3) queue the copies (cf. lzx_commit_batch)
-        {
-          const u32 newP = rdl(opos + olen, n - 1u);
-          u64 mq = mm;
-          if (Q.mcount + (u32) __popcll(mq) > SPQ_CAP) spq_resolve(*spq, Q, out, rdl(opos, 0u), true, lane);
-          bool im = ism;
-          for (;;) {
-            const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
-            const u64 fit = newP <= limit ? mq : ballot(im && opos + olen <= limit);
-            if (fit) {
-              const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
-              spq_push(*spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, vmoff, olen);
-              mq &= ~fit;
-              im = lane_in(mq);
-            }
-            if (!mq) break;
-            spq_resolve(*spq, Q, out, rdl(opos, (u32) __ffsll((long long) mq) - 1u), true, lane);
-          }
-          PH(10);
-          if (spq_due(Q, newP)) spq_resolve(*spq, Q, out, newP, false, lane);
-          PH(11);
         }
-        th += n;
+        else { bad = true; break; }                              // (no tokens after all: the serial path takes the frame)
       }
-      cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
+      if (!edge_done) {
+        // ---- the literals of the frame's first cache line (all below byte 128: known with the first event) ----
+        const u32 ne = rfl(rec->n_edge);
+        for (u32 i = lane; i < ne; i += WAVE)
+          if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
+        edge_done = true;
+      }
+      uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
+      if (th + lane < n_rec) cur0 = gld(mrec + th + lane);
+      if (th + 64u + lane < n_rec) cur1 = gld(mrec + th + 64u + lane);
+      if (th + 128u + lane < n_rec) cur2 = gld(mrec + th + 128u + lane);
+      if (th + 192u + lane < n_rec) cur3 = gld(mrec + th + 192u + lane);
+      for (; th < n_rec && !bad; ) {
+        uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
+        const u32 tb = th + 256u + lane;
+        if (tb < n_rec) nx0 = gld(mrec + tb);
+        if (tb + 64u < n_rec) nx1 = gld(mrec + tb + 64u);
+        if (tb + 128u < n_rec) nx2 = gld(mrec + tb + 128u);
+        if (tb + 192u < n_rec) nx3 = gld(mrec + tb + 192u);
+  #pragma unroll 1
+        for (u32 k = 0; k < 4u && th < n_rec && !bad; k++) {
+          u32 n = n_rec - th; if (n > 64u) n = 64u;
+          const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
+          const bool ism = lane < n;
+          const u32 opos = cur.x, olen = (cur.y >> 2) & 511u, which = cur.y & 3u, c1 = cur.y >> 11;
+          const u64 mm = ballot(ism);
+          // (1) every match's offset through the R0-R2 LRU (cf. lzx_commit_batch)
+          const u32 sR0 = R0, sR1 = R1, sR2 = R2;
+          u32 vmoff = c1;
+          const u64 k1 = ballot(ism && which == 0u);
+          if (!ballot(ism && which >= 2u)) {
+            const u64 below = k1 & ((1ull << lane) - 1ull);
+            const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
+            const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
+            if (which == 1u) vmoff = below ? pv : sR0;
+            if (k1) {
+              u64 m = k1;
+              const u32 j0 = 63u - (u32) __clzll((long long) m);
+              u32 nbv = sR0, ncv = sR1;
+              m &= ~(1ull << j0);
+              if (m) {
+                const u32 j1 = 63u - (u32) __clzll((long long) m);
+                nbv = rdl(c1, j1); ncv = sR0;
+                m &= ~(1ull << j1);
+                if (m) ncv = rdl(c1, 63u - (u32) __clzll((long long) m));
+              }
+              R0 = rdl(c1, j0); R1 = nbv; R2 = ncv;
+            }
+          }
+          else {
+            u32 x = LRU_ID;
+            if (ism) x = which == 0u ? (0x010080u | lane) : (which == 2u ? 0x020001u : (which == 3u ? 0x000102u : LRU_ID));
+            const u32 Cm = lru_scan(x);
+            const u32 e0 = Cm & 0xFFu;
+            const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
+            vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
+            const u32 Cl = rdl(Cm, 63u);
+            const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
+            R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
+            R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
+            R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
+          }
+          // (2) the reference's checks (lzxd.c:613-634); offsets no linear copy serves (0, beyond the window) end the fast path too
+          {
+            const u32 wp = opos - wbase;
+            const bool b = ism && (wp + olen > wsize || LZX_BAD_SOURCE(vmoff, wp, frame_pos, 0u, wsize) ||
+                                   vmoff == 0u || vmoff > wsize || vmoff > opos);
+            if (ballot(b)) { bad = true; break; }
+          }
+  #ifdef LZX_COMMIT_STATS      /* emulator runs: how many matches read bytes of their own batch's output region, by length */
+          {
+            const u32 bs = rdl(opos, 0u);
+            const u64 nearm = ballot(ism && opos - vmoff + olen > bs), longm = ballot(ism && olen > 16u), near2 = ballot(ism && vmoff < 512u);
+            if (lane == 0) { atomicAdd(&g_commit_stats[0], (u32) __popcll(mm)); atomicAdd(&g_commit_stats[1], (u32) __popcll(nearm));
+                             atomicAdd(&g_commit_stats[2], (u32) __popcll(longm)); atomicAdd(&g_commit_stats[3], (u32) __popcll(near2));
+                             atomicAdd(&g_commit_stats[4], (u32) __popcll(nearm | longm)); }
+          }
+  #endif
+          PH(9);
+          // (3) queue the copies (cf. lzx_commit_batch)
+          {
+            const u32 newP = rdl(opos + olen, n - 1u);
+            u64 mq = mm;
+            if (Q.mcount + (u32) __popcll(mq) > SPQ_CAP) spq_resolve(*spq, Q, out, rdl(opos, 0u), true, lane);
+            bool im = ism;
+            for (;;) {
+              const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
+              const u64 fit = newP <= limit ? mq : ballot(im && opos + olen <= limit);
+              if (fit) {
+                const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+                spq_push(*spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, vmoff, olen);
+                mq &= ~fit;
+                im = lane_in(mq);
+              }
+              if (!mq) break;
+              spq_resolve(*spq, Q, out, rdl(opos, (u32) __ffsll((long long) mq) - 1u), true, lane);
+            }
+            PH(10);
+            if (spq_due(Q, newP)) spq_resolve(*spq, Q, out, newP, false, lane);
+            PH(11);
+          }
+          th += n;
+        }
+        cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
+      }
+      if (bad || final) break;
     }
     if (bad) { R0 = eR0; R1 = eR1; R2 = eR2; break; }            // the serial path decodes this frame from its first bit
     spq_resolve(*spq, Q, out, frame_pos + bytes, true, lane);
@@ -2795,8 +2846,9 @@ __device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFram
     r0->rs_frame = rs_frame; r0->rs_partial = rs_partial; r0->rs_P = rs_P; r0->rs_next_bit = rs_next;
     r0->rs_R0 = R0; r0->rs_R1 = R1; r0->rs_R2 = R2; r0->rs_valid = 1u;
 #ifdef LZX_COMMIT_STATS
-    printf("commit stats so far: matches %u, source inside own batch %u, longer than 16 %u, offset < 512 %u, either of the first two %u\n",
-           g_commit_stats[0], g_commit_stats[1], g_commit_stats[2], g_commit_stats[3], g_commit_stats[4]);
+    printf("commit stats so far: matches %u, source inside own batch %u, longer than 16 %u, offset < 512 %u, either of the first two %u; "
+           "events on frames still being parsed %u\n",
+           g_commit_stats[0], g_commit_stats[1], g_commit_stats[2], g_commit_stats[3], g_commit_stats[4], g_commit_stats[5]);
 #endif
   }
   PHFLUSH();

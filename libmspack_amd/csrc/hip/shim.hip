@@ -221,16 +221,17 @@ static_assert(sizeof(LzxPipeLds) <= 10240, "16 waves per CU");
 
 // the two task bodies are real calls: each gets its own register allocation (inlined into the ticket loop they spill)
 __device__ __attribute__((noinline)) void lzx_pipe_task_parse(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
-                                                              lzxn::LzxFrameRec *recs, uint2 *toks, lzxp::LzxShared *sh)
+                                                              lzxn::LzxFrameRec *recs, uint2 *toks, lzxp::LzxShared *sh, const bool stream)
 {
   const mspack_hip_unit u = *up;
-  lzxp::lzx_pipe_parse(u, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], toks + (size_t)(u.frame_base + f) * LZX_TOK_CAP, sh);
+  lzxp::lzx_pipe_parse(u, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], toks + (size_t)(u.frame_base + f) * LZX_TOK_CAP, sh,
+                       stream);
 }
 __device__ __attribute__((noinline)) void lzx_pipe_task_commit(const mspack_hip_unit *up, u8 *out_arena, lzxn::LzxFrameRec *recs,
-                                                               const uint2 *toks, SpecQueueLds *spq)
+                                                               const uint2 *toks, SpecQueueLds *spq, const bool stream)
 {
   const mspack_hip_unit u = *up;
-  lzxn::lzx_pipe_commit(u, out_arena, &recs[u.frame_base], toks + (size_t) u.frame_base * LZX_TOK_CAP, spq);
+  lzxn::lzx_pipe_commit(u, out_arena, &recs[u.frame_base], toks + (size_t) u.frame_base * LZX_TOK_CAP, spq, stream);
 }
 
 #ifdef LZX_PIPE_TRACE      /* analysis builds: one line per ticket = start, end (s_memrealtime, 100 MHz), task, time waited */
@@ -252,6 +253,8 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
   // all units carry a table and have the same number of frames F: section 1 = n_units * (F - 1) tickets, frame-major
   const u32 Fmax = rfl(ctl[0]), Fmin = rfl(ctl[1]);
   const u32 F = (Fmax != 0u && Fmax == Fmin) ? Fmax : 0u;
+  // ctl[3]: the host found wave slots to spare for this launch -- commit tasks take a frame up while it is still being parsed
+  const bool stream = rfl(ctl[3]) != 0u;
   // section 2: the last frames' parse tasks run K units ahead of the units' commit tasks, so that a commit task finds
   // its last frame parsed when it has committed the frames before it (measured: without the lead a unit task waited
   // 0.18 ms on average, and the launch ended with units whose last frame was still being parsed)
@@ -302,14 +305,14 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
     if (!commit) {
       if (!(rfl(up->flags) & MSPACK_HIP_UF_FRAME_TABLE)) continue;
       __builtin_amdgcn_s_setprio(0);
-      lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &sh.p);
+      lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &sh.p, stream);
     }
     else {
       if (!(rfl(up->flags) & MSPACK_HIP_UF_FRAME_TABLE)) continue;       // (no records: mspack_decode_lzx decodes it serially)
       // the commit chain is what a launch with a wave per unit waits for: issue priority over the parse tasks beside it
       // (measured, headline 4096 units: 3.27 -> 3.17 ms; with more units than waves it costs throughput: 6.28 -> 6.45 ms)
       if (n_units <= gridDim.x) __builtin_amdgcn_s_setprio(3);
-      lzx_pipe_task_commit(up, out_arena, recs, toks, &sh.q);
+      lzx_pipe_task_commit(up, out_arena, recs, toks, &sh.q, stream);
     }
 #ifdef LZX_PIPE_TRACE
     if (lane == 0 && t < (1u << 16)) {
@@ -522,7 +525,7 @@ static unsigned mszip_pipe_waves()
 static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
                         const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
                         size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true, unsigned launch_ix = 0,
-                        size_t n_rec_slots = (size_t) -1)
+                        size_t n_rec_slots = (size_t) -1, bool alone = true)
 {
   if (n_rec_slots == (size_t) -1) n_rec_slots = n_frames_total;
   if (n == 0) return;
@@ -531,7 +534,7 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
   case MSPACK_HIP_KIND_LZX: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total, n_rec_slots);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
-    static const u32 hdr_init[4] = { 0u, 0xFFFFFFFFu, 0u, 0u };
+    static const u32 hdr_init[4] = { 0u, 0xFFFFFFFFu, 0u, 0u }, hdr_one = 1u;
     // launches of one batch that run on different streams (host path, several chunks) have their own control words
     u32 *hdr = L.hdr + 8u * (launch_ix & 15u);
     if (frames && !g_no_pipe) {
@@ -542,6 +545,13 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
                          L.recs, hdr);
       const size_t tickets = n_slots + 3u * n;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
+      // Commit tasks may take a frame up while it is still being parsed (ctl[3]) when the launch leaves wave slots free: at
+      // most a third as many units as resident waves, and no other chunk's launch beside it.  Measured: 1024 intervals
+      // 1.51 -> 1.42 ms; with every slot taken the waiting commit waves cost more than the shorter chains bring (4096
+      // intervals 3.09 -> 4.43 ms) -- profiles/round3_stream_commit.txt.  MSPACK_HIP_STREAM_COMMIT=0/1 forces either.
+      static const int stream_env = getenv("MSPACK_HIP_STREAM_COMMIT") ? atoi(getenv("MSPACK_HIP_STREAM_COMMIT")) : -1;
+      const bool stream = stream_env >= 0 ? stream_env != 0 : (alone && n * 3u <= (size_t) lzx_pipe_waves());
+      hipMemcpyAsync(hdr + 3, stream ? &hdr_one : &hdr_init[0], sizeof(u32), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
                          (const u8 *) d_in, (u8 *) d_out, d_results, L.meta, (const u32 *) L.frame_unit, hdr, L.recs, L.toks);
       // what the pipe leaves: the last bytes of every unit's input (the EOF-exact reader's), the look-ahead frame, frames
@@ -991,7 +1001,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       if (!one) { TRY(hipEventRecord(cx.ev_in[ci], st_in)); TRY(hipStreamWaitEvent(st, cx.ev_in[ci], 0)); }
       for (unsigned k = 1; k <= 6; k++)
         launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
-                    c.has_ftab, (unsigned) ci, n_rec_slots);
+                    c.has_ftab, (unsigned) ci, n_rec_slots, one);
       TRY(hipGetLastError());
       TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
       if (!one) { TRY(hipEventRecord(cx.ev_done[ci], st)); issued.store(ci + 1, std::memory_order_release); }

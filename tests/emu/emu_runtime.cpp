@@ -13,6 +13,7 @@
 // This file is compiled WITHOUT instrumentation.
 #include <stdint.h>
 #include <stdio.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sched.h>
@@ -480,6 +481,10 @@ hipError_t hipFree(void *p) {
 }
 hipError_t emu_hipHostMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+void emu_test_delay(void) {
+  static const int us = getenv("MSPACK_EMU_PUBLISH_DELAY_US") ? atoi(getenv("MSPACK_EMU_PUBLISH_DELAY_US")) : 0;
+  if (us > 0) usleep((useconds_t) us);
+}
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { memmove(dst, src, n); return hipSuccess; }
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { memmove(dst, src, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t) { memset(dst, v, n); return hipSuccess; }

@@ -157,6 +157,9 @@ hipError_t hipFree(void *p);
 hipError_t emu_hipHostMalloc(void **p, size_t n);
 template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned flags = 0) { (void) flags; return emu_hipHostMalloc((void **) p, n); }
 hipError_t hipHostFree(void *p);
+/* test hook: a wave pauses (MSPACK_EMU_PUBLISH_DELAY_US microseconds, default 0) right after it has published partial
+ * progress, so that the consumer's path for partial progress runs whatever the host's thread timing is */
+void emu_test_delay(void);
 #define hipHostRegisterDefault 0
 static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }

@@ -65,6 +65,7 @@ def test_kernels_on_the_wavefront_emulator(built, tmp_path):
         subprocess.check_call(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     script = tmp_path / "w.py"
     script.write_text(WORKER % (ROOT, ROOT))
-    env = dict(os.environ, MSPACK_HIP_SO=SO)
+    # (parse waves pause after publishing partial progress: the commit tasks' path for frames still being parsed runs)
+    env = dict(os.environ, MSPACK_HIP_SO=SO, MSPACK_EMU_PUBLISH_DELAY_US="3000")
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert p.returncode == 0 and b"EMU_OK" in p.stdout, p.stdout.decode()[-3000:]
