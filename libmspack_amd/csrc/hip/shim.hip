@@ -546,11 +546,11 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       const size_t tickets = n_slots + 3u * n;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
       // Commit tasks may take a frame up while it is still being parsed (ctl[3]) when the launch leaves wave slots free: at
-      // most a third as many units as resident waves, and no other chunk's launch beside it.  Measured: 1024 intervals
-      // 1.51 -> 1.42 ms; with every slot taken the waiting commit waves cost more than the shorter chains bring (4096
+      // most a quarter as many units as resident waves, and no other chunk's launch beside it.  Measured: 512 intervals
+      // 1.42 -> 1.14 ms, 1024 1.53 -> 1.46, 1365 1.56 -> 1.66; with every slot taken the waiting commit waves cost more than the shorter chains bring (4096
       // intervals 3.09 -> 4.43 ms) -- profiles/round3_stream_commit.txt.  MSPACK_HIP_STREAM_COMMIT=0/1 forces either.
       static const int stream_env = getenv("MSPACK_HIP_STREAM_COMMIT") ? atoi(getenv("MSPACK_HIP_STREAM_COMMIT")) : -1;
-      const bool stream = stream_env >= 0 ? stream_env != 0 : (alone && n * 3u <= (size_t) lzx_pipe_waves());
+      const bool stream = stream_env >= 0 ? stream_env != 0 : (alone && n * 4u <= (size_t) lzx_pipe_waves());
       hipMemcpyAsync(hdr + 3, stream ? &hdr_one : &hdr_init[0], sizeof(u32), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
                          (const u8 *) d_in, (u8 *) d_out, d_results, L.meta, (const u32 *) L.frame_unit, hdr, L.recs, L.toks);
