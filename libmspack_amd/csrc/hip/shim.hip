@@ -547,8 +547,9 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
       // Commit tasks may take a frame up while it is still being parsed (ctl[3]) when the launch leaves wave slots free: at
       // most a quarter as many units as resident waves, and no other chunk's launch beside it.  Measured: 512 intervals
-      // 1.42 -> 1.14 ms, 1024 1.53 -> 1.46, 1365 1.56 -> 1.66; with every slot taken the waiting commit waves cost more than the shorter chains bring (4096
-      // intervals 3.09 -> 4.43 ms) -- profiles/round3_stream_commit.txt.  MSPACK_HIP_STREAM_COMMIT=0/1 forces either.
+      // 1.42 -> 1.14 ms, 1024 1.53 -> 1.46, 1365 1.56 -> 1.66; with every slot taken the waiting commit waves cost more
+      // than the shorter chains bring (4096 intervals 3.09 -> 4.43 ms) -- profiles/round3_stream_commit.txt.
+      // MSPACK_HIP_STREAM_COMMIT=0/1 forces either.
       static const int stream_env = getenv("MSPACK_HIP_STREAM_COMMIT") ? atoi(getenv("MSPACK_HIP_STREAM_COMMIT")) : -1;
       const bool stream = stream_env >= 0 ? stream_env != 0 : (alone && n * 4u <= (size_t) lzx_pipe_waves());
       hipMemcpyAsync(hdr + 3, stream ? &hdr_one : &hdr_init[0], sizeof(u32), hipMemcpyHostToDevice, st);
