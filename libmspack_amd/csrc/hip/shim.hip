@@ -866,11 +866,16 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     want = std::min(want, std::max<size_t>(1, n_sel / chunk_units));
     std::vector<Chunk> chunks;
     {
-      // equal shares of the input bytes.  (MSPACK_HIP_CHUNK_SHAPE=1: 1 : 1 : 2 : 4 ... -- an early first copy-back and a
-      // large last launch; measured at the headline: to the device 4.55 ms against 4.74, to the host 8.06 against 7.62)
-      static const bool geometric = env_int("MSPACK_HIP_CHUNK_SHAPE", 0, 0, 1) != 0;
+      // shares of the input bytes.  MSPACK_HIP_CHUNK_SHAPE: 0 equal (to the device: the default); 1 = 1 : 1 : 2 : 4 ... (measured
+      // at the headline: to the device 4.55 ms against 4.74, to the host 8.06 against 7.62); 2 = a first chunk of half a
+      // share (to the host: the default -- the copy-back, the longest leg, starts as soon as the first chunk is through)
+      static const int shape_env = getenv("MSPACK_HIP_CHUNK_SHAPE") ? env_int("MSPACK_HIP_CHUNK_SHAPE", 0, 0, 2) : -1;
+      const int shape = shape_env >= 0 ? shape_env : (host_out ? 2 : 0);
       uint64_t wsum = 0, w[MSPK_MAX_CHUNKS];
-      for (size_t k = 0; k < want; k++) { w[k] = geometric && k >= 2 ? (uint64_t) 1 << (k - 1) : 1; wsum += w[k]; }
+      for (size_t k = 0; k < want; k++) {
+        w[k] = shape == 1 ? (k >= 2 ? (uint64_t) 2 << (k - 1) : 2) : (shape == 2 && k == 0 && want >= 3 ? 1 : 2);
+        wsum += w[k];
+      }
       size_t a = 0; uint64_t acc = 0, upto = 0;
       for (size_t i = 0; i < n_sel; i++) {
         acc += local[i].in_len;
