@@ -69,3 +69,21 @@ def test_kernels_on_the_wavefront_emulator(built, tmp_path):
     env = dict(os.environ, MSPACK_HIP_SO=SO, MSPACK_EMU_PUBLISH_DELAY_US="3000")
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert p.returncode == 0 and b"EMU_OK" in p.stdout, p.stdout.decode()[-3000:]
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="the emulator build needs ROCm's clang++")
+def test_some_gpu_parity_tests_on_the_emulator(built):
+    """a few of the -m gpu parity tests, unchanged, against the emulator build (fresh pytest process: the ctypes mirror
+    reads MSPACK_HIP_SO when it is imported): MSZIP folders with block tables through the deflate lane parser, LZX units
+    with right and wrong frame tables and other token statistics through mspack_lzx_pipe.  (test_gpu_lzx.py,
+    test_gpu_kat.py, test_gpu_lzx_frames.py and test_gpu_mszip_blocks.py pass on the emulator as a whole -- tens of minutes;
+    these are the ones that finish in a minute.)"""
+    assert os.path.exists(SO), "built by test_kernels_on_the_wavefront_emulator"
+    ids = ["tests/test_gpu_mszip_blocks.py::test_folders_with_tables",
+           "tests/test_gpu_mszip_blocks.py::test_wrong_tables_and_odd_folders",
+           "tests/test_gpu_lzx_frames.py::test_wrong_tables_cost_time_not_correctness",
+           "tests/test_gpu_lzx_frames.py::test_frames_other_plaintexts"]
+    env = dict(os.environ, MSPACK_HIP_SO=SO, MSPACK_EMU_PUBLISH_DELAY_US="500")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + ids, cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1700)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
