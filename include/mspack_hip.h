@@ -136,6 +136,9 @@ const char *mspack_hip_last_error(void);
  *                Was: bit k set = units of kind k may be present (one kernel per codec is launched;
  *                units of other kinds are skipped); 0 = all three codecs
  * MSZIP units need 32768 bytes of slack after out_len in their output region.
+ * Units with a frame / block table: the parse wavefronts store literals into the unit's output region (for MSZIP incl. its
+ * slack) before the unit is known to decode; the first result.out_len bytes are the decoded data, the rest of the region
+ * is unspecified afterwards -- also when the unit fails.
  * Returns 0 or a negative hipError_t from the launch. */
 int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_t *d_order,
                                    size_t n_units, const void *d_in, size_t in_bytes,
