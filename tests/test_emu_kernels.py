@@ -76,8 +76,8 @@ def test_some_gpu_parity_tests_on_the_emulator(built):
     """a few of the -m gpu parity tests, unchanged, against the emulator build (fresh pytest process: the ctypes mirror
     reads MSPACK_HIP_SO when it is imported): MSZIP folders with block tables through the deflate lane parser, LZX units
     with right and wrong frame tables and other token statistics through mspack_lzx_pipe.  (test_gpu_lzx.py,
-    test_gpu_kat.py, test_gpu_lzx_frames.py and test_gpu_mszip_blocks.py pass on the emulator as a whole -- tens of minutes;
-    these are the ones that finish in a minute.)"""
+    test_gpu_kat.py, test_gpu_lzx_frames.py and test_gpu_mszip_blocks.py pass on the emulator too, their 4096-unit batches
+    aside -- tens of minutes; these are the ones that finish in a minute.)"""
     assert os.path.exists(SO), "built by test_kernels_on_the_wavefront_emulator"
     ids = ["tests/test_gpu_mszip_blocks.py::test_folders_with_tables",
            "tests/test_gpu_mszip_blocks.py::test_wrong_tables_and_odd_folders",
