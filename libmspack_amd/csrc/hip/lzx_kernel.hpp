@@ -33,6 +33,7 @@
 // so a source inside the reference data is an ordinary linear copy).
 #include "wave_common.hpp"
 #include "spec_queue.hpp"
+#include "tile_resolve.hpp"
 
 #define LZX_FRAME 32768u
 #undef LZX_MAIN_P

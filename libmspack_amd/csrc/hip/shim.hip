@@ -11,6 +11,7 @@
 #include <array>
 #include "wave_common.hpp"
 #include "spec_queue.hpp"
+#include "tile_resolve.hpp"
 // lzx_kernel.hpp is compiled twice: plain LZX (CAB, CHM) and LZX DELTA (OAB) -- see its header
 namespace lzxn {
 #include "lzx_kernel.hpp"
@@ -82,8 +83,11 @@ __device__ __forceinline__ void frame_map_unit(const mspack_hip_unit &u, const u
     if (hdr[0] < v) atomicMax(&hdr[0], v);
     if (hdr[1] > v) atomicMin(&hdr[1], v);
   }
+  // (units without a usable table own no record slots -- the host path numbers them behind the last slot that has a
+  // record: nothing of theirs is written here; frame_unit[] is preset to ~0 for the launch's slot range)
+  if (!usable) return;
   for (u32 f = threadIdx.x; f < nslots; f += 64u) {
-    frame_unit[u.frame_base + f] = (usable && f < nreal) ? ui : 0xFFFFFFFFu;
+    frame_unit[u.frame_base + f] = f < nreal ? ui : 0xFFFFFFFFu;
     recs[u.frame_base + f].status = 0u;
   }
 }
@@ -103,11 +107,15 @@ void mspack_lzx_pipe_map(const mspack_hip_unit *units, const u32 *order, u32 n_u
     if (u.kind == MSPACK_HIP_KIND_LZX) {
       const bool usable = (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u;
       const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME, nslots = u.out_len / LZX_FRAME + 1u;
-      for (u32 f = 0; f < nslots; f++) {
-        frame_unit[u.frame_base + f] = (usable && f < nreal) ? ui : 0xFFFFFFFFu;
-        recs[u.frame_base + f].status = 0u;
+      // (a unit without a table owns no record slots: the host path numbers such units behind the last slot that has a
+      // record, so nothing of theirs may be written -- frame_unit[] is preset to ~0 for the launch's slot range)
+      if (usable) {
+        for (u32 f = 0; f < nslots; f++) {
+          frame_unit[u.frame_base + f] = f < nreal ? ui : 0xFFFFFFFFu;
+          recs[u.frame_base + f].status = 0u;
+        }
+        recs[u.frame_base].rs_valid = 0u;
       }
-      recs[u.frame_base].rs_valid = 0u;
       fr = usable ? nreal : 0u;
     }
     else other = true;
@@ -216,7 +224,7 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
 // serially.  Hand-off: record + tokens by plain stores, agent-scope release, relaxed status store; the reader polls the
 // status relaxed, then one agent-scope acquire (lzx_kernel.hpp).
 // ---------------------------------------------------------------------------------------------------
-union LzxPipeLds { lzxp::LzxShared p; SpecQueueLds q; };
+union LzxPipeLds { lzxp::LzxShared p; SpecQueueLds q; TileLds t; };
 static_assert(sizeof(LzxPipeLds) <= 10240, "16 waves per CU");
 
 // the two task bodies are real calls: each gets its own register allocation (inlined into the ticket loop they spill)

@@ -206,6 +206,9 @@ static int32_t decode_run(lzx_t *z, int32_t run) {
         len += (int) x;
       }
       if (z->wpos + (uint32_t) len > z->wsize) { b->err = ORC_DECRUNCH; return INT32_MIN; }
+#ifdef ORACLE_MATCH_HOOK      /* analysis tools only (tools/analysis): every match as the decoder applies it */
+      ORACLE_MATCH_HOOK(z->wpos, (uint32_t) len, off, slot);
+#endif
       dst = &win[z->wpos]; i = (uint32_t) len;
       if (off > z->wpos) {                                           /* lzxd.c:622-642 */
         if ((uint64_t) off > z->offset && (off - z->wpos) > z->ref_size) { b->err = ORC_DECRUNCH; return INT32_MIN; }

@@ -26,6 +26,8 @@ if hasattr(L, "mspack_hip_debug_pipe_phases"):
         print("  %-46s %8.1f" % (nm, ph[k] / 100.0 / (2 * n)))
     print("commit tasks, us per unit: front (load, R0-R2, checks) %.1f  push %.1f  resolve %.1f" %
           (ph[16 + 9] / 100.0 / n, ph[16 + 10] / 100.0 / n, ph[16 + 11] / 100.0 / n))
+    print("  (round 4: 'push' = tile fill / flush, 'resolve' = tr_batch: prologue %.1f  rounds %.1f  below-tile write %.1f  slow path %.1f)" %
+          tuple(ph[16 + k] / 100.0 / n for k in (4, 5, 6, 7)))
 assert (res["err"] == 0).all() and np.array_equal(out[:n * ub], plain)
 T = min(3 * n + 2 * n, 1 << 16)
 a = np.zeros(4 * T, dtype=np.uint64)
