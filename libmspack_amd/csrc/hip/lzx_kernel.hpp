@@ -106,6 +106,9 @@ struct __align__(16) LzxShared {
   u32 inbuf[128 + 4];            /* speculative path: two 256-byte input chunks, words pre-swapped */
 #else
   u32 stage[LZX_STAGE_WORDS + 64]; /* lzx_parse_lanes / lzx_parse_emit: 4 KiB (or 8) of a frame's input, words pre-swapped */
+#ifdef LZX_LIT_RING
+  alignas(16) u32 litring[LZX_LIT_RING / 4u];  /* lzx_parse_emit: the literals of the last walk's rounds on their way out (whole 16-byte rows) */
+#endif
   /* what only the block header needs -- its input window and the code lengths -- shares its room with the main tree's
    * second-level table (lzx_build_sub), which is built when the header is done and the lengths are in the frame's record */
   union {
@@ -1502,7 +1505,10 @@ struct __align__(16) LzxFrameRec {
   /* what the unit's commit task leaves for mspack_decode_lzx: where serial decoding resumes (in the unit's FIRST record) */
   u32 rs_valid, rs_frame, rs_partial, rs_P, rs_next_bit, rs_R0, rs_R1, rs_R2;
   u8 edge_lit[128];
-  u8 pad2[48];
+  /* the unit's chain of frames (lzx_pipe_resolve): 0 = open, 1 = this frame and every frame before it are complete in the
+   * output (cR0-cR2: R0-R2 behind its last match), 2 = the chain ended at or before this frame */
+  u32 chain, cR0, cR1, cR2;
+  u8 pad2[32];
 };
 static_assert(sizeof(LzxFrameRec) == 1344, "LzxFrameRec layout");
 // LzxFrameRec::status.  The separate header / parse launches only use 0, 2, 1.  In the dependency-driven launch
@@ -1638,7 +1644,8 @@ __device__ __forceinline__ void lzx_parse_tokens(LzxDec &d, const bool length_em
 #define LZX_LANE_TAIL 384u
 #endif
 #ifndef LZX_SEG
-#define LZX_SEG 16u                 /* lzx_parse_emit: tokens per segment of the balanced last walk (a power of two) */
+#define LZX_SEG 8u                  /* lzx_parse_emit: tokens per segment of the balanced last walk (a power of two): a round's 64 segments
+                                       cover ~1.1 KiB of output -- what the literal ring holds */
 #endif
 template <bool ALIGNED>
 __device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_empty, const u32 start_bit,
@@ -2053,6 +2060,9 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
   u32 tt = 0, B = rfl(start_bit), P = 0;                       // records written, next bit, bytes of the frame done
   bool stop = false;
   if (lane < 4u) sh->cnt[lane] = 0u;                           // the edge literals' positions (128 bits)
+#ifdef LZX_LIT_RING
+  u32 lit_flushed = edge_n;                                    // literals below this position have left the ring (a multiple of 16)
+#endif
 
   while (!stop && B < Eall && P < frame_size) {
     PHE0();
@@ -2240,7 +2250,13 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
         const bool crs = on && t.is_match && pos + t.olen > frame_size;   // lzxd.c:678-693: the serial path reports it
         const bool mt = on && t.is_match && !crs;
         if (lit) {
+#ifdef LZX_LIT_RING
+          // (inside the ring's window: into LDS, written out row by row behind the round; a literal beyond it -- long matches
+          // between the segments -- goes out on its own)
+          if (pos >= edge_n) { if (pos - lit_flushed < LZX_LIT_RING) ((u8 *) sh->litring)[pos & (LZX_LIT_RING - 1u)] = (u8) t.sym; else gst_stream(fout + pos, (u8) t.sym); }
+#else
           if (pos >= edge_n) gst_stream(fout + pos, (u8) t.sym);
+#endif
           else { gst(&rec->edge_lit[pos], (u8) t.sym); atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
         }
         // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
@@ -2253,6 +2269,26 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
         LZX_MARK("emit_last_step_end");
       }
       if (sact && !have_bad && (i < ntok || cross)) { have_bad = true; bad_s = sg; bad_pos = pos; bad_j = j; bad_p = p; }
+#ifdef LZX_LIT_RING
+      {
+        // The round's 64 segments are neighbours in the output: what they left in the ring goes out as whole 16-byte rows (the
+        // bytes of the matches in between are whatever the ring held -- they are not final before the frame's matches are
+        // copied, lzx_pipe_resolve).  Rows up to the last complete one; the rest waits for the next round.  A round that
+        // outran the ring stored its far literals itself: the rows behind the window are skipped for good.
+        u32 rmax = rdl(wave_incl_max(sact ? pos : 0u), 63u);
+        if (rmax > frame_size) rmax = frame_size;
+        if (rmax > lit_flushed) {
+          const bool outran = rmax - lit_flushed > LZX_LIT_RING;
+          const u32 upto = outran ? (rmax + 15u) & ~15u : rmax & ~15u;
+          u32 lim = upto; if (outran) lim = lit_flushed + LZX_LIT_RING;
+          if (lim > (frame_size & ~15u)) lim = frame_size & ~15u;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          for (u32 row = lit_flushed + 16u * lane; row < lim; row += 16u * WAVE)
+            gst((uint4 *)(fout + row), *(const uint4 *)((const u8 *) sh->litring + (row & (LZX_LIT_RING - 1u))));
+          if (upto > lit_flushed) lit_flushed = upto;
+        }
+      }
+#endif
     }
     PHE(8);
     // ---- where did this pass get to?  the first segment that was not emitted completely ends the frame ----
@@ -2288,6 +2324,16 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#if defined(LZX_LIT_RING) && !defined(LZX_EMIT_LANES)
+  if (P > lit_flushed && P - lit_flushed <= LZX_LIT_RING) {
+    // the last rows (the frame's end, or where the parse stopped): byte by byte behind the last complete row
+    const u32 full = P & ~15u;
+    for (u32 row = lit_flushed + 16u * lane; row < full; row += 16u * WAVE)
+      gst((uint4 *)(fout + row), *(const uint4 *)((const u8 *) sh->litring + (row & (LZX_LIT_RING - 1u))));
+    const u32 b0 = full > lit_flushed ? full : lit_flushed;
+    if (b0 + lane < P) gst(fout + b0 + lane, ((const u8 *) sh->litring)[(b0 + lane) & (LZX_LIT_RING - 1u)]);
+  }
+#endif
   if (lane < 4u) rec->edge_mask[lane] = sh->cnt[lane];
   n_rec = tt; end_bit = B; bytes_done = P;
 }
@@ -2642,216 +2688,194 @@ __device__ __forceinline__ int lzx_run_tokens(LzxDec &d, LzxState &s, const u32 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// lzx_pipe_commit -- mspack_lzx_pipe's COMMIT task: the serial rest of a unit whose frames were parsed by
-// lzx_pipe_parse.  Frame by frame, in order: wait for the frame's record, check that it continues the unit exactly
-// where the previous frame ended (bit position, one block of the frame's size), store the few literals the parse wave
-// left in the record, then run down the match records 64 at a time: R0-R2 resolved along the list (lzxd.c:565-586;
-// the same prefix-scan as lzx_commit_batch), the reference's source checks (lzxd.c:613-634), the copies through the
-// position-space resolver (spec_queue.hpp).  It stops at the first frame that is not a complete regular one and
-// leaves, in the unit's first record, where serial decoding has to resume (frame, output position, bit position,
-// R0-R2): mspack_decode_lzx (launched behind the pipe) skips what is done, finishes the rest -- at least the last bytes of
-// the input, which always belong to the EOF-exact reader -- and reports.  A failed check discards the frame: the
-// serial path decodes it again from its first bit and reports the error with the reference's code and byte count.
+// lzx_pipe_resolve -- second half of a frame's task in mspack_lzx_pipe (round 4; round 3 had one COMMIT task per unit that
+// walked the unit's frames one after the other: a serial chain per unit at the end of every launch).  The wave that parsed
+// frame f (lzx_pipe_parse: literals stored, one record per match) waits until frame f - 1 is complete -- its task has an
+// earlier ticket, so a live wave holds it --, checks that the frame continues the unit exactly where that frame ended
+// (bit position, one block of the frame's size), stores the few literals the parse left in the record, and runs down
+// the match records 64 at a time: R0-R2 resolved along the list (lzxd.c:565-586; the same prefix scan as
+// lzx_commit_batch), the reference's source checks (lzxd.c:613-634), the copies through the position-space resolver
+// (spec_queue.hpp).  Then it publishes the frame as complete (`chain` word; R0-R2 behind its last match for the next
+// frame).  The first frame that is not a complete regular one ends the unit's chain: its task leaves, in the unit's first
+// record, where serial decoding has to resume (frame, output position, bit position, R0-R2) and mspack_decode_lzx
+// (launched behind the pipe) skips what is done, finishes the rest -- at least the last bytes of the input, which always
+// belong to the EOF-exact reader -- and reports.  A failed check discards the frame: the serial path decodes it again
+// from its first bit and reports the error with the reference's code and byte count.
+// All frame tasks are alike (parse + resolve, ~1 ms): a launch's waves finish together instead of waiting for the last
+// units' commit chains, and in a unit of many frames the parse of frame f + k runs beside the copies of frame f.
 // ---------------------------------------------------------------------------------------------------
-#ifdef LZX_COMMIT_STATS
-__device__ u32 g_commit_stats[8];
-#endif
-__device__ void lzx_pipe_commit(const mspack_hip_unit &u, u8 *out_arena, LzxFrameRec *urecs, const uint2 *utoks, SpecQueueLds *spq,
-                                const bool stream)
+#define LZX_CH_OPEN 0u
+#define LZX_CH_DONE 1u
+#define LZX_CH_ENDED 2u
+__device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_arena, LzxFrameRec *urecs, const uint2 *mrec, SpecQueueLds *spq,
+                                 const bool merged)
 {
   const u32 lane = threadIdx.x;
   u8 *const out = out_arena + u.out_off;
   const u32 rf = u.reset_frames;
   const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
   const u32 wsize = 1u << u.window_bits;
-  u32 R0 = 1, R1 = 1, R2 = 1;
-  u32 rs_frame = 0, rs_partial = 0, rs_P = 0, rs_next = 0;
-  u32 prev_end = 0;                                              // where the next frame has to begin (bits)
+  LzxFrameRec *rec = &urecs[f];
+  const bool first = rf ? (f % rf) == 0u : f == 0u;
   PHDECL();
-  for (u32 f = 0; f < nreal; f++) {
-    const bool first = rf ? (f % rf) == 0u : f == 0u;
-    if (first) { R0 = R1 = R2 = 1; }                             // lzxd.c:257-270
-    LzxFrameRec *rec = &urecs[f];
-    u32 st = lzx_status_load(&rec->status);
+  // ---- the frames below: complete? ----
+  u32 R0 = 1, R1 = 1, R2 = 1, prev_end = 0;
+  if (f != 0u) {
+    LzxFrameRec *pr = rec - 1;
+    u32 ch = lzx_status_load(&pr->chain);
     LZX_PIPE_WAIT_BEGIN();
-    // (the frame's parse task has an earlier ticket than this task: a live wave holds it, the status becomes final)
-    // (`stream`: the launch has wave slots to spare -- a frame whose header is known is taken up as its passes arrive; else
-    // this wave would hold its slot waiting inside the frame while parse tasks queue for slots: wait for the whole frame)
-    for (u32 tries = 0; (st == LZX_ST_NONE || st == LZX_ST_CLAIMED || (!stream && st == LZX_ST_HEADER)) && tries < (1u << 22); tries++) {
-      __builtin_amdgcn_s_sleep(32);
+    for (u32 tries = 0; ch == LZX_CH_OPEN && tries < (1u << 24); tries++) {
+      __builtin_amdgcn_s_sleep(8);
+      ch = lzx_status_load(&pr->chain);
+    }
+    LZX_PIPE_WAIT_END();
+    // (the chain ended below: whoever ended it has said where the serial path resumes.  Still open after the bound: nobody
+    // says anything -- no rs_valid, the unit kernel decodes the unit from its first byte)
+    if (ch != LZX_CH_DONE) { lzx_status_publish(&rec->chain, LZX_CH_ENDED, lane); return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    prev_end = (rfl(pr->end_bit) + 15u) & ~15u;
+    if (!first) { R0 = rfl(pr->cR0); R1 = rfl(pr->cR1); R2 = rfl(pr->cR2); }       // (a reset frame: lzxd.c:257-270)
+  }
+  // ---- this frame's record: written by this wave (`merged`: parse and resolve are one task), else by the wave that holds
+  // the frame's parse task -- an earlier ticket ----
+  u32 st = lzx_status_load(&rec->status);
+  if (!merged) {
+    LZX_PIPE_WAIT_BEGIN();
+    for (u32 tries = 0; (st == LZX_ST_NONE || st == LZX_ST_CLAIMED || st == LZX_ST_HEADER) && tries < (1u << 24); tries++) {
+      __builtin_amdgcn_s_sleep(8);
       st = lzx_status_load(&rec->status);
     }
     LZX_PIPE_WAIT_END();
-    if (st != LZX_ST_EMITTED && st != LZX_ST_HEADER) break;
-    PH0();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
-    if (rfl(rec->frame_start_bit) != prev_end || rfl(rec->block_length) != fsz) break;
-    const u32 frame_pos = f * LZX_FRAME;
+  }
+  PH0();
+  u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
+  const u32 frame_pos = f * LZX_FRAME;
+  const u32 eR0 = R0, eR1 = R1, eR2 = R2;
+  u32 n_rec = 0, bytes = 0, end_bit = 0;
+  bool bad = st != LZX_ST_EMITTED;
+  if (!bad) {
+    n_rec = rfl(rec->n_tokens); bytes = rfl(rec->bytes_done); end_bit = rfl(rec->end_bit);
+    bad = rfl(rec->frame_start_bit) != prev_end || rfl(rec->block_length) != fsz || bytes > fsz || n_rec > LZX_TOK_CAP;
+  }
+  if (!bad) {
+    // ---- the literals of the frame's first cache line ----
+    const u32 ne = rfl(rec->n_edge);
+    for (u32 i = lane; i < ne; i += WAVE)
+      if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
     // ---- the match records ----
-    const u32 eR0 = R0, eR1 = R1, eR2 = R2;
-    const uint2 *mrec = utoks + (size_t) f * LZX_TOK_CAP;
     const u32 wbase = frame_pos & ~(wsize - 1u);                 // linear position of window index 0 in this pass
     SpecQueue Q;
     spq_init(*spq, Q, frame_pos, lane);
-    bool bad = false;
-    // The frame's records arrive pass by pass (lzx_parse_emit publishes `prog` behind every pass but the last, then the final
-    // status): each event below takes what is in memory so far -- literals below `bytes`, match records below `n_rec` -- so
-    // the commit of a frame's first kilobytes runs while a parse wave is still working on its last ones, and a unit's chain
-    // is the longer of its parse and its commit, not their sum.
-    u32 th = 0, n_rec = 0, bytes = 0, end_bit = 0;
-    bool final = false, edge_done = false;
-    for (u32 tries = 0; ; ) {
-      {
-        const u32 st2 = lzx_status_load(&rec->status), pg = lzx_status_load(&rec->prog);
-        if (st2 == LZX_ST_EMITTED) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          final = true;
-          n_rec = rfl(rec->n_tokens); bytes = rfl(rec->bytes_done); end_bit = rfl(rec->end_bit);
-          if (bytes > fsz || n_rec > LZX_TOK_CAP || n_rec < th) { bad = true; break; }
-        }
-        else if (st2 == LZX_ST_HEADER) {
-          const u32 na = pg & 0x7FFFu, nb = pg >> 15;
-          if (na <= n_rec && nb <= bytes) {                      // nothing new yet
-            if (++tries >= (1u << 22)) { bad = true; break; }
-            LZX_PIPE_WAIT_BEGIN();
-            __builtin_amdgcn_s_sleep(32);
-            LZX_PIPE_WAIT_END();
-            continue;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          if (nb > fsz || na > LZX_TOK_CAP) { bad = true; break; }
-          n_rec = na; bytes = nb;
-#ifdef LZX_COMMIT_STATS
-          if (lane == 0) atomicAdd(&g_commit_stats[5], 1u);      // events that took records of a frame still being parsed
-#endif
-        }
-        else { bad = true; break; }                              // (no tokens after all: the serial path takes the frame)
-      }
-      if (!edge_done) {
-        // ---- the literals of the frame's first cache line (all below byte 128: known with the first event) ----
-        const u32 ne = rfl(rec->n_edge);
-        for (u32 i = lane; i < ne; i += WAVE)
-          if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
-        edge_done = true;
-      }
-      uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
-      if (th + lane < n_rec) cur0 = gld(mrec + th + lane);
-      if (th + 64u + lane < n_rec) cur1 = gld(mrec + th + 64u + lane);
-      if (th + 128u + lane < n_rec) cur2 = gld(mrec + th + 128u + lane);
-      if (th + 192u + lane < n_rec) cur3 = gld(mrec + th + 192u + lane);
-      for (; th < n_rec && !bad; ) {
-        uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
-        const u32 tb = th + 256u + lane;
-        if (tb < n_rec) nx0 = gld(mrec + tb);
-        if (tb + 64u < n_rec) nx1 = gld(mrec + tb + 64u);
-        if (tb + 128u < n_rec) nx2 = gld(mrec + tb + 128u);
-        if (tb + 192u < n_rec) nx3 = gld(mrec + tb + 192u);
-  #pragma unroll 1
-        for (u32 k = 0; k < 4u && th < n_rec && !bad; k++) {
-          u32 n = n_rec - th; if (n > 64u) n = 64u;
-          const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
-          const bool ism = lane < n;
-          const u32 opos = cur.x, olen = (cur.y >> 2) & 511u, which = cur.y & 3u, c1 = cur.y >> 11;
-          const u64 mm = ballot(ism);
-          // (1) every match's offset through the R0-R2 LRU (cf. lzx_commit_batch)
-          const u32 sR0 = R0, sR1 = R1, sR2 = R2;
-          u32 vmoff = c1;
-          const u64 k1 = ballot(ism && which == 0u);
-          if (!ballot(ism && which >= 2u)) {
-            const u64 below = k1 & ((1ull << lane) - 1ull);
-            const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
-            const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
-            if (which == 1u) vmoff = below ? pv : sR0;
-            if (k1) {
-              u64 m = k1;
-              const u32 j0 = 63u - (u32) __clzll((long long) m);
-              u32 nbv = sR0, ncv = sR1;
-              m &= ~(1ull << j0);
-              if (m) {
-                const u32 j1 = 63u - (u32) __clzll((long long) m);
-                nbv = rdl(c1, j1); ncv = sR0;
-                m &= ~(1ull << j1);
-                if (m) ncv = rdl(c1, 63u - (u32) __clzll((long long) m));
-              }
-              R0 = rdl(c1, j0); R1 = nbv; R2 = ncv;
+    u32 th = 0;
+    uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
+    if (th + lane < n_rec) cur0 = gld(mrec + th + lane);
+    if (th + 64u + lane < n_rec) cur1 = gld(mrec + th + 64u + lane);
+    if (th + 128u + lane < n_rec) cur2 = gld(mrec + th + 128u + lane);
+    if (th + 192u + lane < n_rec) cur3 = gld(mrec + th + 192u + lane);
+    for (; th < n_rec && !bad; ) {
+      uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
+      const u32 tb = th + 256u + lane;
+      if (tb < n_rec) nx0 = gld(mrec + tb);
+      if (tb + 64u < n_rec) nx1 = gld(mrec + tb + 64u);
+      if (tb + 128u < n_rec) nx2 = gld(mrec + tb + 128u);
+      if (tb + 192u < n_rec) nx3 = gld(mrec + tb + 192u);
+#pragma unroll 1
+      for (u32 k = 0; k < 4u && th < n_rec && !bad; k++) {
+        u32 n = n_rec - th; if (n > 64u) n = 64u;
+        const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
+        const bool ism = lane < n;
+        const u32 opos = cur.x, olen = (cur.y >> 2) & 511u, which = cur.y & 3u, c1 = cur.y >> 11;
+        const u64 mm = ballot(ism);
+        // (1) every match's offset through the R0-R2 LRU (cf. lzx_commit_batch)
+        const u32 sR0 = R0, sR1 = R1, sR2 = R2;
+        u32 vmoff = c1;
+        const u64 k1 = ballot(ism && which == 0u);
+        if (!ballot(ism && which >= 2u)) {
+          const u64 below = k1 & ((1ull << lane) - 1ull);
+          const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
+          const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
+          if (which == 1u) vmoff = below ? pv : sR0;
+          if (k1) {
+            u64 m = k1;
+            const u32 j0 = 63u - (u32) __clzll((long long) m);
+            u32 nbv = sR0, ncv = sR1;
+            m &= ~(1ull << j0);
+            if (m) {
+              const u32 j1 = 63u - (u32) __clzll((long long) m);
+              nbv = rdl(c1, j1); ncv = sR0;
+              m &= ~(1ull << j1);
+              if (m) ncv = rdl(c1, 63u - (u32) __clzll((long long) m));
             }
+            R0 = rdl(c1, j0); R1 = nbv; R2 = ncv;
           }
-          else {
-            u32 x = LRU_ID;
-            if (ism) x = which == 0u ? (0x010080u | lane) : (which == 2u ? 0x020001u : (which == 3u ? 0x000102u : LRU_ID));
-            const u32 Cm = lru_scan(x);
-            const u32 e0 = Cm & 0xFFu;
-            const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
-            vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
-            const u32 Cl = rdl(Cm, 63u);
-            const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
-            R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
-            R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
-            R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
-          }
-          // (2) the reference's checks (lzxd.c:613-634); offsets no linear copy serves (0, beyond the window) end the fast path too
-          {
-            const u32 wp = opos - wbase;
-            const bool b = ism && (wp + olen > wsize || LZX_BAD_SOURCE(vmoff, wp, frame_pos, 0u, wsize) ||
-                                   vmoff == 0u || vmoff > wsize || vmoff > opos);
-            if (ballot(b)) { bad = true; break; }
-          }
-  #ifdef LZX_COMMIT_STATS      /* emulator runs: how many matches read bytes of their own batch's output region, by length */
-          {
-            const u32 bs = rdl(opos, 0u);
-            const u64 nearm = ballot(ism && opos - vmoff + olen > bs), longm = ballot(ism && olen > 16u), near2 = ballot(ism && vmoff < 512u);
-            if (lane == 0) { atomicAdd(&g_commit_stats[0], (u32) __popcll(mm)); atomicAdd(&g_commit_stats[1], (u32) __popcll(nearm));
-                             atomicAdd(&g_commit_stats[2], (u32) __popcll(longm)); atomicAdd(&g_commit_stats[3], (u32) __popcll(near2));
-                             atomicAdd(&g_commit_stats[4], (u32) __popcll(nearm | longm)); }
-          }
-  #endif
-          PH(9);
-          // (3) queue the copies (cf. lzx_commit_batch)
-          {
-            const u32 newP = rdl(opos + olen, n - 1u);
-            u64 mq = mm;
-            if (Q.mcount + (u32) __popcll(mq) > SPQ_CAP) spq_resolve(*spq, Q, out, rdl(opos, 0u), true, lane);
-            bool im = ism;
-            for (;;) {
-              const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
-              const u64 fit = newP <= limit ? mq : ballot(im && opos + olen <= limit);
-              if (fit) {
-                const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
-                spq_push(*spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, vmoff, olen);
-                mq &= ~fit;
-                im = lane_in(mq);
-              }
-              if (!mq) break;
-              spq_resolve(*spq, Q, out, rdl(opos, (u32) __ffsll((long long) mq) - 1u), true, lane);
-            }
-            PH(10);
-            if (spq_due(Q, newP)) spq_resolve(*spq, Q, out, newP, false, lane);
-            PH(11);
-          }
-          th += n;
         }
-        cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
+        else {
+          u32 x = LRU_ID;
+          if (ism) x = which == 0u ? (0x010080u | lane) : (which == 2u ? 0x020001u : (which == 3u ? 0x000102u : LRU_ID));
+          const u32 Cm = lru_scan(x);
+          const u32 e0 = Cm & 0xFFu;
+          const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
+          vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
+          const u32 Cl = rdl(Cm, 63u);
+          const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
+          R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
+          R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
+          R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
+        }
+        // (2) the reference's checks (lzxd.c:613-634); offsets no linear copy serves (0, beyond the window) end the fast path too
+        {
+          const u32 wp = opos - wbase;
+          const bool b = ism && (wp + olen > wsize || LZX_BAD_SOURCE(vmoff, wp, frame_pos, 0u, wsize) ||
+                                 vmoff == 0u || vmoff > wsize || vmoff > opos);
+          if (ballot(b)) { bad = true; break; }
+        }
+        PH(9);
+        // (3) queue the copies (cf. lzx_commit_batch)
+        {
+          const u32 newP = rdl(opos + olen, n - 1u);
+          u64 mq = mm;
+          if (Q.mcount + (u32) __popcll(mq) > SPQ_CAP) spq_resolve(*spq, Q, out, rdl(opos, 0u), true, lane);
+          bool im = ism;
+          for (;;) {
+            const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
+            const u64 fit = newP <= limit ? mq : ballot(im && opos + olen <= limit);
+            if (fit) {
+              const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+              spq_push(*spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, vmoff, olen);
+              mq &= ~fit;
+              im = lane_in(mq);
+            }
+            if (!mq) break;
+            spq_resolve(*spq, Q, out, rdl(opos, (u32) __ffsll((long long) mq) - 1u), true, lane);
+          }
+          PH(10);
+          if (spq_due(Q, newP)) spq_resolve(*spq, Q, out, newP, false, lane);
+          PH(11);
+        }
+        th += n;
       }
-      if (bad || final) break;
+      cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
     }
-    if (bad) { R0 = eR0; R1 = eR1; R2 = eR2; break; }            // the serial path decodes this frame from its first bit
-    spq_resolve(*spq, Q, out, frame_pos + bytes, true, lane);
-    if (bytes < fsz) { rs_partial = 1; rs_P = frame_pos + bytes; rs_next = end_bit; break; }
-    prev_end = (end_bit + 15u) & ~15u;
-    rs_frame = f + 1u;
+    if (!bad) spq_resolve(*spq, Q, out, frame_pos + bytes, true, lane);
+    PH(11);
   }
-  if (!rs_partial) { rs_P = rs_frame * LZX_FRAME; rs_next = prev_end; }
+  // ---- the frame is complete: the next frame's task may go on.  Anything else ends the unit's chain here: the serial path
+  // (mspack_decode_lzx) resumes at this frame's first bit, or behind its last record when only its end is missing ----
+  const bool whole = !bad && bytes == fsz;
   if (lane == 0) {
-    LzxFrameRec *r0 = &urecs[0];
-    r0->rs_frame = rs_frame; r0->rs_partial = rs_partial; r0->rs_P = rs_P; r0->rs_next_bit = rs_next;
-    r0->rs_R0 = R0; r0->rs_R1 = R1; r0->rs_R2 = R2; r0->rs_valid = 1u;
-#ifdef LZX_COMMIT_STATS
-    printf("commit stats so far: matches %u, source inside own batch %u, longer than 16 %u, offset < 512 %u, either of the first two %u; "
-           "events on frames still being parsed %u\n",
-           g_commit_stats[0], g_commit_stats[1], g_commit_stats[2], g_commit_stats[3], g_commit_stats[4], g_commit_stats[5]);
-#endif
+    if (whole) { rec->cR0 = R0; rec->cR1 = R1; rec->cR2 = R2; }
+    if (!whole || f + 1u == nreal) {
+      LzxFrameRec *r0 = &urecs[0];
+      const bool partial = !bad && !whole;
+      r0->rs_frame = whole ? f + 1u : f; r0->rs_partial = partial ? 1u : 0u;
+      r0->rs_P = whole ? (f + 1u) * LZX_FRAME : (partial ? frame_pos + bytes : frame_pos);
+      r0->rs_next_bit = whole ? ((end_bit + 15u) & ~15u) : (partial ? end_bit : prev_end);
+      r0->rs_R0 = bad ? eR0 : R0; r0->rs_R1 = bad ? eR1 : R1; r0->rs_R2 = bad ? eR2 : R2;
+      r0->rs_valid = 1u;
+    }
   }
+  lzx_status_publish(&rec->chain, whole ? LZX_CH_DONE : LZX_CH_ENDED, lane);
   PHFLUSH();
 }
 #endif  /* !LZX_PARSE_ONLY */

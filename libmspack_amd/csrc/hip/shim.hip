@@ -22,8 +22,13 @@ namespace lzxd {
 }
 #undef LZX_DELTA
 #define LZX_PARSE_ONLY 1
+#ifndef LZX_LIT_RING
+#define LZX_LIT_RING 1024u      /* bytes of literals a parse wave stages in LDS: they leave as whole 16-byte rows (a power of two) */
+#endif
 #ifndef LZX_STAGE_WORDS
-#define LZX_STAGE_WORDS 1024u   /* 4 KiB of a frame's input per pass: parse and unit tasks share one 10 KiB LDS block (mspack_lzx_pipe) */
+#define LZX_STAGE_WORDS 768u    /* 3 KiB of a frame's input per pass + the 1 KiB literal ring: the pipe's 10 KiB LDS block (16 waves per CU).
+                                   Measured (profiles/round4_ring_variants.txt): 4 KiB stage + 2 KiB ring at 12 waves per CU 3.00 / 5.87 ms
+                                   (4096 / 8192 intervals), 2 KiB + 2 KiB at 16 waves 3.06 / 5.92, this 2.89 / 5.58 */
 #endif
 namespace lzxp {
 #include "lzx_kernel.hpp"
@@ -113,6 +118,7 @@ void mspack_lzx_pipe_map(const mspack_hip_unit *units, const u32 *order, u32 n_u
         for (u32 f = 0; f < nslots; f++) {
           frame_unit[u.frame_base + f] = f < nreal ? ui : 0xFFFFFFFFu;
           recs[u.frame_base + f].status = 0u;
+          recs[u.frame_base + f].chain = 0u;
         }
         recs[u.frame_base].rs_valid = 0u;
       }
@@ -207,39 +213,40 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
 }
 
 // ---------------------------------------------------------------------------------------------------
-// mspack_lzx_pipe -- headers, parse and commit of a launch's LZX units as ONE dependency-driven launch.
+// mspack_lzx_pipe -- headers, parse and match resolution of a launch's LZX units as ONE dependency-driven launch.
 //
-// Persistent waves pull TICKETS from a counter; a ticket is a task:
-//   P(u, f)  parse frame f of unit u (header chain link + tokens; lzx_pipe_parse)
-//   C(u)     decode unit u: adopt the frames' records as they become ready, commit their tokens, decode whatever no
-//            record covers serially, E8-translate (exactly what mspack_decode_lzx does; lzx_decode_unit)
-// in an order in which every task only waits for tasks with EARLIER tickets:
-//   section 1   every frame but the last of every unit that carries a frame table -- frame-major (all first frames, all
-//               second frames, ...) when all units have the same number of frames, else in frame-slot order;
-//   section 2   per unit, in launch order (longest first):  P(u, last frame), C(u).
-// So a unit's commit starts while its last frame is still being parsed by another wave, finished waves take the next
-// task instead of idling until a kernel boundary, and the launch ends with one task, not with three slowest waves.
-// No co-residency is assumed anywhere: a wave waits only for a task that a LIVE wave holds (a ticket is pulled by a
-// running wave; status CLAIMED / HEADER); a C task that finds a frame nobody has claimed takes it over and decodes it
-// serially.  Hand-off: record + tokens by plain stores, agent-scope release, relaxed status store; the reader polls the
-// status relaxed, then one agent-scope acquire (lzx_kernel.hpp).
+// Persistent waves pull TICKETS from a counter; a ticket is the task of one FRAME of one unit:
+//   parse (lzx_pipe_parse):     header chain link (waits for the previous frame's code lengths), tables, tokens: literals
+//                               stored in place, one record per match;
+//   resolve (lzx_pipe_resolve): waits until the unit's previous frame is complete, checks that this frame continues it,
+//                               resolves R0-R2 along the records and copies the matches, publishes the frame as complete.
+// Tickets are handed out in an order in which every task only waits for tasks with EARLIER tickets -- frame-major (all first
+// frames in launch order, longest unit first, then all second frames, ...) when all units have the same number of frames,
+// else in frame-slot order (a unit's frames in a row).  No co-residency is assumed: a ticket is pulled by a running wave,
+// so whatever a task waits for is held by a live wave or done.  Round 3 had a separate COMMIT task per unit behind the
+// unit's last parse task; its ~1-1.8 ms chain was what a launch ended with (waves busy 0.77 of the span).  Now all tasks
+// are alike, a wave that took a long first frame takes a short second frame (launch order is longest first in every
+// section), and a unit of many frames has the parse of frame f + k running beside the copies of frame f.
+// Hand-off: payload by plain stores, agent-scope release, relaxed status store; the reader polls the status relaxed, then
+// one agent-scope acquire (lzx_kernel.hpp).  The first frame that is not a complete regular one ends its unit's chain and
+// says where serial decoding resumes; mspack_decode_lzx (launched behind the pipe) finishes every unit.
 // ---------------------------------------------------------------------------------------------------
-union LzxPipeLds { lzxp::LzxShared p; SpecQueueLds q; TileLds t; };
+union LzxPipeLds { lzxp::LzxShared p; SpecQueueLds q; };
 static_assert(sizeof(LzxPipeLds) <= 10240, "16 waves per CU");
 
-// the two task bodies are real calls: each gets its own register allocation (inlined into the ticket loop they spill)
+// the two halves of a task are real calls: each gets its own register allocation (inlined into the ticket loop they spill)
 __device__ __attribute__((noinline)) void lzx_pipe_task_parse(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
-                                                              lzxn::LzxFrameRec *recs, uint2 *toks, lzxp::LzxShared *sh, const bool stream)
+                                                              lzxn::LzxFrameRec *recs, uint2 *toks, lzxp::LzxShared *sh)
 {
   const mspack_hip_unit u = *up;
   lzxp::lzx_pipe_parse(u, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], toks + (size_t)(u.frame_base + f) * LZX_TOK_CAP, sh,
-                       stream);
+                       false);
 }
-__device__ __attribute__((noinline)) void lzx_pipe_task_commit(const mspack_hip_unit *up, u8 *out_arena, lzxn::LzxFrameRec *recs,
-                                                               const uint2 *toks, SpecQueueLds *spq, const bool stream)
+__device__ __attribute__((noinline)) void lzx_pipe_task_resolve(const mspack_hip_unit *up, const u32 f, u8 *out_arena, lzxn::LzxFrameRec *recs,
+                                                                const uint2 *toks, SpecQueueLds *spq, const bool merged)
 {
   const mspack_hip_unit u = *up;
-  lzxn::lzx_pipe_commit(u, out_arena, &recs[u.frame_base], toks + (size_t) u.frame_base * LZX_TOK_CAP, spq, stream);
+  lzxn::lzx_pipe_resolve(u, f, out_arena, &recs[u.frame_base], toks + (size_t)(u.frame_base + f) * LZX_TOK_CAP, spq, merged);
 }
 
 #ifdef LZX_PIPE_TRACE      /* analysis builds: one line per ticket = start, end (s_memrealtime, 100 MHz), task, time waited */
@@ -248,9 +255,6 @@ __device__ unsigned long long g_pipe_trace[4 << 16];
 #ifndef LZX_PIPE_WAVES_PER_EU
 #define LZX_PIPE_WAVES_PER_EU 4
 #endif
-#ifndef LZX_PIPE_LEAD_DIV
-#define LZX_PIPE_LEAD_DIV 8u       /* the last frames' parse tasks lead the commit tasks by n_units / this (measured: 2, 4, 8) */
-#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZX_PIPE_WAVES_PER_EU)))
 void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
                      const u8 *in_arena, u8 *out_arena, mspack_hip_result *results, int32_t *frame_meta,
@@ -258,74 +262,48 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
 {
   __shared__ LzxPipeLds sh;
   const u32 lane = threadIdx.x;
-  // all units carry a table and have the same number of frames F: section 1 = n_units * (F - 1) tickets, frame-major
+  // all units carry a table and have the same number of frames F (CHM reset intervals): 2 * F sections of n_units tickets,
+  // each in launch order (longest unit first) -- P(frame 0), ..., P(frame F-1), R(frame 0), ..., R(frame F-1).  A task's
+  // dependencies lie at least a section back, so with more units than waves nobody waits (one task per frame -- parse +
+  // resolve -- was measured first: the waves that finish the short first frames early take the LONGEST units' second
+  // frames and then sit on their slots until those units' first frames are through: 253 us waited per task, headline 3.25 ms).
+  // Otherwise: one ticket per frame slot, parse + resolve by the same wave, a unit's frames in a row.
   const u32 Fmax = rfl(ctl[0]), Fmin = rfl(ctl[1]);
   const u32 F = (Fmax != 0u && Fmax == Fmin) ? Fmax : 0u;
-  // ctl[3]: the host found wave slots to spare for this launch -- commit tasks take a frame up while it is still being parsed
-  const bool stream = rfl(ctl[3]) != 0u;
-  // section 2: the last frames' parse tasks run K units ahead of the units' commit tasks, so that a commit task finds
-  // its last frame parsed when it has committed the frames before it (measured: without the lead a unit task waited
-  // 0.18 ms on average, and the launch ended with units whose last frame was still being parsed)
-  const u32 K = n_units < LZX_PIPE_LEAD_DIV ? n_units : n_units / LZX_PIPE_LEAD_DIV;
-  const u32 T1 = F ? n_units * (F - 1u) : n_slots, T = T1 + K + 2u * n_units;
+  const u32 T = F ? 2u * n_units * F : n_slots;
   for (;;) {
     u32 t = 0;
     if (lane == 0) t = atomicAdd(&ctl[2], 1u);
     t = rfl(t);
     if (t >= T) break;
     u32 ui = 0xFFFFFFFFu, f = 0;
-    bool commit = false;
-    if (t < T1) {
-      if (F) { ui = rfl(order ? order[t % n_units] : t % n_units); f = t / n_units; }
-      else {
-        const u32 slot = slot_lo + t;
-        ui = rfl(frame_unit[slot]);
-        if (ui != 0xFFFFFFFFu) {
-          f = slot - rfl(units[ui].frame_base);
-          if (f + 1u == (rfl(units[ui].out_len) + LZX_FRAME - 1u) / LZX_FRAME) ui = 0xFFFFFFFFu;     // the last frame: section 2
-        }
-      }
+    bool do_parse = true, do_resolve = true;
+    if (F) {
+      const u32 sct = t / n_units;
+      ui = rfl(order ? order[t % n_units] : t % n_units);
+      if (sct < F) { f = sct; do_resolve = false; } else { f = sct - F; do_parse = false; }
     }
     else {
-      u32 j;
-      if (t - T1 < K) j = t - T1;                                 // P(j)
-      else {
-        const u32 r = t - T1 - K;
-        j = r >> 1;
-        if (!(r & 1u)) commit = true;                             // C(j), then P(j + K)
-        else { j += K; if (j >= n_units) continue; }
-      }
-      ui = rfl(order ? order[j] : j);
-      if (!commit) {
-        const mspack_hip_unit &uu = units[ui];
-        const u32 nreal = (rfl(uu.out_len) + LZX_FRAME - 1u) / LZX_FRAME;
-        if (rfl((u32) uu.kind) != MSPACK_HIP_KIND_LZX || !(rfl(uu.flags) & MSPACK_HIP_UF_FRAME_TABLE) || nreal == 0u) ui = 0xFFFFFFFFu;
-        else f = nreal - 1u;
-      }
+      const u32 slot = slot_lo + t;
+      ui = rfl(frame_unit[slot]);
+      if (ui != 0xFFFFFFFFu) f = slot - rfl(units[ui].frame_base);
     }
     if (ui == 0xFFFFFFFFu) continue;
     const mspack_hip_unit *up = &units[ui];
-    if (rfl((u32) up->kind) != MSPACK_HIP_KIND_LZX) continue;
+    if (rfl((u32) up->kind) != MSPACK_HIP_KIND_LZX || !(rfl(up->flags) & MSPACK_HIP_UF_FRAME_TABLE)) continue;
 #ifdef LZX_PIPE_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) lzxn::g_pipe_wait[blockIdx.x & 0xFFFFu] = 0;
 #endif
-    if (!commit) {
-      if (!(rfl(up->flags) & MSPACK_HIP_UF_FRAME_TABLE)) continue;
-      __builtin_amdgcn_s_setprio(0);
-      lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &sh.p, stream);
+    if (do_parse) {
+      lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &sh.p);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the resolver reuses the LDS
     }
-    else {
-      if (!(rfl(up->flags) & MSPACK_HIP_UF_FRAME_TABLE)) continue;       // (no records: mspack_decode_lzx decodes it serially)
-      // the commit chain is what a launch with a wave per unit waits for: issue priority over the parse tasks beside it
-      // (measured, headline 4096 units: 3.27 -> 3.17 ms; with more units than waves it costs throughput: 6.28 -> 6.45 ms)
-      if (n_units <= gridDim.x) __builtin_amdgcn_s_setprio(3);
-      lzx_pipe_task_commit(up, out_arena, recs, toks, &sh.q, stream);
-    }
+    if (do_resolve) lzx_pipe_task_resolve(up, f, out_arena, recs, toks, &sh.q, do_parse);
 #ifdef LZX_PIPE_TRACE
     if (lane == 0 && t < (1u << 16)) {
       g_pipe_trace[4u * t] = tr0; g_pipe_trace[4u * t + 1u] = __builtin_amdgcn_s_memrealtime();
-      g_pipe_trace[4u * t + 2u] = ((unsigned long long) ui << 32) | (f << 1) | (commit ? 1u : 0u);
+      g_pipe_trace[4u * t + 2u] = ((unsigned long long) ui << 32) | (f << 1) | (do_parse ? 0u : 1u);
       g_pipe_trace[4u * t + 3u] = lzxn::g_pipe_wait[blockIdx.x & 0xFFFFu] | ((unsigned long long) blockIdx.x << 40);
     }
 #endif
@@ -551,16 +529,8 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, 0, st, d_units, d_order, (u32) n, L.frame_unit,
                          L.recs, hdr);
-      const size_t tickets = n_slots + 3u * n;
+      const size_t tickets = 2u * n_slots;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
-      // Commit tasks may take a frame up while it is still being parsed (ctl[3]) when the launch leaves wave slots free: at
-      // most a quarter as many units as resident waves, and no other chunk's launch beside it.  Measured: 512 intervals
-      // 1.42 -> 1.14 ms, 1024 1.53 -> 1.46, 1365 1.56 -> 1.66; with every slot taken the waiting commit waves cost more
-      // than the shorter chains bring (4096 intervals 3.09 -> 4.43 ms) -- profiles/round3_stream_commit.txt.
-      // MSPACK_HIP_STREAM_COMMIT=0/1 forces either.
-      static const int stream_env = getenv("MSPACK_HIP_STREAM_COMMIT") ? atoi(getenv("MSPACK_HIP_STREAM_COMMIT")) : -1;
-      const bool stream = stream_env >= 0 ? stream_env != 0 : (alone && n * 4u <= (size_t) lzx_pipe_waves());
-      hipMemcpyAsync(hdr + 3, stream ? &hdr_one : &hdr_init[0], sizeof(u32), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
                          (const u8 *) d_in, (u8 *) d_out, d_results, L.meta, (const u32 *) L.frame_unit, hdr, L.recs, L.toks);
       // what the pipe leaves: the last bytes of every unit's input (the EOF-exact reader's), the look-ahead frame, frames

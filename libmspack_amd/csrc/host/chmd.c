@@ -250,118 +250,157 @@ static struct mschmd_header *chmd_fast_open(struct mschm_decompressor *b, const 
  * order the directory is sorted in.  Chunks are cached in chm->chunk_cache. */
 #include <wctype.h>
 
-/* one UTF-8 character; never reads past e, does not check continuation bytes, lets some overlong
- * forms through (chmd.c:861-880) */
-static int utf8_next(const unsigned char **s, const unsigned char *e) {
-  const unsigned char *p = *s;
-  unsigned int x = *p++;
-  int c;
-  if (x < 0x80) c = (int) x;
-  else if (x >= 0xC2 && x < 0xE0 && p < e) { c = (int)((x & 0x1F) << 6 | (p[0] & 0x3F)); p += 1; }
-  else if (x >= 0xE0 && x < 0xF0 && p + 1 < e) { c = (int)((x & 0x0F) << 12 | (p[0] & 0x3F) << 6 | (p[1] & 0x3F)); p += 2; }
-  else if (x >= 0xF0 && x <= 0xF5 && p + 2 < e) {
-    c = (int)((x & 0x07) << 18 | (p[0] & 0x3F) << 12 | (p[1] & 0x3F) << 6 | (p[2] & 0x3F));
-    if (c > 0x10FFFF) c = 0xFFFD;
-    p += 3;
-  }
-  else c = 0xFFFD;
-  *s = p;
-  return c;
+/* ---- names ------------------------------------------------------------------------------------------------
+ * Directory names are UTF-8 and the directory is sorted by their code points after simple case folding.  The decoder
+ * below has to accept exactly what the reference's accepts (chmd.c:861-880: lead bytes C2..DF / E0..EF / F0..F5, no
+ * check of the continuation bytes, U+FFFD for everything else and for a sequence the name is too short for), or a
+ * damaged name would be looked for in another place than the reference looks. */
+struct cp_cursor { const unsigned char *at, *stop; };
+
+static unsigned int cp_take(struct cp_cursor *cur)
+{
+  const unsigned int lead = *cur->at++;
+  unsigned int more, cp, i;
+  if (lead < 0x80u) return lead;
+  if (lead >= 0xC2u && lead <= 0xDFu) { more = 1; cp = lead & 0x1Fu; }
+  else if (lead >= 0xE0u && lead <= 0xEFu) { more = 2; cp = lead & 0x0Fu; }
+  else if (lead >= 0xF0u && lead <= 0xF5u) { more = 3; cp = lead & 0x07u; }
+  else return 0xFFFDu;
+  if ((size_t)(cur->stop - cur->at) < more) return 0xFFFDu;     /* cut short: one byte consumed */
+  for (i = 0; i < more; i++) cp = (cp << 6) | (*cur->at++ & 0x3Fu);
+  return cp > 0x10FFFFu ? 0xFFFDu : cp;
 }
 
-static int name_compare(const char *s1, const char *s2, int l1, int l2) {
-  const unsigned char *p1 = (const unsigned char *) s1, *p2 = (const unsigned char *) s2;
-  const unsigned char *e1 = p1 + l1, *e2 = p2 + l2;
-  while (p1 < e1 && p2 < e2) {
-    int c1 = utf8_next(&p1, e1), c2 = utf8_next(&p2, e2);
-    if (c1 == c2) continue;
-    c1 = (int) towlower((wint_t) c1); c2 = (int) towlower((wint_t) c2);
-    if (c1 != c2) return c1 - c2;
+/* < 0, 0, > 0: `want` sorts before / equals / sorts after `have`.  Code points that differ are compared after
+ * towlower(); when one name is a prefix of the other the shorter one sorts first (byte lengths). */
+static int name_order(const char *want, int want_len, const unsigned char *have, int have_len)
+{
+  struct cp_cursor a, b;
+  a.at = (const unsigned char *) want; a.stop = a.at + want_len;
+  b.at = have; b.stop = have + have_len;
+  while (a.at < a.stop && b.at < b.stop) {
+    const unsigned int x = cp_take(&a), y = cp_take(&b);
+    if (x != y) {
+      const int fx = (int) towlower((wint_t) x), fy = (int) towlower((wint_t) y);
+      if (fx != fy) return fx - fy;
+    }
   }
-  return l1 - l2;
+  return want_len - have_len;
 }
 
-static unsigned char *read_chunk(struct chmd_p *self, struct mschmd_header *chm, struct mspack_file *fh, unsigned int n)
+/* ---- directory chunks --------------------------------------------------------------------------------------
+ * A chunk (chm->chunk_size bytes): "PMGL" + free-space length at 4 (+ prev / next chunk numbers at
+ * 0xC / 0x10, entries from 0x14) or "PMGI" + free-space length at 4 (entries from 8).  The entries are packed from the
+ * front -- ENCINT name length, name, then for PMGL three ENCINTs (section, offset, length), for PMGI one (the child
+ * chunk) -- and the chunk ENDS with a 16-bit entry count preceded by the quick-reference table growing downwards: the
+ * i-th word below the count is the offset, from the first entry, of entry i * (1 + 2^density). */
+static unsigned char *chunk_get(struct chmd_p *self, struct mschmd_header *chm, struct mspack_file *fh, unsigned int n)
 {
   struct mspack_system *sys = self->system;
-  unsigned char *buf;
+  const size_t bytes = chm->chunk_size;
+  unsigned char *data;
+  int failed = 0;
   if (n >= chm->num_chunks) return NULL;
   if (!chm->chunk_cache) {
-    size_t size = sizeof(unsigned char *) * chm->num_chunks;
-    if (!(chm->chunk_cache = (unsigned char **) sys->alloc(sys, size))) { self->error = MSPACK_ERR_NOMEMORY; return NULL; }
-    memset(chm->chunk_cache, 0, size);
+    unsigned char **slots = (unsigned char **) sys->alloc(sys, sizeof(unsigned char *) * chm->num_chunks);
+    unsigned int i;
+    if (!slots) { self->error = MSPACK_ERR_NOMEMORY; return NULL; }
+    for (i = 0; i < chm->num_chunks; i++) slots[i] = NULL;
+    chm->chunk_cache = slots;
   }
   if (chm->chunk_cache[n]) return chm->chunk_cache[n];
-  if (!(buf = (unsigned char *) sys->alloc(sys, chm->chunk_size))) { self->error = MSPACK_ERR_NOMEMORY; return NULL; }
-  if (sys->seek(fh, chm->dir_offset + (off_t) n * (off_t) chm->chunk_size, MSPACK_SYS_SEEK_START)) {
-    self->error = MSPACK_ERR_SEEK; sys->free(buf); return NULL;
-  }
-  if (sys->read(fh, buf, (int) chm->chunk_size) != (int) chm->chunk_size) {
-    self->error = MSPACK_ERR_READ; sys->free(buf); return NULL;
-  }
-  if (!(buf[0] == 'P' && buf[1] == 'M' && buf[2] == 'G' && (buf[3] == 'L' || buf[3] == 'I'))) {
-    self->error = MSPACK_ERR_SEEK; sys->free(buf); return NULL;      /* the reference's code for it */
-  }
-  return chm->chunk_cache[n] = buf;
+  if (!(data = (unsigned char *) sys->alloc(sys, bytes))) { self->error = MSPACK_ERR_NOMEMORY; return NULL; }
+  if (sys->seek(fh, chm->dir_offset + (off_t) n * (off_t) bytes, MSPACK_SYS_SEEK_START)) failed = MSPACK_ERR_SEEK;
+  else if (sys->read(fh, data, (int) bytes) != (int) bytes) failed = MSPACK_ERR_READ;
+  else if (memcmp(data, "PMG", 3) != 0 || (data[3] != 'L' && data[3] != 'I')) failed = MSPACK_ERR_SEEK;   /* (the reference's code for a bad signature, chmd.c:676-680) */
+  if (failed) { self->error = failed; sys->free(data); return NULL; }
+  chm->chunk_cache[n] = data;
+  return data;
 }
 
-static void skip_encint(const unsigned char **p, const unsigned char *end) {
-  while (*p < end && (*(*p)++ & 0x80)) ;
+struct chunk_view {
+  const unsigned char *first;        /* the first entry */
+  const unsigned char *limit;        /* end of the entry area = chunk end - free-space length */
+  const unsigned char *count_at;     /* the 16-bit entry count; quick-reference word i sits 2 * i bytes below it */
+  unsigned int n_entries, n_quick, per_quick;
+  int leaf;                          /* PMGL */
+};
+/* one entry: its name and what follows it; 0 when the entry does not fit the entry area */
+static int entry_name(const struct chunk_view *cv, const unsigned char *at, const unsigned char **name, unsigned int *len)
+{
+  int bad = 0;
+  const unsigned int l = (unsigned int) read_encint(&at, cv->limit, &bad);     /* (32 bits of it, as the reference keeps) */
+  if (bad || l > (unsigned int)(cv->limit - at)) return 0;
+  *name = at; *len = l;
+  return 1;
+}
+static const unsigned char *quick_entry(const struct chunk_view *cv, unsigned int i)
+{
+  return cv->first + (i ? rd_le16(cv->count_at - 2u * i) : 0u);
+}
+static const unsigned char *pass_encints(const unsigned char *at, const unsigned char *limit, int count)
+{
+  while (count-- > 0) while (at < limit && (*at++ & 0x80)) ;
+  return at;
 }
 
-/* -1 = malformed chunk, 0 = the name is not here, 1 = found: *res points at the entry's data (PMGL:
- * section, offset, length; PMGI: the child chunk number of the last entry not above the name) */
+/* -1 = malformed chunk, 0 = the name is not here, 1 = found: *res points at the entry's data (PMGL: section, offset,
+ * length; PMGI: the child chunk number of the last entry not above the name), *res_end = end of the entry area.
+ * The quick-reference probes are the reference's (chmd.c:705-800: the middle of a closed interval, rounded down), so
+ * that a chunk whose quick-reference words or entries are damaged is judged by the same entries. */
 static int search_chunk(struct mschmd_header *chm, const unsigned char *chunk, const char *filename,
                         const unsigned char **res, const unsigned char **res_end)
 {
-  const int is_pmgl = (chunk[3] == 'L');
-  const unsigned int entries_off = is_pmgl ? 0x14u : 8u;
-  const unsigned int fname_len = (unsigned int) strlen(filename);
-  const unsigned int qr_size = rd_le32(chunk + 4);
-  const unsigned char *start = chunk + chm->chunk_size - 2;      /* entry count; quick refs grow down from here */
-  const unsigned char *end = chunk + chm->chunk_size - qr_size;
-  unsigned int num_entries = rd_le16(start), qr_density = 1u + (1u << chm->density), qr_entries, name_len;
-  const unsigned char *p;
-  int cmp = 0, err = 0;
+  struct chunk_view cv;
+  const int want_len = (int) strlen(filename);
+  const unsigned int free_len = rd_le32(chunk + 4);
+  const unsigned char *at, *name, *below = NULL;
+  unsigned int len, left, lo, hi;
 
-  qr_entries = (num_entries + qr_density - 1) / qr_density;
-  if (num_entries == 0) return -1;
-  if (qr_size > chm->chunk_size) return -1;
-  *res_end = end;
-  if ((int) qr_entries * 2 > (int)(start - end)) qr_entries = 0;  /* more quick refs than room: do without */
+  cv.leaf = chunk[3] == 'L';
+  cv.first = chunk + (cv.leaf ? 0x14 : 8);
+  cv.count_at = chunk + chm->chunk_size - 2;
+  cv.limit = chunk + chm->chunk_size - free_len;
+  cv.n_entries = rd_le16(cv.count_at);
+  cv.per_quick = 1u + (1u << chm->density);
+  if (cv.n_entries == 0 || free_len > chm->chunk_size) return -1;
+  *res_end = cv.limit;
+  cv.n_quick = (cv.n_entries + cv.per_quick - 1u) / cv.per_quick;
+  if ((int)(2u * cv.n_quick) > (int)(cv.count_at - cv.limit)) cv.n_quick = 0;     /* a table that cannot fit: do without */
 
-  if (qr_entries > 0) {
-    unsigned int L = 0, R = qr_entries - 1, M;
-    do {
-      M = (L + R) >> 1;
-      p = chunk + entries_off + (M ? rd_le16(start - (M << 1)) : 0);
-      name_len = (unsigned int) read_encint(&p, end, &err);
-      if (err || name_len > (unsigned int)(end - p)) return -1;
-      cmp = name_compare(filename, (const char *) p, (int) fname_len, (int) name_len);
-      if (cmp == 0) break;
-      else if (cmp < 0) { if (M) R = M - 1; else return 0; }
-      else L = M + 1;
-    } while (L <= R);
-    M = (L + R) >> 1;
-    if (cmp == 0) { *res = p + name_len; return 1; }
-    p = chunk + entries_off + (M ? rd_le16(start - (M << 1)) : 0);
-    num_entries -= M * qr_density;
-    if (num_entries > qr_density) num_entries = qr_density;
+  /* which group of per_quick entries?  [lo, hi): the quick entries not yet known to sort before (below lo) or after
+   * (from hi on) the name */
+  at = cv.first; left = cv.n_entries;
+  for (lo = 0, hi = cv.n_quick; lo < hi; ) {
+    const unsigned int mid = (lo + hi - 1u) >> 1;
+    int o;
+    at = quick_entry(&cv, mid);
+    if (!entry_name(&cv, at, &name, &len)) return -1;
+    o = name_order(filename, want_len, name, (int) len);
+    if (o == 0) { *res = name + len; return 1; }
+    if (o > 0) lo = mid + 1u;
+    else if (mid == 0u) return 0;                               /* sorts before the chunk's first entry */
+    else hi = mid;
   }
-  else p = chunk + entries_off;
-
-  *res = NULL;
-  while (num_entries-- > 0) {
-    name_len = (unsigned int) read_encint(&p, end, &err);
-    if (err || name_len > (unsigned int)(end - p)) return -1;
-    cmp = name_compare(filename, (const char *) p, (int) fname_len, (int) name_len);
-    p += name_len;
-    if (cmp == 0) { *res = p; return 1; }
-    if (cmp < 0) break;
-    if (is_pmgl) { skip_encint(&p, end); skip_encint(&p, end); skip_encint(&p, end); }
-    else { *res = p; skip_encint(&p, end); }
+  if (cv.n_quick) {
+    /* lo - 1 = the last quick entry that sorts before the name: its group is the only one that can hold it */
+    const unsigned int g = lo - 1u;
+    at = quick_entry(&cv, g);
+    left = cv.n_entries - g * cv.per_quick;
+    if (left > cv.per_quick) left = cv.per_quick;
   }
-  return is_pmgl ? 0 : (*res ? 1 : 0);
+  for (; left > 0; left--) {
+    int o;
+    if (!entry_name(&cv, at, &name, &len)) return -1;
+    o = name_order(filename, want_len, name, (int) len);
+    at = name + len;
+    if (o == 0) { *res = at; return 1; }
+    if (o < 0) break;
+    if (!cv.leaf) below = at;                                   /* (an index chunk: descend below the last name not above ours) */
+    at = pass_encints(at, cv.limit, cv.leaf ? 3 : 1);
+  }
+  *res = below;
+  return below ? 1 : 0;
 }
 
 static int chmd_fast_find(struct mschm_decompressor *base, struct mschmd_header *chm, const char *filename,
@@ -381,7 +420,7 @@ static int chmd_fast_find(struct mschm_decompressor *base, struct mschmd_header 
   if (chm->index_root < chm->num_chunks) {
     n = chm->index_root;
     for (;;) {
-      if (!(chunk = read_chunk(self, chm, fh, n))) { sys->close(fh); return self->error; }
+      if (!(chunk = chunk_get(self, chm, fh, n))) { sys->close(fh); return self->error; }
       if ((result = search_chunk(chm, chunk, filename, &p, &end)) <= 0) break;
       if (chunk[3] == 'L') break;
       n = (unsigned int) read_encint(&p, end, &e);
@@ -390,7 +429,7 @@ static int chmd_fast_find(struct mschm_decompressor *base, struct mschmd_header 
   }
   else {
     for (n = chm->first_pmgl; n <= chm->last_pmgl; n = rd_le32(chunk + 0x10)) {
-      if (!(chunk = read_chunk(self, chm, fh, n))) { err = self->error; break; }
+      if (!(chunk = chunk_get(self, chm, fh, n))) { err = self->error; break; }
       if ((result = search_chunk(chm, chunk, filename, &p, &end)) > 0) break;
       if (n == rd_le32(chunk + 0x10)) break;              /* a chunk that names itself as its successor */
     }

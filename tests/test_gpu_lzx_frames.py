@@ -160,17 +160,14 @@ def test_frames_other_plaintexts(built, fam):
         assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
 
 
-@pytest.mark.parametrize("env", [{}, {"MSPACK_HIP_STREAM_COMMIT": "1"}, {"MSPACK_HIP_STREAM_COMMIT": "0"}, {"MSPACK_HIP_NO_PIPE": "1"},
-                                 {"MSPACK_HIP_NO_FRAME_PARSE": "1"}],
-                         ids=["pipe", "pipe-streaming-commit-everywhere", "pipe-no-streaming-commit", "three-kernels", "serial"])
+@pytest.mark.parametrize("env", [{}, {"MSPACK_HIP_NO_PIPE": "1"}, {"MSPACK_HIP_NO_FRAME_PARSE": "1"}],
+                         ids=["pipe", "three-kernels", "serial"])
 def test_launch_paths_same_bytes(built, env):
     """shim.hip launch_kind: the shipped default (mspack_lzx_pipe: one dependency-driven launch), the header / parse /
     unit kernels one after the other (MSPACK_HIP_NO_PIPE) and the serial kernel alone (MSPACK_HIP_NO_FRAME_PARSE) --
     same results, on launches smaller than, about and larger than the chip, and on units of three frames.  Every unit
-    carries its table; with the pipe every unit must have had all its frames' records adopted.  The pipe also with commit
-    tasks that take frames up while they are still being parsed in EVERY launch (MSPACK_HIP_STREAM_COMMIT=1; the library
-    does that only where a launch leaves wave slots free) and in none.  (Own process: the switches are read when the
-    library loads.)"""
+    carries its table; with the pipe every unit must have had all its frames' records adopted.  (Own process: the
+    switches are read when the library loads.)"""
     import os, subprocess, sys
     code = r"""
 import numpy as np, sys

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, session A: the tile resolver in the commit task -- LZX parity tests, headline bench, per-phase sums (trace build)
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4a; mkdir -p $OUT; cd $R
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4c; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
 ( timeout 600 python -m pytest tests/test_gpu_lzx_frames.py tests/test_gpu_kat.py tests/test_gpu_lzx.py -x -q -m gpu --durations=5 2>&1 | tail -12 ) > $OUT/pytest.log 2>&1
 ( timeout 300 python bench.py --no-cpu --no-extras --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err )

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, quick perf loop: headline / 8192 / 1024 units (no parity gate beyond bit_exact of bench), per-phase sums of the trace build
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4b; mkdir -p $OUT; cd $R
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r4e; mkdir -p $OUT; cd $R
 export TMPDIR=/tmp
 ( timeout 300 python bench.py --no-cpu --no-extras --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err )
 ( timeout 300 python bench.py --no-cpu --no-extras --units 8192 --steps 10 --warmup 3 --exp > $OUT/bench8192.json 2>> $OUT/bench.err )

@@ -24,12 +24,10 @@ if hasattr(L, "mspack_hip_debug_pipe_phases"):
     print("parse tasks, us per frame (%d frames):" % (2 * n))
     for k, nm in enumerate(names):
         print("  %-46s %8.1f" % (nm, ph[k] / 100.0 / (2 * n)))
-    print("commit tasks, us per unit: front (load, R0-R2, checks) %.1f  push %.1f  resolve %.1f" %
+    print("resolve half of the tasks, us per UNIT (two frames): front (load, R0-R2, checks) %.1f  push %.1f  resolve %.1f" %
           (ph[16 + 9] / 100.0 / n, ph[16 + 10] / 100.0 / n, ph[16 + 11] / 100.0 / n))
-    print("  (round 4: 'push' = tile fill / flush, 'resolve' = tr_batch: prologue %.1f  rounds %.1f  below-tile write %.1f  slow path %.1f)" %
-          tuple(ph[16 + k] / 100.0 / n for k in (4, 5, 6, 7)))
 assert (res["err"] == 0).all() and np.array_equal(out[:n * ub], plain)
-T = min(3 * n + 2 * n, 1 << 16)
+T = min(4 * n, 1 << 16)
 a = np.zeros(4 * T, dtype=np.uint64)
 L.mspack_hip_debug_pipe_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert L.mspack_hip_debug_pipe_trace(a.ctypes.data, a.size) == 0
@@ -42,7 +40,7 @@ st = (v[:, 0] - t0) / 100.0; en = (v[:, 1] - t0) / 100.0            # us (100 MH
 kind = (v[:, 2] & 1).astype(int); fr = ((v[:, 2] & 0xFFFFFFFF) >> 1).astype(int)
 wait = (v[:, 3] & ((1 << 40) - 1)) / 100.0; blk = (v[:, 3] >> 40).astype(int)
 print("adopted %.3f; launch span %.0f us; %d tasks traced" % (((res["flags"] & 32) != 0).mean(), en.max(), len(v)))
-for k, f, name in ((0, 0, "P frame 0"), (0, 1, "P frame 1"), (1, None, "C unit")):
+for k, f, name in ((0, 0, "P frame 0"), (0, 1, "P frame 1"), (1, 0, "R frame 0"), (1, 1, "R frame 1")):
     m = (kind == k) & ((fr == f) if f is not None else True)
     if m.any():
         d = en[m] - st[m]
