@@ -64,6 +64,18 @@ def usable_cpus():
     return n
 
 
+def cores_per_socket():
+    """physical cores of one socket of this host (lscpu), or None"""
+    try:
+        txt = subprocess.run(["lscpu"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=10).stdout.decode()
+        for l in txt.splitlines():
+            if l.strip().lower().startswith("core(s) per socket"):
+                return int(l.split(":")[1])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(comp, off, ln, n_units, unit_bytes):
     """Reference CPU path (oracle/_ref = the real libmspack lzxd, built from /root/reference in the
     dev container) over the same units on the host cores.  If oracle/_ref did not travel, the line says so
@@ -377,15 +389,54 @@ def host_path_worker(args):
                                     frame_tabs=tab)
     r = host_inclusive(M, units, comp, out_bytes, plain, n, ub)
     r["process"] = "a separate process holding only the library (one HIP runtime, the library's own streams)"
+    del plain, comp, units
+    if not args.no_api:
+        r["through_api"] = through_api(M)
     print(json.dumps(r), flush=True)
+
+
+def through_api(M, reps=3):
+    """BASELINE configs 2, 3 and 4 as CONTAINERS through the API the north star names -- mspack_create_cab/chm_decompressor() ->
+    open() -> extract() of every file -- driven from C with an in-memory mspack_system (libmspack_amd/csrc/bench/api_bench.c):
+    MB/s of extracted bytes over the whole run, and where the time goes.  Every byte is compared with the plaintext."""
+    from libmspack_amd import apibench as A
+    out = {}
+
+    def measure(key, kind, image, plain, check):
+        runs = []
+        ok = True
+        for k in range(reps + 1):                     # (the first run grows the library's persistent buffers)
+            rc, o, offs, d = A.run(kind, image, plain.size)
+            ok = ok and rc == 0 and d["n_errors"] == 0 and check(o, offs)
+            if k:
+                runs.append(d)
+        best = min(runs, key=lambda d: d["total_s"])
+        s = A.summary(best, "; best of %d runs, mean %.1f MB/s" % (reps, float(np.mean([d["bytes_out"] / d["total_s"] / 1e6 for d in runs]))))
+        s["bit_exact"] = bool(ok)
+        s["container_bytes"] = len(image)
+        out[key] = s
+    try:
+        cab, plain = A.build_config2_cab(M)
+        measure("config 2", "cab", cab, plain, lambda o, offs: np.array_equal(o, plain))
+        out["config 2"]["container"] = "ONE cabinet: 4096 MSZIP folders of one 32 KiB CFDATA block, 4096 files"
+        chm, plain, slices = A.build_config3_chm(M, threads=max(1, usable_cpus()))
+        measure("config 3", "chm", chm, plain,
+                lambda o, offs: all(np.array_equal(o[int(offs[k]):int(offs[k + 1])], plain[a:a + l]) for k, (a, l) in enumerate(slices)))
+        out["config 3"]["container"] = "ONE CHM: 1024 LZX reset intervals of 64 KiB (window 2^21, reset every 2 frames), %d files" % len(slices)
+        cab, plain = A.build_config4_cab(M)
+        measure("config 4", "cab", cab, plain, lambda o, offs: np.array_equal(o, plain))
+        out["config 4"]["container"] = "ONE cabinet: 512 Quantum folders (window 2^21) of 32 CFDATA blocks, 512 files"
+    except Exception as ex:          # pragma: no cover
+        out["error"] = str(ex)
+    return out
 
 
 def run_host_path_worker(args):
     """-> the worker's JSON object, or an object that says why there is none"""
     cmd = [sys.executable, os.path.abspath(__file__), "--host-path-worker", "--units", str(args.units),
-           "--unit-kib", str(args.unit_kib), "--text", str(args.text)]
+           "--unit-kib", str(args.unit_kib), "--text", str(args.text)] + (["--no-api"] if args.no_api else [])
     try:
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         if p.returncode:
             return {"error": "worker exit code %d: %s" % (p.returncode, p.stderr.decode()[-400:])}
         return json.loads(p.stdout.decode().strip().splitlines()[-1])
@@ -429,6 +480,7 @@ def main():
                          "from one ticket counter, then the unit kernel for the last bytes of every unit")
     ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive and the secondary configs")
     ap.add_argument("--host-path-worker", action="store_true", help="internal: the host_inclusive measurement in a process of its own")
+    ap.add_argument("--no-api", action="store_true", help="skip through_api (containers through the object API) in the worker")
     ap.add_argument("--exp", action="store_true", help="kernel experiments: skip the parity gate and the CPU leg (the line is then NOT a valid result)")
     args = ap.parse_args()
 
@@ -571,6 +623,19 @@ def main():
                 secondary_lzx(M, torch, dev, "BASELINE config 5, rank 0's shard of 8: %d of 65536 LZX reset intervals of 64 KiB in one "
                               "launch (strong-scaling seeding)" % (hi5 - lo5), hi5 - lo5, ub, 0xC0F165, first_unit=lo5, threads=threads),
                 secondary_mszip(M, torch, dev, cpu=cpu), secondary_qtm(M, torch, dev, cpu=cpu)]
+            ta = (host_clean or {}).pop("through_api", None) if isinstance(host_clean, dict) else None
+            if "host_inclusive" in line:
+                line["host_inclusive"].pop("through_api", None)
+            if ta:
+                for sec in line["secondary"]:
+                    for key in ("config 2", "config 3", "config 4"):
+                        if ("BASELINE " + key) in sec["config"] and key in ta:
+                            sec["through_api"] = ta[key]
+                            hi = line.get("host_inclusive", {}).get("to_host_MBps")
+                            if hi:
+                                sec["through_api"]["vs_host_inclusive_to_host"] = round(ta[key]["MBps"] / hi, 3)
+                if "error" in ta:
+                    line["through_api_error"] = ta["error"]
         if cpu:
             line["cpu_baseline"] = cpu_baseline(comp, off, ln, n, ub)
             cb = line["cpu_baseline"]
@@ -579,6 +644,14 @@ def main():
                                            "host_to_device": round(line["host_inclusive"]["MBps"] / cb["value"], 2) if extras else None,
                                            "host_to_host": round(line["host_inclusive"]["to_host_MBps"] / cb["value"], 2) if extras else None,
                                            "note": "against %d host threads (the container's CPU quota), not a whole socket" % cb["cores"]}
+                cps = cores_per_socket()
+                if cps and cb.get("one_core_MBps"):
+                    est = cb["one_core_MBps"] * cps
+                    line["vs_cpu_baseline"]["single_socket_estimate"] = {
+                        "physical_cores_per_socket": cps, "MBps": round(est, 1), "device_resident": round(line["value"] / est, 2),
+                        "host_to_device": round(line["host_inclusive"]["MBps"] / est, 2) if extras else None,
+                        "what": "ESTIMATE, not measured: one_core_MBps x the physical cores of one socket (lscpu); the quota of %d CPUs "
+                                "does not allow the measurement.  The north star's target is 10x THIS" % cb["cores"]}
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

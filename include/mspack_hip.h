@@ -70,6 +70,10 @@ extern "C" {
                                            wrong one costs time, never correctness (the unit's wavefront checks every
                                            frame's bit position and falls back to decoding serially).  Ignored for MSZIP
                                            units in repair or KWAJ mode (in_chunk has its other meaning there)        */
+#define MSPACK_HIP_UF_MSZIP_LOG    16u  /* with MSPACK_HIP_UF_MSZIP_REPAIR: report the repaired blocks (what the reference says through
+                                           sys->message, mszipd.c:427).  e8_base = capacity N of a log the unit owns in the output
+                                           arena at out_off + ((out_len + 32768 + 15) & ~15): uint32 count of repaired blocks
+                                           (all of them, also beyond N), then N pairs (output offset of the block, bytes lost) */
 #define MSPACK_HIP_UF_HARD_EOF      2u  /* the feeder's read FAILED at in_len (sys->read < 0, e.g. a bad
                                            CFDATA block, cabd.c:1322-1324): ERR_READ at once, without the
                                            two fabricated zero bytes of a clean EOF (readbits.h:194-208) */
@@ -200,6 +204,13 @@ double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32
                                     void *d_out, size_t out_bytes, mspack_hip_result *d_results,
                                     void *d_frame_scratch, size_t n_frames_total, unsigned kind_mask,
                                     void *stream, int iters);
+
+/* ---- diagnostics: where the host-buffer entry points spend their time ------------------------------------
+ * Milliseconds summed over every call of mspack_hip_decode_batch / _to_device / _multi in this process since the last
+ * reset: ms4[0] planning + growing the persistent buffers, ms4[1] issuing (the H2D copies of pageable input are
+ * synchronous: this is mostly H2D) and launching, ms4[2] waiting for the kernels and the copies back, ms4[3] the number
+ * of calls.  ms4 may be NULL; reset != 0 clears the sums after reading.  (bench infrastructure: csrc/bench/api_bench.c) */
+void mspack_hip_host_path_stats(double *ms4, int reset);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 
   libmspack_amd/libmspack_hip.so     hipcc --offload-arch=gfx950: kernels + C ABI (+ C host drivers)
   libmspack_amd/libmspack_corpus.so  gcc: synthetic corpus generators (test/bench infrastructure)
+  libmspack_amd/libmspack_apibench.so gcc: the object API driven by a C in-memory mspack_system (bench/test infrastructure)
   oracle/liboracle.so                gcc: CPU restatement (test infrastructure)
   oracle/_ref/*.so                   gcc on /root/reference sources, only where they exist
 """
@@ -68,6 +69,18 @@ def build_corpus(force=False):
     return CORPUS_SO
 
 
+APIBENCH_SO = os.path.join(HERE, "libmspack_apibench.so")
+
+
+def build_apibench(force=False):
+    """csrc/bench/api_bench.c: the object API timed with a C in-memory mspack_system (bench / test infrastructure)"""
+    src = os.path.join(CSRC, "bench", "api_bench.c")
+    if force or _newer(APIBENCH_SO, [src, HIP_SO, os.path.join(ROOT, "include", "mspack.h"), os.path.join(ROOT, "include", "mspack_hip.h")]):
+        _run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", APIBENCH_SO, src,
+              "-L", HERE, "-l:libmspack_hip.so", "-Wl,-rpath,$ORIGIN"])
+    return APIBENCH_SO
+
+
 def build_oracle():
     _run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
     if os.path.isdir("/root/reference/libmspack/mspack"):
@@ -84,6 +97,7 @@ def build_all(force=False):
     build_corpus(force)
     build_oracle()
     build_hip(force)
+    build_apibench(force)
     build_reftests()
 
 

@@ -79,6 +79,7 @@ struct ZipDec {
   // output / window
   u8 *out;
   u32 B, wpos; bool flushed;
+  u32 ref_bo;              // the reference's zip->bytes_output for the current block: every flush adds, also the one that overflows (mszipd.c:320-331)
   u32 hist_n;                    // entries in the (B, length) stack, most recent first
   u32 lit_buf, lit_n;
   // what the reference's stream struct holds (STORE_BITS, readbits.h:119-124): repair mode restarts from it
@@ -161,6 +162,7 @@ struct ZipDec {
   __device__ __forceinline__ bool wrap_if_needed() {
     if (wpos == ZIP_FRAME) {
       flush_lits();
+      ref_bo += ZIP_FRAME;
       if (flushed) return false;
       flushed = true; wpos = 0;
     }
@@ -870,6 +872,7 @@ __device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
   } while (!last_block);
   d.flush_lits();
   bytes_output = (d.flushed ? ZIP_FRAME : 0u) + d.wpos;
+  d.ref_bo += d.wpos;
   if (d.flushed && d.wpos) return ZIP_E_FORMAT;                                   // mszipd.c:309-311,326-331
   return 0;
 }
@@ -900,6 +903,12 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
   const bool use_recs = recs != nullptr && (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u && !repair && !kwaj;
   u32 blk = 0;                    // CFDATA blocks started so far (the frame slot of the next one)
   const u32 nblk = (u.out_len + ZIP_FRAME - 1u) / ZIP_FRAME;
+  // repair mode with MSPACK_HIP_UF_MSZIP_LOG: which blocks were repaired and how many bytes each lost -- what the reference
+  // tells sys->message (mszipd.c:427) -- for the driver: behind the unit's slack, u32 count, then (output offset, bytes lost)
+  const bool logging = repair && (u.flags & MSPACK_HIP_UF_MSZIP_LOG) != 0u;
+  u32 *const rlog = (u32 *)(out_arena + u.out_off + (((size_t) u.out_len + ZIP_FRAME + 15u) & ~(size_t) 15u));
+  const u32 rlog_cap = logging ? (u32) u.e8_base : 0u;
+  u32 n_repaired = 0;
 
   while (remaining > 0u || kwaj) {
     d.byte_align();
@@ -929,7 +938,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
       if (!rd_ok) { err = ERR_READ; break; }
     }
 
-    d.wpos = 0; d.flushed = false;
+    d.wpos = 0; d.flushed = false; d.ref_bo = 0;
     d.store_bits();                                                              // mszipd.c:419
     u32 bytes_output = 0;
     int r = 0;
@@ -966,6 +975,12 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
         if (bo == 0u && d.wpos > 0u) bo = d.wpos;
         for (u32 k = bo + lane; k < ZIP_FRAME; k += WAVE) d.out[d.B + k] = 0;
         bytes_output = ZIP_FRAME;
+        if (logging) {
+          // (the reference's count: its bytes_output includes a flush that overflowed the frame -- the number can wrap)
+          const u32 rbo = (d.ref_bo == 0u && d.wpos > 0u) ? d.wpos : d.ref_bo;
+          if (lane == 0 && n_repaired < rlog_cap) { rlog[1u + 2u * n_repaired] = d.B; rlog[2u + 2u * n_repaired] = ZIP_FRAME - rbo; }
+          n_repaired++;
+        }
         if (r < 0) {
           // The next block starts from the reference's STRUCT state (RESTORE_BITS, mszipd.c:404): bit
           // buffer and bits_left as of the last STORE_BITS (mszipd.c:419,223,149), but i_ptr rewound to
@@ -1026,6 +1041,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
     }
     d.B += n;
   }
+  if (logging && lane == 0) rlog[0] = n_repaired;
   if (lane == 0) {
     res->err = err; res->flags = rflags; res->out_len = written; res->good_len = written; res->in_next = 0;
     res->in_used = d.w.origin + ((d.cons_bits() + (d.careful ? (u32) d.rbl : 0u)) >> 3);

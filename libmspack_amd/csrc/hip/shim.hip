@@ -722,6 +722,7 @@ static hipError_t grow(DevBuf &b, size_t need, bool pinned) {
   return hipSuccess;
 }
 
+static void host_path_account(double plan_ms, double issue_ms, double drain_ms);
 struct Chunk {
   size_t a, b;                          // local unit range [a, b)
   uint64_t in_lo, in_hi, out_lo, out_hi;
@@ -735,7 +736,13 @@ static inline uint64_t unit_below(const mspack_hip_unit &u) {
   return (u.kind == MSPACK_HIP_KIND_LZSS || u.kind == MSPACK_HIP_KIND_KWAJ_LZH) ? 4096u
        : (u.kind == MSPACK_HIP_KIND_LZX_DELTA ? u.ref_len : 0u);
 }
-static inline uint64_t unit_above(const mspack_hip_unit &u) { return u.kind == MSPACK_HIP_KIND_MSZIP ? 32768u : 0u; }
+static inline uint64_t unit_above(const mspack_hip_unit &u) {
+  if (u.kind != MSPACK_HIP_KIND_MSZIP) return 0u;
+  uint64_t a = 32768u;
+  if ((u.flags & MSPACK_HIP_UF_MSZIP_REPAIR) && (u.flags & MSPACK_HIP_UF_MSZIP_LOG))      // the repair log behind the slack
+    a = ((((uint64_t) u.out_len + 32768u + 15u) & ~15ull) - u.out_len) + 4u + 8u * (uint64_t)(u.e8_base > 0 ? u.e8_base : 0);
+  return a;
+}
 static inline bool unit_has_ftab(const mspack_hip_unit &u) {
   if (!(u.flags & MSPACK_HIP_UF_FRAME_TABLE)) return false;
   if (u.kind == MSPACK_HIP_KIND_LZX) return true;
@@ -1013,6 +1020,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       if (local[i].kind == 0) { memset(&results[idx[i]], 0, sizeof(mspack_hip_result)); results[idx[i]].err = ERR_ARGS; }
     }
     t3 = tnow();
+    host_path_account(tms(t0, t1), tms(t1, t2), tms(t2, t3));
     if (trace)
       fprintf(stderr, "mspack_hip[dev %d]: %zu units in %zu chunks (%d streams): plan+alloc %.2f ms, issue (H2D %.1f MB) %.2f ms, "
               "drain (D2H %.1f MB) %.2f ms (page-locking %.2f ms beside the issue, release %.2f ms)\n", dev, n_sel, chunks.size(), cx.ns,
@@ -1025,6 +1033,13 @@ done:
 }
 
 static int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d; }
+
+static std::mutex g_stats_mu;
+static double g_stats_ms[4] = { 0, 0, 0, 0 };
+static void host_path_account(double plan_ms, double issue_ms, double drain_ms) {
+  std::lock_guard<std::mutex> lock(g_stats_mu);
+  g_stats_ms[0] += plan_ms; g_stats_ms[1] += issue_ms; g_stats_ms[2] += drain_ms; g_stats_ms[3] += 1.0;
+}
 
 extern "C" {
 
@@ -1099,6 +1114,13 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
   for (int sh = 0; sh < n_shards; sh++)
     if (rcs[sh]) { snprintf(g_err, sizeof(g_err), "shard %d: %s", sh, errs[sh].data()); return rcs[sh]; }
   return 0;
+}
+
+void mspack_hip_host_path_stats(double *ms4, int reset)
+{
+  std::lock_guard<std::mutex> lock(g_stats_mu);
+  if (ms4) for (int i = 0; i < 4; i++) ms4[i] = g_stats_ms[i];
+  if (reset) for (int i = 0; i < 4; i++) g_stats_ms[i] = 0.0;
 }
 
 // free every persistent context (device arenas, pinned staging, streams) of this process

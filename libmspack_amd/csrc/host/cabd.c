@@ -30,6 +30,7 @@
 #define CAB_FOLDERMAX  65535u
 
 struct cab_p;
+struct out_store { unsigned char *base; size_t refs; };   /* one batch's output arena, kept as the folders' decoded bytes */
 struct fseg {                         /* where a folder's CFDATA blocks live: one entry per cabinet */
   struct fseg *next;
   struct cab_p *cab;
@@ -41,7 +42,9 @@ struct folder_p {
   struct mscabd_file *merge_prev, *merge_next;
   /* decoded state */
   int decoded;
-  unsigned char *dec;                 /* decoded bytes (good prefix valid)                         */
+  unsigned char *dec;                 /* decoded bytes (good prefix valid): inside `store`, the output arena of the batch that
+                                         decoded the folder -- the folders of a batch share it, the last one to go frees it */
+  struct out_store *store;
   unsigned int total;                 /* sum of the blocks' uncompressed sizes                     */
   unsigned int good_len;              /* bytes that decode without error                           */
   unsigned int n_frames_good;         /* LZX: complete frames in good_len                          */
@@ -49,6 +52,15 @@ struct folder_p {
   int read_err;                       /* what the feeder would have reported for ERR_READ          */
   int hard_eof;                       /* the block chain ended with a read failure, not cleanly    */
   unsigned int res_flags;
+  /* MSZIP repair mode (MSCABD_PARAM_FIXMSZIP): the blocks the codec repaired, in stream order: rep[2 i] = output offset of
+   * the block, rep[2 i + 1] = bytes lost (what mszipd tells sys->message, mszipd.c:427) */
+  unsigned int rep_n;
+  unsigned int *rep;
+  /* the same for the feeder's "bad block checksum" warnings of such a folder (checksums are ignored in repair mode,
+   * cabd.c:1408-1421): rep_ck[i] = the output offset at which the reference has read block i's header and complained --
+   * the block whose decoding pulls the input chunk (MSCABD_PARAM_DECOMPBUF bytes) that block i starts in */
+  unsigned int ck_n;
+  unsigned int *rep_ck;
 };
 struct cab_p {
   struct mscabd_cabinet base;
@@ -57,6 +69,7 @@ struct cab_p {
 /* the CFDATA feeder of one folder (the subset of the reference's mscabd_decompress_state, cab.h:95-110,
  * that cabd_sys_read_block works on) */
 struct blk_reader {
+  int quiet_cksum, bad_cksum;          /* do not say "bad block checksum" now: the caller notes it (bad_cksum) and says it later */
   struct folder_p *folder;
   struct fseg *seg;                   /* cabinet the next block header is read from                */
   struct mspack_file *fh;
@@ -76,6 +89,10 @@ struct cabd_p {
   unsigned int st_offset;             /* bytes produced so far from st.folder                      */
   int st_active;
   struct folder_p *last_folder;       /* folder of the previous extract()                          */
+  /* the reference's decompressor as far as its MESSAGES go: which folder it is on, how far it has decoded (cabd.c:1136-1175:
+   * another folder or an earlier offset starts it again from the folder's first block, and it says everything again) */
+  struct folder_p *msg_folder;
+  unsigned int msg_offset, msg_next, msg_next_ck;
 };
 
 static void stored_reset(struct cabd_p *self);
@@ -83,6 +100,19 @@ static void stored_reset(struct cabd_p *self);
 /* ---- small helpers -------------------------------------------------------------------------------- */
 static unsigned int cab_checksum(const unsigned char *data, unsigned int bytes, unsigned int cksum) {
   unsigned int n = bytes >> 2, tail = 0;
+#if defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+  {
+    /* (the XOR of the dwords: four independent 64-bit lanes, folded at the end) */
+    uint64_t a = 0, b = 0, c = 0, d = 0, w[4];
+    while (n >= 8) {
+      memcpy(w, data, 32);
+      a ^= w[0]; b ^= w[1]; c ^= w[2]; d ^= w[3];
+      data += 32; n -= 8;
+    }
+    a ^= b ^ c ^ d;
+    cksum ^= (unsigned int) a ^ (unsigned int)(a >> 32);
+  }
+#endif
   while (n--) { cksum ^= rd_le32(data); data += 4; }
   switch (bytes & 3) {
   case 3: tail |= (unsigned int) *data++ << 16; /* fall through */
@@ -107,7 +137,10 @@ static char *read_cstring(struct mspack_system *sys, struct mspack_file *fh, int
 }
 
 static void free_folder_cache(struct mspack_system *sys, struct folder_p *f) {
-  sys->free(f->dec); f->dec = NULL; f->decoded = 0;
+  if (f->store && --f->store->refs == 0) { sys->free(f->store->base); sys->free(f->store); }
+  f->store = NULL; f->dec = NULL; f->decoded = 0;
+  sys->free(f->rep); f->rep = NULL; f->rep_n = 0;
+  sys->free(f->rep_ck); f->rep_ck = NULL; f->ck_n = 0;
 }
 
 /* ---- headers (reference cabd.c:317-628) ------------------------------------------------------------- */
@@ -544,7 +577,8 @@ static int reader_block(struct cabd_p *self, struct blk_reader *r, unsigned int 
       unsigned int sum = cab_checksum(r->input + r->i_end, len, 0);
       if (cab_checksum(hdr + 4, 4, sum) != cksum) {
         if (!ignore_cksum) return MSPACK_ERR_CHECKSUM;
-        sys->message(r->fh, "WARNING; bad block checksum found");
+        if (r->quiet_cksum) r->bad_cksum = 1;
+        else sys->message(r->fh, "WARNING; bad block checksum found");
       }
     }
     r->i_end += len;
@@ -674,10 +708,21 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
   if (!(g->stream = (unsigned char *) sys->alloc(sys, g->cap + 64))) {
     reader_close(self, &r); if (g->boff) { sys->free(g->boff); g->boff = NULL; } return MSPACK_ERR_NOMEMORY;
   }
+  r.quiet_cksum = self->fix_mszip && method == MSCAB_COMP_MSZIP && g->boff != NULL;
   while (r.block < fol->base.num_blocks) {
     unsigned int ulen = 0;
     r.block++;
+    r.bad_cksum = 0;
     if ((err = reader_block(self, &r, &ulen, ignore_cksum, ignore_size))) { g->read_err = err; g->hard_eof = 1; break; }
+    if (r.bad_cksum) {
+      /* said when the reference would say it (cabd_extract): remember the block */
+      unsigned int *nw = (unsigned int *) sys->alloc(sys, ((size_t) fol->ck_n + 1) * sizeof(unsigned int));
+      if (nw) {
+        if (fol->ck_n) sys->copy(fol->rep_ck, nw, (size_t) fol->ck_n * sizeof(unsigned int));
+        sys->free(fol->rep_ck); fol->rep_ck = nw;
+        fol->rep_ck[fol->ck_n++] = g->nblk;               /* (block index for now: turned into an output offset below) */
+      }
+    }
     if (g->len + r.i_end + 1 > g->cap) {
       size_t ncap = (g->cap + r.i_end + 1) * 2;
       unsigned char *n = (unsigned char *) sys->alloc(sys, ncap + 64);
@@ -694,6 +739,19 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
     g->total += ulen;
   }
   reader_close(self, &r);
+  if (fol->ck_n && g->boff) {
+    /* block i is read when the codec's refill reaches the input chunk it starts in; that refill happens while the block
+     * that holds the chunk's first byte is being decoded (every block but the last decodes to 32 KiB) */
+    const size_t q = (size_t)(self->buf_size > 0 ? self->buf_size : 4096);
+    unsigned int i;
+    for (i = 0; i < fol->ck_n; i++) {
+      const unsigned int b = fol->rep_ck[i];
+      const size_t chunk_start = ((size_t) g->boff[b] / q) * q;
+      unsigned int t = b;
+      while (t > 0 && (size_t) g->boff[t] > chunk_start) t--;
+      fol->rep_ck[i] = t * CAB_BLOCKMAX;
+    }
+  }
   if (!g->hard_eof) g->read_err = self->salvage ? MSPACK_ERR_OK : MSPACK_ERR_DATAFORMAT;  /* ran out of blocks */
   else {
     /* the codec pulls buf_size bytes per read; a read that reaches the bad block fails as a whole,
@@ -759,11 +817,15 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     }
     units[k].out_off = out_bytes; units[k].out_len = gs[k].total;
     out_bytes += ((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15;
+    if (self->fix_mszip && method == MSCAB_COMP_MSZIP) {        /* the repair log behind the unit's slack (mspack_hip.h) */
+      units[k].e8_base = (int32_t)(fp->base.num_blocks + 8u);
+      out_bytes += (4u + 8u * (size_t) units[k].e8_base + 15u) & ~(size_t) 15;
+    }
     units[k].kind = (uint8_t)((method >= 1 && method <= 3) ? method : 0);   /* 0: no codec (cabd.c:1254), skipped */
     units[k].window_bits = (uint8_t)((fp->base.comp_type >> 8) & 0x1F);
-    units[k].reset_frames = 0; units[k].e8_base = 0;
+    units[k].reset_frames = 0;
     units[k].flags = (gs[k].hard_eof ? MSPACK_HIP_UF_HARD_EOF : 0) |
-                     ((self->fix_mszip && method == MSCAB_COMP_MSZIP) ? MSPACK_HIP_UF_MSZIP_REPAIR : 0) |
+                     ((self->fix_mszip && method == MSCAB_COMP_MSZIP) ? (MSPACK_HIP_UF_MSZIP_REPAIR | MSPACK_HIP_UF_MSZIP_LOG) : 0) |
                      (gs[k].frames_ok ? MSPACK_HIP_UF_FRAME_TABLE : 0);
     if (!gs[k].frames_ok) units[k].in_chunk = (uint32_t)((self->buf_size + 1) & ~1);    /* mszipd.c:348 */
   }
@@ -790,21 +852,36 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
       }
     }
   }
-  if (!err) {
-    for (k = 0; k < n; k++) {
+  if (!err && n) {
+    /* the output arena stays: every folder's decoded bytes are where the batch put them (no copy per folder) */
+    struct out_store *store = (struct out_store *) sys->alloc(sys, sizeof(*store));
+    if (!store) err = MSPACK_ERR_NOMEMORY;
+    else { store->base = out_arena; store->refs = 0; }
+    for (k = 0; k < n && !err; k++) {
       struct folder_p *fp = gs[k].fol;
       int method = fp->base.comp_type & 0x0F;
       fp->total = gs[k].total; fp->read_err = gs[k].read_err; fp->hard_eof = gs[k].hard_eof;
-      if (!(fp->dec = (unsigned char *) sys->alloc(sys, (size_t) gs[k].total + 1))) { err = MSPACK_ERR_NOMEMORY; break; }
+      fp->store = store; store->refs++;
+      fp->dec = out_arena + units[k].out_off;
       if (method >= 1 && method <= 3) {
         unsigned int g = res[k].good_len > gs[k].total ? gs[k].total : res[k].good_len;
-        sys->copy(out_arena + units[k].out_off, fp->dec, g);
         fp->good_len = g; fp->dec_err = res[k].err; fp->res_flags = res[k].flags;
+        if (units[k].flags & MSPACK_HIP_UF_MSZIP_LOG) {
+          const unsigned char *lg = out_arena + units[k].out_off + (((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15);
+          unsigned int cnt = rd_le32(lg), i;
+          if (cnt > (unsigned int) units[k].e8_base) cnt = (unsigned int) units[k].e8_base;
+          if (cnt && (fp->rep = (unsigned int *) sys->alloc(sys, (size_t) cnt * 2 * sizeof(unsigned int)))) {
+            for (i = 0; i < 2 * cnt; i++) fp->rep[i] = rd_le32(lg + 4 + 4 * (size_t) i);
+            fp->rep_n = cnt;
+          }
+        }
       }
       else { fp->good_len = 0; fp->dec_err = MSPACK_ERR_DATAFORMAT; fp->res_flags = 0; }   /* cabd.c:1254 */
       fp->n_frames_good = fp->good_len / CAB_BLOCKMAX;
       fp->decoded = 1;
     }
+    if (store && store->refs) out_arena = NULL;            /* the folders own it now */
+    else if (store) sys->free(store);
   }
   for (k = 0; k < n; k++) { sys->free(gs[k].stream); sys->free(gs[k].boff); }
   sys->free(gs); sys->free(units); sys->free(res); sys->free(in_arena); sys->free(out_arena);
@@ -891,6 +968,28 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
 
   if (!(fh = sys->open(sys, filename, MSPACK_SYS_OPEN_WRITE))) return self->error = MSPACK_ERR_OPEN;
   self->error = MSPACK_ERR_OK;
+  /* What the codec would have said on the way: mszipd in repair mode reports every block it repairs when it decodes it
+   * (mszipd.c:420-433), i.e. when the first byte of that block is asked for -- by this file, or by the skip to its offset.
+   * The reference's decompressor starts over (and says it all again) for another folder or an earlier offset. */
+  if ((fol->rep_n || fol->ck_n) && filelen) {
+    const unsigned int end = file->offset + filelen;
+    if (self->msg_folder != fol || self->msg_offset > file->offset) { self->msg_folder = fol; self->msg_next = 0; self->msg_next_ck = 0; }
+    for (;;) {
+      const int have_ck = self->msg_next_ck < fol->ck_n && fol->rep_ck[self->msg_next_ck] < end;
+      const int have_rp = self->msg_next < fol->rep_n && fol->rep[2 * self->msg_next] < end;
+      if (have_ck && (!have_rp || fol->rep_ck[self->msg_next_ck] <= fol->rep[2 * self->msg_next])) {
+        sys->message(NULL, "WARNING; bad block checksum found");
+        self->msg_next_ck++;
+      }
+      else if (have_rp) {
+        sys->message(NULL, "MSZIP error, %u bytes of data lost.", fol->rep[2 * self->msg_next + 1]);
+        self->msg_next++;
+      }
+      else break;
+    }
+    self->msg_offset = end;
+  }
+  else if (filelen) { self->msg_folder = fol; self->msg_offset = file->offset + filelen; self->msg_next = 0; self->msg_next_ck = 0; }
   if (filelen) {
     /* skip phase: getting to file->offset must itself be error free (cabd.c:1195-1199) */
     int err = file->offset ? folder_status(fol, file->offset, self->read_error) : MSPACK_ERR_OK;
@@ -947,6 +1046,7 @@ struct mscab_decompressor *mspack_create_cab_decompressor(struct mspack_system *
   self->searchbuf_size = 32768; self->fix_mszip = 0; self->buf_size = 4096; self->salvage = 0;
   self->devices = 1; self->cache_mb = 2048;
   memset(&self->st, 0, sizeof(self->st)); self->st_offset = 0; self->st_active = 0; self->last_folder = NULL;
+  self->msg_folder = NULL; self->msg_offset = 0; self->msg_next = 0; self->msg_next_ck = 0;
   return &self->base;
 }
 

@@ -88,7 +88,32 @@ static off_t m_tell(struct mspack_file *file) {
   struct memfile *f = (struct memfile *) file;
   return f ? (off_t) f->pos : 0;
 }
-static void m_msg(struct mspack_file *file, const char *format, ...) { (void) file; (void) format; }
+/* what the library says through sys->message, formatted, one line each (driver tests compare our drivers' log with it;
+ * single-threaded use only -- the timing entry points never produce messages) */
+static char g_msgs[1 << 16];
+static size_t g_msgs_len;
+static void msg_append(const char *line) {
+  size_t n = strlen(line);
+  if (g_msgs_len + n + 2 > sizeof(g_msgs)) return;
+  memcpy(g_msgs + g_msgs_len, line, n); g_msgs_len += n;
+  g_msgs[g_msgs_len++] = '\n'; g_msgs[g_msgs_len] = 0;
+}
+static void m_msg(struct mspack_file *file, const char *format, ...) {
+  char line[512];
+  va_list ap;
+  (void) file;
+  va_start(ap, format);
+  vsnprintf(line, sizeof(line), format, ap);
+  va_end(ap);
+  msg_append(line);
+}
+/* copy the log out (NUL-terminated, at most cap - 1 bytes) and clear it; returns its length */
+size_t refh_messages(char *buf, size_t cap) {
+  size_t n = g_msgs_len < cap ? g_msgs_len : (cap ? cap - 1 : 0);
+  if (cap) { memcpy(buf, g_msgs, n); buf[n] = 0; }
+  g_msgs_len = 0; g_msgs[0] = 0;
+  return n;
+}
 /* Allocation: lzxd_init mallocs a fresh 2 MiB window per stream; at one stream per 64 KiB unit that
  * is an mmap/munmap pair per unit and, with hundreds of threads, mostly kernel time.  To give the CPU
  * baseline its best showing the harness recycles blocks per thread (a size-keyed free list behind
@@ -257,6 +282,7 @@ int refh_cab_extract(const uint8_t *cab, size_t cab_len, const int *order, int n
     int k = order[i];
     while (f && k-- > 0) f = f->next;
     if (!f) { errs[i] = MSPACK_ERR_ARGS; out_offs[i] = pos; out_lens[i] = 0; continue; }
+    { char mark[32]; snprintf(mark, sizeof(mark), "#extract %d", i); msg_append(mark); }
     errs[i] = d->extract(d, f, (const char *) &dst);
     out_offs[i] = pos;
     out_lens[i] = dst.written;
@@ -397,6 +423,7 @@ int refh_chm_extract(const uint8_t *chm, size_t chm_len, const int *order, int n
     int k = order[i];
     while (f && k-- > 0) f = f->next;
     if (!f) { errs[i] = MSPACK_ERR_ARGS; out_offs[i] = pos; out_lens[i] = 0; continue; }
+    { char mark[32]; snprintf(mark, sizeof(mark), "#extract %d", i); msg_append(mark); }
     errs[i] = d->extract(d, f, (const char *) &dst);
     out_offs[i] = pos;
     out_lens[i] = dst.written;

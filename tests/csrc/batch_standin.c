@@ -65,3 +65,9 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
   (void) n_devices;
   return mspack_hip_decode_batch(units, n_units, in, in_bytes, out, out_bytes, results);
 }
+
+void mspack_hip_host_path_stats(double *ms4, int reset)
+{
+  (void) reset;
+  if (ms4) ms4[0] = ms4[1] = ms4[2] = ms4[3] = 0.0;
+}

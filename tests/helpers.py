@@ -153,8 +153,18 @@ def ref():
         lib.refh_bench.restype = C.c_double
         lib.refh_bench.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]
+        lib.refh_messages.restype = C.c_size_t
+        lib.refh_messages.argtypes = [C.c_char_p, C.c_size_t]
         _ref = lib
     return _ref
+
+
+def ref_messages():
+    """what the reference said through sys->message since the last call (formatted lines; ref_cab_extract puts a
+    '#extract i' line in front of every extract call)"""
+    buf = C.create_string_buffer(1 << 16)
+    ref().refh_messages(buf, len(buf))
+    return buf.value.decode("latin1").splitlines()
 
 
 def ref_lzx(data, out_bytes, window_bits, reset_frames=0, length=None):
@@ -349,3 +359,35 @@ def folder_stream(folder):
     (Quantum: 0xFF appended after every block, cabd.c:1330-1332)."""
     qtm = (folder["comp_type"] & 0x0F) == 2
     return b"".join(p + (b"\xff" if qtm else b"") for p, _ in folder["blocks"])
+
+
+def cab_cut_folders(cab, n_blocks):
+    """A copy of a single cabinet whose folders hold only their first n_blocks CFDATA blocks: CFFOLDER.cCFData and the
+    files' cbFile / uoffFolderStart clipped (cab.h offsets).  Files that start beyond the cut keep a length of 0."""
+    import struct
+    b = bytearray(cab)
+    assert b[:4] == b"MSCF"
+    coff_files, = struct.unpack_from("<I", b, 16)
+    n_folders, n_files, flags = struct.unpack_from("<HHH", b, 26)
+    pos = 36
+    folder_resv = 0
+    if flags & 4:
+        hdr_resv, folder_resv, _data_resv = struct.unpack_from("<HBB", b, 36)
+        pos = 40 + hdr_resv
+    for _ in range(2):                       # szCabinetPrev/szDiskPrev, szCabinetNext/szDiskNext
+        if flags & (1 if _ == 0 else 2):
+            for _s in range(2):
+                pos = b.index(0, pos) + 1
+    limit = n_blocks * 32768
+    for i in range(n_folders):
+        o = pos + i * (8 + folder_resv)
+        nb, = struct.unpack_from("<H", b, o + 4)
+        struct.pack_into("<H", b, o + 4, min(nb, n_blocks))
+    o = coff_files
+    for i in range(n_files):
+        length, start = struct.unpack_from("<II", b, o)
+        end = min(start + length, limit)
+        struct.pack_into("<I", b, o, max(end - min(start, limit), 0))
+        o += 16
+        o = b.index(0, o) + 1
+    return bytes(b)

@@ -277,14 +277,41 @@ elif mode == "n8192":
     for i in (0, 1, 4095, 4096, n - 1):
         e, o, r = oracle_lzx(comp[int(off[i]):int(off[i]) + int(ln[i]) + 4].tobytes(), ub, 21, 2)
         assert e == 0 and r.in_next == res["in_next"][i] and (int(res["flags"][i]) & ~M.F_FRAMES_ADOPTED) == r.flags
+elif mode == "full65536":
+    # BASELINE config 5 AT FULL SIZE on one device: the global list of 65 536 intervals (bench.py --scaling strong: seed
+    # 0xC0F165, unit seeds follow the global index), cut into 8 contiguous shards by mspack_hip_decode_batch_multi
+    # (MSPACK_HIP_FORCE_SHARDS=8) -- 4 GiB of output.  Every byte against the plaintext, two units of every shard against
+    # the oracle's flags / in_next.
+    n_sh, per, ub = 8, 8192, 65536
+    parts = [M.corpus_lzx_units(0xC0F165, 0, per, ub, 21, first_unit=s * per, frame_tables=True) for s in range(n_sh)]
+    sizes = [p[1].size for p in parts]
+    base = np.cumsum([0] + sizes)
+    arena = np.zeros(int(base[-1]) + 64, dtype=np.uint8)
+    for s, p in enumerate(parts):
+        arena[base[s]:base[s] + sizes[s]] = p[1]
+    offs = np.concatenate([p[2].astype(np.int64) + base[s] for s, p in enumerate(parts)])
+    lens = np.concatenate([p[3].astype(np.int64) + 4 for p in parts])
+    tabs = np.concatenate([p[4].astype(np.int64) + base[s] for s, p in enumerate(parts)])
+    n = n_sh * per
+    units, out_bytes = M.make_units(M.KIND_LZX, offs, lens, np.full(n, ub), window_bits=21, reset_frames=2, frame_tabs=tabs)
+    out, res = M.decode_batch(units, arena, out_bytes, n_devices=8)
+    assert (res["err"] == 0).all() and (res["out_len"] == ub).all()
+    assert ((res["flags"] & M.F_FRAMES_ADOPTED) != 0).all()
+    for s, p in enumerate(parts):
+        assert np.array_equal(out[s * per * ub:(s + 1) * per * ub], p[0]), s
+        for i in (s * per, s * per + per - 1):
+            e, o, r = oracle_lzx(arena[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes(), ub, 21, 2)
+            assert e == 0 and r.in_next == res["in_next"][i] and (int(res["flags"][i]) & ~M.F_FRAMES_ADOPTED) == r.flags, i
 print("BIG_OK")
 '''
 
 
-@pytest.mark.parametrize("mode,env", [("n8192", {}), ("shard8", {"MSPACK_HIP_FORCE_SHARDS": "8"})])
+@pytest.mark.parametrize("mode,env", [("n8192", {}), ("shard8", {"MSPACK_HIP_FORCE_SHARDS": "8"}),
+                                      ("full65536", {"MSPACK_HIP_FORCE_SHARDS": "8"})])
 def test_config5_shapes(built, mode, env, tmp_path):
-    """BASELINE config 5's per-GPU shard (8192 intervals in one launch) and the sharded entry point over 16 384 mixed
-    units whose outputs do NOT ascend with their inputs (the shards then copy back unit by unit)."""
+    """BASELINE config 5's per-GPU shard (8192 intervals in one launch), the sharded entry point over 16 384 mixed
+    units whose outputs do NOT ascend with their inputs (the shards then copy back unit by unit), and config 5 at full
+    size: all 65 536 intervals through the sharded entry point with 8 forced shards on the one device."""
     script = tmp_path / "w.py"
     script.write_text(BIG_WORKER % (ROOT, ROOT))
     p = subprocess.run([sys.executable, str(script), mode], env=dict(os.environ, **env), stdout=subprocess.PIPE,

@@ -71,6 +71,26 @@ def run(report=print):
 
 
 @pytest.mark.gpu
+def test_large_files_prefix(built):
+    """the same cabinet with every folder cut to its first 4096 CFDATA blocks (128 MiB each; tests/helpers.cab_cut_folders):
+    runs by default, so that the three Microsoft-made folders -- MSZIP, LZX-15 and LZX-21 units of 4096 frames, each one
+    long chain of frames -- are covered without the opt-in.  Expected MD5s: what the real libmspack extracts from the same
+    cut cabinet (tests/golden/large_prefix.json, made by tests/golden/make_large_prefix_golden.py with oracle/_ref)."""
+    from helpers import cab_cut_folders
+    gold = json.load(open(os.path.join(os.path.dirname(KAT), "large_prefix.json")))
+    cab = cab_cut_folders(inner_cabinet(), gold["n_blocks"])
+    with api.Cab(cab, mem=True) as c:
+        assert c.open_error == 0 and len(c.files) == 3
+        for g in gold["files"]:
+            t0 = time.time()
+            err, out = c.extract(g["index"])
+            dt = time.time() - t0
+            assert err == 0 and len(out) == g["bytes"] == gold["length"], (g["index"], err, len(out))
+            assert hashlib.md5(out).hexdigest() == g["md5"], g["index"]
+            print("folder %d: %d bytes in %.2f s (%.0f MB/s through cabd->extract())" % (g["index"], len(out), dt, len(out) / dt / 1e6))
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(not os.environ.get("MSPACK_TEST_LARGE"), reason="slow and large: set MSPACK_TEST_LARGE=1")
 def test_large_files(built):
     for err, n, md5 in run():
