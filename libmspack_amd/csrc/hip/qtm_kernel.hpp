@@ -30,6 +30,14 @@
 #endif
 
 struct QtmShared { SpecQueueLds spq; };
+#ifdef QTM_TIMERS       /* analysis builds: cycles per part of the token loop, block 0's wave (mspack_hip_debug_qtm_timers) */
+__device__ unsigned long long g_qtm_tm[8];
+#define QT0() unsigned long long qt_ = __builtin_amdgcn_s_memtime()
+#define QT(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); d.tm[k] += (u32)(n_ - qt_); qt_ = n_; } while (0)
+#else
+#define QT0() do { } while (0)
+#define QT(k) do { } while (0)
+#endif
 
 struct QtmDec {
   InWindow w;
@@ -37,11 +45,25 @@ struct QtmDec {
   int rbl;            // the reference's bits_left
   u32 lane;
   u32 H, L, C;        // 16-bit registers kept in 32-bit scalars
+#ifdef QTM_TIMERS
+  u32 tm[8];
+#endif
 
   __device__ __forceinline__ u32 cons_bits() const { return w.wi * 32u - (u32) bl; }
+  // The window's dwords are byte-swapped ONCE PER LANE when a chunk is loaded (two BE16 words in stream order,
+  // qtmd.c:30-35), so that a refill is a v_readlane into an SGPR and nothing else: swapped behind the readlane (there is
+  // no scalar byte swap) the dword came back in a VGPR, and the whole coder chain -- bit buffer, C, L, H, the
+  // renormalisation -- ran as vector instructions on wave-uniform values at twice the scalar latency.
+  __device__ __forceinline__ void seek_swapped(u32 byte_pos) {
+    w.origin = byte_pos; w.wi = 0;
+    w.cur = __builtin_bswap32(w.load_chunk(0, lane));
+    w.nxt = __builtin_bswap32(w.load_chunk(1, lane));
+  }
   __device__ __forceinline__ void refill() {
-    u32 d = w.next_dword(lane);
-    bb |= (u64) __builtin_bswap32(d) << (32 - bl);      // two BE16 words in stream order (qtmd.c:30-35)
+    const u32 d = rdl(w.cur, w.wi & 63u);
+    w.wi++;
+    if ((w.wi & 63u) == 0u) { w.cur = w.nxt; w.nxt = __builtin_bswap32(w.load_chunk((w.wi >> 6) + 1u, lane)); }
+    bb |= (u64) d << (32 - bl);
     bl += 32;
   }
   __device__ __forceinline__ void need(int n) { if (bl < n) refill(); }
@@ -57,6 +79,23 @@ struct QtmDec {
     while (rbl < n) { if (!ref_fill()) return false; }
     v = (u32)(bb >> (64 - n));
     bb <<= n; bl -= n; rbl -= n;
+    return true;
+  }
+  // the same far from the end of the input (`FAST`: the caller has checked that >= 96 bytes lie ahead, a READ_BYTES cannot
+  // fail): the reference's bits_left is still tracked -- two adds -- so that the exact reader can take over at any token
+  template <bool FAST> __device__ __forceinline__ bool fill_t() { if (FAST) { rbl += 16; return true; } return ref_fill(); }
+  template <bool FAST> __device__ __forceinline__ bool read_many_t(int n, u32 &v) {
+    if (!FAST) return read_many(n, v);
+    u32 val = 0;
+    while (n > 0) {
+      if (rbl <= 16) rbl += 16;
+      int run = rbl < n ? rbl : n;
+      need(run);
+      val = (val << run) | (u32)(bb >> (64 - run));
+      bb <<= run; bl -= run; rbl -= run;
+      n -= run;
+    }
+    v = val;
     return true;
   }
   __device__ __forceinline__ bool read_many(int n, u32 &v) {      // READ_MANY_BITS (readbits.h:143-153)
@@ -85,7 +124,10 @@ __device__ __forceinline__ u32 qtm_shfl_up(u32 v, u32 delta, u32 lane, u32 fill)
   return (lane >= delta) ? r : fill;
 }
 
-__device__ void qtm_update_model(u32 &m, u32 entries, int &shiftsleft, u32 lane)
+// (a real call -- it runs once per ~50..400 symbols of a model -- and BY VALUE: with reference parameters the models'
+// registers had their address taken and lived in scratch memory, a load and a store per symbol)
+struct QtmUpd { u32 m; int shiftsleft; };
+__device__ __attribute__((noinline)) QtmUpd qtm_update_model(u32 m, const u32 entries, int shiftsleft, const u32 lane)
 {
   u32 sym = m >> 16, cf = m & 0xFFFFu;
   const bool act = lane < entries;
@@ -131,50 +173,66 @@ __device__ void qtm_update_model(u32 &m, u32 entries, int &shiftsleft, u32 lane)
     sym = pair >> 16; cf = c & 0xFFFFu;
   }
   if (act) m = (sym << 16) | cf;
+  QtmUpd r; r.m = m; r.shiftsleft = shiftsleft;
+  return r;
 }
 
 // GET_SYMBOL (qtmd.c:92-123).  Returns the symbol, or -1 on ERR_READ.
-__device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, int &shiftsleft)
+// Round 4: (1) every lane divides ITS OWN entry's cumfreq * range by the total while the search for the symbol runs --
+// H and L are then two readlanes of finished quotients (the division used to start only when the symbol was known: two
+// readlanes, a multiply and the reciprocal chain behind the search); (2) FAST = far from the end of the input no read can
+// fail: no bounds arithmetic, no failure paths (the reference's bits_left is still tracked, see QtmDec::fill_t).
+// `shifts`: the nine models' shiftsleft counters (qtm.h:52), one per LANE of a vector register -- they are touched once
+// per ~50..400 symbols, and nine more scalar registers were what made the coder's hot state spill.
+template <bool FAST>
+__device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, u32 &shifts, const u32 model_ix)
 {
   const u32 lane = d.lane;
   QTM_MARK("qtm_sym_begin");
+  QT0();
   u32 H = d.H, L = d.L, C = d.C;
   const u32 cf = m & 0xFFFFu;
   const u32 tot = rdl(cf, 0);
-  u32 range = ((H - L) & 0xFFFFu) + 1u;
-  u32 X = (u32)((int)(C - L + 1u) * (int) tot - 1);      // int arithmetic, then unsigned (qtmd.c:94)
-  bool hit;
-  if (range < 65536u && X >= (range << 16)) {            // quotient would not fit 16 bits: do as C does
-    u32 symf = (X / range) & 0xFFFFu;
-    hit = cf <= symf;
-  }
-  else hit = cf * range <= X;                            // cf <= floor(X / range), division-free
-  u64 hm = ballot(hit && lane >= 1u && lane < entries);
-  u32 i = hm ? ((u32) __ffsll((long long) hm) - 1u) : entries;
-  u32 e_im1 = rdl(m, i - 1u);
-  u32 cf_i = (i < entries) ? (rdl(m, i & 63u) & 0xFFFFu) : 0u;
-  int sym = (int)(e_im1 >> 16);
-  u32 range2 = (u32)((int) H - (int) L + 1);
-  // H = L + (cf[i-1]*range)/tot - 1 ; L = L + (cf[i]*range)/tot : both quotients from ONE division
-  u32 num = (lane == 0u) ? (e_im1 & 0xFFFFu) * range2 : cf_i * range2;
-  // exact 32-bit / 16-bit division through one single-precision reciprocal (a generic integer division is ~25
-  // dependent instructions; round 2 used a double-precision reciprocal + a Newton step: four slow instructions on the
-  // chain).  num < 2^32 and the quotient is at most 65536: float(num) is off by 2^-24, v_rcp_f32 by one ulp, the product
-  // by 2^-24 -- relative 2^-22, i.e. less than 0.02 on the quotient: the truncated estimate is off by at most one.
+  const u32 range = ((H - L) & 0xFFFFu) + 1u;
+  const u32 range2 = (u32)((int) H - (int) L + 1);
+  // ---- per entry: floor(cumfreq * range / total), exact through one single-precision reciprocal (num < 2^32, quotient
+  // <= 65536: float(num) is off by 2^-24, v_rcp_f32 by one ulp, the product by 2^-24 -- the truncated estimate is off by
+  // at most one) ----
   u32 quo;
   {
+    const u32 num = cf * range2;
     const float rc = __builtin_amdgcn_rcpf((float) tot);
     quo = (u32)((float) num * rc);
-    u32 rem = num - quo * tot;
+    const u32 rem = num - quo * tot;
     if ((int) rem < 0) quo--;
     else if (rem >= tot) quo++;
   }
-  H = (L + rdl(quo, 0) - 1u) & 0xFFFFu;
-  L = (L + rdl(quo, 1)) & 0xFFFFu;
+  // ---- the symbol: first entry i >= 1 with cumfreq[i] <= floor(X / range) ----
+  const u32 X = (u32)((int)(C - L + 1u) * (int) tot - 1);      // int arithmetic, then unsigned (qtmd.c:94)
+  bool hit;
+  if (range < 65536u && X >= (range << 16)) {                  // quotient would not fit 16 bits: do as C does
+    const u32 symf = (X / range) & 0xFFFFu;
+    hit = cf <= symf;
+  }
+  else hit = cf * range <= X;                                  // cf <= floor(X / range), division-free
+  // (entries 1 .. entries - 1 as a mask of the ballot: a constant for most models -- as a lane predicate it was a
+  // loop-invariant exec mask per model that spilled and came back through two v_readlane per symbol)
+  const u64 hm = ballot(hit) & (((entries < 64u ? (1ull << entries) : 0ull) - 1ull) & ~1ull);
+  const u32 i = hm ? ((u32) __ffsll((long long) hm) - 1u) : entries;
+  const int sym = (int)(rdl(m, i - 1u) >> 16);
+  // H = L + (cf[i-1]*range)/tot - 1 ; L = L + (cf[i]*range)/tot
+  const u32 q_hi = rdl(quo, i - 1u), q_lo = (i < entries) ? rdl(quo, i & 63u) : 0u;
+  H = (L + q_hi - 1u) & 0xFFFFu;
+  L = (L + q_lo) & 0xFFFFu;
   // cumfreq[0..i-1] += 8; rescale when the total passes 3800
   if (lane < i) m += 8u;
   QTM_MARK("qtm_sym_interval_done");
-  if (tot + 8u > 3800u) qtm_update_model(m, entries, shiftsleft, lane);
+  QT(0);
+  if (tot + 8u > 3800u) {
+    const QtmUpd up = qtm_update_model(m, entries, (int) rdl(shifts, model_ix), lane);
+    m = up.m; shifts = wrl(shifts, (u32) up.shiftsleft, model_ix);
+  }
+  QT(1);
   QTM_MARK("qtm_sym_renorm_begin");
   // Renormalisation (qtmd.c:107-122) in closed form.  The reference's bit-at-a-time loop is always
   // n shifts while the top bits of L and H agree, then m "underflow" steps while L = 01.., H = 10..
@@ -189,15 +247,18 @@ __device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, in
     const u32 k = n + mu;
     if (k) {
       // k one-bit reads: the reference refills 16 bits whenever bits_left is 0 at a read
-      u32 have = (u32) d.rbl;
-      while (have < k) {
-        if (!d.ref_fill()) {                                            // ERR_READ at the bit that needed it
-          u32 used = (u32) d.rbl;                                       // bits consumed before the failing read
-          d.need((int) used); if (used) { d.bb <<= used; d.bl -= (int) used; }
-          d.rbl = 0; d.H = H; d.L = L; d.C = C;
-          return -1;
+      if (FAST) { if ((u32) d.rbl < k) { d.rbl += 16; if ((u32) d.rbl < k) d.rbl += 16; } }
+      else {
+        u32 have = (u32) d.rbl;
+        while (have < k) {
+          if (!d.ref_fill()) {                                          // ERR_READ at the bit that needed it
+            u32 used = (u32) d.rbl;                                     // bits consumed before the failing read
+            d.need((int) used); if (used) { d.bb <<= used; d.bl -= (int) used; }
+            d.rbl = 0; d.H = H; d.L = L; d.C = C;
+            return -1;
+          }
+          have = (u32) d.rbl;
         }
-        have = (u32) d.rbl;
       }
       d.need((int) k);
       const u32 nb = (u32)(d.bb >> (64u - k));
@@ -214,6 +275,10 @@ __device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, in
   }
   d.H = H; d.L = L; d.C = C;
   QTM_MARK("qtm_sym_end");
+  QT(2);
+#ifdef QTM_TIMERS
+  d.tm[4]++;
+#endif
   return sym;
 }
 
@@ -268,6 +333,51 @@ __device__ __forceinline__ void qtm_copy(u8 *out, u32 P, u32 off, u32 len, u32 o
   }
 }
 
+// the nine models (qtm.h:49-77) and their shift counters
+struct QtmModels {
+  u32 m0, m1, m2, m3, m4, m5, m6, m6l, m7;
+  u32 shifts;                      /* lane k: shiftsleft of model k (0-3 literals, 4, 5, 6, 7 = 6len, 8 = selector) */
+  u32 n4, n5, n6;
+};
+enum { QTM_T_LIT = 0, QTM_T_MATCH = 1, QTM_T_READ = -1, QTM_T_DECRUNCH = -2 };
+// one token (qtmd.c:292-350): the selector, then a literal from one of four models or a match's length / offset.
+// Every model has its own inlined copy of GET_SYMBOL (round 3 moved the literal models through a temporary: a chain of
+// selects in front of and behind every literal); FAST as in qtm_get_symbol.
+template <bool FAST>
+__device__ __forceinline__ int qtm_token(QtmDec &d, QtmModels &M, u32 &val, u32 &mlen)
+{
+  const int sel = qtm_get_symbol<FAST>(d, M.m7, 7, M.shifts, 8u);
+  int sym;
+  u32 base, extra, v;
+  switch (sel) {
+  case 0: sym = qtm_get_symbol<FAST>(d, M.m0, 64, M.shifts, 0u); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
+  case 1: sym = qtm_get_symbol<FAST>(d, M.m1, 64, M.shifts, 1u); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
+  case 2: sym = qtm_get_symbol<FAST>(d, M.m2, 64, M.shifts, 2u); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
+  case 3: sym = qtm_get_symbol<FAST>(d, M.m3, 64, M.shifts, 3u); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
+  case 4:
+    sym = qtm_get_symbol<FAST>(d, M.m4, M.n4, M.shifts, 4u); if (sym < 0) return QTM_T_READ;
+    qtm_pos_slot((u32) sym, base, extra);
+    if (!d.template read_many_t<FAST>((int) extra, v)) return QTM_T_READ;
+    val = base + v + 1u; mlen = 3u; return QTM_T_MATCH;
+  case 5:
+    sym = qtm_get_symbol<FAST>(d, M.m5, M.n5, M.shifts, 5u); if (sym < 0) return QTM_T_READ;
+    qtm_pos_slot((u32) sym, base, extra);
+    if (!d.template read_many_t<FAST>((int) extra, v)) return QTM_T_READ;
+    val = base + v + 1u; mlen = 4u; return QTM_T_MATCH;
+  case 6:
+    sym = qtm_get_symbol<FAST>(d, M.m6l, 27, M.shifts, 7u); if (sym < 0) return QTM_T_READ;
+    qtm_len_slot((u32) sym, base, extra);
+    if (!d.template read_many_t<FAST>((int) extra, v)) return QTM_T_READ;
+    mlen = base + v + 5u;
+    sym = qtm_get_symbol<FAST>(d, M.m6, M.n6, M.shifts, 6u); if (sym < 0) return QTM_T_READ;
+    qtm_pos_slot((u32) sym, base, extra);
+    if (!d.template read_many_t<FAST>((int) extra, v)) return QTM_T_READ;
+    val = base + v + 1u; return QTM_T_MATCH;
+  default:
+    return sel < 0 ? QTM_T_READ : QTM_T_DECRUNCH;
+  }
+}
+
 __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
                                 mspack_hip_result *res, QtmShared *sh)
 {
@@ -281,16 +391,21 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   d.lane = lane;
   d.w.unit = in_arena + u.in_off; d.w.in_len = u.in_len;
   d.w.eofs = (u.flags & MSPACK_HIP_UF_HARD_EOF) ? 0u : 2u;
-  d.w.seek(0, lane);
+  d.seek_swapped(0);
   d.bb = 0; d.bl = 0; d.rbl = 0; d.H = 0; d.L = 0; d.C = 0;
+#ifdef QTM_TIMERS
+  for (int k_ = 0; k_ < 8; k_++) d.tm[k_] = 0;
+  const unsigned long long qt_unit_ = __builtin_amdgcn_s_memtime();
+#endif
   u8 *out = out_arena + u.out_off;
   const u32 wsize = 1u << wb, out_len = u.out_len;
 
-  const u32 n4 = (2u * wb > 24u) ? 24u : 2u * wb, n5 = (2u * wb > 36u) ? 36u : 2u * wb, n6 = 2u * wb;
-  u32 m0 = qtm_model_init(lane, 0, 64), m1 = qtm_model_init(lane, 64, 64), m2 = qtm_model_init(lane, 128, 64),
-      m3 = qtm_model_init(lane, 192, 64), m4 = qtm_model_init(lane, 0, n4), m5 = qtm_model_init(lane, 0, n5),
-      m6 = qtm_model_init(lane, 0, n6), m6l = qtm_model_init(lane, 0, 27), m7 = qtm_model_init(lane, 0, 7);
-  int s0 = 4, s1 = 4, s2 = 4, s3 = 4, s4 = 4, s5 = 4, s6 = 4, s6l = 4, s7 = 4;
+  QtmModels M;
+  M.n4 = (2u * wb > 24u) ? 24u : 2u * wb; M.n5 = (2u * wb > 36u) ? 36u : 2u * wb; M.n6 = 2u * wb;
+  M.m0 = qtm_model_init(lane, 0, 64); M.m1 = qtm_model_init(lane, 64, 64); M.m2 = qtm_model_init(lane, 128, 64);
+  M.m3 = qtm_model_init(lane, 192, 64); M.m4 = qtm_model_init(lane, 0, M.n4); M.m5 = qtm_model_init(lane, 0, M.n5);
+  M.m6 = qtm_model_init(lane, 0, M.n6); M.m6l = qtm_model_init(lane, 0, 27); M.m7 = qtm_model_init(lane, 0, 7);
+  M.shifts = 4u;
 
   // the reference's loop variables (qtmd.c:257-479): window_posn, frame_todo, o_ptr/o_end as window
   // indices, out_bytes still wanted.  P is the linear position of window_posn.
@@ -338,47 +453,17 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
 
     while (wpos < frame_end) {
       good = P;
-      int sel = qtm_get_symbol(d, m7, 7, s7);
-      if (sel < 0) { err = ERR_READ; stop = true; break; }
-      if (sel < 4) {
-        // ONE copy of the symbol decoder for the four literal models: the model moves through a
-        // temporary (a few selects) instead of four inlined copies of GET_SYMBOL
-        u32 mm = sel == 0 ? m0 : (sel == 1 ? m1 : (sel == 2 ? m2 : m3));
-        int ss = sel == 0 ? s0 : (sel == 1 ? s1 : (sel == 2 ? s2 : s3));
-        int sym = qtm_get_symbol(d, mm, 64, ss);
-        if (sel == 0) { m0 = mm; s0 = ss; } else if (sel == 1) { m1 = mm; s1 = ss; }
-        else if (sel == 2) { m2 = mm; s2 = ss; } else { m3 = mm; s3 = ss; }
-        if (sym < 0) { err = ERR_READ; stop = true; break; }
-        lit_buf = wrl(lit_buf, (u32) sym, lit_n); lit_pos = wrl(lit_pos, P, lit_n);
+      u32 moff = 0, mlen = 0;
+      // (far from the end of the input -- a token reads fewer than 96 bytes -- no read can fail: the lean decoder)
+      const bool fast = d.w.origin + d.w.wi * 4u + 96u <= d.w.in_len;
+      const int tk = fast ? qtm_token<true>(d, M, moff, mlen) : qtm_token<false>(d, M, moff, mlen);
+      if (tk < 0) { err = tk == QTM_T_READ ? ERR_READ : ERR_DECRUNCH; stop = true; break; }
+      if (tk == QTM_T_LIT) {
+        lit_buf = wrl(lit_buf, moff, lit_n); lit_pos = wrl(lit_pos, P, lit_n);
         if (++lit_n == WAVE) QTM_FLUSH();
         P++; wpos++; frame_todo--;
         continue;
       }
-      u32 moff, mlen, base, extra;
-      int sym;
-      if (sel == 4 || sel == 5) {
-        u32 mm = sel == 4 ? m4 : m5;
-        int ss = sel == 4 ? s4 : s5;
-        sym = qtm_get_symbol(d, mm, sel == 4 ? n4 : n5, ss);
-        if (sel == 4) { m4 = mm; s4 = ss; } else { m5 = mm; s5 = ss; }
-        if (sym < 0) { err = ERR_READ; stop = true; break; }
-        qtm_pos_slot((u32) sym, base, extra);
-        if (!d.read_many((int) extra, v)) { err = ERR_READ; stop = true; break; }
-        moff = base + v + 1u; mlen = sel == 4 ? 3u : 4u;
-      }
-      else if (sel == 6) {
-        sym = qtm_get_symbol(d, m6l, 27, s6l);
-        if (sym < 0) { err = ERR_READ; stop = true; break; }
-        qtm_len_slot((u32) sym, base, extra);
-        if (!d.read_many((int) extra, v)) { err = ERR_READ; stop = true; break; }
-        mlen = base + v + 5u;
-        sym = qtm_get_symbol(d, m6, n6, s6);
-        if (sym < 0) { err = ERR_READ; stop = true; break; }
-        qtm_pos_slot((u32) sym, base, extra);
-        if (!d.read_many((int) extra, v)) { err = ERR_READ; stop = true; break; }
-        moff = base + v + 1u;
-      }
-      else { err = ERR_DECRUNCH; stop = true; break; }
 
       frame_todo -= mlen;
       if (wpos + mlen > wsize) {                                      // qtmd.c:358-390
@@ -430,6 +515,12 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   }
 #undef QTM_COPY
 #undef QTM_FLUSH
+#ifdef QTM_TIMERS
+  if (blockIdx.x == 0 && lane == 0) {
+    for (int k_ = 0; k_ < 5; k_++) g_qtm_tm[k_] = d.tm[k_];
+    g_qtm_tm[5] = __builtin_amdgcn_s_memtime() - qt_unit_; g_qtm_tm[6] = P;
+  }
+#endif
   if (err == ERR_OK && need) { written += (u32) need; }
   if (err == ERR_OK) good = written;
   if (lane == 0) {

@@ -605,6 +605,11 @@ int mspack_hip_debug_counters(unsigned long long *out8) {
   return hipMemcpyToSymbol(HIP_SYMBOL(spq_tm), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef QTM_TIMERS
+int mspack_hip_debug_qtm_timers(unsigned long long *out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_qtm_tm), 64) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef LZX_PIPE_TRACE
 int mspack_hip_debug_pipe_trace(unsigned long long *out, size_t n_words) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pipe_trace), n_words * 8) == hipSuccess ? 0 : -1;
