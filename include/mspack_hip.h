@@ -133,7 +133,11 @@ const char *mspack_hip_last_error(void);
  *   d_results  : n_units results
  *   d_frame_scratch : >= mspack_hip_frame_scratch_bytes(total LZX frames incl. 1 spare per unit) bytes of LZX
  *                work space: per frame the E8 decision, and -- for units with a frame table -- the parse
- *                waves' records and token lists (about 129 KiB per frame slot).  Contents need no
+ *                waves' records and a POOL of match records shared by the launch's frames: about 49.4 KiB per frame
+ *                slot (1.4 KiB of record + 48 KiB of pool: 1.5x the decoded bytes; round 3 reserved the worst case
+ *                of 16384 matches for every slot, 129 KiB).  A frame takes pool chunks of 1024 records as its parse
+ *                needs them; when the pool runs dry (more than 6144 matches per frame on average over the launch)
+ *                the frames that find it empty are decoded by the serial path -- slower, same result.  Contents need no
  *                initialisation; may be NULL if the batch has no LZX units (LZX then decodes serially only)
  *   kind_mask  : bit k set = units of kind k may be present; MSPACK_HIP_MASK_FRAME_TABLES set = LZX units may
  *                carry frame tables (MSPACK_HIP_UF_FRAME_TABLE): only then are the parse wavefronts launched.

@@ -1509,8 +1509,9 @@ struct __align__(16) LzxFrameRec {
    * output (cR0-cR2: R0-R2 behind its last match), 2 = the chain ended at or before this frame */
   u32 chain, cR0, cR1, cR2;
   u8 pad2[32];
+  u32 chunk[REC_CHUNKS];            /* where the frame's match records are: wave_common.hpp, RecPool */
 };
-static_assert(sizeof(LzxFrameRec) == 1344, "LzxFrameRec layout");
+static_assert(sizeof(LzxFrameRec) == 1408, "LzxFrameRec layout");
 // LzxFrameRec::status.  The separate header / parse launches only use 0, 2, 1.  In the dependency-driven launch
 // (mspack_lzx_pipe, shim.hip) the word is also the hand-off flag between the frame's parse task and the unit's wave:
 //   0 untouched | 5 a parse wave claimed the frame | 2 its code lengths are in the record, tokens still being parsed |
@@ -2044,7 +2045,7 @@ __device__ __forceinline__ EmitTok lzx_emit_token(const LzxShared *sh, const boo
 template <bool ALIGNED>
 __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empty, const u32 start_bit, const u32 frame_end_bit,
                                                u8 *const fout, const u32 frame_pos, const u32 frame_size, const u32 edge_n,
-                                               LzxFrameRec *rec, uint2 *mrec, u32 &n_rec, u32 &end_bit, u32 &bytes_done,
+                                               LzxFrameRec *rec, RecWriter &W, u32 &n_rec, u32 &end_bit, u32 &bytes_done,
                                                const bool two_level, const bool stream)
 {
   LzxShared *sh = d.sh;
@@ -2167,6 +2168,8 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     const u32 cvb = lane < mm ? nb : 0u, cvm = lane < mm ? nmr : 0u;
     const u32 inclb = wave_incl_scan(cvb), inclm = wave_incl_scan(cvm);
     PHE(7);
+    // room for this pass's match records (taken from the launch's pool, a chunk at a time): without it the frame ends here
+    if (!W.ensure(tt + (mm ? rdl(inclm, mm - 1u) : 0u), lane)) { stop = true; break; }
 #ifdef LZX_EMIT_LANES
     // ---- last walk: literals into the output, one record per match ----
     const u32 my_n = lane < mm ? n : 0u;
@@ -2185,7 +2188,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
         else { gst(&rec->edge_lit[pos], (u8) t.sym); atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
       }
       // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
-      if (mt) gst_stream(mrec + j, make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
+      if (mt) gst_stream(W.at(j), make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
                                                        (t.expl ? 0u : t.slot + 1u)));
       cross = cross || crs;
       const bool adv = lit || mt;
@@ -2260,7 +2263,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
           else { gst(&rec->edge_lit[pos], (u8) t.sym); atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
         }
         // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
-        if (mt) gst_stream(mrec + j, make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
+        if (mt) gst_stream(W.at(j), make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
                                                          (t.expl ? 0u : t.slot + 1u)));
         cross = cross || crs;
         const bool adv = lit || mt;
@@ -2478,7 +2481,7 @@ __device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 
 // Waiting is safe: the task it waits for has an earlier ticket (shim.hip), i.e. a live wave is working on it.
 // ---------------------------------------------------------------------------------------------------
 __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, u8 *out_arena, LzxFrameRec *urecs,
-                               uint2 *tok, LzxShared *sh, const bool stream)
+                               const RecPool &pool, LzxShared *sh, const bool stream)
 {
   const u32 lane = threadIdx.x;
   LzxFrameRec *rec = &urecs[f];
@@ -2500,9 +2503,12 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   else {
     const LzxFrameRec *pr = rec - 1;
     u32 ps;
-    for (;;) {
+    // (the previous frame's task has an earlier ticket: a live wave holds it.  The bound is a safety net -- giving up means
+    // this frame and the ones behind it go to the serial path, never a hang)
+    for (u32 tries = 0; ; tries++) {
       ps = lzx_status_load(&pr->status);
       if (ps != LZX_ST_NONE && ps != LZX_ST_CLAIMED) break;
+      if (tries >= (1u << 24)) { ps = LZX_ST_FAILED; break; }
       __builtin_amdgcn_s_sleep(8);
     }
     if (ps == LZX_ST_FAILED || ps == LZX_ST_TAKEN) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
@@ -2577,8 +2583,11 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     u8 *const fout = out_arena + u.out_off + (size_t) f * LZX_FRAME;
     // the frame's first bytes up to the next 128-byte line: another wave may be writing that line (see lzx_parse_emit)
     const u32 edge_n = (128u - (u32)((size_t) fout & 127u)) & 127u;
-    if (s.block_type == 2u) lzx_parse_emit<true>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done, two_level, stream);
-    else lzx_parse_emit<false>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, tok, n_rec, end_bit, bytes_done, two_level, stream);
+    // (the frame's chunk list in LDS: the room of the pretree's table -- only a block header uses that, and this frame's is read)
+    RecWriter W;
+    W.begin(pool, (u32 *) sh->pre_tab, rec->chunk);
+    if (s.block_type == 2u) lzx_parse_emit<true>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream);
+    else lzx_parse_emit<false>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream);
   }
   if (lane == 0) {
     rec->n_tokens = n_rec; rec->end_bit = end_bit; rec->bytes_done = bytes_done;
@@ -2707,31 +2716,98 @@ __device__ __forceinline__ int lzx_run_tokens(LzxDec &d, LzxState &s, const u32 
 #define LZX_CH_OPEN 0u
 #define LZX_CH_DONE 1u
 #define LZX_CH_ENDED 2u
-__device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_arena, LzxFrameRec *urecs, const uint2 *mrec, SpecQueueLds *spq,
+
+// one batch of match records: every match's offset through the R0-R2 LRU (lzxd.c:565-586; cf. lzx_commit_batch) and the
+// reference's checks (lzxd.c:613-634) -- offsets no linear copy serves (0, beyond the window) end the fast path too.
+// Returns false when a check fails.
+__device__ __forceinline__ bool lzx_front_batch(const bool ism, const u32 lane, const u32 opos, const u32 olen, const u32 which, const u32 c1,
+                                                u32 &R0, u32 &R1, u32 &R2, const u32 frame_pos, const u32 wbase, const u32 wsize, u32 &vmoff_out)
+{
+  const u32 sR0 = R0, sR1 = R1, sR2 = R2;
+  u32 vmoff = c1;
+  const u64 k1 = ballot(ism && which == 0u);
+  if (!ballot(ism && which >= 2u)) {
+    const u64 below = k1 & ((1ull << lane) - 1ull);
+    const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
+    const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
+    if (which == 1u) vmoff = below ? pv : sR0;
+    if (k1) {
+      u64 m = k1;
+      const u32 j0 = 63u - (u32) __clzll((long long) m);
+      u32 nbv = sR0, ncv = sR1;
+      m &= ~(1ull << j0);
+      if (m) {
+        const u32 j1 = 63u - (u32) __clzll((long long) m);
+        nbv = rdl(c1, j1); ncv = sR0;
+        m &= ~(1ull << j1);
+        if (m) ncv = rdl(c1, 63u - (u32) __clzll((long long) m));
+      }
+      R0 = rdl(c1, j0); R1 = nbv; R2 = ncv;
+    }
+  }
+  else {
+    u32 x = LRU_ID;
+    if (ism) x = which == 0u ? (0x010080u | lane) : (which == 2u ? 0x020001u : (which == 3u ? 0x000102u : LRU_ID));
+    const u32 Cm = lru_scan(x);
+    const u32 e0 = Cm & 0xFFu;
+    const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
+    vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
+    const u32 Cl = rdl(Cm, 63u);
+    const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
+    R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
+    R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
+    R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
+  }
+  vmoff_out = vmoff;
+  const u32 wp = opos - wbase;
+  const bool b = ism && (wp + olen > wsize || LZX_BAD_SOURCE(vmoff, wp, frame_pos, 0u, wsize) ||
+                         vmoff == 0u || vmoff > wsize || vmoff > opos);
+  return !ballot(b);
+}
+
+// wait until the chain word of the frame below is one of the states a caller can act on
+__device__ __forceinline__ u32 lzx_chain_wait(const u32 *p, const bool)
+{
+  u32 ch = lzx_status_load(p);
+  LZX_PIPE_WAIT_BEGIN();
+  for (u32 tries = 0; ch == LZX_CH_OPEN && tries < (1u << 24); tries++) {
+    __builtin_amdgcn_s_sleep(4);
+    ch = lzx_status_load(p);
+  }
+  LZX_PIPE_WAIT_END();
+  return ch;
+}
+
+#ifndef LZX_RESOLVE_TILE
+#define LZX_RESOLVE_TILE 0          /* 1: every resolve task copies through the LDS tile (tile_resolve.hpp); 2: only the tasks of
+                                       units that are one chain of frames (`merged`); 0: spec_queue.hpp everywhere */
+#endif
+union LzxResolveLds { SpecQueueLds q; TileLds t; };
+__device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_arena, LzxFrameRec *urecs, const uint2 *pool_base, LzxResolveLds *rl,
                                  const bool merged)
 {
+  // record j of this frame (wave_common.hpp: RecPool); a batch of 64 that starts at a multiple of 64 lies in one chunk
+#define MREC(j_) rec_at(pool_base, rec->chunk, (j_))
+  SpecQueueLds *const spq = &rl->q;
   const u32 lane = threadIdx.x;
   u8 *const out = out_arena + u.out_off;
   const u32 rf = u.reset_frames;
   const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
   const u32 wsize = 1u << u.window_bits;
   LzxFrameRec *rec = &urecs[f];
+  LzxFrameRec *pr = rec - 1;
   const bool first = rf ? (f % rf) == 0u : f == 0u;
   PHDECL();
-  // ---- the frames below: complete? ----
+  // ---- the frame below: complete?  (Tried in round 4: R0-R2 published as soon as a first pass over the records has
+  // resolved them, so that only the copies wait for the frame below -- no gain: a 512-frame folder's chain stayed at 242 us
+  // per frame, which is the copies; the first pass is 10 % of a frame's resolve.) ----
   u32 R0 = 1, R1 = 1, R2 = 1, prev_end = 0;
+  u32 pch = LZX_CH_DONE;
   if (f != 0u) {
-    LzxFrameRec *pr = rec - 1;
-    u32 ch = lzx_status_load(&pr->chain);
-    LZX_PIPE_WAIT_BEGIN();
-    for (u32 tries = 0; ch == LZX_CH_OPEN && tries < (1u << 24); tries++) {
-      __builtin_amdgcn_s_sleep(8);
-      ch = lzx_status_load(&pr->chain);
-    }
-    LZX_PIPE_WAIT_END();
+    pch = lzx_chain_wait(&pr->chain, false);
     // (the chain ended below: whoever ended it has said where the serial path resumes.  Still open after the bound: nobody
     // says anything -- no rs_valid, the unit kernel decodes the unit from its first byte)
-    if (ch != LZX_CH_DONE) { lzx_status_publish(&rec->chain, LZX_CH_ENDED, lane); return; }
+    if (pch != LZX_CH_DONE) { lzx_status_publish(&rec->chain, LZX_CH_ENDED, lane); return; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     prev_end = (rfl(pr->end_bit) + 15u) & ~15u;
     if (!first) { R0 = rfl(pr->cR0); R1 = rfl(pr->cR1); R2 = rfl(pr->cR2); }       // (a reset frame: lzxd.c:257-270)
@@ -2751,35 +2827,90 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
   PH0();
   u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
   const u32 frame_pos = f * LZX_FRAME;
+  const u32 wbase = frame_pos & ~(wsize - 1u);                 // linear position of window index 0 in this pass
   const u32 eR0 = R0, eR1 = R1, eR2 = R2;
   u32 n_rec = 0, bytes = 0, end_bit = 0;
   bool bad = st != LZX_ST_EMITTED;
   if (!bad) {
     n_rec = rfl(rec->n_tokens); bytes = rfl(rec->bytes_done); end_bit = rfl(rec->end_bit);
-    bad = rfl(rec->frame_start_bit) != prev_end || rfl(rec->block_length) != fsz || bytes > fsz || n_rec > LZX_TOK_CAP;
+    bad = rfl(rec->frame_start_bit) != prev_end || rfl(rec->block_length) != fsz || bytes > fsz || n_rec > REC_CHUNK * REC_CHUNKS;
   }
-  if (!bad) {
+  const bool use_tile = LZX_RESOLVE_TILE == 1 || (LZX_RESOLVE_TILE == 2 && merged);
+  if (!bad && use_tile) {
+    // ---- the copies through the LDS tile (tile_resolve.hpp): a batch of 64 matches per pass, chains collapsed ----
+    TileLds *const tl = &rl->t;
+    const u32 ne = rfl(rec->n_edge);
+    for (u32 i = lane; i < ne; i += WAVE)
+      if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
+    tr_clear_map(*tl, lane);
+    TileState T;
+    T.T0 = 0; T.hi = 0; T.live = false;
+    u32 th = 0;
+    uint2 cur = make_uint2(0u, 0u), nxt = cur;
+    if (th + lane < n_rec) cur = tr_gld(MREC(th + lane));
+    if (th + 64u + lane < n_rec) nxt = tr_gld(MREC(th + 64u + lane));
+    while (th < n_rec && !bad) {
+      u32 n = n_rec - th; if (n > 64u) n = 64u;
+      const u32 opos = cur.x, olen = (cur.y >> 2) & 511u, which = cur.y & 3u, c1 = cur.y >> 11;
+      // the tile: every record of the batch has to start inside it
+      {
+        const u32 p_first = rdl(opos, 0u), p_last = rdl(opos, n - 1u);
+        if (p_first < frame_pos || p_last < p_first || p_last >= frame_pos + bytes) { bad = true; break; }    // (a record list no parse wave wrote)
+        if (T.live && p_last - T.T0 >= TR_TILE && p_first - T.T0 >= 16u) { tr_flush(*tl, out, T.T0, T.hi, lane); T.live = false; }
+        if (!T.live) { T.T0 = p_first & ~15u; T.hi = T.T0; tr_fill(*tl, out, T.T0, frame_pos + fsz, lane); T.live = true; }
+        if (p_last - T.T0 >= TR_TILE) n = (u32) __popcll(ballot(lane < n && opos - T.T0 < TR_TILE));            // (>= 1: the first one does)
+      }
+      PH(10);
+      const bool ism = lane < n;
+      u32 vmoff;
+      if (!lzx_front_batch(ism, lane, opos, olen, which, c1, R0, R1, R2, frame_pos, wbase, wsize, vmoff)) { bad = true; break; }
+      {
+        // what the tile takes for granted: records in position order, inside the bytes the parse wave stored
+        const u32 nextp = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane + 1u) & 63u) << 2), (int) opos);
+        if (ballot(ism && (olen < 2u || olen > 257u || opos + olen > frame_pos + bytes || (lane + 1u < n && opos + olen > nextp) || opos < T.hi))) { bad = true; break; }
+      }
+      PH(9);
+      if (tr_batch(*tl, out, T.T0, frame_pos, true, true, ism, false, opos, olen, vmoff, lane)) { bad = true; break; }   // (nothing is deferred here)
+      T.hi = rdl(opos + olen, n - 1u);
+      PH(11);
+      th += n;
+      if (n == 64u) { cur = nxt; nxt = make_uint2(0u, 0u); if (th + 64u + lane < n_rec) nxt = tr_gld(MREC(th + 64u + lane)); }
+      else {                                                     // (a batch cut at the tile's end)
+        cur = make_uint2(0u, 0u); nxt = cur;
+        if (th + lane < n_rec) cur = tr_gld(MREC(th + lane));
+        if (th + 64u + lane < n_rec) nxt = tr_gld(MREC(th + 64u + lane));
+      }
+    }
+    if (T.live && !bad) tr_flush(*tl, out, T.T0, T.hi, lane);
+    PH(10);
+  }
+  else if (!bad) {
     // ---- the literals of the frame's first cache line ----
     const u32 ne = rfl(rec->n_edge);
     for (u32 i = lane; i < ne; i += WAVE)
       if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
     // ---- the match records ----
-    const u32 wbase = frame_pos & ~(wsize - 1u);                 // linear position of window index 0 in this pass
     SpecQueue Q;
     spq_init(*spq, Q, frame_pos, lane);
     u32 th = 0;
     uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
-    if (th + lane < n_rec) cur0 = gld(mrec + th + lane);
-    if (th + 64u + lane < n_rec) cur1 = gld(mrec + th + 64u + lane);
-    if (th + 128u + lane < n_rec) cur2 = gld(mrec + th + 128u + lane);
-    if (th + 192u + lane < n_rec) cur3 = gld(mrec + th + 192u + lane);
+    {
+      const uint2 *g0 = rec_group(pool_base, rec->chunk, 0u);     // (groups of four batches: one chunk lookup per 256 records)
+      if (th + lane < n_rec) cur0 = gld(g0 + lane);
+      if (th + 64u + lane < n_rec) cur1 = gld(g0 + 64u + lane);
+      if (th + 128u + lane < n_rec) cur2 = gld(g0 + 128u + lane);
+      if (th + 192u + lane < n_rec) cur3 = gld(g0 + 192u + lane);
+    }
     for (; th < n_rec && !bad; ) {
       uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
       const u32 tb = th + 256u + lane;
-      if (tb < n_rec) nx0 = gld(mrec + tb);
-      if (tb + 64u < n_rec) nx1 = gld(mrec + tb + 64u);
-      if (tb + 128u < n_rec) nx2 = gld(mrec + tb + 128u);
-      if (tb + 192u < n_rec) nx3 = gld(mrec + tb + 192u);
+      if (th + 256u < n_rec) {
+        const uint2 *g1 = rec_group(pool_base, rec->chunk, th + 256u);
+        if (tb < n_rec) nx0 = gld(g1 + lane);
+        if (tb + 64u < n_rec) nx1 = gld(g1 + 64u + lane);
+        if (tb + 128u < n_rec) nx2 = gld(g1 + 128u + lane);
+        if (tb + 192u < n_rec) nx3 = gld(g1 + 192u + lane);
+      }
 #pragma unroll 1
       for (u32 k = 0; k < 4u && th < n_rec && !bad; k++) {
         u32 n = n_rec - th; if (n > 64u) n = 64u;
@@ -2787,49 +2918,9 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
         const bool ism = lane < n;
         const u32 opos = cur.x, olen = (cur.y >> 2) & 511u, which = cur.y & 3u, c1 = cur.y >> 11;
         const u64 mm = ballot(ism);
-        // (1) every match's offset through the R0-R2 LRU (cf. lzx_commit_batch)
-        const u32 sR0 = R0, sR1 = R1, sR2 = R2;
         u32 vmoff = c1;
-        const u64 k1 = ballot(ism && which == 0u);
-        if (!ballot(ism && which >= 2u)) {
-          const u64 below = k1 & ((1ull << lane) - 1ull);
-          const u32 src = below ? 63u - (u32) __clzll((long long) below) : 0u;
-          const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)(src << 2), (int) c1);
-          if (which == 1u) vmoff = below ? pv : sR0;
-          if (k1) {
-            u64 m = k1;
-            const u32 j0 = 63u - (u32) __clzll((long long) m);
-            u32 nbv = sR0, ncv = sR1;
-            m &= ~(1ull << j0);
-            if (m) {
-              const u32 j1 = 63u - (u32) __clzll((long long) m);
-              nbv = rdl(c1, j1); ncv = sR0;
-              m &= ~(1ull << j1);
-              if (m) ncv = rdl(c1, 63u - (u32) __clzll((long long) m));
-            }
-            R0 = rdl(c1, j0); R1 = nbv; R2 = ncv;
-          }
-        }
-        else {
-          u32 x = LRU_ID;
-          if (ism) x = which == 0u ? (0x010080u | lane) : (which == 2u ? 0x020001u : (which == 3u ? 0x000102u : LRU_ID));
-          const u32 Cm = lru_scan(x);
-          const u32 e0 = Cm & 0xFFu;
-          const u32 pv = (u32) __builtin_amdgcn_ds_bpermute((int)((e0 & 63u) << 2), (int) c1);
-          vmoff = (e0 & 0x80u) ? pv : (e0 == 0u ? sR0 : (e0 == 1u ? sR1 : sR2));
-          const u32 Cl = rdl(Cm, 63u);
-          const u32 f0 = Cl & 0xFFu, f1 = (Cl >> 8) & 0xFFu, f2 = (Cl >> 16) & 0xFFu;
-          R0 = (f0 & 0x80u) ? rdl(c1, f0 & 63u) : (f0 == 0u ? sR0 : (f0 == 1u ? sR1 : sR2));
-          R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
-          R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
-        }
-        // (2) the reference's checks (lzxd.c:613-634); offsets no linear copy serves (0, beyond the window) end the fast path too
-        {
-          const u32 wp = opos - wbase;
-          const bool b = ism && (wp + olen > wsize || LZX_BAD_SOURCE(vmoff, wp, frame_pos, 0u, wsize) ||
-                                 vmoff == 0u || vmoff > wsize || vmoff > opos);
-          if (ballot(b)) { bad = true; break; }
-        }
+        // (1) offsets through the R0-R2 LRU, (2) the reference's checks
+        if (!lzx_front_batch(ism, lane, opos, olen, which, c1, R0, R1, R2, frame_pos, wbase, wsize, vmoff)) { bad = true; break; }
         PH(9);
         // (3) queue the copies (cf. lzx_commit_batch)
         {
@@ -2877,6 +2968,7 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
   }
   lzx_status_publish(&rec->chain, whole ? LZX_CH_DONE : LZX_CH_ENDED, lane);
   PHFLUSH();
+#undef MREC
 }
 #endif  /* !LZX_PARSE_ONLY */
 #endif  /* !LZX_DELTA */

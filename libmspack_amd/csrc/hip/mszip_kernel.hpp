@@ -29,9 +29,9 @@
 #define ZIP_LANE_TAIL 384u         /* bits a lane walks in front of its stretch's end to find its exit */
 #define ZIP_LANE_ROUNDS 5u         /* walks before the consistent prefix is taken as it is */
 
-#define ZIP_TOK_CAP 16384u         /* tokens a parse wave stores per CFDATA block (same slot size as LZX_TOK_CAP) */
+#define ZIP_TOK_CAP (REC_CHUNK * REC_CHUNKS)   /* match records a CFDATA block can have at most in the launch's pool (a block has <= 10923) */
 
-// what a parse wave leaves for the unit's wave (same 1344-byte slots as LzxFrameRec; only the head is used)
+// what a parse wave leaves for the unit's wave (same slots as LzxFrameRec; only the head is used)
 struct ZipBlockRec {
   u32 status;                      /* 0 = not yet, 1 = the whole CFDATA block was parsed, 2 = the parse wave gave up */
   u32 n_tokens;
@@ -39,9 +39,10 @@ struct ZipBlockRec {
   u32 end_bit;                     /* first bit behind the last end-of-block symbol */
   u32 eob_rbl;                     /* the reference's bits_left there */
   u32 total_out;                   /* bytes the block produces (<= 32768) */
+  u32 chunk[REC_CHUNKS];           /* where the block's match records are (wave_common.hpp: RecPool) */
   u32 pad[330];
 };
-static_assert(sizeof(ZipBlockRec) == 1344, "ZipBlockRec slot size");
+static_assert(sizeof(ZipBlockRec) == 1408, "ZipBlockRec slot size");
 
 struct __align__(16) MszipShared {
   u16 lit_tab[1 << ZIP_LIT_P];
@@ -52,6 +53,7 @@ struct __align__(16) MszipShared {
   u16 bl_sorted[20];
   u32 cnt[20];
   u32 hist_B[ZIP_HIST], hist_len[ZIP_HIST];
+  u32 ctab[REC_CHUNKS];            /* parse waves: the block's chunk list (RecWriter) */
   u8  lit_len[288];
   u8  dist_len[32];
   u8  bl_len[20];
@@ -503,7 +505,7 @@ __device__ __forceinline__ int zip_run_spec(ZipDec &d)
     r_ = (u64)(u32) __builtin_amdgcn_alignbit(x1_, x0_, s_) | ((u64)(u32) __builtin_amdgcn_alignbit(x2_, x1_, s_) << 32); \
   }
 
-__device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, uint2 *tok, u32 &tt, u32 &outc)
+__device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, RecWriter &W, u32 &tt, u32 &outc)
 {
   MszipShared *sh = d.sh;
   const u32 lane = d.lane;
@@ -579,7 +581,7 @@ __device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, uint2 
     const u32 cvn = lane < mm ? n : 0u, cvb = lane < mm ? nb : 0u, cvm = lane < mm ? nmr : 0u;
     const u32 inclb = wave_incl_scan(cvb), inclm = wave_incl_scan(cvm);
     const u32 tot_m = rdl(inclm, 63u), tot_b = rdl(inclb, 63u);
-    if (tt + tot_m > ZIP_TOK_CAP || outc + tot_b > ZIP_FRAME) return -1;
+    if (outc + tot_b > ZIP_FRAME || !W.ensure(tt + tot_m, lane)) return -1;
     // ---- last walk: literals into the output, one record per match ----
     {
       u32 p = entry, i = 0, pos = outc + inclb - cvb, j = tt + inclm - cvm;
@@ -589,7 +591,7 @@ __device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, uint2 
         ZIP_STAGE_R(on ? p : 0u, r)
         const ZipTok t = zip_spec_token(sh, lit_fov, llim, r, dlim, dist_fov);
         if (on && t.kind == 0u) gst_stream(fout + pos, (u8) t.sym);
-        if (on && t.kind == 1u) gst_stream(tok + j, make_uint2(pos, (t.dist << 9) | t.olen));
+        if (on && t.kind == 1u) gst_stream(W.at(j), make_uint2(pos, (t.dist << 9) | t.olen));
         p += on ? t.tot : 0u; i += on ? 1u : 0u;
         pos += on ? t.olen : 0u; j += (on && t.kind == 1u) ? 1u : 0u;
       }
@@ -642,8 +644,10 @@ __device__ __forceinline__ void zip_status_publish(u32 *p, const u32 v, const u3
 
 // one parse wave: CFDATA block `b` of unit u; true = the record is complete
 __device__ __forceinline__ bool zip_parse_block_body(const mspack_hip_unit &u, const u32 b, const u8 *in_arena, u8 *out_arena, ZipBlockRec *rec,
-                                uint2 *tok, MszipShared *sh)
+                                const RecPool &pool, MszipShared *sh)
 {
+  RecWriter W;
+  W.begin(pool, sh->ctab, rec->chunk);
   u8 *const fout = out_arena + u.out_off + (size_t) b * ZIP_FRAME;      // (inside the unit's region: b < ceil(out_len / 32768), 32 KiB of slack)
   const u32 lane = threadIdx.x;
   ZipDec d;
@@ -671,7 +675,7 @@ __device__ __forceinline__ bool zip_parse_block_body(const mspack_hip_unit &u, c
     if (huff_build<ZIP_LIT_P>(sh->lit_len, 288, 9, sh->lit_tab, sh->lit_sorted, sh->cnt, d.hr_lit, lane, true)) return false;
     if (huff_build<ZIP_DIST_P>(sh->dist_len, 32, 6, sh->dist_tab, sh->dist_sorted, sh->cnt, d.hr_dist, lane, true)) return false;
     for (;;) {
-      const int rc = zip_parse_lanes(d, fout, tok, tt, outc);
+      const int rc = zip_parse_lanes(d, fout, W, tt, outc);
       if (rc < 0) return false;
       if (rc == 1) break;
       // a token the lane-parallel decoder does not take (a long distance code, ...): one scalar token (mszipd.c:228-303)
@@ -679,7 +683,7 @@ __device__ __forceinline__ bool zip_parse_block_body(const mspack_hip_unit &u, c
       const u32 st = d.cons_bits();
       int sym = d.decode_sym<ZIP_LIT_P>(sh->lit_tab, sh->lit_sorted, d.hr_lit, true);
       if (sym < 0) return false;
-      if (tt + 1u > ZIP_TOK_CAP || outc >= ZIP_FRAME) return false;
+      if (outc >= ZIP_FRAME || !W.ensure(tt + 1u, lane)) return false;
       if (sym < 256) { if (lane == 0) fout[outc] = (u8) sym; outc++; continue; }
       if (sym == 256) {                                      // bits_left behind it: ENSURE_BITS(16) at its first bit, minus its length
         d.rbl = (int)(16u + ((0u - st) & 7u) - (d.cons_bits() - st));
@@ -696,7 +700,7 @@ __device__ __forceinline__ bool zip_parse_block_body(const mspack_hip_unit &u, c
       zip_dist_code((u32) ds, dbase, dextra);
       if (!d.read_bits((int) dextra, ev)) return false;
       if (outc + length > ZIP_FRAME) return false;
-      if (lane == 0) tok[tt] = make_uint2(outc, ((dbase + ev) << 9) | length);
+      if (lane == 0) *W.at(tt) = make_uint2(outc, ((dbase + ev) << 9) | length);
       tt++; outc += length;
     }
   } while (!last_block);
@@ -707,9 +711,9 @@ __device__ __forceinline__ bool zip_parse_block_body(const mspack_hip_unit &u, c
   return true;
 }
 __device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 *in_arena, u8 *out_arena, ZipBlockRec *rec,
-                                uint2 *tok, MszipShared *sh)
+                                const RecPool &pool, MszipShared *sh)
 {
-  const bool ok = zip_parse_block_body(u, b, in_arena, out_arena, rec, tok, sh);
+  const bool ok = zip_parse_block_body(u, b, in_arena, out_arena, rec, pool, sh);
   zip_status_publish(&rec->status, ok ? 1u : 2u, threadIdx.x);
 }
 
@@ -717,7 +721,7 @@ __device__ void zip_parse_block(const mspack_hip_unit &u, const u32 b, const u8 
 // (position in the block, distance << 9 | length) in position order; they are queued and resolved in position space
 // (spec_queue.hpp).  false: a match needs bytes this path cannot serve (history that is not a full block right
 // below) or a record is not what a parse wave writes: the caller decodes the block the serial way.
-__device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *tok, const u32 n_tok_, const u32 total_)
+__device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *pool_base, const u32 *chunk, const u32 n_tok_, const u32 total_)
 {
   MszipShared *sh = d.sh;
   const u32 lane = d.lane;
@@ -733,19 +737,25 @@ __device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *tok, cons
   // four batches are queued, and the registers change hands once per four batches -- a load is only waited for
   // long after it was issued
   uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
-  if (lane < n_tok) cur0 = tok[lane];
-  if (64u + lane < n_tok) cur1 = tok[64u + lane];
-  if (128u + lane < n_tok) cur2 = tok[128u + lane];
-  if (192u + lane < n_tok) cur3 = tok[192u + lane];
+  if (n_tok) {
+    const uint2 *g0 = rec_group(pool_base, chunk, 0u);            // (groups of four batches: one chunk lookup per 256 records)
+    if (lane < n_tok) cur0 = gld(g0 + lane);
+    if (64u + lane < n_tok) cur1 = gld(g0 + 64u + lane);
+    if (128u + lane < n_tok) cur2 = gld(g0 + 128u + lane);
+    if (192u + lane < n_tok) cur3 = gld(g0 + 192u + lane);
+  }
   bool done = false;
   u32 th = 0;
   while (!done && th < n_tok) {
     uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
     const u32 tb = th + 256u + lane;
-    if (tb < n_tok) nx0 = tok[tb];
-    if (tb + 64u < n_tok) nx1 = tok[tb + 64u];
-    if (tb + 128u < n_tok) nx2 = tok[tb + 128u];
-    if (tb + 192u < n_tok) nx3 = tok[tb + 192u];
+    if (th + 256u < n_tok) {
+      const uint2 *g1 = rec_group(pool_base, chunk, th + 256u);
+      if (tb < n_tok) nx0 = gld(g1 + lane);
+      if (tb + 64u < n_tok) nx1 = gld(g1 + 64u + lane);
+      if (tb + 128u < n_tok) nx2 = gld(g1 + 128u + lane);
+      if (tb + 192u < n_tok) nx3 = gld(g1 + 192u + lane);
+    }
 #pragma unroll 1
     for (u32 k = 0; k < 4u; k++, th += 64u) {
       if (th >= n_tok) { done = true; break; }
@@ -955,7 +965,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
       else st_ = rfl(rc_->status);
       // (and only where the parse wave put the literals: every earlier block of the folder a full one)
       if (st_ == 1u && rfl(rc_->start_bit) == d.w.origin * 8u + d.cons_bits() && d.B == blk * ZIP_FRAME &&
-          zip_run_tokens(d, toks + (size_t)(u.frame_base + blk) * ZIP_TOK_CAP, rc_->n_tokens, rc_->total_out)) {
+          zip_run_tokens(d, toks, rc_->chunk, rc_->n_tokens, rc_->total_out)) {
         const u32 eb = rfl(rc_->end_bit), total = rfl(rc_->total_out);
         d.restart(eb >> 3);
         { const u32 sk = eb & 7u; if (sk) { d.need((int) sk); d.bb >>= sk; d.bl -= (int) sk; } }

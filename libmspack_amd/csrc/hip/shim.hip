@@ -51,27 +51,30 @@ __device__ __forceinline__ bool pick_unit(const mspack_hip_unit *units, const u3
   return units[ui].kind == kind;
 }
 
-// ---- LZX work scratch (d_frame_scratch of the C ABI), n = n_frames_total + 1 frame slots ----------------
+// ---- LZX / MSZIP work scratch (d_frame_scratch of the C ABI), n = n_frames_total + 1 frame slots ----------------
 //   int32  meta[n]        per frame: intel_filesize to apply in the E8 pass (0 = none)
 //   u32    frame_unit[n]  per frame slot: the unit it belongs to when a parse wave should take it, else ~0
-//   LzxFrameRec recs[n]   what the parse wave of that frame assumed and found (lzx_kernel.hpp)
-//   uint2  toks[n][LZX_TOK_CAP]  its tokens
 //   u32    hdr[256]       per launch (up to 32 concurrent ones) 8 words: [0] = most, [1] = fewest frames of a unit with a
-//                         frame table, [2] = ticket counter of mspack_lzx_pipe
-struct LzxScratch { int32_t *meta; u32 *frame_unit; u32 *hdr; lzxn::LzxFrameRec *recs; uint2 *toks; size_t bytes; };
-// n_rec_slots: frame slots that can hold a record + tokens -- all of them for a caller's own scratch (the size
+//                         frame table, [2] = ticket counter of mspack_lzx_pipe, [4] = chunks handed out of the launch's pool
+//   LzxFrameRec recs[n]   what the parse wave of that frame assumed and found (lzx_kernel.hpp), incl. its chunk list
+//   uint2  pool[n * REC_POOL_PER_SLOT * REC_CHUNK]   the frames' match records (wave_common.hpp: RecPool): 48 KiB per slot
+//                         on average instead of round 3's 128 KiB worst case per slot; a launch uses the part that
+//                         belongs to its slot range
+struct LzxScratch { int32_t *meta; u32 *frame_unit; u32 *hdr; lzxn::LzxFrameRec *recs; uint2 *pool; size_t bytes; };
+// n_rec_slots: frame slots that can hold a record + records -- all of them for a caller's own scratch (the size
 // mspack_hip_frame_scratch_bytes states); the host path numbers the units that carry a table first and gives only those
-// the 130 KiB per slot (a batch of OAB blocks or of folders without tables needs the 4-byte meta words only)
+// a record and a share of the pool (a batch of OAB blocks or of folders without tables needs the 4-byte meta words only)
+#define REC_SLOT_RECORDS ((size_t) REC_POOL_PER_SLOT * REC_CHUNK)
 __host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_frames_total, size_t n_rec_slots)
 {
   const size_t n0 = n_frames_total + 1, n = n_rec_slots + 1, a = 255;
   const size_t o_fu = (n0 * 4 + a) & ~a, o_hdr = o_fu + ((n * 4 + a) & ~a), o_rec = o_hdr + 1024,
-               o_tok = o_rec + n * sizeof(lzxn::LzxFrameRec);
+               o_pool = (o_rec + n * sizeof(lzxn::LzxFrameRec) + a) & ~a;
   LzxScratch L;
   char *b = (char *) base;
   L.meta = (int32_t *) b; L.frame_unit = (u32 *)(b + o_fu); L.hdr = (u32 *)(b + o_hdr); L.recs = (lzxn::LzxFrameRec *)(b + o_rec);
-  L.toks = (uint2 *)(b + o_tok);
-  L.bytes = o_tok + n * (size_t) LZX_TOK_CAP * sizeof(uint2);
+  L.pool = (uint2 *)(b + o_pool);
+  L.bytes = o_pool + n * REC_SLOT_RECORDS * sizeof(uint2);
   return L;
 }
 
@@ -146,44 +149,6 @@ void mspack_lzx_frame_map(const mspack_hip_unit *units, const u32 *order, u32 n_
   frame_map_unit(units[ui], ui, frame_unit, recs, hdr, kind);
 }
 
-// the header wave of every unit that carries a frame table, then one parse wave per frame slot
-// (lzx_kernel.hpp: "Frame-level parse parallelism"; both from the LZX_PARSE_ONLY build: 5.5 KiB of LDS)
-__global__ __launch_bounds__(64)
-void mspack_lzx_headers(const mspack_hip_unit *units, const u32 *order, u32 n_units, const u8 *in_arena,
-                        lzxn::LzxFrameRec *recs, u32 *frame_unit, u32 *hdr)
-{
-  __shared__ lzxp::LzxShared sh;
-  u32 ui;
-  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_LZX, ui)) { if (threadIdx.x == 0 && hdr[1] != 0u) atomicMin(&hdr[1], 0u); return; }
-  const mspack_hip_unit u = units[ui];
-  frame_map_unit(u, ui, frame_unit, recs, hdr, MSPACK_HIP_KIND_LZX);       // (LZX: no separate map launch)
-  if (!(u.flags & MSPACK_HIP_UF_FRAME_TABLE)) return;
-  lzxp::lzx_walk_headers(u, in_arena, (lzxp::LzxFrameRec *) recs, &sh);
-}
-
-__global__ __launch_bounds__(64)
-void mspack_lzx_parse(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
-                      const u8 *in_arena, const u32 *frame_unit, const u32 *hdr, lzxn::LzxFrameRec *recs, uint2 *toks)
-{
-  __shared__ lzxp::LzxShared sh;
-  if (blockIdx.x >= n_slots) return;
-  u32 slot = slot_lo + blockIdx.x;
-  // When every unit of the launch has the same number of frames (CHM intervals), blocks follow the LAUNCH order of
-  // the units (longest compressed unit first): the frames that start last are then the short ones, and the
-  // launch ends with the longest chain instead of one that started late
-  const u32 F = rfl(hdr[0]);
-  if (F != 0u && F == rfl(hdr[1])) {
-    const u32 j = blockIdx.x / F, f = blockIdx.x % F;
-    if (j >= n_units) return;
-    const u32 uj = rfl(order ? order[j] : j);
-    slot = units[uj].frame_base + f;
-  }
-  const u32 ui = rfl(frame_unit[slot]);
-  if (ui == 0xFFFFFFFFu) return;
-  const mspack_hip_unit u = units[ui];
-  lzxp::lzx_parse_frame(u, slot - u.frame_base, in_arena, (lzxp::LzxFrameRec *) &recs[slot], toks + (size_t) slot * LZX_TOK_CAP, &sh);
-}
-
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_units,
                        const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
@@ -231,22 +196,23 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
 // one agent-scope acquire (lzx_kernel.hpp).  The first frame that is not a complete regular one ends its unit's chain and
 // says where serial decoding resumes; mspack_decode_lzx (launched behind the pipe) finishes every unit.
 // ---------------------------------------------------------------------------------------------------
-union LzxPipeLds { lzxp::LzxShared p; SpecQueueLds q; };
+union LzxPipeLds { lzxp::LzxShared p; lzxn::LzxResolveLds r; };
 static_assert(sizeof(LzxPipeLds) <= 10240, "16 waves per CU");
 
 // the two halves of a task are real calls: each gets its own register allocation (inlined into the ticket loop they spill)
 __device__ __attribute__((noinline)) void lzx_pipe_task_parse(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
-                                                              lzxn::LzxFrameRec *recs, uint2 *toks, lzxp::LzxShared *sh)
+                                                              lzxn::LzxFrameRec *recs, uint2 *pool, u32 *pool_head, const u32 pool_chunks,
+                                                              lzxp::LzxShared *sh)
 {
   const mspack_hip_unit u = *up;
-  lzxp::lzx_pipe_parse(u, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], toks + (size_t)(u.frame_base + f) * LZX_TOK_CAP, sh,
-                       false);
+  RecPool rp; rp.base = pool; rp.head = pool_head; rp.cap = pool_chunks;
+  lzxp::lzx_pipe_parse(u, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], rp, sh, false);
 }
 __device__ __attribute__((noinline)) void lzx_pipe_task_resolve(const mspack_hip_unit *up, const u32 f, u8 *out_arena, lzxn::LzxFrameRec *recs,
-                                                                const uint2 *toks, SpecQueueLds *spq, const bool merged)
+                                                                uint2 *toks, lzxn::LzxResolveLds *rl, const bool merged)
 {
   const mspack_hip_unit u = *up;
-  lzxn::lzx_pipe_resolve(u, f, out_arena, &recs[u.frame_base], toks + (size_t)(u.frame_base + f) * LZX_TOK_CAP, spq, merged);
+  lzxn::lzx_pipe_resolve(u, f, out_arena, &recs[u.frame_base], toks, rl, merged);
 }
 
 #ifdef LZX_PIPE_TRACE      /* analysis builds: one line per ticket = start, end (s_memrealtime, 100 MHz), task, time waited */
@@ -258,7 +224,7 @@ __device__ unsigned long long g_pipe_trace[4 << 16];
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZX_PIPE_WAVES_PER_EU)))
 void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
                      const u8 *in_arena, u8 *out_arena, mspack_hip_result *results, int32_t *frame_meta,
-                     const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks)
+                     const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks, u32 pool_chunks)
 {
   __shared__ LzxPipeLds sh;
   const u32 lane = threadIdx.x;
@@ -296,10 +262,10 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
     if (lane == 0) lzxn::g_pipe_wait[blockIdx.x & 0xFFFFu] = 0;
 #endif
     if (do_parse) {
-      lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &sh.p);
+      lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh.p);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the resolver reuses the LDS
     }
-    if (do_resolve) lzx_pipe_task_resolve(up, f, out_arena, recs, toks, &sh.q, do_parse);
+    if (do_resolve) lzx_pipe_task_resolve(up, f, out_arena, recs, toks, &sh.r, do_parse);
 #ifdef LZX_PIPE_TRACE
     if (lane == 0 && t < (1u << 16)) {
       g_pipe_trace[4u * t] = tr0; g_pipe_trace[4u * t + 1u] = __builtin_amdgcn_s_memrealtime();
@@ -339,10 +305,10 @@ void mspack_decode_lzxd(const mspack_hip_unit *units, const u32 *order, u32 n_un
 }
 
 // one parse wave per CFDATA block of the MSZIP units that carry a frame table (mszip_kernel.hpp: "Block-level parse
-// parallelism"); same slot mapping as mspack_lzx_parse
+// parallelism")
 __global__ __launch_bounds__(64)
 void mspack_mszip_parse(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
-                        const u8 *in_arena, u8 *out_arena, const u32 *frame_unit, const u32 *hdr, lzxn::LzxFrameRec *recs, uint2 *toks)
+                        const u8 *in_arena, u8 *out_arena, const u32 *frame_unit, u32 *hdr, lzxn::LzxFrameRec *recs, uint2 *toks, u32 pool_chunks)
 {
   __shared__ MszipShared sh;
   if (blockIdx.x >= n_slots) return;
@@ -357,7 +323,8 @@ void mspack_mszip_parse(const mspack_hip_unit *units, const u32 *order, u32 n_un
   const u32 ui = rfl(frame_unit[slot]);
   if (ui == 0xFFFFFFFFu) return;
   const mspack_hip_unit u = units[ui];
-  zip_parse_block(u, slot - u.frame_base, in_arena, out_arena, (ZipBlockRec *) &recs[slot], toks + (size_t) slot * ZIP_TOK_CAP, &sh);
+  RecPool rp; rp.base = toks; rp.head = &hdr[4]; rp.cap = pool_chunks;
+  zip_parse_block(u, slot - u.frame_base, in_arena, out_arena, (ZipBlockRec *) &recs[slot], rp, &sh);
 }
 
 __global__ __launch_bounds__(64)
@@ -382,10 +349,11 @@ void mspack_decode_mszip(const mspack_hip_unit *units, const u32 *order, u32 n_u
 // waited for (a block's bytes lie at or below its index * 32 KiB), so no parse wave's literals can arrive afterwards.
 // ---------------------------------------------------------------------------------------------------
 __device__ __attribute__((noinline)) void mszip_pipe_task_parse(const mspack_hip_unit *up, const u32 b, const u8 *in_arena, u8 *out_arena,
-                                                                lzxn::LzxFrameRec *recs, uint2 *toks, MszipShared *sh)
+                                                                lzxn::LzxFrameRec *recs, uint2 *toks, u32 *pool_head, const u32 pool_chunks, MszipShared *sh)
 {
   const mspack_hip_unit u = *up;
-  zip_parse_block(u, b, in_arena, out_arena, (ZipBlockRec *) &recs[u.frame_base + b], toks + (size_t)(u.frame_base + b) * ZIP_TOK_CAP, sh);
+  RecPool rp; rp.base = toks; rp.head = pool_head; rp.cap = pool_chunks;
+  zip_parse_block(u, b, in_arena, out_arena, (ZipBlockRec *) &recs[u.frame_base + b], rp, sh);
 }
 __device__ __attribute__((noinline)) void mszip_pipe_task_folder(const mspack_hip_unit *up, const u8 *in_arena, u8 *out_arena,
                                                                  mspack_hip_result *res, const lzxn::LzxFrameRec *recs, const uint2 *toks,
@@ -399,7 +367,7 @@ static_assert(sizeof(MszipShared) <= 10240, "16 waves per CU");
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 void mspack_mszip_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
                        const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
-                       const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks)
+                       const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks, u32 pool_chunks)
 {
   __shared__ MszipShared sh;
   const u32 lane = threadIdx.x;
@@ -420,7 +388,7 @@ void mspack_mszip_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_uni
         if (ui == 0xFFFFFFFFu) continue;
         b = slot - rfl(units[ui].frame_base);
       }
-      mszip_pipe_task_parse(&units[ui], b, in_arena, out_arena, recs, toks, &sh);
+      mszip_pipe_task_parse(&units[ui], b, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh);
     }
     else {
       const u32 j = t - n_slots;
@@ -431,7 +399,7 @@ void mspack_mszip_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_uni
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the next task reuses the LDS
   }
 }
-static_assert(ZIP_TOK_CAP == LZX_TOK_CAP && sizeof(ZipBlockRec) == sizeof(lzxn::LzxFrameRec), "MSZIP and LZX share the work scratch");
+static_assert(sizeof(ZipBlockRec) == sizeof(lzxn::LzxFrameRec), "MSZIP and LZX share the work scratch");
 
 __global__ __launch_bounds__(64)
 void mspack_decode_qtm(const mspack_hip_unit *units, const u32 *order, u32 n_units,
@@ -470,6 +438,7 @@ void mspack_decode_kwaj_lzh(const mspack_hip_unit *units, const u32 *order, u32 
 // ---------------------------------------------------------------------------------------------------
 #include <mutex>
 #include <atomic>
+#define MSPK_MAX_DEV_CACHE 64
 static thread_local char g_err[256] = "";
 static int fail(hipError_t e, const char *what) {
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
@@ -482,32 +451,27 @@ static int fail(hipError_t e, const char *what) {
 // of the work scratch belong to this launch).
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
 static const bool g_mszip_pipe = getenv("MSPACK_HIP_MSZIP_PIPE") != nullptr;         // experiments: mspack_mszip_pipe instead of parse + folder kernels
-static const bool g_no_pipe = getenv("MSPACK_HIP_NO_PIPE") != nullptr;               // experiments: header / parse / unit kernels one after the other
 // persistent waves of mspack_lzx_pipe: as many as the device holds at once (nothing depends on that number being right)
-static unsigned lzx_pipe_waves()
+// (cached per device: mspack_hip_decode_batch_multi runs one host thread per device)
+static unsigned pipe_waves_for(int which)
 {
-  static unsigned waves = 0;
-  if (!waves) {
-    int dev = 0, per_cu = 0; hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 4096u;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_lzx_pipe, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
-    const char *e = getenv("MSPACK_HIP_PIPE_WAVES_PER_CU");
-    if (e && atoi(e) > 0) per_cu = atoi(e);
-    waves = (unsigned) pr.multiProcessorCount * (unsigned) per_cu;
+  static std::mutex mu;
+  static unsigned cache[2][MSPK_MAX_DEV_CACHE] = { { 0 } };
+  int dev = 0, per_cu = 0; hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MSPK_MAX_DEV_CACHE) return 4096u;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cache[which][dev]) {
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 4096u;
+    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_lzx_pipe, 64, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_mszip_pipe, 64, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 16;
+    if (which == 0) { const char *ev = getenv("MSPACK_HIP_PIPE_WAVES_PER_CU"); if (ev && atoi(ev) > 0) per_cu = atoi(ev); }
+    cache[which][dev] = (unsigned) pr.multiProcessorCount * (unsigned) per_cu;
   }
-  return waves;
+  return cache[which][dev];
 }
-static unsigned mszip_pipe_waves()
-{
-  static unsigned waves = 0;
-  if (!waves) {
-    int dev = 0, per_cu = 0; hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 4096u;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_mszip_pipe, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
-    waves = (unsigned) pr.multiProcessorCount * (unsigned) per_cu;
-  }
-  return waves;
-}
+static unsigned lzx_pipe_waves() { return pipe_waves_for(0); }
+static unsigned mszip_pipe_waves() { return pipe_waves_for(1); }
 static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
                         const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
                         size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true, unsigned launch_ix = 0,
@@ -520,11 +484,14 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
   case MSPACK_HIP_KIND_LZX: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total, n_rec_slots);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
-    static const u32 hdr_init[4] = { 0u, 0xFFFFFFFFu, 0u, 0u }, hdr_one = 1u;
-    // launches of one batch that run on different streams (host path, several chunks) have their own control words
+    static const u32 hdr_init[8] = { 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u };
+    // launches of one batch that run on different streams (host path, several chunks) have their own control words, and
+    // their own part of the record pool: the part that belongs to their frame slots
     u32 *hdr = L.hdr + 8u * (launch_ix & 15u);
-    if (frames && !g_no_pipe) {
-      // one dependency-driven launch: parse tasks and unit tasks from a ticket counter (mspack_lzx_pipe)
+    uint2 *pool = L.pool + slot_lo * REC_SLOT_RECORDS;
+    const u32 pool_chunks = (u32)(n_slots * REC_POOL_PER_SLOT);
+    if (frames) {
+      // one dependency-driven launch: parse and resolve tasks from a ticket counter (mspack_lzx_pipe)
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, 0, st, d_units, d_order, (u32) n, L.frame_unit,
@@ -532,24 +499,15 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
       const size_t tickets = 2u * n_slots;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
       hipLaunchKernelGGL(mspack_lzx_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
-                         (const u8 *) d_in, (u8 *) d_out, d_results, L.meta, (const u32 *) L.frame_unit, hdr, L.recs, L.toks);
+                         (const u8 *) d_in, (u8 *) d_out, d_results, L.meta, (const u32 *) L.frame_unit, hdr, L.recs, pool, pool_chunks);
       // what the pipe leaves: the last bytes of every unit's input (the EOF-exact reader's), the look-ahead frame, frames
-      // that are not one regular block, errors, E8, the results -- the unit kernel, resuming where each unit's commit task stopped
+      // that are not one regular block, errors, E8, the results -- the unit kernel, resuming where each unit's chain of frames ended
       hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                         d_results, L.meta, (const lzxn::LzxFrameRec *) L.recs, (const uint2 *) L.toks, 1u);
+                         d_results, L.meta, (const lzxn::LzxFrameRec *) L.recs, (const uint2 *) pool, 1u);
       break;
     }
-    if (frames) {
-      hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
-      hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
-      hipLaunchKernelGGL(mspack_lzx_headers, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, L.recs,
-                         L.frame_unit, hdr);
-      hipLaunchKernelGGL(mspack_lzx_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
-                         (u32) n_slots, (const u8 *) d_in, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
-    }
     hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results, d_fm ? L.meta : nullptr, frames ? (const lzxn::LzxFrameRec *) L.recs : nullptr,
-                       (const uint2 *) L.toks, 0u);
+                       d_results, d_fm ? L.meta : nullptr, (const lzxn::LzxFrameRec *) nullptr, (const uint2 *) nullptr, 0u);
     break; }
   case MSPACK_HIP_KIND_LZX_DELTA:
     hipLaunchKernelGGL(mspack_decode_lzxd, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
@@ -557,9 +515,13 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
   case MSPACK_HIP_KIND_MSZIP: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total, n_rec_slots);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
+    uint2 *pool = nullptr;
+    u32 pool_chunks = 0;
     if (frames) {
-      static const u32 hdr_init[4] = { 0u, 0xFFFFFFFFu, 0u, 0u };
+      static const u32 hdr_init[8] = { 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u };
       u32 *hdr = L.hdr + 8u * (16u + (launch_ix & 15u));
+      pool = L.pool + slot_lo * REC_SLOT_RECORDS;
+      pool_chunks = (u32)(n_slots * REC_POOL_PER_SLOT);
       hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
       hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
       hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
@@ -573,14 +535,14 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
         const size_t tickets = n_slots + n;
         const unsigned waves = (unsigned) std::min<size_t>(tickets, mszip_pipe_waves());
         hipLaunchKernelGGL(mspack_mszip_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
-                           (const u8 *) d_in, (u8 *) d_out, d_results, (const u32 *) L.frame_unit, hdr, L.recs, L.toks);
+                           (const u8 *) d_in, (u8 *) d_out, d_results, (const u32 *) L.frame_unit, hdr, L.recs, pool, pool_chunks);
         break;
       }
       hipLaunchKernelGGL(mspack_mszip_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
-                         (u32) n_slots, (const u8 *) d_in, (u8 *) d_out, (const u32 *) L.frame_unit, (const u32 *) hdr, L.recs, L.toks);
+                         (u32) n_slots, (const u8 *) d_in, (u8 *) d_out, (const u32 *) L.frame_unit, hdr, L.recs, pool, pool_chunks);
     }
     hipLaunchKernelGGL(mspack_decode_mszip, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results, frames ? (const lzxn::LzxFrameRec *) L.recs : nullptr, (const uint2 *) L.toks);
+                       d_results, frames ? (const lzxn::LzxFrameRec *) L.recs : nullptr, (const uint2 *) pool);
     break; }
   case MSPACK_HIP_KIND_QUANTUM:
     hipLaunchKernelGGL(mspack_decode_qtm, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
@@ -955,7 +917,8 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     } pins;
     struct Joiner { std::thread &t; std::atomic<bool> &stop; ~Joiner() { if (t.joinable()) { stop.store(true); t.join(); } } } joiner{back, stop};
     static const bool pin_out = env_int("MSPACK_HIP_PIN_OUT", 1, 0, 1) != 0;
-    if (host_out && !one)
+    bool back_started = false;
+    if (host_out && !one) try {
       back = std::thread([&]() {
         hipError_t be = hipSetDevice(dev);
         const uintptr_t PG = 4096u, base = (uintptr_t) host_out;
@@ -983,6 +946,8 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
         }
         back_err = be;
       });
+      back_started = true;
+    } catch (...) { back_started = false; }      // (no helper thread: the copies back are issued below, in this thread)
     for (size_t ci = 0; ci < chunks.size(); ci++) {
       const Chunk &c = chunks[ci];
       hipStream_t st = one ? cx.st[0] : cx.st[2 + ci % n_comp];
@@ -1013,6 +978,15 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
         for (size_t i = c.a; i < c.b; i++)
           TRY(hipMemcpyAsync((char *) host_out + out_lo + local[i].out_off, d_out + local[i].out_off, local[i].out_len,
                              hipMemcpyDeviceToHost, st_out));
+    }
+    if (host_out && !one && !back_started) {
+      // (the helper thread could not be created: plain copies, chunk by chunk, behind each chunk's launches)
+      for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const Chunk &c = chunks[ci];
+        TRY(hipStreamWaitEvent(st_out, cx.ev_done[ci], 0));
+        TRY(hipMemcpyAsync((char *) host_out + c.out_lo, d_out + (c.out_lo - out_lo), (size_t)(c.out_hi - c.out_lo),
+                           hipMemcpyDeviceToHost, st_out));
+      }
     }
     if (back.joinable()) {
       back.join();

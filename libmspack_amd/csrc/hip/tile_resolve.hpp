@@ -34,6 +34,9 @@
 #define TR_ROWS (TR_BYTES / 16u)           /* 273 rows of 16 bytes */
 #define TR_NB 16u                          /* a lane copies up to this many bytes of its own match */
 #define TR_FRAME 32768u                    /* bytes the not-final map covers: an LZX frame, an MSZIP block */
+#ifndef TR_COLLAPSE
+#define TR_COLLAPSE 1                      /* chains of matches that read each other are collapsed before the rounds (tr_batch) */
+#endif
 
 struct __align__(16) TileLds {
   u32 tile[TR_BYTES / 4u + 8u];            /* (+32 bytes: a lane's five source / destination dwords may look past the end) */
@@ -204,14 +207,59 @@ __device__ __forceinline__ u64 tr_batch(TileLds &L, const u8 *out, const u32 T0,
 {
   TR_MARK("tr_batch_begin");
   TR_T0();
-  const u32 pr = pos - T0, pf = pos - F0, s0 = pos - off;
+  const u32 pr = pos - T0, pf = pos - F0;
+  u32 s0 = pos - off;
   if (setbits) tr_bits(L.nf, ism, pf, pf + len, true);
+  // ---- CHAINS.  On record-like data match after match reads the match before it ("literal + 3 bytes at distance 4", over
+  // and over): rounds would copy such a batch one link at a time (19.5 rounds per batch on the bench corpus, 40 on its
+  // binary third -- profiles/round4_tile_resolver_experiment.txt).  But a match whose source lies INSIDE one earlier,
+  // not self-overlapping match's destination reads what that match reads, shifted: it takes over that match's source --
+  // and, by pointer jumping, its source's source -- until its source is something that is not a queued match's bytes.
+  // Blocker = the last lane whose position is <= my source's first byte (a binary search over the sorted positions, six
+  // ds_bpermute); then log2(chain length) jump steps of three ds_bpermute.  Left with ~2 rounds per batch. ----
+  if (TR_COLLAPSE) {
+    const bool cand0 = ism && !unknown && len <= TR_NB && off >= len && s0 >= T0;
+    bool blocked = false;
+    if (cand0 && s0 >= F0) {
+      const u32 sf0 = s0 - F0, w = sf0 >> 5, o = sf0 & 31u;
+      const u64 x = ((((u64) L.nf[w + 1u]) << 32) | L.nf[w]) >> o;
+      blocked = (x & ((1ull << len) - 1ull)) != 0ull;
+    }
+    if (ballot(blocked)) {
+      const u32 key = ism ? pos : 0xFFFFFFFFu;
+      u32 cnt = 0;                                                // lanes whose position is <= s0 (positions ascend with the lane)
+#pragma unroll
+      for (u32 step = 32u; step >= 1u; step >>= 1) {
+        const u32 probe = cnt + step - 1u;
+        const u32 pk = (u32) __builtin_amdgcn_ds_bpermute((int)((probe & 63u) << 2), (int) key);
+        if (probe < 64u && pk <= s0) cnt += step;
+      }
+      // a link needs: a blocker in this batch, not self-overlapping, of known distance, whose destination holds my source
+      const u32 meta = len | ((ism && !unknown && off >= len) ? 0x10000u : 0u);
+      const u32 bl_ = cnt ? cnt - 1u : 0u;
+      const u32 bpos = (u32) __builtin_amdgcn_ds_bpermute((int)(bl_ << 2), (int) key);
+      const u32 bmeta = (u32) __builtin_amdgcn_ds_bpermute((int)(bl_ << 2), (int) meta);
+      const bool link = blocked && cnt != 0u && (bmeta & 0x10000u) && s0 + len <= bpos + (bmeta & 0xFFFFu);
+      u32 blk = link ? bl_ : 64u, dd = s0 - bpos, src = s0;
+      for (int it = 0; it < 6; it++) {
+        if (!ballot(blk < 64u)) break;
+        const u32 a = (blk & 63u) << 2;
+        const u32 bsrc = (u32) __builtin_amdgcn_ds_bpermute((int) a, (int) src);
+        const u32 bblk = (u32) __builtin_amdgcn_ds_bpermute((int) a, (int) blk);
+        const u32 bdd = (u32) __builtin_amdgcn_ds_bpermute((int) a, (int) dd);
+        if (blk < 64u) { src = bsrc + dd; dd = bdd + dd; blk = bblk; }
+      }
+      // (still linked after six doublings: cannot be -- a chain inside 64 lanes is shorter; such a lane keeps its own source)
+      if (link && blk >= 64u) s0 = src;
+    }
+  }
+  const u32 eoff = pos - s0;                                      // the distance in effect (>= off: a redirected source lies further back)
   // never copied in this pass: distance unknown, or a source byte below the frame while those are not final
   const bool predef = ism && (unknown || (!lowfinal && s0 < F0));
   const bool live = ism && !predef;
   const bool below = live && s0 + len <= T0;                      // the whole source lies below the tile
   const bool inside = live && s0 >= T0;
-  const bool shortm = live && len <= TR_NB && off >= len && (below || inside);
+  const bool shortm = live && len <= TR_NB && eoff >= len && (below || inside);
   const bool slow = live && !shortm;
   const u32 sr = s0 - T0;                                         // (inside) source offset in the tile
   const u32 sf = s0 - F0;                                         // source offset in the frame (s0 >= F0)
@@ -311,7 +359,7 @@ __device__ __forceinline__ u64 tr_batch(TileLds &L, const u8 *out, const u32 T0,
       const u64 sm = ballot(srdy);
       if (!sm) { defer |= todo; TR_T(3); break; }
       const u32 j = (u32) __ffsll((long long) sm) - 1u;
-      const u32 P = rdl(pos, j), Ln = rdl(len, j), Of = rdl(off, j);
+      const u32 P = rdl(pos, j), Ln = rdl(len, j), Of = rdl(eoff, j);
       tr_copy_one(L, out, T0, P, Ln, Of, lane);
       {
         // its bits, a word per lane

@@ -245,3 +245,50 @@ __device__ __forceinline__ u32 wave_incl_max(u32 x)
   t = (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
   return v;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Match records of the frame-parallel paths (LZX frames, MSZIP blocks): a POOL per launch instead of a worst-case region
+// per frame slot.  A 32 KiB frame can hold 16384 matches (128 KiB of records), the frames of the bench corpus hold ~4200,
+// and round 3's scratch reserved the worst case for every slot: 4x the decoded bytes.  Now a launch's frames take chunks
+// of REC_CHUNK records from one pool as their parse needs them (one atomic per chunk); a frame's chunk list -- at most
+// REC_CHUNKS entries -- lives in its record.  The pool holds REC_POOL_PER_SLOT chunks per frame slot (48 KiB: 1.5x the
+// decoded bytes); a frame that finds it empty is simply not parsed ahead (the serial path decodes it).
+// Record index j of a frame lives at pool[chunk[j / REC_CHUNK] + j % REC_CHUNK]; readers work in batches of 64 records
+// that start at multiples of 64, i.e. inside one chunk.
+// ---------------------------------------------------------------------------------------------------
+#define REC_CHUNK 1024u
+#define REC_CHUNKS 16u
+#define REC_POOL_PER_SLOT 6u
+struct RecPool { uint2 *base; u32 *head; u32 cap; };          /* records, chunks handed out so far (device counter), chunks in the pool */
+struct RecWriter {
+  RecPool pool;
+  u32 *ctab;                       /* LDS: REC_CHUNKS words, the frame's chunk list (record index of each chunk's first record) */
+  u32 *gtab;                       /* the same in the frame's record (global memory), for the reader */
+  u32 n_chunks;
+  __device__ __forceinline__ void begin(const RecPool &p, u32 *lds_tab, u32 *rec_tab) { pool = p; ctab = lds_tab; gtab = rec_tab; n_chunks = 0; }
+  // room for the records with index < upto?  (wave-uniform; false: the pool is empty or the frame has more than 16384)
+  __device__ __forceinline__ bool ensure(const u32 upto, const u32 lane) {
+    bool grew = false;
+    while (n_chunks * REC_CHUNK < upto) {
+      if (n_chunks >= REC_CHUNKS) return false;
+      u32 c = 0;
+      if (lane == 0) c = atomicAdd(pool.head, 1u);
+      c = rfl(c);
+      if (c >= pool.cap) return false;
+      if (lane == 0) { ctab[n_chunks] = c * REC_CHUNK; gtab[n_chunks] = c * REC_CHUNK; }
+      n_chunks++; grew = true;
+    }
+    if (grew) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    return true;
+  }
+  __device__ __forceinline__ uint2 *at(const u32 j) const { return pool.base + ctab[j >> 10] + (j & (REC_CHUNK - 1u)); }
+};
+// reader side: the records [g, g + 256) of a frame, g a multiple of 256, lie in one chunk: their common base (wave-uniform)
+__device__ __forceinline__ const uint2 *rec_group(const uint2 *pool_base, const u32 *chunk, const u32 g) {
+  return pool_base + rfl(gld(chunk + (g >> 10))) + (g & (REC_CHUNK - 1u));
+}
+// reader side: record j of a frame whose chunk list is `chunk` (global memory)
+__device__ __forceinline__ const uint2 *rec_at(const uint2 *pool_base, const u32 *chunk, const u32 j) {
+  return pool_base + gld(chunk + (j >> 10)) + (j & (REC_CHUNK - 1u));
+}
+

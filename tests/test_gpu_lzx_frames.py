@@ -160,11 +160,10 @@ def test_frames_other_plaintexts(built, fam):
         assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
 
 
-@pytest.mark.parametrize("env", [{}, {"MSPACK_HIP_NO_PIPE": "1"}, {"MSPACK_HIP_NO_FRAME_PARSE": "1"}],
-                         ids=["pipe", "three-kernels", "serial"])
+@pytest.mark.parametrize("env", [{}, {"MSPACK_HIP_NO_FRAME_PARSE": "1"}], ids=["pipe", "serial"])
 def test_launch_paths_same_bytes(built, env):
-    """shim.hip launch_kind: the shipped default (mspack_lzx_pipe: one dependency-driven launch), the header / parse /
-    unit kernels one after the other (MSPACK_HIP_NO_PIPE) and the serial kernel alone (MSPACK_HIP_NO_FRAME_PARSE) --
+    """shim.hip launch_kind: the shipped default (mspack_lzx_pipe: one dependency-driven launch) and the serial kernel alone
+    (MSPACK_HIP_NO_FRAME_PARSE; round 2's header / parse / unit kernels in a row were removed in round 4) --
     same results, on launches smaller than, about and larger than the chip, and on units of three frames.  Every unit
     carries its table; with the pipe every unit must have had all its frames' records adopted.  (Own process: the
     switches are read when the library loads.)"""
@@ -186,7 +185,7 @@ def go(n, ub):
     return float(((res['flags'] & ADOPTED) != 0).mean())
 print(go(1024, 65536), go(3600, 32768), go(3600, 3 * 32768), go(6144, 32768))
 """
-    e2 = dict(os.environ); e2.pop("MSPACK_HIP_NO_PIPE", None); e2.pop("MSPACK_HIP_NO_FRAME_PARSE", None); e2.update(env)
+    e2 = dict(os.environ); e2.pop("MSPACK_HIP_NO_FRAME_PARSE", None); e2.update(env)
     r = subprocess.run([sys.executable, "-c", code], env=e2, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stderr[-2000:]
     adopted = [float(x) for x in r.stdout.split()[-4:]]
