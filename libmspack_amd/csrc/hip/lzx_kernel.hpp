@@ -105,7 +105,7 @@ struct __align__(16) LzxShared {
 #ifndef LZX_PARSE_ONLY
   u32 inbuf[128 + 4];            /* speculative path: two 256-byte input chunks, words pre-swapped */
 #else
-  u32 stage[LZX_STAGE_WORDS + 64]; /* lzx_parse_lanes / lzx_parse_emit: 4 KiB (or 8) of a frame's input, words pre-swapped */
+  u32 stage[LZX_STAGE_WORDS + 64]; /* lzx_parse_emit: a stretch of a frame's input, words pre-swapped */
 #ifdef LZX_LIT_RING
   alignas(16) u32 litring[LZX_LIT_RING / 4u];  /* lzx_parse_emit: the literals of the last walk's rounds on their way out (whole 16-byte rows) */
 #endif
@@ -861,8 +861,7 @@ __device__ __forceinline__ u32 lru_scan(u32 x)
 
 #ifndef LZX_PARSE_ONLY
 // ---- COMMIT: one batch of parsed tokens, one token per lane ---------------------------------------------
-// Shared by the speculative run (tokens from the LDS queue) and by the frame-parallel path (tokens a parse
-// wave left in global memory, lzx_run_tokens).
+// Used by the speculative runs of the serial path (tokens from the LDS queue).
 struct LzxCommit {                  // wave-uniform commit-side state of a run
   u32 P, R0, R1, R2;
   u32 run_end, wbase, wsize, offset_written, ref_size;
@@ -894,8 +893,7 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
   // tokens are decoded only while the run lasts (lzxd.c:538): the first one that would start at or
   // after run_end, and everything parsed behind it, is not part of this run
   if (newP >= run_end) {
-    // (a literal run -- up to four literals in one record, lzx_parse_lanes -- that would cross the end of the run
-    //  is not taken either: it can only come from a record parsed beyond its frame, and the serial path goes on there)
+    // (a literal run that would cross the end of the run is not taken either: the serial path goes on there)
     const u64 late = ballot(lane < n && (opos >= run_end || (kind == 0u && opos + olen > run_end)));
     if (late) { const u32 j = (u32) __ffsll((long long) late) - 1u; n = j; newP = rdl(opos, j); marker = 0; }
   }
@@ -1467,23 +1465,21 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
 // Every 32 KiB frame starts on a 16-bit boundary of the compressed stream (lzxd.c:695-697) at an offset the
 // container states up front -- one CFDATA block per frame in a cabinet (cabd.c:1362-1479), one reset-table
 // entry per frame in a CHM (chmd.c:1146-1149).  The serial chain of a unit is "where does the next token
-// start"; it needs the Huffman tables, not the window and not R0-R2.  So, per unit, a HEADER wave
-// (mspack_lzx_headers) walks the block headers frame by frame (code lengths are deltas on the previous block's,
-// lzxd.c:138-183: a chain, but a short one) and leaves every frame's code lengths in its record; then a PARSE
-// wave per frame (mspack_lzx_parse) builds the tables, parses the frame's tokens with the 64-positions-per-round
-// scheme and leaves them in global memory.  Both work on the guess that every frame holds exactly ONE verbatim /
-// aligned block that begins where the frame begins -- what encoders do -- and give up silently otherwise.
-// The unit's own wave (mspack_decode_lzx) stays the only judge: frame by frame it checks that its bit
-// position is the one the record was parsed from and that no block is open, adopts the record, and commits
-// the tokens 64 at a time (lzx_run_tokens: positions, literals, R0-R2, the reference's checks, match queue).
-// Whatever a record does not cover -- the last bytes of the input, a frame with several blocks, stored blocks,
-// a damaged stream, a wrong table -- is decoded by the serial path exactly as before, so error codes and
-// byte counts cannot differ.
+// start"; it needs the Huffman tables, not the window and not R0-R2.  So mspack_lzx_pipe gives every FRAME a parse
+// task (lzx_pipe_parse): it waits for the code lengths of the frame before it (code lengths are deltas on the previous
+// block's, lzxd.c:138-183: a chain, but a short one -- one header per link), reads its own block header, publishes
+// its code lengths, builds the tables and parses the frame's tokens with every lane walking its own stretch of the bits
+// (lzx_parse_emit): literals go straight to the output, matches become 8-byte records in the launch's record pool.
+// The parse works on the guess that every frame holds exactly ONE verbatim / aligned block that begins where the frame
+// begins -- what encoders do -- and gives up silently otherwise.  A resolve task per frame (lzx_pipe_resolve) then
+// turns the records into copies in stream order: R0-R2, the reference's checks, the match queue.  Whatever the tasks
+// do not cover -- the last bytes of the input, a frame with several blocks, stored blocks, a damaged stream, a wrong
+// table -- ends the unit's chain there (rs_* in the unit's first record) and is decoded by the serial path
+// (mspack_decode_lzx, resume) from that very bit, so error codes and byte counts cannot differ.
 // ---------------------------------------------------------------------------------------------------
-#define LZX_TOK_CAP 16384u          /* tokens a parse wave stores per frame (8 bytes each) */
 
 struct __align__(16) LzxFrameRec {
-  u32 status;                       /* 2 = header known (lzx_walk_headers), 1 = tokens parsed too */
+  u32 status;                       /* LZX_ST_*: 2 = header known (code lengths published), 7 = literals stored, records written */
   u32 n_tokens;
   u32 hdr_start_bit;                /* bit positions count from the unit's first compressed byte */
   u32 end_bit;                      /* first bit that was not parsed */
@@ -1578,50 +1574,9 @@ __device__ __forceinline__ void lzx_seek_bit(LzxDec &d, const u32 abs_bit)
   if (sk) { d.bb <<= sk; d.bl -= (int) sk; }
 }
 
-// the PARSE phase of lzx_run_spec alone, tokens to global memory
-template <bool ALIGNED>
-__device__ __forceinline__ void lzx_parse_tokens(LzxDec &d, const bool length_empty, const u32 frame_size,
-                                                 uint2 *tok, u32 &n_tok, u32 &end_bit)
-{
-  LzxShared *sh = d.sh;
-  const u32 lane = d.lane;
-  const u32 bit_limit = spec_bit_limit(d, 56u);
-  const u32 base_bit = rfl(d.w.origin) * 8u;
-  u32 bitpos, cb, pf;
-  spec_stage(d, bitpos, cb, pf);
-  u32 mlim[16 - LZX_MAIN_P];
-#pragma unroll
-  for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
-  u32 tt = 0, outc = 0;
-  while (bitpos < bit_limit && outc < frame_size && tt <= LZX_TOK_CAP - 64u) {
-    spec_slide(d, bitpos, cb, pf);
-    const u32 rel = bitpos - (cb << 11) + lane;
-    const u32 k = rel >> 5, sft = rel & 31u;
-    const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
-    const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
-    const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
-    const SpecTok t = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0, w1);
-    const u32 vn = t.unk ? (256u + lane) : (lane + t.tot);
-    u64 chain = 0;
-    u32 q = 0;
-    do { chain |= 1ull << q; q = rdl(vn, q); } while (q < 64u);
-    bool hit_unknown = false;
-    if (q >= 256u) { q -= 256u; hit_unknown = true; chain &= ~(1ull << q); }
-    const bool on = (chain >> lane) & 1ull;
-    const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(chain >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain, 0u));
-    if (on) tok[tt + rank] = make_uint2(t.kind | (t.olen << 3) | (((base_bit + bitpos + lane) & 0xFFFFFu) << 12),
-                                        t.kind == 0u ? t.sym : t.off);
-    tt += (u32) __popcll(chain);
-    outc += rdl(wave_incl_scan(on ? t.olen : 0u), 63u);
-    bitpos += q;
-    if (hit_unknown) break;                              // the unit's own wave takes (and judges) this token
-  }
-  n_tok = tt; end_bit = base_bit + bitpos;
-}
-
 #ifdef LZX_PARSE_ONLY
 // ---------------------------------------------------------------------------------------------------
-// lzx_parse_lanes -- a frame's tokens, every lane walking its own stretch of the bit stream.
+// The lane parser -- a frame's tokens, every lane walking its own stretch of the bit stream.
 //
 // The 64-positions-per-round parser above spends its vector instructions on 64 lanes of which the ~5 on the chain
 // matter.  Here the frame's bits [B, E) -- E is what the frame table says, a hint -- are cut into 64 stretches and
@@ -1648,193 +1603,12 @@ __device__ __forceinline__ void lzx_parse_tokens(LzxDec &d, const bool length_em
 #define LZX_SEG 8u                  /* lzx_parse_emit: tokens per segment of the balanced last walk (a power of two): a round's 64 segments
                                        cover ~1.1 KiB of output -- what the literal ring holds */
 #endif
-template <bool ALIGNED>
-__device__ __forceinline__ void lzx_parse_lanes(LzxDec &d, const bool length_empty, const u32 start_bit,
-                                                const u32 frame_end_bit, uint2 *tok, u32 &n_tok, u32 &end_bit)
-{
-  LzxShared *sh = d.sh;
-  const u32 lane = d.lane;
-  // bit positions count from the unit's first byte; the last 56 bytes of the input belong to the EOF-exact reader
-  const u32 in_limit = d.w.in_len > 56u ? (d.w.in_len - 56u) * 8u : 0u;
-  const u32 Eall = frame_end_bit < in_limit ? frame_end_bit : in_limit;
-  u32 mlim[16 - LZX_MAIN_P];
-#pragma unroll
-  for (int l = LZX_MAIN_P + 1; l <= 16; l++) mlim[l - LZX_MAIN_P - 1] = rdl(d.hr_main.limv, (u32) l);
-  const u32 main_fov = d.hr_main.fov;
-  u32 tt = 0, B = rfl(start_bit);
-  bool stop = false;
-#ifdef LZX_PHASE_TIMERS
-  u64 pl_t0 = __builtin_amdgcn_s_memtime(), pl_x = pl_t0; u32 pl_stage = 0, pl_walk = 0, pl_emit = 0, pl_iters = 0, pl_rounds = 0, pl_pass = 0;
-#define PLT(acc) do { const u64 n_ = __builtin_amdgcn_s_memtime(); acc += (u32)(n_ - pl_x); pl_x = n_; } while (0)
-#else
-#define PLT(acc) do { } while (0)
-#endif
-
-  while (!stop && B < Eall && tt < LZX_TOK_CAP) {
-    PLT(pl_walk);
-    // ---- stage the input from the dword that holds bit B ----
-    const u32 sb_byte = (B >> 5) << 2, sb_bit = sb_byte * 8u;
-    u32 E = sb_bit + LZX_STAGE_WORDS * 32u; if (E > Eall) E = Eall;
-    const u32 b0 = B - sb_bit, e0 = E - sb_bit;
-    d.w.origin = sb_byte;
-    {
-      const u32 nck = (e0 + 128u + 2047u) >> 11;               // a token that starts below e0 ends below e0 + 53
-      for (u32 c = 0; c < nck; c += 4u) {                       // (four loads in flight; chunks beyond nck are inside the pad or harmless)
-        const u32 v0 = d.w.load_chunk(c, lane), v1 = d.w.load_chunk(c + 1u, lane);
-        const u32 v2 = d.w.load_chunk(c + 2u, lane), v3 = d.w.load_chunk(c + 3u, lane);
-        sh->stage[c * 64u + lane] = SWAP16(v0);
-        if (c + 1u < nck) sh->stage[(c + 1u) * 64u + lane] = SWAP16(v1);
-        if (c + 2u < nck) sh->stage[(c + 2u) * 64u + lane] = SWAP16(v2);
-        if (c + 3u < nck) sh->stage[(c + 3u) * 64u + lane] = SWAP16(v3);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    PLT(pl_stage);
-#ifdef LZX_PHASE_TIMERS
-    pl_pass++;
-#endif
-    u32 S = (e0 - b0 + 63u) >> 6; if (S < 64u) S = 64u;        // a token is at most 53 bits: it never skips a stretch
-    const u32 nl = (e0 - b0 + S - 1u) / S;                     // lanes that own a stretch
-    const u32 rstart = b0 + lane * S;
-    u32 rend = rstart + S; if (rend > e0) rend = e0;
-    // (the first walk only has to find the exit: it starts LZX_LANE_TAIL bits before the stretch's end, far enough to
-    //  fall into step; a wrong exit is caught like any other: the right neighbour's entry moves again)
-    u32 entry = lane == 0u ? b0 : (rend > rstart + LZX_LANE_TAIL ? rend - LZX_LANE_TAIL : rstart);
-    u32 n = 0, nm = 0, exitp = entry, stop_at = 0;      // n: tokens of the stretch, nm: records they make (literal runs merged)
-    bool dead = false, changed = lane < nl;
-    // up to four literals in a row become ONE record (kind 0, output length 1..4, the bytes in c1): fewer records to
-    // store and fewer, fuller batches to commit.  A literal that starts in the frame's last 16 bits is never merged:
-    // what follows the frame's last token there is padding, and a record must not mix real tokens with it.
-    const u32 nomerge = frame_end_bit - sb_bit >= 16u ? frame_end_bit - sb_bit - 16u : 0u;
-    for (u32 round = 0; ; ) {
-      // ---- the lanes whose entry moved walk their stretch ----
-      u32 p = entry, cnt = 0, cntm = 0, run = 0, sa = 0;
-      bool dd = false;
-      LZX_MARK("lanes_walk_begin");
-      while (ballot(changed && p < rend)) {
-        const bool on = changed && p < rend;
-        const u32 pp = on ? p : 0u;
-        const u32 k = pp >> 5, sft = pp & 31u;
-        const u32 i0 = sh->stage[k], i1 = sh->stage[k + 1u];
-        const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
-        u32 w1 = 0;
-        if (ALIGNED) { const u32 i2 = sh->stage[k + 2u]; w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32); }
-        u32 e = sh->main_tab[w0 >> (32 - LZX_MAIN_P)];
-        if (ballot(on && e == 0u)) {                            // main codes beyond the direct table (cf. lzx_spec_token)
-          const u32 peek16 = w0 >> 16;
-          u32 ln = LZX_MAIN_P + 1u;
-#pragma unroll
-          for (int l = LZX_MAIN_P + 1; l <= 16; l++) ln += (peek16 >= mlim[l - LZX_MAIN_P - 1]) ? 1u : 0u;
-          const u32 lq = ln <= 16u ? ln : 0u;
-          const u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) main_fov);
-          u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
-          if (idx >= LZX_MAIN_SYMS) idx = 0;
-          const u32 ls = sh->main_sorted[idx];
-          if (e == 0u && lq != 0u) e = ls | (lq << LZX_MSH);
-        }
-        bool unk;
-        const u32 tot = lzx_adv_from_entry<ALIGNED>(sh, length_empty, e, w0, w1, unk);
-        if (on) {
-          if (unk || e == 0u) { dd = true; sa = p; p = rend; }
-          else {
-            const bool lit = (e & LZX_MMASK) < 256u;
-            const bool merge = lit && run != 0u && run != 4u && p < nomerge;
-            if (!merge) cntm++;
-            run = lit ? (merge ? run + 1u : 1u) : 0u;
-            cnt++; p += tot;
-          }
-        }
-#ifdef LZX_PHASE_TIMERS
-        pl_iters++;
-#endif
-      }
-#ifdef LZX_PHASE_TIMERS
-      pl_rounds++;
-#endif
-      LZX_MARK("lanes_walk_end");
-      if (changed) { n = cnt; nm = cntm; exitp = p; dead = dd; stop_at = sa; }
-      round++;
-      // ---- every lane's entry is its left neighbour's exit ----
-      const u32 pe = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) exitp);
-      const u32 ne = lane == 0u ? b0 : pe;
-      changed = lane < nl && ne != entry;
-      entry = ne;
-      if (!ballot(changed) || round >= LZX_LANE_ROUNDS) break;
-    }
-    // ---- the consistent prefix: lanes < m; it ends early at a lane that met a token it cannot take ----
-    u32 m = nl;
-    { const u64 chm = ballot(changed); if (chm) m = (u32) __ffsll((long long) chm) - 1u; }
-    u32 mm = m, dl = 0;
-    bool hit = false;
-    { const u64 dm = ballot(dead && lane < m); if (dm) { dl = (u32) __ffsll((long long) dm) - 1u; mm = dl + 1u; hit = true; } }
-    const u32 cntv = lane < mm ? nm : 0u;
-    const u32 incl = wave_incl_scan(cntv);
-    {
-      const u32 room = LZX_TOK_CAP - tt;
-      const u32 fit = (u32) __popcll(ballot(lane < mm && incl <= room));
-      if (fit < mm) { mm = fit; hit = false; stop = true; }
-    }
-    const u32 base = tt + incl - cntv;
-    PLT(pl_walk);
-    // ---- values: every lane walks its stretch once more and stores its tokens ----
-    {
-      const u32 my_n = lane < mm ? n : 0u;
-      u32 p = entry, i = 0, j = base, run = 0, pc0 = 0, pc1 = 0;        // (pc0, pc1): the record being assembled
-      u32 h0 = 0, h1 = 0;                                               // a finished record at an even index waits for its
-                                                                        // neighbour: two records leave in one 16-byte store
-      LZX_MARK("lanes_emit_begin");
-      while (ballot(i < my_n)) {
-        const bool on = i < my_n;
-        const u32 pp = on ? p : 0u;
-        const u32 k = pp >> 5, sft = pp & 31u;
-        const u32 i0 = sh->stage[k], i1 = sh->stage[k + 1u], i2 = sh->stage[k + 2u];
-        const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
-        const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
-        const SpecTok t = lzx_spec_token<ALIGNED>(sh, main_fov, mlim, length_empty, w0, w1);
-        if (on) {
-          const bool lit = t.kind == 0u;
-          if (lit && run != 0u && run != 4u && p < nomerge) { pc1 |= t.sym << (8u * run); pc0 += 1u << 3; run++; }
-          else {
-            if (i != 0u) {
-              if (j & 1u) {
-                if (j != base) *(uint4 *)(tok + (j - 1u)) = make_uint4(h0, h1, pc0, pc1);
-                else tok[j] = make_uint2(pc0, pc1);                     // (the lane's first record sits at an odd index)
-              }
-              else { h0 = pc0; h1 = pc1; }
-              j++;
-            }
-            pc0 = t.kind | (t.olen << 3) | (((sb_bit + p) & 0xFFFFFu) << 12); pc1 = lit ? t.sym : t.off;
-            run = lit ? 1u : 0u;
-          }
-          p += t.tot; i++;
-        }
-      }
-      if (my_n != 0u) {
-        if ((j & 1u) && j != base) *(uint4 *)(tok + (j - 1u)) = make_uint4(h0, h1, pc0, pc1);
-        else tok[j] = make_uint2(pc0, pc1);
-      }
-      LZX_MARK("lanes_emit_end");
-    }
-    PLT(pl_emit);
-    if (mm) tt += rdl(incl, mm - 1u);
-    if (hit) { B = sb_bit + rdl(stop_at, dl); stop = true; }
-    else if (mm == 0u) stop = true;
-    else B = sb_bit + rdl(exitp, mm - 1u);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the stage is rewritten by the next pass
-  }
-#ifdef LZX_PHASE_TIMERS
-  if (lane == 0 && (blockIdx.x % 1000u) == 0u)
-    printf("lzx parse block %u: total %llu clk: stage %u, walks %u (%u iterations, %u rounds, %u passes), values %u; %u tokens\n", blockIdx.x,
-           (unsigned long long)(__builtin_amdgcn_s_memtime() - pl_t0), pl_stage, pl_walk, pl_iters, pl_rounds, pl_pass, pl_emit, tt);
-#endif
-  n_tok = tt; end_bit = B;
-}
 #endif  /* LZX_PARSE_ONLY */
 
 
 #ifdef LZX_PARSE_ONLY
 // ---------------------------------------------------------------------------------------------------
-// lzx_parse_emit -- lzx_parse_lanes taken one step further (mspack_lzx_pipe): the parse wave does not leave TOKENS
+// lzx_parse_emit -- the lane parser taken one step further (mspack_lzx_pipe): the parse wave does not leave TOKENS
 // for the unit's wave, it leaves the frame's LITERALS IN PLACE and a list of MATCH RECORDS.
 //
 // A frame starts at a known output position (f * 32 KiB), so once the lanes' stretches are consistent every lane
@@ -2366,118 +2140,14 @@ __device__ __forceinline__ bool lzx_side_setup(LzxDec &d, LzxState &s, const msp
   return s.num_offsets != 0u;
 }
 
-// The HEADER wave of a unit (mspack_lzx_headers): code lengths are deltas on the previous block's (lzxd.c:138-183),
-// so the block headers of a unit form a chain.  One wave walks it -- frame by frame it reads the header the frame
-// table points at (lengths only, no decode tables) and leaves the resulting code lengths, the block's type and size
-// and the bit positions in the frame's record -- so that the parse waves can all start at once.  It stops guessing
-// for the rest of a reset interval as soon as a frame is not "one verbatim / aligned block that starts where the
-// frame starts and covers it exactly".
-__device__ void lzx_walk_headers(const mspack_hip_unit &u, const u8 *in_arena, LzxFrameRec *recs, LzxShared *sh)
-{
-  const u32 lane = threadIdx.x;
-  LzxDec d;
-  LzxState s;
-  if (!lzx_side_setup(d, s, u, in_arena, sh)) return;
-  if (u.in_len >= (1u << 28)) return;                         // bit positions of the records are 32-bit: no guesses beyond 256 MiB
-  const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
-  const u32 rf = u.reset_frames;
-  const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
-  bool chain = false;
-  for (u32 f = 0; f < nreal; f++) {
-    const bool first = rf ? (f % rf) == 0u : f == 0u;
-    if (first) { lzx_reset_state(d, s); chain = true; }
-    if (!chain) { if (rf == 0u) return; continue; }
-    chain = false;
-    const u32 fo = rfl(ftab[f]);
-    if (fo >= u.in_len || u.in_len - fo <= 64u) continue;      // the last bytes of the input belong to the EOF-exact reader
-    d.w.seek(fo, lane);
-    d.bb = 0; d.bl = 0; d.rbl = 0; d.near_end = false; d.careful = false; d.err = 0;
-    if (first) {                                                // the interval's (stream's) 1 + 32 header bits, lzxd.c:447-453
-      u32 v, hi, lo;
-      if (!d.read_bits(1, v)) continue;
-      if (v) { if (!d.read_bits(16, hi) || !d.read_bits(16, lo)) continue; }
-    }
-    const u32 hdr_start = fo * 8u + d.cons_bits();
-    s.block_type = 0;
-    if (!lzx_block_header(d, s, false)) continue;
-    if (d.careful || d.near_end) continue;
-    u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
-    if ((s.block_type != 1u && s.block_type != 2u) || s.block_length != fsz) continue;   // one block per frame, or no guess
-    LzxFrameRec *rec = &recs[u.frame_base + f];
-    for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) rec->main_len[i] = sh->main_len[i];
-    for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) rec->len_len[i] = sh->len_len[i];
-    if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
-    if (lane == 0) {
-      rec->n_tokens = 0; rec->hdr_start_bit = hdr_start; rec->end_bit = fo * 8u + d.cons_bits();   // = first token
-      rec->block_type = s.block_type; rec->block_length = s.block_length;
-      rec->flags = (sh->main_len[0xE8] != 0 ? 2u : 0u);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      rec->status = 2u;                                         // header known; tokens not parsed yet
-    }
-    chain = true;
-  }
-}
-
-// one PARSE wave: the tokens of frame f of unit u, from the state the header wave left in the record
-__device__ void lzx_parse_frame(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, LzxFrameRec *rec,
-                                uint2 *tok, LzxShared *sh)
-{
-  const u32 lane = threadIdx.x;
-  if (rfl(rec->status) != 2u) return;
-  LzxDec d;
-  LzxState s;
-  if (!lzx_side_setup(d, s, u, in_arena, sh)) return;
-  for (u32 i = lane; i < LZX_MAIN_SYMS + 16; i += WAVE) sh->main_len[i] = rec->main_len[i];
-  for (u32 i = lane; i < LZX_LEN_SYMS + 70; i += WAVE) sh->len_len[i] = rec->len_len[i];
-  if (lane < 8u) sh->ali_len[lane] = rec->ali_len[lane];
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  s.block_type = rfl(rec->block_type);
-  if (huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
-                                                   sh->cnt, d.hr_main, lane, false)) return;
-  const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, lane, false);
-  if (r == 1) return;
-  s.length_empty = (r == 2);
-  if (s.block_type == 2u && huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false)) return;
-  const u32 start_bit = rfl(rec->end_bit);
-  {                                                             // continue reading at the first token
-    const u32 wbyte = (start_bit >> 4) << 1, sk = start_bit - wbyte * 8u;
-    d.w.seek(wbyte, lane);
-    d.refill(); d.refill();
-    if (sk) { d.bb <<= sk; d.bl -= (int) sk; }
-  }
-  u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
-  u32 n_tok = 0, end_bit = 0;
-#if defined(LZX_PARSE_ONLY) && !defined(LZX_PARSE_ROUNDS64)
-  {
-    // where the frame table says the frame ends (a hint: a wrong one costs time, not correctness)
-    const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
-    const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
-    u32 fe = (f + 1u < nreal) ? rfl(ftab[f + 1u]) : u.in_len;
-    if (fe > u.in_len || fe * 8u <= start_bit) fe = u.in_len;
-    (void) fsz;
-    if (s.block_type == 2u) lzx_parse_lanes<true>(d, s.length_empty, start_bit, fe * 8u, tok, n_tok, end_bit);
-    else lzx_parse_lanes<false>(d, s.length_empty, start_bit, fe * 8u, tok, n_tok, end_bit);
-  }
-#else
-  if (s.block_type == 2u) lzx_parse_tokens<true>(d, s.length_empty, fsz, tok, n_tok, end_bit);
-  else lzx_parse_tokens<false>(d, s.length_empty, fsz, tok, n_tok, end_bit);
-#endif
-  if (lane == 0) {
-    rec->n_tokens = n_tok; rec->end_bit = end_bit;
-    rec->flags = rec->flags | (s.length_empty ? 1u : 0u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    rec->status = 1u;
-  }
-}
-
 #ifdef LZX_PARSE_ONLY
 // ---------------------------------------------------------------------------------------------------
 // mspack_lzx_pipe's PARSE task: header + tokens of frame f of unit u, by one wave.
 // The block headers of a reset interval are a chain (code lengths are deltas on the previous block's,
 // lzxd.c:138-183): the wave takes the previous frame's lengths from that frame's record as soon as its parse wave
 // has published them (status HEADER or later), reads its own header at the position the frame table states, publishes
-// its lengths, and only then parses its tokens (lzx_parse_lanes) -- so the chain costs one header per link, not one
-// frame.  Same guesses and same give-up rules as lzx_walk_headers + lzx_parse_frame; the unit's own wave stays the judge.
+// its lengths, and only then parses its tokens (lzx_parse_emit) -- so the chain costs one header per link, not one
+// frame.  It works on guesses (one block per frame, at the table's position) and gives up silently; the serial path stays the judge.
 // Waiting is safe: the task it waits for has an earlier ticket (shim.hip), i.e. a live wave is working on it.
 // ---------------------------------------------------------------------------------------------------
 __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, u8 *out_arena, LzxFrameRec *urecs,
@@ -2519,7 +2189,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
   PH(0);
-  // ---- the header the frame table points at (cf. lzx_walk_headers) ----
+  // ---- the header the frame table points at ----
   const u32 fo = rfl(ftab[f]);
   bool ok = !(fo >= u.in_len || u.in_len - fo <= 64u);         // the last bytes of the input belong to the EOF-exact reader
   u32 hdr_start = 0, intel = 0;
@@ -2622,78 +2292,6 @@ __device__ __forceinline__ void lzx_restore_tables(LzxDec &d, LzxState &s)
   const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, d.lane, false);
   s.length_empty = (r == 2);
   if (s.block_type == 2u) huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, d.lane, false);
-}
-
-// commit a frame's pre-parsed tokens; next_bit = where the stream goes on
-__device__ __forceinline__ int lzx_run_tokens(LzxDec &d, LzxState &s, const u32 run_end_, const u32 wbase_,
-                                              const uint2 *tok, const u32 n_tok_, const u32 end_bit_, u32 &next_bit)
-{
-  LzxShared *sh = d.sh;
-  const u32 lane = d.lane;
-  u8 *const out = d.out;
-  const u32 n_tok = rfl(n_tok_), end_bit = rfl(end_bit_);
-  LzxCommit C;
-  C.run_end = rfl(run_end_); C.wbase = rfl(wbase_);
-  C.P = rfl(d.P);
-  C.R0 = rfl(s.R0); C.R1 = rfl(s.R1); C.R2 = rfl(s.R2);
-  C.wsize = rfl(s.wsize); C.offset_written = rfl(s.offset); C.ref_size = 0;
-  int rc = LZX_RUN_DONE;
-  d.flush_lits();
-  spq_init(sh->spq, C.Q, C.P, lane);
-  u32 th = 0;
-  // Tokens come from memory four batches (256 tokens) at a time: the next four loads are issued before the current
-  // four batches are committed, and the registers change hands once per four batches -- a load is only waited for
-  // long after it was issued.  (Handing a single batch's register on every iteration waits for the load that
-  // iteration issued: the whole memory latency, every batch.)
-  uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
-  if (lane < n_tok) cur0 = tok[lane];
-  if (64u + lane < n_tok) cur1 = tok[64u + lane];
-  if (128u + lane < n_tok) cur2 = tok[128u + lane];
-  if (192u + lane < n_tok) cur3 = tok[192u + lane];
-  bool done = false;
-  while (!done && C.P < C.run_end && th < n_tok) {
-    uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
-    const u32 tb = th + 256u + lane;
-    if (tb < n_tok) nx0 = tok[tb];
-    if (tb + 64u < n_tok) nx1 = tok[tb + 64u];
-    if (tb + 128u < n_tok) nx2 = tok[tb + 128u];
-    if (tb + 192u < n_tok) nx3 = tok[tb + 192u];
-#pragma unroll 1
-    for (u32 k = 0; k < 4u; k++) {
-      if (!(C.P < C.run_end && th < n_tok)) { done = true; break; }
-      u32 n = n_tok - th; if (n > 64u) n = 64u;
-      const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
-      u32 marker; bool fail_after;
-#ifdef LZX_PHASE_TIMERS
-      u64 pt_ = __builtin_amdgcn_s_memtime();
-#endif
-      const u32 took = lzx_commit_batch(d, C, cur.x, cur.y, n, marker, fail_after);
-      th += took;
-#ifdef LZX_PHASE_TIMERS
-      { const u64 n_ = __builtin_amdgcn_s_memtime(); d.st_t[0] += (u32)(n_ - pt_); pt_ = n_; d.st_t[2]++; }
-#endif
-#ifndef LZX_EXP_NOCOPY
-      if (spq_due(C.Q, C.P)) spq_resolve(sh->spq, C.Q, out, C.P, false, lane);
-#endif
-#ifdef LZX_PHASE_TIMERS
-      d.st_t[1] += (u32)(__builtin_amdgcn_s_memtime() - pt_);
-#endif
-      if (fail_after) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; done = true; break; }
-      if (took < n) { done = true; break; }                           // the run ended inside this batch
-    }
-    cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
-  }
-#ifndef LZX_EXP_NOCOPY
-  spq_resolve(sh->spq, C.Q, out, C.P, true, lane);
-#endif
-  next_bit = end_bit;
-  if (th < n_tok) {                                                   // parsed beyond the run: back to the first such token
-    const u32 s20 = rfl(tok[th].x) >> 12;                             // (records carry the low 20 bits of their start)
-    next_bit = end_bit - ((end_bit - s20) & 0xFFFFFu);
-  }
-  d.P = C.P;
-  s.R0 = C.R0; s.R1 = C.R1; s.R2 = C.R2;
-  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2980,7 +2578,7 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
 __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
                                 int32_t *frame_meta, mspack_hip_result *res, LzxShared *sh)
 #else
-// recs / toks: the parse waves' records and tokens for this launch (NULL: none), indexed by frame slot
+// recs: the pipe's frame records for this launch (NULL: none), indexed by frame slot; toks: its record pool (not read here)
 // resume: the launch ran mspack_lzx_pipe first -- the unit's first record says how far its commit task got (rs_*: so many
 // complete frames, possibly part of the next one).  Those frames are not decoded again: only their bookkeeping (interval
 // header, E8 decision, offsets, in_next) is replayed from their records, and decoding goes on serially where the pipe stopped
@@ -3044,7 +2642,6 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
 
 #ifndef LZX_DELTA
   const bool use_recs = recs != nullptr && (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u;
-  bool chain_ok = use_recs;                 // every frame since the last reset point was adopted
   const LzxFrameRec *stale = nullptr;       // adopted record whose code lengths / tables are not in LDS (yet)
   bool stale_tables = false;
   // where mspack_lzx_pipe's commit task stopped (resume): rs_frame complete frames, then possibly part of frame rs_frame
@@ -3066,7 +2663,7 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
         // a reset in raw mode keeps reading bits from raw_pos (no pad byte: block_type is cleared)
         lzx_reset_state(d, s);
 #ifndef LZX_DELTA
-        chain_ok = use_recs; stale = nullptr; stale_tables = false;
+        stale = nullptr; stale_tables = false;
 #endif
       }
 #ifndef LZX_DELTA
@@ -3124,8 +2721,6 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
         ff_end = (rfl(frec->end_bit) + 15u) & ~15u;                  // behind the 16-bit realignment (lzxd.c:695-697)
         todo = 0;
       }
-      // ---- a parse wave's record for this frame?  adopt it if it was parsed from exactly this state ----
-      const LzxFrameRec *adopt = nullptr;
       if (pf) {
         s.block_type = rfl(frec->block_type);
         s.block_length = s.block_remaining = rfl(frec->block_length);
@@ -3134,24 +2729,8 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
         if (rfl_ & 2u) s.intel_started = true;
         stale = frec; stale_tables = true;
         flags |= MSPACK_HIP_F_FRAMES_ADOPTED;
-        rs_inject = true; rs_on = false; chain_ok = false;
+        rs_inject = true; rs_on = false;
       }
-      else if (chain_ok && todo > 0 && s.block_remaining == 0u && !s.raw_mode && !d.careful && !d.near_end) {
-        const LzxFrameRec *r = &recs[u.frame_base + s.frame];
-        const u32 st = rfl(r->status);
-        if (st == LZX_ST_PARSED && rfl(r->hdr_start_bit) == rfl(d.w.origin) * 8u + rfl(d.cons_bits()) &&
-            rfl(r->block_length) == frame_size) adopt = r;
-      }
-      if (adopt) {
-        s.block_type = rfl(adopt->block_type);
-        s.block_length = s.block_remaining = rfl(adopt->block_length);
-        const u32 rfl_ = rfl(adopt->flags);
-        s.length_empty = (rfl_ & 1u) != 0u;
-        if (rfl_ & 2u) s.intel_started = true;
-        stale = adopt; stale_tables = true;
-        flags |= MSPACK_HIP_F_FRAMES_ADOPTED;
-      }
-      else chain_ok = false;
 #endif
       while (todo > 0) {
 #ifdef LZX_EXP_STATS
@@ -3175,21 +2754,7 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
           const u32 wbase = d.P - s.wpos;          // linear position of window index 0
           bool respec = true;                      // try the speculative path (again)
 #ifndef LZX_DELTA
-          if (adopt) {
-            u32 next_bit;
-#ifdef LZX_PHASE_TIMERS
-            const u64 rt_ = __builtin_amdgcn_s_memtime();
-#endif
-            const int rc = lzx_run_tokens(d, s, run_end, wbase, toks + (size_t)(u.frame_base + s.frame) * LZX_TOK_CAP,
-                                          adopt->n_tokens, adopt->end_bit, next_bit);
-#ifdef LZX_PHASE_TIMERS
-            d.st_t[3] += (u32)(__builtin_amdgcn_s_memtime() - rt_); d.st_t[4] += rfl(adopt->n_tokens);
-#endif
-            adopt = nullptr;
-            if (rc == LZX_RUN_FAIL) { fail = true; }
-            else lzx_seek_bit(d, next_bit);
-          }
-          else if (rs_inject) {
+          if (rs_inject) {
             // the pipe committed this frame's records up to rs_P: go on from the bit behind the last of them
             rs_inject = false; positioned = true;
             d.flush_lits();
