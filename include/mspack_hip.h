@@ -74,6 +74,11 @@ extern "C" {
                                            sys->message, mszipd.c:427).  e8_base = capacity N of a log the unit owns in the output
                                            arena at out_off + ((out_len + 32768 + 15) & ~15): uint32 count of repaired blocks
                                            (all of them, also beyond N), then N pairs (output offset of the block, bytes lost) */
+#define MSPACK_HIP_UF_LZX_LOG      32u  /* MSPACK_HIP_KIND_LZX with reset_frames != 0: report the reset points that found a block still
+                                           open -- where the reference says "WARNING; invalid reset interval detected during LZX
+                                           decompression" (lzxd.c:423-431).  ref_len = capacity N of a log the unit owns in the
+                                           output arena at out_off + ((out_len + 32768 + 15) & ~15): uint32 count (all of them,
+                                           also beyond N), then N frame indices (counted from the unit's first frame) */
 #define MSPACK_HIP_UF_HARD_EOF      2u  /* the feeder's read FAILED at in_len (sys->read < 0, e.g. a bad
                                            CFDATA block, cabd.c:1322-1324): ERR_READ at once, without the
                                            two fabricated zero bytes of a clean EOF (readbits.h:194-208) */
@@ -91,7 +96,8 @@ typedef struct mspack_hip_unit {
   uint16_t reset_frames; /* LZX: lzxd_init reset_interval in 32 KiB frames (0 = never, CAB)        */
   uint32_t flags;        /* MSPACK_HIP_UF_*                                                        */
   uint32_t ref_len;      /* LZX DELTA: bytes of reference data (lzxd_set_reference_data, lzxd.c:348-382)
-                            that the caller placed in the output arena at [out_off - ref_len, out_off) */
+                            that the caller placed in the output arena at [out_off - ref_len, out_off);
+                            LZX with MSPACK_HIP_UF_LZX_LOG: capacity of the unit's log */
   uint32_t in_chunk;     /* MSZIP repair mode: input_buffer_size of mszipd_init (mszipd.c:338-375), i.e.
                             the chunking of the folder stream by the reference's feeder; where the
                             next block is looked for after a failed one depends on it (mszipd.c:404,

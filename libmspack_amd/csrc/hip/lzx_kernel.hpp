@@ -2629,7 +2629,12 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
 #endif
   }
   if (s.num_offsets == 0u) {
-    if (lane == 0) { res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->in_next = 0; }
+    if (lane == 0) {
+      res->err = ERR_ARGS; res->flags = 0; res->out_len = 0; res->in_used = 0; res->good_len = 0; res->in_next = 0;
+#ifndef LZX_DELTA
+      if (u.flags & MSPACK_HIP_UF_LZX_LOG) *(u32 *)(out_arena + u.out_off + (((size_t) u.out_len + LZX_FRAME + 15u) & ~(size_t) 15u)) = 0u;
+#endif
+    }
     return;
   }
   lzx_reset_state(d, s);
@@ -2656,10 +2661,22 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
     }
   }
 #endif
+#ifndef LZX_DELTA
+  u32 *const olog = (u32 *)(out_arena + u.out_off + (((size_t) u.out_len + LZX_FRAME + 15u) & ~(size_t) 15u));
+  u32 n_open_resets = 0;
+#endif
   if (out_bytes != 0u) {
     const u32 end_frame = out_bytes / LZX_FRAME + 1u;                      // lzxd.c:419
     while (s.frame < end_frame) {
       if (s.reset_frames && (s.frame % s.reset_frames) == 0u) {
+#ifndef LZX_DELTA
+        // a block that is still open at a reset point: a format error the reference warns about and decodes through
+        // (lzxd.c:423-431); MSPACK_HIP_UF_LZX_LOG: the frame goes into the unit's log for the driver's sys->message
+        if (s.block_remaining != 0u && (u.flags & MSPACK_HIP_UF_LZX_LOG) != 0u) {
+          if (d.lane == 0 && n_open_resets < u.ref_len) olog[1u + n_open_resets] = s.frame;
+          n_open_resets++;
+        }
+#endif
         // a reset in raw mode keeps reading bits from raw_pos (no pad byte: block_type is cleared)
         lzx_reset_state(d, s);
 #ifndef LZX_DELTA
@@ -2928,6 +2945,9 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
   if (err == 0 && remaining) err = ERR_DECRUNCH;                                  // lzxd.c:758-761
   if (err == ERR_READ && remaining == 0u) flags |= MSPACK_HIP_F_LOOKAHEAD_READ;
   if (lane == 0) {
+#ifndef LZX_DELTA
+    if (u.flags & MSPACK_HIP_UF_LZX_LOG) olog[0] = n_open_resets;
+#endif
     res->err = err; res->flags = flags; res->out_len = s.offset; res->good_len = s.offset; res->in_next = in_next;
     res->in_used = s.raw_mode ? s.raw_pos : d.iptr();
 #ifdef LZX_EXP_CNT

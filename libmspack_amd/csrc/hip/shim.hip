@@ -704,6 +704,8 @@ static inline uint64_t unit_below(const mspack_hip_unit &u) {
        : (u.kind == MSPACK_HIP_KIND_LZX_DELTA ? u.ref_len : 0u);
 }
 static inline uint64_t unit_above(const mspack_hip_unit &u) {
+  if (u.kind == MSPACK_HIP_KIND_LZX && (u.flags & MSPACK_HIP_UF_LZX_LOG))                   // the reset log, where MSZIP's would be
+    return ((((uint64_t) u.out_len + 32768u + 15u) & ~15ull) - u.out_len) + 4u + 4u * (uint64_t) u.ref_len;
   if (u.kind != MSPACK_HIP_KIND_MSZIP) return 0u;
   uint64_t a = 32768u;
   if ((u.flags & MSPACK_HIP_UF_MSZIP_REPAIR) && (u.flags & MSPACK_HIP_UF_MSZIP_LOG))      // the repair log behind the slack
@@ -754,7 +756,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
   for (size_t i = 0; i < n_sel; i++) {
     mspack_hip_unit &u = local[i];
     u = units[idx[i]];
-    if (u.kind != MSPACK_HIP_KIND_LZX_DELTA) u.ref_len = 0;
+    if (u.kind != MSPACK_HIP_KIND_LZX_DELTA && !(u.kind == MSPACK_HIP_KIND_LZX && (u.flags & MSPACK_HIP_UF_LZX_LOG))) u.ref_len = 0;
     if (u.kind > 6) { snprintf(errbuf, errcap, "unit %u: unknown kind %u", idx[i], u.kind); return -1; }
     // kind 0 = "no codec": the unit is carried along, no kernel takes it, its result says MSPACK_ERR_ARGS
     const uint64_t below = unit_below(u);
@@ -955,7 +957,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
                          hipMemcpyHostToDevice, st_in));
       if (host_out)
         for (size_t i = c.a; i < c.b; i++)               // LZX DELTA reference data sits below the unit's output
-          if (local[i].ref_len)
+          if (local[i].ref_len && local[i].kind == MSPACK_HIP_KIND_LZX_DELTA)
             TRY(hipMemcpyAsync(d_out + local[i].out_off - local[i].ref_len,
                                (const char *) host_out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
                                hipMemcpyHostToDevice, st_in));
@@ -976,7 +978,8 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
                            hipMemcpyDeviceToHost, st_out));
       else
         for (size_t i = c.a; i < c.b; i++)
-          TRY(hipMemcpyAsync((char *) host_out + out_lo + local[i].out_off, d_out + local[i].out_off, local[i].out_len,
+          TRY(hipMemcpyAsync((char *) host_out + out_lo + local[i].out_off, d_out + local[i].out_off,
+                             (size_t) local[i].out_len + ((local[i].flags & (MSPACK_HIP_UF_MSZIP_LOG | MSPACK_HIP_UF_LZX_LOG)) ? (size_t) unit_above(local[i]) : 0u),   // (a unit's log lies behind its slack)
                              hipMemcpyDeviceToHost, st_out));
     }
     if (host_out && !one && !back_started) {

@@ -75,6 +75,7 @@ struct blk_reader {
   struct mspack_file *fh;
   unsigned int block;                 /* blocks started                                            */
   unsigned char *input;               /* one (possibly reassembled) block                          */
+  int borrowed;                       /* `input` is the caller's (gather: a place in the input arena), not reader_open's */
   unsigned int i_ptr, i_end;
 };
 struct cabd_p {
@@ -148,6 +149,8 @@ static int read_files(struct mspack_system *sys, struct mspack_file *fh, struct 
                       int num_folders, int num_files, int salvage)
 {
   struct mscabd_file *tail = NULL;
+  struct mscabd_folder *cur = NULL;
+  unsigned int cur_idx = 0;
   unsigned char buf[16];
   int i, err;
   for (i = 0; i < num_files; i++) {
@@ -163,9 +166,10 @@ static int read_files(struct mspack_system *sys, struct mspack_file *fh, struct 
     f->folder = NULL;
     if (fidx < 0xFFFD) {
       if ((int) fidx < num_folders) {
-        struct mscabd_folder *fo = cab->base.folders;
-        while (fidx-- && fo) fo = fo->next;
-        f->folder = fo;
+        /* (files come sorted by folder: walk on from the previous file's folder, not from the head of the list) */
+        if (!cur || fidx < cur_idx) { cur = cab->base.folders; cur_idx = 0; }
+        while (cur_idx < fidx && cur) { cur = cur->next; cur_idx++; }
+        f->folder = cur;
       }
     }
     else {
@@ -540,16 +544,16 @@ static int cabd_prepend(struct mscab_decompressor *base, struct mscabd_cabinet *
 
 static void reader_close(struct cabd_p *self, struct blk_reader *r) {
   if (r->fh) self->system->close(r->fh);
-  self->system->free(r->input);
+  if (!r->borrowed) self->system->free(r->input);
   memset(r, 0, sizeof(*r));
 }
 
 /* start reading a folder's blocks: MSPACK_ERR_OPEN / SEEK / NOMEMORY as extract() reports them */
-static int reader_open(struct cabd_p *self, struct blk_reader *r, struct folder_p *fol) {
+static int reader_open(struct cabd_p *self, struct blk_reader *r, struct folder_p *fol, int borrowed) {
   struct mspack_system *sys = self->system;
   memset(r, 0, sizeof(*r));
-  r->folder = fol; r->seg = &fol->data;
-  if (!(r->input = (unsigned char *) sys->alloc(sys, CAB_INPUTBUF))) return MSPACK_ERR_NOMEMORY;
+  r->folder = fol; r->seg = &fol->data; r->borrowed = borrowed;
+  if (!borrowed && !(r->input = (unsigned char *) sys->alloc(sys, CAB_INPUTBUF))) return MSPACK_ERR_NOMEMORY;
   if (!(r->fh = sys->open(sys, r->seg->cab->base.filename, MSPACK_SYS_OPEN_READ))) { reader_close(self, r); return MSPACK_ERR_OPEN; }
   if (sys->seek(r->fh, r->seg->offset, MSPACK_SYS_SEEK_START)) { reader_close(self, r); return MSPACK_ERR_SEEK; }
   return MSPACK_ERR_OK;
@@ -645,7 +649,7 @@ static int stored_extract(struct cabd_p *self, struct folder_p *fol, struct msca
   if (!self->st_active || self->st.folder != fol || self->st_offset > file->offset) {
     int err;
     stored_reset(self);
-    if ((err = reader_open(self, &self->st, fol))) return self->error = err;
+    if ((err = reader_open(self, &self->st, fol, 0))) return self->error = err;
     self->st_active = 1; self->st_offset = 0;
     self->read_error = MSPACK_ERR_OK;                     /* lasts for the lifetime of a decompressor */
   }
@@ -669,20 +673,40 @@ static int stored_extract(struct cabd_p *self, struct folder_p *fol, struct msca
 }
 
 /* ---- gather + batch decode ------------------------------------------------------------------------------ */
+/* the batch's input arena: the folders' CFDATA payloads are READ straight into it, one folder behind the other (no buffer
+ * per folder, no second copy); it grows by doubling */
+struct in_arena { unsigned char *p; size_t len, cap; };
+
+static int arena_room(struct mspack_system *sys, struct in_arena *a, size_t need)
+{
+  size_t ncap;
+  unsigned char *n;
+  if (a->len + need <= a->cap) return 1;
+  ncap = a->cap * 2;
+  if (ncap < a->len + need) ncap = a->len + need;
+  if (!(n = (unsigned char *) mspack_arena_alloc(sys, ncap))) return 0;
+  if (a->len) sys->copy(a->p, n, a->len);
+  sys->free(a->p);
+  a->p = n; a->cap = ncap;
+  return 1;
+}
+
 struct gathered {
   struct folder_p *fol;
-  unsigned char *stream; size_t len, cap;      /* codec input: payloads (+0xFF per block for Quantum) */
+  size_t in_off, len;                           /* codec input in the arena: payloads (+0xFF per block for Quantum), then 64
+                                                   zero bytes */
+  size_t tab_off;                               /* frames_ok: the frame table (uint32 per block) in the arena */
   unsigned int total;                           /* sum of uncompressed sizes of the blocks read     */
   int read_err; int hard_eof;
-  uint32_t *boff; unsigned int nblk;            /* where every block's payload starts in `stream`; frames_ok: every
+  uint32_t *boff; unsigned int nblk;            /* where every block's payload starts in the stream; frames_ok: every
                                                    block but the last holds exactly one 32 KiB frame  */
   int frames_ok;
 };
 
 /* walk the CFDATA chain of one folder (reference cabd.c:1283-1345 + 1362-1459), following it through
- * the cabinets of a set.  Returns MSPACK_ERR_OPEN / SEEK / NOMEMORY when nothing could be started;
- * every later failure ends the chain and is recorded as the feeder's error (g->read_err, g->hard_eof). */
-static int gather_folder(struct cabd_p *self, struct gathered *g)
+ * the cabinets of a set.  Returns MSPACK_ERR_OPEN / SEEK / NOMEMORY when nothing could be started (the arena is as it
+ * was); every later failure ends the chain and is recorded as the feeder's error (g->read_err, g->hard_eof). */
+static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_arena *A)
 {
   struct mspack_system *sys = self->system;
   struct folder_p *fol = g->fol;
@@ -690,29 +714,30 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
   const int method = fol->base.comp_type & 0x0F;
   const int ignore_cksum = self->salvage || (self->fix_mszip && method == MSCAB_COMP_MSZIP);
   const int ignore_size = self->salvage;
+  const size_t len0 = A->len;
   int err;
   g->len = 0; g->total = 0; g->read_err = MSPACK_ERR_OK; g->hard_eof = 0;
-  g->cap = (size_t) fol->base.num_blocks * 1024 + 65536;
-  g->stream = NULL;
-  g->nblk = 0; g->frames_ok = 1;
+  g->nblk = 0; g->frames_ok = 1; g->tab_off = 0;
+  if (!arena_room(sys, A, 16 + 64 + 32)) return MSPACK_ERR_NOMEMORY;
+  while (A->len & 15) A->p[A->len++] = 0;
+  g->in_off = A->len;
   g->boff = (method == MSCAB_COMP_LZX || method == MSCAB_COMP_MSZIP)
           ? (uint32_t *) sys->alloc(sys, ((size_t) fol->base.num_blocks + 1) * sizeof(uint32_t)) : NULL;
-  if ((err = reader_open(self, &r, fol))) {
-    if (err != MSPACK_ERR_SEEK) { if (g->boff) { sys->free(g->boff); g->boff = NULL; } return err; }
+  if ((err = reader_open(self, &r, fol, 1))) {
+    if (err != MSPACK_ERR_SEEK) { sys->free(g->boff); g->boff = NULL; A->len = len0; return err; }
     /* the reference fails extract() with SEEK before any decoding; keep it as this folder's error */
-    if (!(g->stream = (unsigned char *) sys->alloc(sys, 64))) { if (g->boff) { sys->free(g->boff); g->boff = NULL; } return MSPACK_ERR_NOMEMORY; }
-    memset(g->stream, 0, 64);
-    g->read_err = MSPACK_ERR_SEEK; g->hard_eof = 1;
+    memset(A->p + A->len, 0, 64); A->len += 64;
+    g->read_err = MSPACK_ERR_SEEK; g->hard_eof = 1; g->frames_ok = 0;
     return MSPACK_ERR_OK;
-  }
-  if (!(g->stream = (unsigned char *) sys->alloc(sys, g->cap + 64))) {
-    reader_close(self, &r); if (g->boff) { sys->free(g->boff); g->boff = NULL; } return MSPACK_ERR_NOMEMORY;
   }
   r.quiet_cksum = self->fix_mszip && method == MSCAB_COMP_MSZIP && g->boff != NULL;
   while (r.block < fol->base.num_blocks) {
     unsigned int ulen = 0;
     r.block++;
     r.bad_cksum = 0;
+    /* (a block, reassembled from the cabinets of a set or not, is at most CAB_INPUTBUF bytes: reader_block) */
+    if (!arena_room(sys, A, (size_t) CAB_INPUTBUF + 1 + 64 + 16)) { reader_close(self, &r); sys->free(g->boff); g->boff = NULL; A->len = len0; return MSPACK_ERR_NOMEMORY; }
+    r.input = A->p + A->len;
     if ((err = reader_block(self, &r, &ulen, ignore_cksum, ignore_size))) { g->read_err = err; g->hard_eof = 1; break; }
     if (r.bad_cksum) {
       /* said when the reference would say it (cabd_extract): remember the block */
@@ -723,22 +748,16 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
         fol->rep_ck[fol->ck_n++] = g->nblk;               /* (block index for now: turned into an output offset below) */
       }
     }
-    if (g->len + r.i_end + 1 > g->cap) {
-      size_t ncap = (g->cap + r.i_end + 1) * 2;
-      unsigned char *n = (unsigned char *) sys->alloc(sys, ncap + 64);
-      if (!n) { sys->free(g->stream); g->stream = NULL; if (g->boff) { sys->free(g->boff); g->boff = NULL; } reader_close(self, &r); return MSPACK_ERR_NOMEMORY; }
-      sys->copy(g->stream, n, g->len); sys->free(g->stream); g->stream = n; g->cap = ncap;
-    }
     if (g->boff) {
       if (g->total % CAB_BLOCKMAX) g->frames_ok = 0;          /* an earlier block was not a whole frame */
-      g->boff[g->nblk++] = (uint32_t) g->len;
+      g->boff[g->nblk++] = (uint32_t)(A->len - g->in_off);
     }
-    sys->copy(r.input, g->stream + g->len, r.i_end);
-    g->len += r.i_end;
-    if (method == MSCAB_COMP_QUANTUM) g->stream[g->len++] = 0xFF;
+    A->len += r.i_end;
+    if (method == MSCAB_COMP_QUANTUM) A->p[A->len++] = 0xFF;
     g->total += ulen;
   }
   reader_close(self, &r);
+  g->len = A->len - g->in_off;
   if (fol->ck_n && g->boff) {
     /* block i is read when the codec's refill reaches the input chunk it starts in; that refill happens while the block
      * that holds the chunk's first byte is being decoded (every block but the last decodes to 32 KiB) */
@@ -759,7 +778,19 @@ static int gather_folder(struct cabd_p *self, struct gathered *g)
     size_t q = (size_t)((self->buf_size + 1) & ~1);
     g->len -= g->len % q;
   }
-  memset(g->stream + g->len, 0, 64);
+  A->len = g->in_off + g->len;
+  memset(A->p + A->len, 0, 64 + 16); A->len += 64;           /* (room for both: arena_room above / at the top) */
+  /* LZX: every CFDATA block is one frame (cabd.c:1362-1479); MSZIP: every block is a deflate stream of its own
+   * (mszipd.c:406-418).  The block sizes are the folder's frame table: the blocks' tokens are parsed by one
+   * wavefront each (MSPACK_HIP_UF_FRAME_TABLE) before the folder's wavefront commits them */
+  g->frames_ok = g->frames_ok && g->boff && !g->hard_eof &&
+                 (method == MSCAB_COMP_LZX || (method == MSCAB_COMP_MSZIP && !self->fix_mszip)) &&
+                 g->nblk >= 2 && (size_t) g->nblk * CAB_BLOCKMAX >= g->total;
+  if (g->frames_ok) {
+    A->len = (A->len + 3) & ~(size_t) 3;
+    if (!arena_room(sys, A, (size_t) g->nblk * 4 + 16)) g->frames_ok = 0;       /* (decodes without the table) */
+    else { g->tab_off = A->len; memcpy(A->p + A->len, g->boff, (size_t) g->nblk * 4); A->len += (size_t) g->nblk * 4; }
+  }
   return MSPACK_ERR_OK;
 }
 
@@ -771,15 +802,22 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   struct gathered *gs;
   mspack_hip_unit *units;
   mspack_hip_result *res;
-  unsigned char *in_arena = NULL, *out_arena = NULL;
-  size_t n = 0, k, in_bytes = 0, out_bytes = 0, budget = (size_t) self->cache_mb << 20, used = 0;
+  struct in_arena A = { NULL, 0, 0 };
+  unsigned char *out_arena = NULL;
+  size_t n = 0, k, out_bytes = 0, budget = (size_t) self->cache_mb << 20, used = 0;
   int err = MSPACK_ERR_OK, rc;
 
   for (fo = cab->base.folders; fo; fo = fo->next) n++;
   gs = (struct gathered *) sys->alloc(sys, n * sizeof(*gs));
   units = (mspack_hip_unit *) sys->alloc(sys, n * sizeof(*units));
   res = (mspack_hip_result *) sys->alloc(sys, n * sizeof(*res));
-  if (!gs || !units || !res) { sys->free(gs); sys->free(units); sys->free(res); return MSPACK_ERR_NOMEMORY; }
+  /* (first guess for the arena: the cabinet's stated length, within reason -- it grows when that was wrong or the folders
+   *  go on in other cabinets) */
+  A.cap = (size_t) cab->base.length;
+  if (A.cap > ((size_t) 256 << 20)) A.cap = (size_t) 256 << 20;
+  A.cap += n * 96 + 65536;
+  A.p = (unsigned char *) mspack_arena_alloc(sys, A.cap);
+  if (!gs || !units || !res || !A.p) { sys->free(gs); sys->free(units); sys->free(res); sys->free(A.p); return MSPACK_ERR_NOMEMORY; }
   n = 0;
   for (fo = cab->base.folders; fo; fo = fo->next) {
     struct folder_p *fp = (struct folder_p *) fo;
@@ -788,33 +826,23 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     if ((fo->comp_type & 0x0F) == MSCAB_COMP_NONE || fp->merge_prev) continue;   /* streamed / not extractable */
     if (fp != want && used + est > budget) continue;
     gs[n].fol = fp;
-    err = gather_folder(self, &gs[n]);
+    err = gather_folder(self, &gs[n], &A);
     if (err == MSPACK_ERR_OPEN && fp != want) { err = MSPACK_ERR_OK; continue; }   /* that folder stays undecoded */
     if (err) break;
     used += est;
     n++;
   }
-  if (err) { for (k = 0; k < n; k++) { sys->free(gs[k].stream); sys->free(gs[k].boff); } sys->free(gs); sys->free(units); sys->free(res); return err; }
+  if (!err && !arena_room(sys, &A, 64)) err = MSPACK_ERR_NOMEMORY;
+  if (err) { for (k = 0; k < n; k++) sys->free(gs[k].boff); sys->free(gs); sys->free(units); sys->free(res); sys->free(A.p); return err; }
+  memset(A.p + A.len, 0, 64);
 
-  /* lay the units out in two arenas */
+  /* the units: where gather_folder put their input, one stretch of the output arena each */
   memset(units, 0, n * sizeof(*units));
   for (k = 0; k < n; k++) {
     struct folder_p *fp = gs[k].fol;
     int method = fp->base.comp_type & 0x0F;
-    in_bytes = (in_bytes + 15) & ~(size_t) 15;
-    units[k].in_off = in_bytes; units[k].in_len = (uint32_t) gs[k].len;
-    in_bytes += gs[k].len;
-    /* LZX: every CFDATA block is one frame (cabd.c:1362-1479); MSZIP: every block is a deflate stream of its own
-     * (mszipd.c:406-418).  The block sizes are the folder's frame table: the blocks' tokens are parsed by one
-     * wavefront each (MSPACK_HIP_UF_FRAME_TABLE) before the folder's wavefront commits them */
-    gs[k].frames_ok = gs[k].frames_ok && gs[k].boff && !gs[k].hard_eof &&
-                      (method == MSCAB_COMP_LZX || (method == MSCAB_COMP_MSZIP && !self->fix_mszip)) &&
-                      gs[k].nblk >= 2 && (size_t) gs[k].nblk * CAB_BLOCKMAX >= gs[k].total;
-    if (gs[k].frames_ok) {
-      in_bytes = (in_bytes + 64 + 3) & ~(size_t) 3;          /* (zero bytes behind the stream, as before) */
-      units[k].in_chunk = (uint32_t)(in_bytes / 4);
-      in_bytes += (size_t) gs[k].nblk * 4;
-    }
+    units[k].in_off = gs[k].in_off; units[k].in_len = (uint32_t) gs[k].len;
+    if (gs[k].frames_ok) units[k].in_chunk = (uint32_t)(gs[k].tab_off / 4);
     units[k].out_off = out_bytes; units[k].out_len = gs[k].total;
     out_bytes += ((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15;
     if (self->fix_mszip && method == MSCAB_COMP_MSZIP) {        /* the repair log behind the unit's slack (mspack_hip.h) */
@@ -829,23 +857,17 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
                      (gs[k].frames_ok ? MSPACK_HIP_UF_FRAME_TABLE : 0);
     if (!gs[k].frames_ok) units[k].in_chunk = (uint32_t)((self->buf_size + 1) & ~1);    /* mszipd.c:348 */
   }
-  in_arena = (unsigned char *) sys->alloc(sys, in_bytes + 64);
-  out_arena = (unsigned char *) sys->alloc(sys, out_bytes + 64);
-  if (!in_arena || !out_arena) err = MSPACK_ERR_NOMEMORY;
+  out_arena = (unsigned char *) mspack_arena_alloc(sys, out_bytes + 64);
+  if (!out_arena) err = MSPACK_ERR_NOMEMORY;
   else {
     size_t nhip = 0;
-    memset(in_arena, 0, in_bytes + 64);
-    for (k = 0; k < n; k++) {
-      sys->copy(gs[k].stream, in_arena + units[k].in_off, gs[k].len);
-      if (gs[k].frames_ok) memcpy(in_arena + (size_t) units[k].in_chunk * 4, gs[k].boff, (size_t) gs[k].nblk * 4);
-    }
     for (k = 0; k < n; k++) if (units[k].kind != 0) nhip++;
     memset(res, 0, n * sizeof(*res));
     if (nhip) {
       /* kinds other than 1..3 are answered with MSPACK_ERR_ARGS by the kernels; fix them up below */
       rc = (self->devices > 1)
-        ? mspack_hip_decode_batch_multi(units, n, in_arena, in_bytes + 64, out_arena, out_bytes + 64, res, self->devices)
-        : mspack_hip_decode_batch(units, n, in_arena, in_bytes + 64, out_arena, out_bytes + 64, res);
+        ? mspack_hip_decode_batch_multi(units, n, A.p, A.len + 64, out_arena, out_bytes + 64, res, self->devices)
+        : mspack_hip_decode_batch(units, n, A.p, A.len + 64, out_arena, out_bytes + 64, res);
       if (rc) {
         sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error());
         err = MSPACK_ERR_DECRUNCH;
@@ -883,8 +905,8 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     if (store && store->refs) out_arena = NULL;            /* the folders own it now */
     else if (store) sys->free(store);
   }
-  for (k = 0; k < n; k++) { sys->free(gs[k].stream); sys->free(gs[k].boff); }
-  sys->free(gs); sys->free(units); sys->free(res); sys->free(in_arena); sys->free(out_arena);
+  for (k = 0; k < n; k++) sys->free(gs[k].boff);
+  sys->free(gs); sys->free(units); sys->free(res); sys->free(A.p); sys->free(out_arena);
   return err;
 }
 

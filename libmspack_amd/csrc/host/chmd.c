@@ -52,6 +52,9 @@ struct chm_p {
   struct chm_chunk *chunks; unsigned int n_chunks, chunk_int; unsigned long stamp;
   /* the serial span of the virtual decoder (damaged / table-less files) */
   int s_valid, s_mode; off_t s_init, s_cover; unsigned char *s_buf; mspack_hip_result s_res;
+  unsigned int s_log_n, s_log_cap;     /* the serial span's reset log (MSPACK_HIP_UF_LZX_LOG): frames, counted from s_init, whose
+                                          reset found a block open; it lies in s_buf behind the span (s_log) */
+  const unsigned char *s_log;
 };
 struct vdec {                     /* the reference's lzxd instance, replayed (chmd.c:989-1040)       */
   int alive, mode, serial, seek_pending;   /* mode 0: created at a reset-table entry, 1: at offset 0 with SpanInfo */
@@ -600,7 +603,7 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
       if (!find_sys_file(self, sec, &sec->rtable, rtable_name) && sec->rtable->length >= 0x28 && sec->rtable->length <= 1000000)
         extra = (size_t) sec->rtable->length + (size_t) c->fper * 4u;
       arena_alloc = want + 128 + extra + 16;
-      if (!(c->arena = (unsigned char *) sys->alloc(sys, arena_alloc))) return MSPACK_ERR_NOMEMORY;
+      if (!(c->arena = (unsigned char *) mspack_arena_alloc(sys, arena_alloc))) return MSPACK_ERR_NOMEMORY;
       memset(c->arena, 0, arena_alloc);
       c->arena_room = want + 64;
     }
@@ -704,7 +707,7 @@ static int ensure_chunk(struct chmd_p *self, struct chm_p *c, unsigned int k, in
       sys->free(lru->buf); lru->buf = NULL;
     }
   }
-  if (!(ch->buf = (unsigned char *) sys->alloc(sys, (size_t) count * (size_t) c->interval_bytes + 128))) return MSPACK_ERR_NOMEMORY;
+  if (!(ch->buf = (unsigned char *) mspack_arena_alloc(sys, (size_t) count * (size_t) c->interval_bytes + 128))) return MSPACK_ERR_NOMEMORY;
   err = decode_intervals(self, c, first, count, 0, ch->buf, &c->ires[first]);
   if (err) { sys->free(ch->buf); ch->buf = NULL; return err; }
   ch->res_valid = 1;
@@ -724,6 +727,8 @@ static int ensure_serial(struct chmd_p *self, struct chm_p *c, off_t need)
   off_t full = v->length - v->init, cover;
   mspack_hip_unit u;
   uint64_t off = v->in_off;
+  unsigned int log_cap;
+  size_t log_off;
   if (need > full) need = full;
   if (c->s_valid && c->s_init == v->init && c->s_mode == v->mode && c->s_cover >= need) return MSPACK_ERR_OK;
   cover = need + (off_t) CHM_SERIAL_SLACK * c->interval_bytes;
@@ -731,7 +736,10 @@ static int ensure_serial(struct chmd_p *self, struct chm_p *c, off_t need)
   if (cover >= full) cover = full;
   if (cover > 0xFFFF0000LL) return MSPACK_ERR_DATAFORMAT;                /* ours: 32-bit unit length */
   sys->free(c->s_buf); c->s_buf = NULL; c->s_valid = 0;
-  if (!(c->s_buf = (unsigned char *) sys->alloc(sys, (size_t) cover + 128))) return MSPACK_ERR_NOMEMORY;
+  /* (one log entry per reset point the span can reach, the look-ahead frame's included) */
+  log_cap = (unsigned int)(cover / c->interval_bytes) + 2u;
+  log_off = ((size_t) cover + 32768 + 15) & ~(size_t) 15;
+  if (!(c->s_buf = (unsigned char *) mspack_arena_alloc(sys, log_off + 4 + 4 * (size_t) log_cap + 128))) return MSPACK_ERR_NOMEMORY;
   memset(&u, 0, sizeof(u));
   if (off > (uint64_t) c->arena_len) off = c->arena_len;
   u.in_off = off;
@@ -739,10 +747,13 @@ static int ensure_serial(struct chmd_p *self, struct chm_p *c, off_t need)
   u.out_off = 0; u.out_len = (uint32_t) cover;
   u.kind = MSPACK_HIP_KIND_LZX; u.window_bits = (uint8_t) c->window_bits; u.reset_frames = (uint16_t) c->fper;
   u.e8_base = 0;
-  if (mspack_hip_decode_batch(&u, 1, c->arena, c->arena_len + 64, c->s_buf, (size_t) cover + 64, &c->s_res)) {
+  u.flags = MSPACK_HIP_UF_LZX_LOG; u.ref_len = log_cap;
+  if (mspack_hip_decode_batch(&u, 1, c->arena, c->arena_len + 64, c->s_buf, log_off + 4 + 4 * (size_t) log_cap + 64, &c->s_res)) {
     sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error());
     return MSPACK_ERR_DECRUNCH;
   }
+  c->s_log = c->s_buf + log_off + 4; c->s_log_cap = log_cap;
+  c->s_log_n = rd_le32(c->s_buf + log_off); if (c->s_log_n > log_cap) c->s_log_n = log_cap;
   c->s_valid = 1; c->s_init = v->init; c->s_mode = v->mode; c->s_cover = cover;
   return MSPACK_ERR_OK;
 }
@@ -811,6 +822,21 @@ static int vdec_decode(struct chmd_p *self, struct chm_p *c, off_t A, off_t B, o
     const mspack_hip_result *r = &c->s_res;
     if ((err = ensure_serial(self, c, need))) return err;
     nframes = (c->s_cover + FRAME - 1) / FRAME;
+    {
+      /* "invalid reset interval": said once per lzxd_decompress call that enters -- decodes or fails in -- a frame whose
+       * reset found a block still open (lzxd.c:423-431; the warning comes before anything of that frame is read) */
+      const off_t ra = (A - v->init) / FRAME;
+      off_t last = rfe;
+      unsigned int i;
+      if (r->err && !((off_t) r->good_len >= full) && (off_t)(r->good_len / FRAME) < last) last = (off_t)(r->good_len / FRAME);
+      for (i = 0; i < c->s_log_n; i++) {
+        const off_t f = (off_t) rd_le32(c->s_log + 4 * (size_t) i);
+        if (f >= ra && f <= last) {
+          self->system->message(NULL, "WARNING; invalid reset interval detected during LZX decompression");
+          break;
+        }
+      }
+    }
     if (c->s_cover < full) {
       /* a partial span is good for the frames it holds completely */
       if ((off_t) r->good_len / FRAME > rfe) return MSPACK_ERR_OK;
@@ -852,7 +878,7 @@ static int vdec_emit(struct chmd_p *self, struct chm_p *c, struct mspack_file *f
     if (shifted) {
       unsigned int cnt = k1 - k + 1;
       mspack_hip_result *r2 = (mspack_hip_result *) sys->alloc(sys, cnt * sizeof(*r2));
-      unsigned char *tmp = (unsigned char *) sys->alloc(sys, (size_t) cnt * (size_t) c->interval_bytes + 128);
+      unsigned char *tmp = (unsigned char *) mspack_arena_alloc(sys, (size_t) cnt * (size_t) c->interval_bytes + 128);
       err = (!r2 || !tmp) ? MSPACK_ERR_NOMEMORY : decode_intervals(self, c, k, cnt, v->init, tmp, r2);
       if (!err) err = write_slice(sys, fh, tmp + (from - (off_t) k * c->interval_bytes), (size_t)(stop - from));
       sys->free(r2); sys->free(tmp);

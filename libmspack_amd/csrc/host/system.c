@@ -5,6 +5,23 @@
 #include <stdlib.h>
 #include <stdarg.h>
 #include "host_common.h"
+#ifdef __linux__
+#include <sys/mman.h>
+#endif
+
+void *mspack_arena_alloc(struct mspack_system *sys, size_t bytes) {
+  void *p = sys->alloc(sys, bytes);
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
+  static int on = -1;                 /* MSPACK_ARENA_HUGEPAGES=0 turns the advice off */
+  if (on < 0) { const char *e = getenv("MSPACK_ARENA_HUGEPAGES"); on = !(e && e[0] == '0'); }
+  if (on && p && bytes >= ((size_t) 4 << 20)) {
+    const uintptr_t H = (uintptr_t) 2 << 20;
+    const uintptr_t a = ((uintptr_t) p + H - 1) & ~(H - 1), b = ((uintptr_t) p + bytes) & ~(H - 1);
+    if (b > a) (void) madvise((void *) a, (size_t)(b - a), MADV_HUGEPAGE);       /* (whole 2 MiB pages inside the block only) */
+  }
+#endif
+  return p;
+}
 
 int mspack_version(int entity) {
   switch (entity) {

@@ -225,6 +225,15 @@ static int32_t decode_run(lzx_t *z, int32_t run) {
   return run;
 }
 
+/* the reset points of the LAST decode call of this thread that found a block open (lzxd.c:423-431) */
+#define ORC_OPEN_MAX 256
+static __thread uint32_t g_open_n, g_open_frames[ORC_OPEN_MAX];
+uint32_t oracle_lzx_open_resets(uint32_t *frames, uint32_t cap) {
+  uint32_t i;
+  for (i = 0; i < g_open_n && i < cap && i < ORC_OPEN_MAX; i++) frames[i] = g_open_frames[i];
+  return g_open_n;
+}
+
 int oracle_lzx_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
                       uint64_t out_bytes, uint64_t length, int window_bits, int reset_frames,
                       int32_t e8_base, oracle_result *res)
@@ -245,6 +254,7 @@ int oracle_lzxd_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t ou
   uint32_t end_frame, flags = 0;
   int err = ORC_OK;
 
+  g_open_n = 0;
   memset(res, 0, sizeof(*res));
   if (is_delta ? (window_bits < 17 || window_bits > 25) : (window_bits < 15 || window_bits > 21)) { res->err = ORC_ARGS; return ORC_ARGS; }
   if (reset_frames < 0 || (ref_len && !is_delta) || ref_len > ((size_t) 1 << window_bits)) { res->err = ORC_ARGS; return ORC_ARGS; }
@@ -269,7 +279,12 @@ int oracle_lzxd_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t ou
     const uint8_t *fsrc;
     uint8_t e8buf[FRAME];
 
-    if (z->reset_frames && (z->frame % z->reset_frames) == 0) reset_state(z);
+    if (z->reset_frames && (z->frame % z->reset_frames) == 0) {
+      /* a block still open at a reset point: the reference says "WARNING; invalid reset interval detected during LZX
+       * decompression" (once per call) and decodes on (lzxd.c:423-431).  Which frames: oracle_lzx_open_resets() */
+      if (z->block_remaining) { if (g_open_n < ORC_OPEN_MAX) g_open_frames[g_open_n] = z->frame; g_open_n++; }
+      reset_state(z);
+    }
     if (z->is_delta) { if (ensure(&z->b, 16)) goto fail; DROP(&z->b, 16); }     /* chunk size, lzxd.c:440-444 */
     if (!z->header_read) {
       hi = lo = 0;

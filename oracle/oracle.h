@@ -56,6 +56,9 @@ int oracle_lzx_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
                       int32_t e8_base, oracle_result *res);
 /* the same with LZX DELTA (is_delta: window 2^17..2^25, per-frame chunk size, extended match lengths)
  * and its reference data (lzxd_set_reference_data, lzxd.c:348-382) */
+/* the reset points (frame indices) at which the last oracle_lzx_decode / oracle_lzxd_decode of THIS thread found a block still
+ * open -- lzxd.c:423-431, where the reference warns through sys->message.  Returns how many there were (also beyond cap). */
+uint32_t oracle_lzx_open_resets(uint32_t *frames, uint32_t cap);
 int oracle_lzxd_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
                        uint64_t out_bytes, uint64_t length, int window_bits, int reset_frames,
                        int32_t e8_base, int is_delta, const uint8_t *ref, size_t ref_len, oracle_result *res);

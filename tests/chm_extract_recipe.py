@@ -49,6 +49,15 @@ def build(case):
             struct.pack_into("<I", chm, lay["control"] + m[1], m[2])
         elif op == "spaninfo":
             struct.pack_into("<Q", chm, lay["spaninfo"], m[1])
+        elif op == "lzx_bits":              # [op, frame, first bit, bit count, value]: rewrite bits of the LZX stream, counted
+            for k in range(m[3]):           # from the frame's start in the order the decoder reads them (16-bit LE words,
+                b = m[2] + k                # most significant bit first: readbits.h) -- e.g. a block header's length field
+                pos = lay["content"] + int(fo[m[1]]) + 2 * (b // 16) + (1 if (b % 16) < 8 else 0)
+                bit = 7 - (b % 8)
+                if (m[4] >> (m[3] - 1 - k)) & 1:
+                    chm[pos] |= 1 << bit
+                else:
+                    chm[pos] &= ~(1 << bit) & 0xFF
         elif op == "cut":                   # [op, bytes to drop from the end]
             del chm[len(chm) - m[1]:]
         else:

@@ -37,12 +37,22 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *
       snprintf(g_err, sizeof(g_err), "unit outside arena"); return -1;
     }
     /* the frame table is a hint for the GPU's frame-parallel parse; results do not depend on it */
-    if (u->flags & ~MSPACK_HIP_UF_FRAME_TABLE) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
+    if (u->flags & ~(MSPACK_HIP_UF_FRAME_TABLE | (u->kind == MSPACK_HIP_KIND_LZX ? MSPACK_HIP_UF_LZX_LOG : 0u))) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
     if (u->kind == 0) { r->err = 1; continue; }
     switch (u->kind) {
     case MSPACK_HIP_KIND_LZX:
       oracle_lzx_decode(src, u->in_len, dst, u->out_len, u->out_len, u->out_len, u->window_bits, u->reset_frames,
                         u->e8_base, &o);
+      if (u->flags & MSPACK_HIP_UF_LZX_LOG) {                 /* the unit's reset log (mspack_hip.h) */
+        uint8_t *lg = dst + (((size_t) u->out_len + 32768 + 15) & ~(size_t) 15);
+        uint32_t fr[256], cnt, k;
+        if (u->out_off + (((size_t) u->out_len + 32768 + 15) & ~(size_t) 15) + 4 + 4 * (size_t) u->ref_len > out_bytes) {
+          snprintf(g_err, sizeof(g_err), "unit's log outside arena"); return -1;
+        }
+        cnt = oracle_lzx_open_resets(fr, 256);
+        memcpy(lg, &cnt, 4);
+        for (k = 0; k < cnt && k < u->ref_len && k < 256; k++) memcpy(lg + 4 + 4 * (size_t) k, &fr[k], 4);
+      }
       break;
     case MSPACK_HIP_KIND_MSZIP:
       oracle_mszip_decode(src, u->in_len, dst, u->out_len, u->out_len, 0, NULL, 0, NULL, &o);

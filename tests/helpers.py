@@ -66,6 +66,29 @@ def oracle_lzx(data, out_bytes, window_bits, reset_frames=0, length=None, e8_bas
     return res.err, buf.raw[:min(res.out_len, out_bytes)], res
 
 
+def oracle_lzx_open_resets(cap=256):
+    """the reset points (frame indices) at which the LAST oracle_lzx call of this thread found a block still open
+    (lzxd.c:423-431: where the reference warns) -> (count, [frames])"""
+    fr = (C.c_uint32 * cap)()
+    f = oracle().oracle_lzx_open_resets
+    f.restype = C.c_uint32
+    n = f(fr, cap)
+    return n, list(fr[:min(n, cap)])
+
+
+def lzx_set_bits(buf, byte_off, first_bit, n_bits, value):
+    """rewrite n_bits of an LZX stream (bytearray / uint8 array), counted from byte_off in the order the decoder reads them:
+    16-bit little-endian words, most significant bit first (readbits.h)"""
+    for k in range(n_bits):
+        b = first_bit + k
+        pos = byte_off + 2 * (b // 16) + (1 if (b % 16) < 8 else 0)
+        bit = 7 - (b % 8)
+        if (value >> (n_bits - 1 - k)) & 1:
+            buf[pos] |= 1 << bit
+        else:
+            buf[pos] &= ~(1 << bit) & 0xFF
+
+
 def oracle_lzxd(data, out_bytes, window_bits, ref=b"", reset_frames=0, length=None, e8_base=0):
     """LZX DELTA through the oracle -> (err, bytes, OracleResult)"""
     if length is None:

@@ -1,0 +1,25 @@
+/* scratch (host-path profiling on a machine without a GPU): a batch ABI that decodes NOTHING -- every unit is answered
+ * "all bytes produced", the output arena is touched once (as the D2H copy would) and left zero.  Lets the C drivers'
+ * own work (gather, checksums, arenas, slicing, sys->write) be timed and profiled alone.  Never part of the product. */
+#include <string.h>
+#include <time.h>
+static double g_ms;
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
+#include "mspack_hip.h"
+const char *mspack_hip_version(void) { return "null batch (profiling only)"; }
+const char *mspack_hip_last_error(void) { return ""; }
+int mspack_hip_device_count(void) { return 1; }
+int mspack_hip_set_device(int d) { (void) d; return 0; }
+int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n, const void *in, size_t in_bytes, void *out, size_t out_bytes,
+                            mspack_hip_result *res)
+{
+  size_t k;
+  (void) in; (void) in_bytes;
+  { const double t0 = now_ms(); memset(out, 0, out_bytes); g_ms += now_ms() - t0; }      /* (first touch of the arena) */
+  for (k = 0; k < n; k++) { memset(&res[k], 0, sizeof(res[k])); res[k].out_len = res[k].good_len = units[k].out_len; }
+  return 0;
+}
+int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n, const void *in, size_t in_bytes, void *out, size_t out_bytes,
+                                  mspack_hip_result *res, int devices)
+{ (void) devices; return mspack_hip_decode_batch(units, n, in, in_bytes, out, out_bytes, res); }
+void mspack_hip_host_path_stats(double *ms4, int reset) { (void) reset; if (ms4) { ms4[0] = ms4[1] = ms4[3] = 0; ms4[2] = g_ms; } if (reset) g_ms = 0; }
