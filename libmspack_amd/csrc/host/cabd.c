@@ -785,7 +785,7 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
    * wavefront each (MSPACK_HIP_UF_FRAME_TABLE) before the folder's wavefront commits them */
   g->frames_ok = g->frames_ok && g->boff && !g->hard_eof &&
                  (method == MSCAB_COMP_LZX || (method == MSCAB_COMP_MSZIP && !self->fix_mszip)) &&
-                 g->nblk >= 2 && (size_t) g->nblk * CAB_BLOCKMAX >= g->total;
+                 g->nblk >= 1 && (size_t) g->nblk * CAB_BLOCKMAX >= g->total;     /* (one block too: the lane parser beats the serial one) */
   if (g->frames_ok) {
     A->len = (A->len + 3) & ~(size_t) 3;
     if (!arena_room(sys, A, (size_t) g->nblk * 4 + 16)) g->frames_ok = 0;       /* (decodes without the table) */

@@ -604,7 +604,7 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
         extra = (size_t) sec->rtable->length + (size_t) c->fper * 4u;
       arena_alloc = want + 128 + extra + 16;
       if (!(c->arena = (unsigned char *) mspack_arena_alloc(sys, arena_alloc))) return MSPACK_ERR_NOMEMORY;
-      memset(c->arena, 0, arena_alloc);
+      memset(c->arena + want, 0, arena_alloc - want);         /* (the stream itself is read over the rest) */
       c->arena_room = want + 64;
     }
     c->ftab_off = 0;
