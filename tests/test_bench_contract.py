@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the line the final build printed on the GPU box (profiles/round3_final_bench.json,
+"""The bench line's contract, checked on the line the final build printed on the GPU box (profiles/round4_final_bench.json,
 copied there from the gpurun session): the keys the driver reads, the roofline and cpu_baseline objects, internal
 consistency of the numbers.  bench.py itself needs a GPU; what it prints must not drift from what is documented."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def line():
-    return json.loads(open(os.path.join(ROOT, "profiles", "round3_final_bench.json")).read().strip().splitlines()[-1])
+    return json.loads(open(os.path.join(ROOT, "profiles", "round4_final_bench.json")).read().strip().splitlines()[-1])
 
 
 def test_driver_keys_and_types():
@@ -50,3 +50,30 @@ def test_host_inclusive_and_secondary_configs():
     for s in sec:
         if "MSZIP" in s["config"] or "Quantum" in s["config"]:
             assert s["cpu_baseline"]["kind"] == "reference" and s["cpu_baseline"]["value"] > 0
+
+
+def test_through_api_and_socket_estimate():
+    """the product timed through its own object API (configs 2, 3, 4 as containers) in the line, with the
+    time split and the bit-exactness of every extracted byte; the CPU ratio also against an estimated whole socket."""
+    d = line()
+    apis = [s["through_api"] for s in d["secondary"] if s.get("through_api")]
+    assert len(apis) == 3
+    for t in apis:
+        assert t["bit_exact"] is True and t["errors"] == 0 and t["MBps"] > 0 and t["files"] > 0 and t["batch_calls"] >= 1
+        assert abs(sum(t["split_ms"].values()) - t["seconds"] * 1e3) < 0.05 * t["seconds"] * 1e3 + 0.1     # the split adds up
+        assert 0 < t["vs_host_inclusive_to_host"] < 1.0          # the object API cannot beat the batch ABI it sits on
+    e = d["vs_cpu_baseline"]["single_socket_estimate"]
+    assert e["physical_cores_per_socket"] >= 1 and "ESTIMATE" in e["what"]
+    assert abs(e["MBps"] - d["cpu_baseline"]["one_core_MBps"] * e["physical_cores_per_socket"]) / e["MBps"] < 0.01
+    assert abs(e["device_resident"] - d["value"] / e["MBps"]) < 0.02
+
+
+def test_traffic_file_is_this_rounds():
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert t["round"] == "round 4" and os.path.exists(os.path.join(ROOT, t["source"]))
+    src = json.load(open(os.path.join(ROOT, t["source"])))
+    assert src["fetch_kib_per_launch"] == t["fetch_kib_per_launch"] and src["write_kib_per_launch"] == t["write_kib_per_launch"]
+    d = line()
+    # (the line was printed a session before the final --pmc passes: same build, within a few per cent)
+    now = (2 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024
+    assert abs(d["roofline"]["traffic"] - now) / now < 0.05
