@@ -25,7 +25,9 @@
 #define ZIP_BL_P 7
 #define ZIP_HIST 8
 
-#define ZIP_STAGE_WORDS 1024u      /* zip_parse_lanes: 4 KiB of a CFDATA block's input per pass */
+#define ZIP_STAGE_WORDS 768u       /* zip_parse_lanes: 3 KiB of a CFDATA block's input per pass */
+#define ZIP_SEG 8u                 /* zip_parse_lanes: tokens per segment of the balanced last walk (lzx_parse_emit's scheme) */
+#define ZIP_LIT_RING 1024u         /* zip_parse_lanes: bytes of the literal ring (the last walk's literals leave as 16-byte rows) */
 #define ZIP_LANE_TAIL 384u         /* bits a lane walks in front of its stretch's end to find its exit */
 #define ZIP_LANE_ROUNDS 5u         /* walks before the consistent prefix is taken as it is */
 
@@ -64,7 +66,11 @@ struct __align__(16) MszipShared {
       SpecQueueLds spq;          /* speculative path: queued matches + start flags (spec_queue.hpp) */
       u32 tq0[128], tq1[128];    /* speculative path: parsed tokens waiting for their commit (zip_run_spec) */
     };
-    u32 stage[ZIP_STAGE_WORDS + 64u + 4u];   /* parse waves (zip_parse_lanes): the input of one pass, stream order */
+    struct {
+      u32 stage[ZIP_STAGE_WORDS + 64u + 4u];   /* parse waves (zip_parse_lanes): the input of one pass, stream order */
+      alignas(16) u32 litring[ZIP_LIT_RING / 4u];   /* ... the literals of the last walk's rounds on their way out */
+      u8 owner[512];                            /* ... which lane's stretch a segment of the last walk belongs to */
+    };
   };
 };
 
@@ -523,6 +529,7 @@ __device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, RecWri
   for (int l = ZIP_DIST_P + 1; l <= 16; l++) dlim[l - ZIP_DIST_P - 1] = rdl(d.hr_dist.limv, (u32) l);
   const u32 lit_fov = d.hr_lit.fov, dist_fov = d.hr_dist.fov;
   int rc = 0, eob_rbl = 0;
+  u32 lit_flushed = (outc + 15u) & ~15u;                  // literals below this position have left the ring (a multiple of 16)
   for (;;) {
     // ---- stage the input from the dword that holds bit `bitpos` ----
     const u32 sw = bitpos >> 5, sb_bit = sw << 5;
@@ -551,11 +558,24 @@ __device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, RecWri
     u32 entry = lane == 0u ? b0 : (rend > rstart + ZIP_LANE_TAIL ? rend - ZIP_LANE_TAIL : rstart);
     u32 n = 0, nb = 0, nmr = 0, exitp = entry, stop_at = 0, stop_tot = 0, ended = 0;     // ended: 1 end of block, 2 a token not taken
     bool changed = lane < nl;
+    // checkpoints of the lane's walk, one per ZIP_SEG tokens: bit position | output bytes so far << 16, and matches so far
+    // (a byte each).  All walking lanes take a token per step, so the capture is a wave-uniform branch every ZIP_SEG steps.
+    u32 ckA1 = 0, ckA2 = 0, ckA3 = 0, ckA4 = 0, ckA5 = 0, ckA6 = 0, ckA7 = 0, ckM0 = 0, ckM1 = 0;
     for (u32 round = 0; ; ) {
       u32 p = entry, cnt = 0, cb = 0, cm = 0, sa = 0, st = 0, en = 0;
-      for (;;) {
+      for (u32 it = 0; ; it++) {
         const bool act = changed && p < rend;
         if (!ballot(act)) break;
+        if ((it & (ZIP_SEG - 1u)) == 0u && it != 0u && it < 8u * ZIP_SEG) {
+          // (a lane that has stopped keeps cnt < it: its checkpoints beyond its last token are never used)
+          const u32 a = p | (cb << 16), k = it / ZIP_SEG;
+          if (changed) {
+            if (k == 1u) ckA1 = a; else if (k == 2u) ckA2 = a; else if (k == 3u) ckA3 = a; else if (k == 4u) ckA4 = a;
+            else if (k == 5u) ckA5 = a; else if (k == 6u) ckA6 = a; else ckA7 = a;
+            if (k <= 4u) ckM0 = (ckM0 & ~(0xFFu << (8u * (k - 1u)))) | (cm << (8u * (k - 1u)));
+            else ckM1 = (ckM1 & ~(0xFFu << (8u * (k - 5u)))) | (cm << (8u * (k - 5u)));
+          }
+        }
         ZIP_STAGE_R(act ? p : 0u, r)
         const ZipTok t = zip_spec_token(sh, lit_fov, llim, r, dlim, dist_fov);
         const bool die = act && t.unk, eob = act && !t.unk && t.kind == 2u, ok = act && !die && !eob;
@@ -582,18 +602,66 @@ __device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, RecWri
     const u32 inclb = wave_incl_scan(cvb), inclm = wave_incl_scan(cvm);
     const u32 tot_m = rdl(inclm, 63u), tot_b = rdl(inclb, 63u);
     if (outc + tot_b > ZIP_FRAME || !W.ensure(tt + tot_m, lane)) return -1;
-    // ---- last walk: literals into the output, one record per match ----
+    // ---- last walk, BALANCED (lzx_parse_emit's scheme): the pass's tokens are cut into segments of ZIP_SEG tokens (the
+    // lanes' checkpoints) and segment r * 64 + l goes to lane l in round r -- every lane decodes the same number of tokens
+    // per round, and a round's 64 segments are NEIGHBOURS in the output and in the record list.  Literals go into an LDS
+    // ring and leave as whole 16-byte rows behind the round (the bytes of the matches in between are whatever the ring
+    // held: they are not final before the folder's wave has copied the block's matches, zip_run_tokens).
     {
-      u32 p = entry, i = 0, pos = outc + inclb - cvb, j = tt + inclm - cvm;
-      for (;;) {
-        const bool on = i < cvn;
-        if (!ballot(on)) break;
-        ZIP_STAGE_R(on ? p : 0u, r)
-        const ZipTok t = zip_spec_token(sh, lit_fov, llim, r, dlim, dist_fov);
-        if (on && t.kind == 0u) gst_stream(fout + pos, (u8) t.sym);
-        if (on && t.kind == 1u) gst_stream(W.at(j), make_uint2(pos, (t.dist << 9) | t.olen));
-        p += on ? t.tot : 0u; i += on ? 1u : 0u;
-        pos += on ? t.olen : 0u; j += (on && t.kind == 1u) ? 1u : 0u;
+      u32 segc = lane < mm ? (cvn + ZIP_SEG - 1u) / ZIP_SEG : 0u;
+      if (segc > 8u) segc = 8u;                                     // (a stretch of more than 8 segments: the last one is long)
+      const u32 seginc = wave_incl_scan(segc);
+      const u32 T = rdl(seginc, 63u);
+      u8 *const owner = sh->owner;
+      for (u32 q = 0; q < segc; q++) owner[seginc - segc + q] = (u8) lane;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const u32 info0 = entry | (cvn << 16), info1 = outc + inclb - cvb, info2 = tt + inclm - cvm, info3 = (seginc - segc) | (segc << 16);
+      for (u32 r = 0; r * 64u < T; r++) {
+        const u32 sg = r * 64u + lane;
+        const bool sact = sg < T;
+        const u32 o = sact ? (u32) owner[sg] : 0u, oa = o << 2;
+        const u32 i0_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) info0), i1_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) info1);
+        const u32 i2_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) info2), i3_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) info3);
+        const u32 k = sg - (i3_ & 0xFFFFu), osegc = i3_ >> 16, on_ = i0_ >> 16;
+        const u32 a1 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA1), a2 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA2);
+        const u32 a3 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA3), a4 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA4);
+        const u32 a5 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA5), a6 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA6);
+        const u32 a7 = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckA7);
+        const u32 m0_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckM0), m1_ = (u32) __builtin_amdgcn_ds_bpermute((int) oa, (int) ckM1);
+        const u32 ca = k == 0u ? (i0_ & 0xFFFFu) : (k == 1u ? a1 : (k == 2u ? a2 : (k == 3u ? a3 : (k == 4u ? a4 : (k == 5u ? a5 : (k == 6u ? a6 : a7))))));
+        const u32 cmk = k == 0u ? 0u : (k <= 4u ? (m0_ >> (8u * (k - 1u))) & 0xFFu : (m1_ >> (8u * (k - 5u))) & 0xFFu);
+        const u32 ntok = sact ? (k + 1u == osegc ? on_ - k * ZIP_SEG : ZIP_SEG) : 0u;
+        u32 p = ca & 0xFFFFu, i = 0, pos = i1_ + (k == 0u ? 0u : ca >> 16), j = i2_ + cmk;
+        for (;;) {
+          const bool on = i < ntok;
+          if (!ballot(on)) break;
+          ZIP_STAGE_R(on ? p : 0u, rr)
+          const ZipTok t = zip_spec_token(sh, lit_fov, llim, rr, dlim, dist_fov);
+          if (on && t.kind == 0u) {
+            // (inside the ring's window: into LDS; a literal below the first whole row or beyond the window -- long matches
+            // between the segments -- goes out on its own)
+            if (pos >= lit_flushed && pos - lit_flushed < ZIP_LIT_RING) ((u8 *) sh->litring)[pos & (ZIP_LIT_RING - 1u)] = (u8) t.sym;
+            else gst_stream(fout + pos, (u8) t.sym);
+          }
+          if (on && t.kind == 1u) gst_stream(W.at(j), make_uint2(pos, (t.dist << 9) | t.olen));
+          p += on ? t.tot : 0u; i += on ? 1u : 0u;
+          pos += on ? t.olen : 0u; j += (on && t.kind == 1u) ? 1u : 0u;
+        }
+        {
+          // rows up to the last complete one; the rest waits for the next round.  A round that outran the ring stored its
+          // far literals itself: the rows behind the window are skipped for good.
+          u32 rmax = rdl(wave_incl_max(sact ? pos : 0u), 63u);
+          if (rmax > ZIP_FRAME) rmax = ZIP_FRAME;
+          if (rmax > lit_flushed) {
+            const bool outran = rmax - lit_flushed > ZIP_LIT_RING;
+            const u32 upto = outran ? (rmax + 15u) & ~15u : rmax & ~15u;
+            u32 lim = upto; if (outran) lim = lit_flushed + ZIP_LIT_RING;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            for (u32 row = lit_flushed + 16u * lane; row < lim; row += 16u * WAVE)
+              gst((uint4 *)(fout + row), *(const uint4 *)((const u8 *) sh->litring + (row & (ZIP_LIT_RING - 1u))));
+            if (upto > lit_flushed) lit_flushed = upto;
+          }
+        }
       }
     }
     tt += tot_m; outc += tot_b;
@@ -614,6 +682,15 @@ __device__ __forceinline__ int zip_parse_lanes(ZipDec &d, u8 *const fout, RecWri
     bitpos = sb_bit + rdl(exitp, mm - 1u);
     if (bitpos >= bit_limit) return -1;
   }
+  if (outc > lit_flushed && outc - lit_flushed <= ZIP_LIT_RING) {
+    // the ring's last rows (where this call's tokens end): byte by byte behind the last complete row
+    const u32 full = outc & ~15u;
+    for (u32 row = lit_flushed + 16u * lane; row < full; row += 16u * WAVE)
+      gst((uint4 *)(fout + row), *(const uint4 *)((const u8 *) sh->litring + (row & (ZIP_LIT_RING - 1u))));
+    const u32 t0 = full > lit_flushed ? full : lit_flushed;
+    if (t0 + lane < outc) gst(fout + t0 + lane, ((const u8 *) sh->litring)[(t0 + lane) & (ZIP_LIT_RING - 1u)]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   // hand the exact bit position to the scalar reader
   {
     const u32 wi = bitpos >> 5, ch = wi >> 6;
