@@ -217,6 +217,12 @@ struct LzxDec {
 };
 
 __device__ __forceinline__ u32 lzx_read_lens_spec(LzxDec &d, u8 *lens, u32 first, u32 last);
+#if defined(LZX_PARSE_ONLY) && defined(LZX_HDR_LANES)
+__device__ __forceinline__ u32 lzx_hdr_lanes(LzxDec &d, u8 *lens, u32 first, u32 last);
+#endif
+#if defined(LZX_HDR_DEBUG) && defined(LZX_PARSE_ONLY) && !defined(MSPACK_WAVE_EMU)
+__device__ u8 g_hdr_cp[4096 * 1024];
+#endif
 
 // lzxd_read_lens (lzxd.c:138-183).  Every length is a delta against the previous block's lens[x], but
 // the tokens of one call never depend on each other: far from the end of the input they are decoded
@@ -236,7 +242,40 @@ __device__ __forceinline__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u3
   }
   HT(0);
 #ifndef LZX_NO_SPEC
+#if defined(LZX_PARSE_ONLY) && defined(LZX_HDR_LANES)      /* (an experiment that lost: see lzx_read_lens_lanes) */
+#if defined(LZX_HDR_DEBUG)
+  if (!d.careful) {
+#ifdef MSPACK_WAVE_EMU
+    static thread_local u8 cp[4096];
+#else
+    u8 *const cp = g_hdr_cp + (size_t)(blockIdx.x & 4095u) * 1024u;
+#endif
+    LzxDec d2 = d;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (u32 i = d.lane; i < last + 64u; i += WAVE) cp[i] = lens[i];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#ifdef LZX_HDR_DEBUG_LANES_FIRST
+    const u32 f1 = lzx_hdr_lanes(d, lens, first, last);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const u32 f2 = lzx_read_lens_spec(d2, cp, first, last);
+#else
+    const u32 f2 = lzx_read_lens_spec(d2, cp, first, last);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const u32 f1 = lzx_hdr_lanes(d, lens, first, last);
+#endif
+    const u32 b1 = d.w.origin * 8u + d.cons_bits(), b2 = d2.w.origin * 8u + d2.cons_bits();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    int bad = -1;
+    for (u32 i = 0; i < last + 60u; i++) if (cp[i] != lens[i]) { bad = (int) i; break; }
+    if (d.lane == 0 && (f1 != f2 || b1 != b2 || bad >= 0)) printf("HDR first %u last %u: lanes X %u bit %u | spec X %u bit %u | first diff %d (%u vs %u)\n", first, last, f1, b1, f2, b2, bad, bad >= 0 ? lens[bad] : 0, bad >= 0 ? cp[bad] : 0);
+    first = f1;
+  }
+#else
+  if (!d.careful) first = lzx_hdr_lanes(d, lens, first, last);       // (the parse tasks of mspack_lzx_pipe: every lane its own stretch)
+#endif
+#else
   if (!d.careful) first = lzx_read_lens_spec(d, lens, first, last);
+#endif
 #endif
   for (u32 x = first; x < last; ) {
     d.need(32);
@@ -1740,6 +1779,183 @@ __device__ __forceinline__ bool lzx_build_sub(LzxShared *sh, const HuffRegs &hr,
     if (WANT1) { const u32 x2_ = q_[1]; w1_ = (u32) __builtin_amdgcn_alignbit(x1_, x2_, a_); } \
   }
 
+#ifdef LZX_HDR_LANES
+// ---------------------------------------------------------------------------------------------------
+// lzx_read_lens_lanes -- lzxd_read_lens (lzxd.c:138-183) with the lane parser's scheme (parse tasks only).
+// lzx_read_lens_spec decodes 64 bit positions per round and follows the ~13 real tokens among them with one v_readlane hop
+// each: ~70 rounds of ~1300 cycles for a block header's ~900 pretree tokens, 89 of a parse task's ~670 microseconds.
+// Here the header's bits are staged (sh->stage: free until the frame's tokens are parsed) and cut into stretches of
+// LZX_HDR_S bits, one per lane: a first walk from LZX_HDR_LEAD bits in front of the stretch finds the lane's exit (a walk
+// that starts inside a token falls into step with the real chain after a few tokens: pretree codes are short), then every
+// lane walks from its left neighbour's exit, counting the lengths its tokens set (1, or a run of 4..51), until no entry
+// moves; a prefix sum gives every lane its first index x, and the last walk rewrites lens[x .. x + y) token by token.  The
+// run ends at the first token whose x has reached `last` (tokens are read only while x < last, lzxd.c:148; a run may
+// overshoot, it is not clipped, :159).  A token the pretree does not hold ends the consistent prefix: the scalar loop of
+// lzx_read_lens takes (and judges) it, as it takes everything within 56 bytes of the end of the input.
+// Returns the index the scalar loop continues from; the decoder stands behind the last token taken.
+// MEASURED AND NOT SHIPPED (round 4, profiles/round4_header_lanes_experiment.txt; build with -DLZX_HDR_LANES): bit-exact as a real
+// call, but a block header is too short for the scheme -- ~300 tokens per run, 5-7 per lane, so the sync rounds are most of the
+// steps and every step is a chain of dependent LDS reads: header decode 143 us per frame against 89 with lzx_read_lens_spec.
+// ---------------------------------------------------------------------------------------------------
+#define LZX_HDR_S 32u
+#define LZX_HDR_LEAD 40u
+#define LZX_HDR_ROUNDS 6u
+struct PreTok { u32 tot, y, zz; bool zero, unk; };
+// one pretree token at the bits (w0, w1), every lane its own.  The rare parts -- a code longer than the direct table, the second
+// symbol of a "same" run -- are behind wave-uniform branches (any ACTIVE lane needs them): a step is then two dependent LDS
+// reads (the staged bits, the direct table) instead of five.
+__device__ __forceinline__ PreTok lzx_pre_token(const LzxShared *sh, const bool act, const u32 *plim, const u32 pre_fov, const u32 w0, const u32 w1)
+{
+  PreTok t;
+  u64 r = ((u64) w0 << 32) | w1;
+  u32 e = sh->pre_tab[w0 >> (32 - LZX_PRE_P)];
+  if (ballot(act && e == 0u)) {
+    const u32 peek16 = w0 >> 16;
+    u32 ln = LZX_PRE_P + 1u;
+#pragma unroll
+    for (int l = LZX_PRE_P + 1; l <= 16; l++) ln += (peek16 >= plim[l - LZX_PRE_P - 1]) ? 1u : 0u;
+    const u32 lq = ln <= 16u ? ln : 0u;
+    const u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) pre_fov);
+    u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
+    if (idx >= 20u) idx = 0;
+    const u32 ls = sh->pre_sorted[idx];
+    if (e == 0u && lq != 0u) e = ls | (lq << 10);
+  }
+  t.unk = (e == 0u);
+  const u32 z = e & 1023u;
+  u32 tot = e >> 10;
+  r <<= tot;
+  const u32 nb = z == 17u ? 4u : (z == 18u ? 5u : (z == 19u ? 1u : 0u));
+  const u32 xb = nb ? (u32)(r >> (64u - nb)) : 0u;
+  r <<= nb; tot += nb;
+  t.y = z == 17u ? 4u + xb : (z == 18u ? 20u + xb : (z == 19u ? 4u + xb : 1u));
+  t.zz = z;
+  if (ballot(act && z == 19u)) {
+    const u32 e2 = sh->pre_tab[(u32)(r >> (64 - LZX_PRE_P))];       // second symbol of a "same" run
+    if (z == 19u) { t.unk = t.unk || e2 == 0u; tot += e2 >> 10; t.zz = e2 & 1023u; }   // (a long second code: the scalar loop)
+  }
+  t.zero = z == 17u || z == 18u;
+  t.tot = tot;
+  return t;
+}
+
+// (a real call with everything by value: inlined into the block header's three call sites the function was not only large but
+// WRONG on the hardware -- right on the emulator and in every build that added code around it --, and a decoder passed by
+// reference lives in scratch memory from then on)
+struct HdrLanes { u32 X, B, moved; };
+#ifndef LZX_HDR_INLINE
+__device__ __attribute__((noinline))
+#else
+__device__ __forceinline__
+#endif
+HdrLanes lzx_read_lens_lanes(LzxShared *sh, const u8 *unit, const u32 unit_len, const u32 B_, const u32 pre_limv, const u32 pre_fov,
+                             u8 *lens, const u32 first, const u32 last_, const u32 lane)
+{
+  const u32 last = rfl(last_);
+  u32 X = rfl(first);
+  const u32 in_limit = unit_len > 56u ? (unit_len - 56u) * 8u : 0u;        // bits from the unit's first byte, like B
+  u32 B = rfl(B_);
+  u32 plim[16 - LZX_PRE_P];
+#pragma unroll
+  for (int l = LZX_PRE_P + 1; l <= 16; l++) plim[l - LZX_PRE_P - 1] = rdl(pre_limv, (u32) l);
+  bool moved = false, stop = false;
+  while (!stop && X < last && B + 64u < in_limit) {
+    // ---- stage the input from the dword that holds bit B (16-bit words pre-swapped: a plain MSB-first bit string) ----
+    const u32 sb_byte = (B >> 5) << 2, sb_bit = sb_byte * 8u;
+    const u32 b0 = B - sb_bit;
+    u32 e0 = b0 + 64u * LZX_HDR_S; if (e0 > in_limit - sb_bit) e0 = in_limit - sb_bit;
+    {
+      const u32 nck = (e0 + 128u + 2047u) >> 11;               // a token that starts below e0 ends below e0 + 37
+      InWindow ws; ws.unit = unit; ws.in_len = unit_len; ws.eofs = 0u; ws.origin = sb_byte; ws.wi = 0u; ws.cur = 0u; ws.nxt = 0u;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {                            // (64 x 32 bits + 31 + 128: at most two chunks)
+        const u32 v = (u32) c < nck ? ws.load_chunk((u32) c, lane) : 0u;
+        sh->stage[(u32) c * 64u + lane] = SWAP16(v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const u32 nl = (e0 - b0 + LZX_HDR_S - 1u) / LZX_HDR_S;     // >= 1
+    const u32 rstart = b0 + lane * LZX_HDR_S;
+    u32 rend = rstart + LZX_HDR_S; if (rend > e0) rend = e0;
+    u32 entry = (lane == 0u || rstart < b0 + LZX_HDR_LEAD) ? b0 : rstart - LZX_HDR_LEAD;
+    u32 n = 0, ny = 0, exitp = entry, stop_at = 0;
+    bool dead = false, changed = lane < nl;
+    for (u32 round = 0; ; ) {
+      u32 p = entry, cnt = 0, cy = 0, sa = 0;
+      bool dd = false;
+      for (;;) {
+        const bool act = changed && p < rend;
+        if (!ballot(act)) break;
+        STAGE_BITS(act ? p : 0u, w0, w1, true)
+        const PreTok t = lzx_pre_token(sh, act, plim, pre_fov, w0, w1);
+        const bool ok = act && !t.unk, die = act && t.unk;
+        dd = dd || die; sa = die ? p : sa;
+        cnt += ok ? 1u : 0u; cy += ok ? t.y : 0u;
+        p = die ? rend : p + (ok ? t.tot : 0u);
+      }
+      if (changed) { n = cnt; ny = cy; exitp = p; dead = dd; stop_at = sa; }
+      round++;
+      const u32 pe = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) exitp);
+      const u32 ne = lane == 0u ? b0 : pe;
+      changed = lane < nl && ne != entry;
+      entry = ne;
+      if (!ballot(changed) || round >= LZX_HDR_ROUNDS) break;
+    }
+    // ---- the consistent prefix: lanes < mm (lane 0 always is: it starts at a real token) ----
+    u32 m = nl;
+    { const u64 chm = ballot(changed); if (chm) m = (u32) __ffsll((long long) chm) - 1u; }
+    u32 mm = m, dl = 0;
+    bool hit = false;
+    { const u64 dm = ballot(dead && lane < m); if (dm) { dl = (u32) __ffsll((long long) dm) - 1u; mm = dl + 1u; hit = true; } }
+    if (mm == 0u) break;
+    const u32 cvn = lane < mm ? n : 0u, cvy = lane < mm ? ny : 0u;
+    const u32 incly = wave_incl_scan(cvy);
+    // ---- last walk: every token rewrites its own lens[x .. x + y) ----
+    u32 p = entry, i = 0, x = X + incly - cvy, endp = 0;
+    bool ended = false;
+    for (;;) {
+      const bool on = i < cvn && !ended;
+      if (!ballot(on)) break;
+      STAGE_BITS(on ? p : 0u, w0, w1, true)
+      const PreTok t = lzx_pre_token(sh, on, plim, pre_fov, w0, w1);
+      if (on && x >= last) { ended = true; endp = p; }             // lengths are read only while x < last (lzxd.c:148)
+      else if (on) {
+        int nv = 0;
+        if (!t.zero) { nv = (int)(u32) lens[x] - (int) t.zz; if (nv < 0) nv += 17; }
+        for (u32 k = 0; k < t.y; k++) lens[x + k] = (u8) nv;     // (a run may overshoot `last`: it is not clipped, lzxd.c:159)
+        x += t.y; p += t.tot; i++;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // (the next pass restages; lens[] is read by the next call)
+    moved = true;
+    // the first token (in stream order) that found x >= last ends the run: every lane to its right marks its own first token
+    const u64 em = ballot(lane < mm && ended);
+    const u32 xend = rdl(incly, mm - 1u) + X;                     // index behind the prefix's last token
+    if (em) {
+      const u32 le = (u32) __ffsll((long long) em) - 1u;
+      B = sb_bit + rdl(endp, le);
+      X = rdl(x, le);                                             // >= last
+      stop = true;
+    }
+    else {
+      X = xend;
+      if (hit) { B = sb_bit + rdl(stop_at, dl); stop = true; }
+      else B = sb_bit + rdl(exitp, mm - 1u);
+    }
+  }
+  HdrLanes res; res.X = X; res.B = B; res.moved = moved ? 1u : 0u;
+  return res;
+}
+
+__device__ __forceinline__ u32 lzx_hdr_lanes(LzxDec &d, u8 *lens, u32 first, u32 last)
+{
+  const HdrLanes r = lzx_read_lens_lanes(d.sh, d.w.unit, d.w.in_len, rfl(d.w.origin) * 8u + rfl(d.cons_bits()), d.hr_pre.limv, d.hr_pre.fov,
+                                         lens, first, last, d.lane);
+  if (rfl(r.moved)) lzx_seek_bit(d, rfl(r.B));
+  return rfl(r.X);
+}
+#endif  /* LZX_HDR_LANES */
+
 // One token at the bits (w0, w1), every lane its own: main-tree entry (codes beyond the direct table resolved for all
 // lanes at once when any lane has one), length footer, offset bits, aligned-offset symbol.  Everything is computed for
 // every lane and selected -- no divergent branches in the walks' loop bodies.  unk: the tables do not hold this token.
@@ -2211,7 +2427,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
   if (ok) ok = (s.block_type == 1u || s.block_type == 2u) && s.block_length == fsz;    // one block per frame, or no guess
   if (!ok) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
-  const u32 start_bit = fo * 8u + d.cons_bits();                // the frame's first token
+  const u32 start_bit = rfl(d.w.origin) * 8u + rfl(d.cons_bits());                // the frame's first token
   PH(1);
   for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) gst((u32 *) rec->main_len + i, ((const u32 *) sh->main_len)[i]);
   for (u32 i = lane; i < (LZX_LEN_SYMS + 70) / 4u; i += WAVE) gst((u32 *) rec->len_len + i, ((const u32 *) sh->len_len)[i]);
