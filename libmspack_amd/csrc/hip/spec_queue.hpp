@@ -20,7 +20,9 @@
 #pragma once
 #include "wave_common.hpp"
 
+#ifndef SPQ_CAP
 #define SPQ_CAP 160
+#endif
 #define SPQ_RING 2048u            /* positions the start-flag ring covers (one BIT per position) */
 #ifndef SPQ_SPAN
 #define SPQ_SPAN 512u             /* resolve when this many output bytes are pending */
