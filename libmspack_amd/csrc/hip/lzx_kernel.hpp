@@ -220,9 +220,6 @@ __device__ __forceinline__ u32 lzx_read_lens_spec(LzxDec &d, u8 *lens, u32 first
 #if defined(LZX_PARSE_ONLY) && defined(LZX_HDR_LANES)
 __device__ __forceinline__ u32 lzx_hdr_lanes(LzxDec &d, u8 *lens, u32 first, u32 last);
 #endif
-#if defined(LZX_HDR_DEBUG) && defined(LZX_PARSE_ONLY) && !defined(MSPACK_WAVE_EMU)
-__device__ u8 g_hdr_cp[4096 * 1024];
-#endif
 
 // lzxd_read_lens (lzxd.c:138-183).  Every length is a delta against the previous block's lens[x], but
 // the tokens of one call never depend on each other: far from the end of the input they are decoded
@@ -243,36 +240,7 @@ __device__ __forceinline__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u3
   HT(0);
 #ifndef LZX_NO_SPEC
 #if defined(LZX_PARSE_ONLY) && defined(LZX_HDR_LANES)      /* (an experiment that lost: see lzx_read_lens_lanes) */
-#if defined(LZX_HDR_DEBUG)
-  if (!d.careful) {
-#ifdef MSPACK_WAVE_EMU
-    static thread_local u8 cp[4096];
-#else
-    u8 *const cp = g_hdr_cp + (size_t)(blockIdx.x & 4095u) * 1024u;
-#endif
-    LzxDec d2 = d;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    for (u32 i = d.lane; i < last + 64u; i += WAVE) cp[i] = lens[i];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#ifdef LZX_HDR_DEBUG_LANES_FIRST
-    const u32 f1 = lzx_hdr_lanes(d, lens, first, last);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const u32 f2 = lzx_read_lens_spec(d2, cp, first, last);
-#else
-    const u32 f2 = lzx_read_lens_spec(d2, cp, first, last);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const u32 f1 = lzx_hdr_lanes(d, lens, first, last);
-#endif
-    const u32 b1 = d.w.origin * 8u + d.cons_bits(), b2 = d2.w.origin * 8u + d2.cons_bits();
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    int bad = -1;
-    for (u32 i = 0; i < last + 60u; i++) if (cp[i] != lens[i]) { bad = (int) i; break; }
-    if (d.lane == 0 && (f1 != f2 || b1 != b2 || bad >= 0)) printf("HDR first %u last %u: lanes X %u bit %u | spec X %u bit %u | first diff %d (%u vs %u)\n", first, last, f1, b1, f2, b2, bad, bad >= 0 ? lens[bad] : 0, bad >= 0 ? cp[bad] : 0);
-    first = f1;
-  }
-#else
-  if (!d.careful) first = lzx_hdr_lanes(d, lens, first, last);       // (the parse tasks of mspack_lzx_pipe: every lane its own stretch)
-#endif
+  if (!d.careful) first = lzx_hdr_lanes(d, lens, first, last);       // (an experiment: every lane its own stretch of the header)
 #else
   if (!d.careful) first = lzx_read_lens_spec(d, lens, first, last);
 #endif
