@@ -222,6 +222,16 @@ double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32
  * of calls.  ms4 may be NULL; reset != 0 clears the sums after reading.  (bench infrastructure: csrc/bench/api_bench.c) */
 void mspack_hip_host_path_stats(double *ms4, int reset);
 
+/* ---- optional: page-lock a caller's input arena ---------------------------------------------------------
+ * The host-buffer entry points copy their input with the runtime's pageable path unless the caller's buffer is
+ * page-locked; for an arena that was just written (the C drivers' gather) that path runs at 5-6 GB/s.  mspack_hip_pin()
+ * page-locks [p, p + bytes) (whole pages around it) so that those copies are plain DMA; mspack_hip_unpin(p) releases it --
+ * before the memory is freed.  Both are advice: pin returns 0 when the range is locked now, a non-zero code when it is not
+ * (no device, already locked, the runtime refuses) and the calls work either way.  (Output buffers are handled inside
+ * mspack_hip_decode_batch itself, chunk by chunk; a buffer that is used for many calls is better locked by its owner.) */
+int  mspack_hip_pin(const void *p, size_t bytes);
+void mspack_hip_unpin(const void *p);
+
 #ifdef __cplusplus
 }
 #endif

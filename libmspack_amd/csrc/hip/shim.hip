@@ -919,6 +919,11 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     } pins;
     struct Joiner { std::thread &t; std::atomic<bool> &stop; ~Joiner() { if (t.joinable()) { stop.store(true); t.join(); } } } joiner{back, stop};
     static const bool pin_out = env_int("MSPACK_HIP_PIN_OUT", 1, 0, 1) != 0;
+    // The INPUT is not locked here by default (MSPACK_HIP_PIN_IN=1 does it, one range per call): for a caller's warm buffer the
+    // runtime's pageable path is as fast as the lock costs (to the host 7.4 -> 8.1 ms on the headline batch); for an arena that was
+    // just written -- the C drivers' gather -- it runs at 5-6 GB/s, and those callers lock their arena themselves (mspack_hip_pin).
+    static const bool pin_in = env_int("MSPACK_HIP_PIN_IN", 0, 0, 1) != 0;
+    Pins pins_in;
     bool back_started = false;
     if (host_out && !one) try {
       back = std::thread([&]() {
@@ -950,6 +955,12 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       });
       back_started = true;
     } catch (...) { back_started = false; }      // (no helper thread: the copies back are issued below, in this thread)
+    if (pin_in && in_span >= ((size_t) 4 << 20)) {
+      // (ONE range, every page the copies below read: the chunks' input ranges may overlap -- frame tables behind the streams)
+      const uintptr_t PG = 4096u, ra = ((uintptr_t) in + in_lo) & ~(PG - 1u), rb = ((uintptr_t) in + in_hi + PG - 1u) & ~(PG - 1u);
+      if (hipHostRegister((void *) ra, rb - ra, hipHostRegisterDefault) == hipSuccess) pins_in.p[pins_in.n++] = (char *) ra;
+      else (void) hipGetLastError();
+    }
     for (size_t ci = 0; ci < chunks.size(); ci++) {
       const Chunk &c = chunks[ci];
       hipStream_t st = one ? cx.st[0] : cx.st[2 + ci % n_comp];
@@ -996,7 +1007,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       if (back_err != hipSuccess) TRY(back_err);
     }
     for (int i = 0; i < cx.ns; i++) TRY(hipStreamSynchronize(cx.st[i]));
-    { auto r0 = tnow(); pins.release(); unpin_ms = tms(r0, tnow()); }
+    { auto r0 = tnow(); pins.release(); pins_in.release(); unpin_ms = tms(r0, tnow()); }
     for (size_t i = 0; i < n_sel; i++) {
       results[idx[i]] = h_res[i];
       if (local[i].kind == 0) { memset(&results[idx[i]], 0, sizeof(mspack_hip_result)); results[idx[i]].err = ERR_ARGS; }
@@ -1096,6 +1107,30 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
   for (int sh = 0; sh < n_shards; sh++)
     if (rcs[sh]) { snprintf(g_err, sizeof(g_err), "shard %d: %s", sh, errs[sh].data()); return rcs[sh]; }
   return 0;
+}
+
+// page-locked caller arenas (mspack_hip_pin / _unpin): user pointer -> the page-aligned base that was registered
+static std::mutex g_pin_mu;
+static std::vector<std::pair<const void *, void *>> g_pins;
+int mspack_hip_pin(const void *p, size_t bytes)
+{
+  if (!p || !bytes) return -1;
+  const uintptr_t PG = 4096u, ra = (uintptr_t) p & ~(PG - 1u), rb = ((uintptr_t) p + bytes + PG - 1u) & ~(PG - 1u);
+  const hipError_t e = hipHostRegister((void *) ra, rb - ra, hipHostRegisterPortable);       // (every device of the process: _multi)
+  if (e != hipSuccess) { (void) hipGetLastError(); return (int) e; }
+  std::lock_guard<std::mutex> lock(g_pin_mu);
+  g_pins.emplace_back(p, (void *) ra);
+  return 0;
+}
+void mspack_hip_unpin(const void *p)
+{
+  void *base = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    for (size_t i = 0; i < g_pins.size(); i++)
+      if (g_pins[i].first == p) { base = g_pins[i].second; g_pins.erase(g_pins.begin() + (long) i); break; }
+  }
+  if (base && hipHostUnregister(base) != hipSuccess) (void) hipGetLastError();
 }
 
 void mspack_hip_host_path_stats(double *ms4, int reset)

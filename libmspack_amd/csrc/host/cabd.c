@@ -864,10 +864,13 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     for (k = 0; k < n; k++) if (units[k].kind != 0) nhip++;
     memset(res, 0, n * sizeof(*res));
     if (nhip) {
+      /* the arena was written a moment ago: page-locked, its copy to the device is plain DMA (mspack_hip.h; advice only) */
+      const int pinned = A.len >= ((size_t) 4 << 20) && mspack_hip_pin(A.p, A.len + 64) == 0;
       /* kinds other than 1..3 are answered with MSPACK_ERR_ARGS by the kernels; fix them up below */
       rc = (self->devices > 1)
         ? mspack_hip_decode_batch_multi(units, n, A.p, A.len + 64, out_arena, out_bytes + 64, res, self->devices)
         : mspack_hip_decode_batch(units, n, A.p, A.len + 64, out_arena, out_bytes + 64, res);
+      if (pinned) mspack_hip_unpin(A.p);
       if (rc) {
         sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error());
         err = MSPACK_ERR_DECRUNCH;

@@ -43,6 +43,7 @@ struct chm_p {
   unsigned int n_fast;            /* intervals [0, n_fast) have a reset-table entry                 */
   int span_err; off_t span_len;   /* SpanInfo: the fallback stream length (chmd.c:1159-1166)        */
   unsigned char *arena; size_t arena_len;     /* the CHM file from the start of Content to its end  */
+  int arena_pinned;                           /* page-locked (mspack_hip_pin) until free_sec1                */
   off_t content_start;            /* file offset of the Content stream                              */
   uint64_t *ioff;                 /* reset-table entry (compressed offset) of intervals [0, n_fast)  */
   size_t ftab_off;                /* arena offset of the per-frame tables (0: none), n_fast * fper uint32: every
@@ -544,6 +545,7 @@ static int decode_intervals(struct chmd_p *self, struct chm_p *c, unsigned int f
 static void free_sec1(struct mspack_system *sys, struct chm_p *c) {
   unsigned int i;
   if (c->chunks) for (i = 0; i < c->n_chunks; i++) sys->free(c->chunks[i].buf);
+  if (c->arena_pinned) { mspack_hip_unpin(c->arena); c->arena_pinned = 0; }
   sys->free(c->chunks); sys->free(c->arena); sys->free(c->ioff); sys->free(c->ires); sys->free(c->s_buf);
   c->chunks = NULL; c->arena = NULL; c->ioff = NULL; c->ires = NULL; c->s_buf = NULL; c->sec1_state = 0;
   c->n_chunks = 0; c->s_valid = 0;
@@ -672,6 +674,9 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
     if (c->span_len <= 0) c->span_err = MSPACK_ERR_DATAFORMAT;
     else if (c->span_len > 0xFFFF0000LL) c->span_err = MSPACK_ERR_DATAFORMAT;   /* ours: a unit's out_len is 32 bits */
   }
+
+  /* every batch of this CHM reads the arena: page-locked once, its copies to the device are plain DMA (advice only) */
+  if (!c->arena_pinned && arena_alloc >= ((size_t) 4 << 20)) c->arena_pinned = mspack_hip_pin(c->arena, arena_alloc) == 0;
 
   /* fast-result bookkeeping */
   if (c->n_fast) {

@@ -81,3 +81,5 @@ void mspack_hip_host_path_stats(double *ms4, int reset)
   (void) reset;
   if (ms4) ms4[0] = ms4[1] = ms4[2] = ms4[3] = 0.0;
 }
+int mspack_hip_pin(const void *p, size_t bytes) { (void) p; (void) bytes; return 1; }      /* (nothing to lock without a device) */
+void mspack_hip_unpin(const void *p) { (void) p; }

@@ -161,6 +161,7 @@ hipError_t hipHostFree(void *p);
  * progress, so that the consumer's path for partial progress runs whatever the host's thread timing is */
 void emu_test_delay(void);
 #define hipHostRegisterDefault 0
+#define hipHostRegisterPortable 1
 static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s = 0);
