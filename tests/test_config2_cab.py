@@ -47,3 +47,35 @@ def test_config2_cab_gpu(built):
         for i in list(range(N - 1, -1, -1))[:64] + list(range(N)):        # some backwards, then all in order
             err, data = c.extract(i)
             assert err == 0 and data == plain[i * UB:(i + 1) * UB].tobytes(), i
+
+
+def test_cab_gather_grows_its_arena_cpu(built, hostlogic):
+    """cabd.c gathers the CFDATA payloads of all folders straight into ONE growing input arena whose first size is a guess from the
+    cabinet header's length field (round 4).  A header that understates the length (the reference never checks the field
+    against the file) makes the arena grow several times WHILE blocks are being read into it: the folders, their frame tables
+    and the block that is being read must all survive every move.  Host logic on the CPU stand-in for the batch ABI; expected
+    bytes: the plaintext (which the real reference also extracts from this cabinet, where it is built)."""
+    import struct
+    n, fb = 24, 5                                              # 24 MSZIP folders of 5 blocks: ~1.4 MiB of payload
+    ub = fb * UB
+    plain = M.gen_plaintext(0xFEED, 2, n * ub)                 # (the binary family: compresses badly, large payloads)
+    folders, files = [], []
+    for i in range(n):
+        blocks, d = [], None
+        for b in range(fb):
+            co = zlib.compressobj(6, zlib.DEFLATED, -15) if d is None else zlib.compressobj(6, zlib.DEFLATED, -15, zdict=d)
+            d = plain[i * ub + b * UB:i * ub + (b + 1) * UB].tobytes()
+            blocks.append(b"CK" + co.compress(d) + co.flush())
+        folders.append((1, blocks, [UB] * fb))
+        files.append((b"g%02d.bin" % i, ub, 0, i))
+    cab = bytearray(M.cab_write(folders, files))
+    assert len(cab) > (1 << 20)
+    struct.pack_into("<I", cab, 8, 64)                         # cbCabinet: "this cabinet is 64 bytes long"
+    if helpers.have_ref():
+        rc, outs = helpers.ref_cab_extract(bytes(cab), [0, n - 1], cap=2 * ub + 4096)
+        assert rc == 0 and [e for e, _d in outs] == [0, 0] and outs[1][1] == plain[(n - 1) * ub:].tobytes()
+    with api.Cab(bytes(cab), mem=True, L=hostlogic) as c:
+        assert c.open_error == 0 and len(c.files) == n
+        for i in [n - 1, 0] + list(range(n)):
+            err, data = c.extract(i)
+            assert err == 0 and data == plain[i * ub:(i + 1) * ub].tobytes(), i

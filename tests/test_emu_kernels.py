@@ -82,7 +82,8 @@ def test_some_gpu_parity_tests_on_the_emulator(built):
     ids = ["tests/test_gpu_mszip_blocks.py::test_folders_with_tables",
            "tests/test_gpu_mszip_blocks.py::test_wrong_tables_and_odd_folders",
            "tests/test_gpu_lzx_frames.py::test_wrong_tables_cost_time_not_correctness",
-           "tests/test_gpu_lzx_frames.py::test_frames_other_plaintexts"]
+           "tests/test_gpu_lzx_frames.py::test_frames_other_plaintexts",
+           "tests/test_gpu_lzx_log.py"]            # (the reset log of units whose blocks outlive their frames: serial and with tables)
     env = dict(os.environ, MSPACK_HIP_SO=SO, MSPACK_EMU_PUBLISH_DELAY_US="500")
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + ids, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1700)
