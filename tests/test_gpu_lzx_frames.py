@@ -191,3 +191,34 @@ print(go(1024, 65536), go(3600, 32768), go(3600, 3 * 32768), go(6144, 32768))
     adopted = [float(x) for x in r.stdout.split()[-4:]]
     want = 0.0 if "MSPACK_HIP_NO_FRAME_PARSE" in env else 1.0
     assert all(a == want for a in adopted), r.stdout
+
+
+@pytest.mark.parametrize("shape", ["one_table_among_900", "900_tables_and_a_few_without"])
+def test_units_with_and_without_tables_in_one_batch(built, shape):
+    """the host path numbers the units that carry a frame table first and sizes the frame records and
+    the record pool for THOSE slots only; units without a table get frame slots behind them.  The map kernels used to write the
+    records of every LZX unit -- with many table-less units far past the scratch (hdr control words, other launches' records):
+    the unit with the table then silently dropped off the frame-parallel path, or memory was corrupted.  Both mixes, every
+    unit against the oracle, and the units with tables must really have gone through mspack_lzx_pipe."""
+    big = M.gen_plaintext(4242, M.TEXT_MIX, 3 * 32768)
+    streams, params, tabs = [], [], []
+    if shape == "one_table_among_900":
+        n_small, n_tab = 900, 1
+    else:
+        n_small, n_tab = 7, 900
+    for i in range(n_tab):
+        d = big if n_tab == 1 else M.gen_plaintext(5000 + i, i & 3, 32768 + 700 * (i % 40))
+        lz, fo = M.lzx_encode(d, 17, 0)
+        streams.append(lz.tobytes()); params.append((d.size, 17, 0, 0)); tabs.append(np.asarray(fo[:-1], dtype=np.uint32))
+    for i in range(n_small):
+        d = M.gen_plaintext(9000 + i, i & 3, 1500 + 37 * (i % 50))
+        lz, _fo = M.lzx_encode(d, 16, 0)
+        streams.append(lz.tobytes()); params.append((d.size, 16, 0, 0)); tabs.append(None)
+    # (the units with tables in the middle of the list: arena order is not slot order)
+    perm = np.random.default_rng(3).permutation(len(streams))
+    streams = [streams[j] for j in perm]; params = [params[j] for j in perm]; tabs = [tabs[j] for j in perm]
+    units, out, res = run(streams, params, tabs)
+    check(streams, params, units, out, res)
+    with_tab = np.array([t is not None for t in tabs])
+    assert ((res["flags"][with_tab] & ADOPTED) != 0).all(), "a unit with a frame table did not take the frame-parallel path"
+    assert ((res["flags"][~with_tab] & ADOPTED) == 0).all()
