@@ -1093,15 +1093,18 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
   std::vector<int> rcs(n_shards, 0);
   std::vector<std::array<char, 256>> errs(n_shards);
   std::vector<std::thread> th;
+  auto run_shard = [&](int sh) {
+    const int dv = sh % n_devices;
+    errs[sh][0] = 0;
+    hipError_t e = hipSetDevice(dv);
+    if (e != hipSuccess) { snprintf(errs[sh].data(), 256, "hipSetDevice(%d): %s", dv, hipGetErrorString(e)); rcs[sh] = -(int) e; return; }
+    rcs[sh] = pipeline_on_current_device(dv, units, shard[sh].data(), shard[sh].size(), in, in_bytes, out, nullptr,
+                                         out_bytes, results, errs[sh].data(), 256, !ascending);
+  };
+  th.reserve((size_t) n_shards);
   for (int sh = 0; sh < n_shards; sh++) {
-    th.emplace_back([&, sh]() {
-      const int dv = sh % n_devices;
-      errs[sh][0] = 0;
-      hipError_t e = hipSetDevice(dv);
-      if (e != hipSuccess) { snprintf(errs[sh].data(), 256, "hipSetDevice(%d): %s", dv, hipGetErrorString(e)); rcs[sh] = -(int) e; return; }
-      rcs[sh] = pipeline_on_current_device(dv, units, shard[sh].data(), shard[sh].size(), in, in_bytes, out, nullptr,
-                                           out_bytes, results, errs[sh].data(), 256, !ascending);
-    });
+    // (a thread that cannot be created must not throw through the C ABI: that shard runs here, after the others were started)
+    try { th.emplace_back(run_shard, sh); } catch (...) { run_shard(sh); }
   }
   for (auto &t : th) t.join();
   for (int sh = 0; sh < n_shards; sh++)
