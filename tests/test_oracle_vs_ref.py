@@ -270,3 +270,27 @@ def test_szdd_kwaj_corpus_and_oracle_vs_reference(built):
             else:
                 continue
             assert (e, o) == (r["err"], r["data"]), (name, len(v))
+
+
+def test_lzx_open_block_at_reset_warning_vs_reference(built):
+    """lzxd.c:423-431: a block still open at a reset point makes the reference say "WARNING; invalid reset interval detected
+    during LZX decompression" (once per lzxd_decompress call) and decode on.  The oracle's list of such reset points
+    (oracle_lzx_open_resets -- what the kernels' MSPACK_HIP_UF_LZX_LOG is tested against) must be non-empty exactly when the
+    reference warns, and both must produce the same bytes and error code."""
+    import libmspack_amd as M
+    from helpers import lzx_set_bits, oracle_lzx_open_resets, ref_messages
+    F = 32768
+    for seed, wb, rf, nfr, patches in ((1, 16, 1, 6, {1: 100, 3: 7}), (2, 17, 2, 8, {3: 50}), (3, 16, 2, 6, {}), (4, 16, 3, 9, {2: 11, 8: 5})):
+        d = M.gen_plaintext(4000 + seed, seed & 1, nfr * F)
+        lz, fo = M.lzx_encode(d, wb, rf)
+        lz = bytearray(lz.tobytes())
+        for fr, extra in patches.items():
+            lzx_set_bits(lz, int(fo[fr]), 4 if fr % rf == 0 else 3, 24, F + extra)
+        ref_messages()
+        re_, rb, _ = ref_lzx(bytes(lz), nfr * F, wb, rf)
+        said = [l for l in ref_messages() if "invalid reset interval" in l]
+        oe, ob, _r = oracle_lzx(bytes(lz), nfr * F, wb, rf)
+        cnt, frames = oracle_lzx_open_resets()
+        assert (oe, ob) == (re_, rb), seed
+        assert (cnt > 0) == (len(said) > 0) and len(said) <= 1, (seed, cnt, said)
+        assert frames == sorted((fr // rf + 1) * rf for fr in patches), (seed, frames)
