@@ -1,0 +1,103 @@
+"""scratch: randomized differential fuzz of the CABINET driver's host logic (libmspack_amd/csrc/host/cabd.c on the CPU stand-in for the
+batch ABI, tests/_build/libhostlogic_cpu.so) against the REAL reference driver (oracle/_ref): a synthetic four-folder cabinet (MSZIP with
+history, LZX, Quantum, stored) with random byte damage, truncation and header edits; for every file, in two extraction orders and in
+the plain and salvage modes: the reference's error code and every byte.  Needs the development container (oracle/_ref).
+LIMITS of the stand-in (test infrastructure): no MSPACK_HIP_UF_HARD_EOF and no MSZIP repair mode -- cabinets whose block chain ends in a
+read failure (truncation, bad checksums outside salvage mode) come back as "GPU batch decode failed" and are reported as such, not as
+driver bugs; those paths are covered on the GPU by tests/test_gpu_drivers.py.  What this fuzz found in round 4: DESIGN.md section 7,
+"a failed extract() and the reference's decompressor afterwards".
+    python tools/fuzz_drivers_cpu.py <seed> [cases]"""
+import ctypes, glob, os, subprocess, sys, zlib
+import numpy as np
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import libmspack_amd as M
+from libmspack_amd import api
+import helpers
+
+def hostlogic():
+    bdir = os.path.join(R, "tests", "_build"); os.makedirs(bdir, exist_ok=True)
+    so = os.path.join(bdir, "libhostlogic_cpu.so")
+    srcs = sorted(glob.glob(os.path.join(R, "libmspack_amd", "csrc", "host", "*.c"))) + [os.path.join(R, "tests", "csrc", "batch_standin.c")] + \
+        sorted(glob.glob(os.path.join(R, "oracle", "*_oracle.c")))
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-comment", "-I", os.path.join(R, "include"), "-o", so] + srcs + ["-lpthread"])
+    return ctypes.CDLL(so)
+
+def base_cab(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(40000, 140000))
+    data = M.gen_plaintext(seed, int(rng.integers(0, 4)), n)
+    mb, mu, prev = [], [], None
+    for k in range(0, n, 32768):
+        b = data[k:k + 32768].tobytes()
+        c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, 0, prev) if prev else zlib.compressobj(6, zlib.DEFLATED, -15)
+        mb.append(b"CK" + c.compress(b) + c.flush()); mu.append(len(b)); prev = b
+    wb = int(rng.integers(15, 19))
+    lz, fo = M.lzx_encode(data, wb, 0)
+    lb = [lz[int(fo[i]):int(fo[i + 1])].tobytes() for i in range(len(fo) - 1)]
+    qs, fs = M.qtm_encode(data, 15)
+    pos, qb = 0, []
+    for s in fs:
+        qb.append(bytes(qs[pos:pos + int(s)])); pos += int(s) + 1
+    sb = [data[k:k + 32768].tobytes() for k in range(0, n, 32768)]
+    folders = [(1, mb, mu), (3 | (wb << 8), lb, mu), (2 | (15 << 8), qb, mu), (0, sb, mu)]
+    cut = int(rng.integers(1, n - 1))
+    files = []
+    for fi in range(4):
+        files.append((b"a%d.bin" % fi, cut, 0, fi)); files.append((b"b%d.bin" % fi, n - cut, cut, fi))
+    return bytearray(M.cab_write(folders, files))
+
+def mutate(cab, rng):
+    c = bytearray(cab)
+    kind = int(rng.integers(0, 6))
+    if kind == 0:                                        # flip a few bytes in the data area
+        for _ in range(int(rng.integers(1, 4))):
+            c[int(rng.integers(60, len(c)))] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 1:                                      # truncate
+        del c[int(rng.integers(40, len(c))):]
+    elif kind == 2:                                      # a header / folder / file table byte
+        c[int(rng.integers(8, 200))] = int(rng.integers(0, 256))
+    elif kind == 3:                                      # a CFDATA header field somewhere: find "CK" and damage the 8 bytes before
+        i = bytes(c).find(b"CK", int(rng.integers(60, len(c))))
+        if i > 8: c[i - 1 - int(rng.integers(0, 8))] ^= 1 << int(rng.integers(0, 8))
+    elif kind == 4:                                      # zero a stretch
+        a = int(rng.integers(60, len(c))); n = min(int(rng.integers(1, 300)), len(c) - a); c[a:a + n] = bytes(n)
+    return bytes(c)
+
+LAST = []
+def mine(L, cab, order, **kw):
+    with api.Cab(cab, mem=True, L=L, **kw) as c:
+        if c.open_error: return c.open_error, []
+        r = [c.extract(i) if i < len(c.files) else (None, b"") for i in order]
+        LAST[:] = [m for m in c.mem.messages if b"GPU" in (m if isinstance(m, bytes) else m.encode())]
+        L.mspack_hip_last_error.restype = ctypes.c_char_p
+        if LAST: LAST.append(L.mspack_hip_last_error())
+        return 0, r
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    assert helpers.have_ref()
+    L = hostlogic()
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for k in range(cases):
+        if k % 25 == 0: cab0 = base_cab(seed * 1000 + k)
+        cab = mutate(cab0, rng) if k % 10 else bytes(cab0)
+        e, lst = helpers.ref_cab_list(cab)
+        for kw in (dict(), dict(salvage=1)):            # (fix-MSZIP mode needs the kernels: the stand-in has no repair mode)
+            n = len(lst) if e == 0 else 0
+            for order in ([list(range(n)), list(range(n - 1, -1, -1))] if n else [[]]):
+                rc, want = helpers.ref_cab_extract(cab, order, cap=(n + 1) * 160000 + 4096, **kw) if e == 0 else (e, [])
+                me, got = mine(L, cab, order, **kw)
+                if e != 0 or rc != 0:
+                    if (me != 0) != True: bad += 1; print("case %d %s: reference open/extract rc %d/%d, mine open %d" % (k, kw, e, rc, me))
+                    continue
+                if me != 0: bad += 1; print("case %d %s: mine open error %d, reference opens" % (k, kw, me)); continue
+                for i, ((we, wb_), (ge, gb)) in enumerate(zip(want, got)):
+                    if we != ge or (we == 0 and wb_ != gb) or (we != 0 and kw.get("salvage") and wb_ != gb):
+                        bad += 1; print("case %d %s order %s file %d: reference (%d, %d bytes) mine (%s, %d bytes)" % (k, kw, order[:3], order[i], we, len(wb_), ge, len(gb)), LAST[-1:]); break
+    print("seed %d: %d cases, %d mismatches" % (seed, cases, bad))
+
+if __name__ == "__main__":
+    main()
