@@ -90,6 +90,13 @@ struct cabd_p {
   unsigned int st_offset;             /* bytes produced so far from st.folder                      */
   int st_active;
   struct folder_p *last_folder;       /* folder of the previous extract()                          */
+  /* the reference's ONE decompressor as far as its answers go (cabd.c:1136-1175): it lives on across extract() calls while the
+   * files of a folder are asked for at ascending offsets -- also after a call that FAILED: its codec then answers every further
+   * call with the same error (lzxd.c / mszipd.c / qtmd.c: "if (x->error) return x->error") and writes nothing -- and it starts
+   * over for another folder or for an offset below what it has written so far */
+  struct folder_p *live_folder;
+  unsigned int live_offset;           /* bytes the reference's decompressor has handed to cabd_sys_write (cabd.c:1347-1354) */
+  int live_failed, live_err;          /* it is in its error state; what extract() returns from then on (READ already mapped) */
   /* the reference's decompressor as far as its MESSAGES go: which folder it is on, how far it has decoded (cabd.c:1136-1175:
    * another folder or an earlier offset starts it again from the folder's first block, and it says everything again) */
   struct folder_p *msg_folder;
@@ -307,6 +314,8 @@ static void cabd_close(struct mscab_decompressor *base, struct mscabd_cabinet *o
       nfo = fo->next;
       if (self->st_active && self->st.folder == (struct folder_p *) fo) stored_reset(self);
       if (self->last_folder == (struct folder_p *) fo) self->last_folder = NULL;
+      if (self->live_folder == (struct folder_p *) fo) self->live_folder = NULL;
+      if (self->msg_folder == (struct folder_p *) fo) self->msg_folder = NULL;
       free_folder_cache(sys, (struct folder_p *) fo);
       for (sg = ((struct folder_p *) fo)->data.next; sg; sg = nsg) { nsg = sg->next; sys->free(sg); }
       sys->free(fo);
@@ -524,6 +533,8 @@ static int cabd_merge(struct mscab_decompressor *base, struct mscabd_cabinet *lc
     free_folder_cache(sys, rfol);
     if (self->st_active && (self->st.folder == rfol || self->st.folder == lfol)) stored_reset(self);
     if (self->last_folder == rfol) self->last_folder = NULL;
+    if (self->live_folder == rfol || self->live_folder == lfol) self->live_folder = NULL;     /* (the merged folder is decoded anew) */
+    if (self->msg_folder == rfol) self->msg_folder = NULL;
     sys->free(rfol);
   }
   /* every cabinet of the set shows the same lists */
@@ -914,9 +925,10 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
 }
 
 /* can the reference produce bytes [0, end) of this folder, and with which error if not? */
-static int folder_status(struct folder_p *fp, unsigned int end, int read_error)
+static int folder_status(struct folder_p *fp, unsigned int end, int read_error, int *failed)
 {
   int method = fp->base.comp_type & 0x0F, ok;
+  *failed = 1;                        /* (a failure whose code is the feeder's may read MSPACK_ERR_OK in salvage mode) */
   if (fp->dec_err == MSPACK_ERR_OK && end > fp->total) {
     /* the request goes past everything the blocks hold.  After a failed block read the codec's
      * next refill fails (-> the feeder's error); after a clean end LZX knows the stream length and
@@ -933,9 +945,26 @@ static int folder_status(struct folder_p *fp, unsigned int end, int read_error)
     else ok = (need_f < fp->n_frames_good);
   }
   else ok = (end <= fp->good_len);
-  if (ok) return MSPACK_ERR_OK;
+  if (ok) { *failed = 0; return MSPACK_ERR_OK; }
   if (fp->dec_err == MSPACK_ERR_OK) return read_error;
   return (fp->dec_err == MSPACK_ERR_READ) ? read_error : fp->dec_err;
+}
+
+/* what the reference's decompressor has WRITTEN when a call fails (its d->offset, cabd.c:1352): lzxd and mszipd hand over every
+ * frame / block once it is decoded (lzxd.c:738-751, mszipd.c:440-452), so everything below the failing frame is out -- but no more
+ * than the call asked for; qtmd writes when its window wraps and at the end of a call that succeeds (qtmd.c:420-428, 468-474) */
+static unsigned int flushed_at_failure(struct folder_p *fp, unsigned int end)
+{
+  const int method = fp->base.comp_type & 0x0F;
+  const unsigned int reached = (fp->dec_err == MSPACK_ERR_OK || fp->good_len > fp->total) ? fp->total : fp->good_len;
+  unsigned int f;
+  if (method == MSCAB_COMP_QUANTUM) {
+    const unsigned int w = 1u << ((fp->base.comp_type >> 8) & 0x1F);
+    f = reached / w * w;
+  }
+  else if (method == MSCAB_COMP_LZX && fp->dec_err != MSPACK_ERR_OK && fp->good_len < fp->total) f = fp->n_frames_good * CAB_BLOCKMAX;
+  else f = (reached == fp->total) ? fp->total : reached / CAB_BLOCKMAX * CAB_BLOCKMAX;
+  return f < end ? f : end;
 }
 
 static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *file, const char *filename)
@@ -983,13 +1012,16 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
   /* one decompression state per decompressor: another folder ends the stored folder's stream */
   if (self->last_folder != fol) stored_reset(self);
   self->last_folder = fol;
-  if ((fol->base.comp_type & 0x0F) == MSCAB_COMP_NONE) return stored_extract(self, fol, file, filelen, filename);
+  if ((fol->base.comp_type & 0x0F) == MSCAB_COMP_NONE) { self->live_folder = NULL; return stored_extract(self, fol, file, filelen, filename); }
 
   if (!fol->decoded) {
     int err = decode_cabinet(self, (struct cab_p *) fol->data.cab, fol);
     if (err) return self->error = err;
   }
   self->read_error = fol->read_err;
+  if (self->live_folder != fol || self->live_offset > file->offset) {    /* cabd.c:1136: another folder, or an earlier offset */
+    self->live_folder = fol; self->live_offset = 0; self->live_failed = 0; self->live_err = MSPACK_ERR_OK;
+  }
 
   if (!(fh = sys->open(sys, filename, MSPACK_SYS_OPEN_WRITE))) return self->error = MSPACK_ERR_OPEN;
   self->error = MSPACK_ERR_OK;
@@ -1015,17 +1047,30 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
     self->msg_offset = end;
   }
   else if (filelen) { self->msg_folder = fol; self->msg_offset = file->offset + filelen; self->msg_next = 0; self->msg_next_ck = 0; }
-  if (filelen) {
+  if (filelen && self->live_failed) self->error = self->live_err;      /* (the codec's sticky error: nothing decoded, nothing written) */
+  else if (filelen) {
     /* skip phase: getting to file->offset must itself be error free (cabd.c:1195-1199) */
-    int err = file->offset ? folder_status(fol, file->offset, self->read_error) : MSPACK_ERR_OK;
+    int failed = 0;
+    int err = file->offset ? folder_status(fol, file->offset, self->read_error, &failed) : MSPACK_ERR_OK;
+    unsigned int end = file->offset;
     if (!err) {
-      unsigned int end = file->offset + filelen;
-      unsigned int have = fol->good_len > file->offset ? fol->good_len - file->offset : 0;
-      if (have > filelen) have = filelen;
-      err = folder_status(fol, end, self->read_error);
-      if (write_slice(sys, fh, fol->dec + file->offset, have) != MSPACK_ERR_OK) err = MSPACK_ERR_WRITE;
+      /* (a skip that failed with a code that reads OK -- salvage mode, out of blocks -- is followed by the emit call, which meets
+       * the codec's sticky error: the same code again, nothing written) */
+      if (!failed) {
+        unsigned int have = fol->good_len > file->offset ? fol->good_len - file->offset : 0;
+        if (have > filelen) have = filelen;
+        end = file->offset + filelen;
+        err = folder_status(fol, end, self->read_error, &failed);
+        if (write_slice(sys, fh, fol->dec + file->offset, have) != MSPACK_ERR_OK) err = MSPACK_ERR_WRITE;
+      }
     }
     self->error = err;
+    if (failed) {
+      const unsigned int fl = flushed_at_failure(fol, end);
+      self->live_failed = 1; self->live_err = err;
+      if (fl > self->live_offset) self->live_offset = fl;
+    }
+    else self->live_offset = file->offset + filelen;
   }
   sys->close(fh);
   return self->error;
@@ -1072,6 +1117,7 @@ struct mscab_decompressor *mspack_create_cab_decompressor(struct mspack_system *
   self->devices = 1; self->cache_mb = 2048;
   memset(&self->st, 0, sizeof(self->st)); self->st_offset = 0; self->st_active = 0; self->last_folder = NULL;
   self->msg_folder = NULL; self->msg_offset = 0; self->msg_next = 0; self->msg_next_ck = 0;
+  self->live_folder = NULL; self->live_offset = 0; self->live_failed = 0; self->live_err = MSPACK_ERR_OK;
   return &self->base;
 }
 

@@ -1,0 +1,45 @@
+"""Makes tests/golden/cab_sticky.json (development container, oracle/_ref): what the REAL cabd answers when extract() calls follow a
+FAILED call in the same folder.  The reference keeps one decompressor alive while the files' offsets ascend (cabd.c:1136-1175); after
+a failure its codec repeats its error for every further call and writes nothing, until a file's offset lies below what it has written
+so far and the folder is started over.  A four-folder cabinet (MSZIP, LZX, Quantum, stored; tests/cab_recipe.py) whose
+file table is edited: one file's offset is moved far beyond its folder -- in salvage mode the skip to it "succeeds" with nothing
+written (out of blocks reads as MSPACK_ERR_OK, cabd.c:1339-1345) and leaves the decompressor in its error state.
+    python tests/golden/make_cab_sticky_golden.py"""
+import hashlib
+import json
+import os
+import struct
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import helpers
+import cab_recipe as F
+
+
+def main():
+    assert helpers.have_ref()
+    helpers.ref().refh_zero_alloc(1)
+    gold = []
+    # the file whose offset is damaged: Quantum / MSZIP / LZX folder; and the Quantum folder again with its second file starting in the
+    # folder's LAST window (qtmd writes when its 32 KiB window wraps: that file lies above everything the failed call wrote)
+    for seed, victim, cut in ((7000, 4, None), (7025, 0, None), (7050, 2, None), (7075, 4, "last_window")):
+        cab = F.base_cab(seed, cut)
+        ents = F.file_entry_offsets(cab)
+        struct.pack_into("<I", cab, ents[victim] + 4, 4521984)     # uoffFolderStart
+        cab = bytes(cab)
+        v = dict(seed=seed, victim=victim, cut=cut, cab_md5=hashlib.md5(cab).hexdigest(), runs=[])
+        for salvage in (1, 0):
+            for order in ([victim, victim + 1], [victim + 1, victim, victim + 1], [victim, victim, victim + 1], [victim + 1, victim],
+                          [victim, 7, victim + 1], list(range(8)), list(range(7, -1, -1))):
+                rc, res = helpers.ref_cab_extract(cab, order, cap=len(order) * 160000 + 4096, salvage=salvage)
+                assert rc == 0
+                v["runs"].append(dict(salvage=salvage, order=order,
+                                      results=[dict(err=e, n=len(b), md5=hashlib.md5(b).hexdigest()) for e, b in res]))
+                print(seed, salvage, order, [(e, len(b)) for e, b in res])
+        gold.append(v)
+    json.dump(gold, open(os.path.join(HERE, "cab_sticky.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""extract() after a FAILED extract() in the same folder (found by tools/fuzz_drivers_cpu.py, round 4).  The reference keeps one
+decompressor alive while the files of a folder are asked for at ascending offsets (cabd.c:1136-1175) -- also after a call that
+failed: its codec then repeats its error for every further call and writes nothing (lzxd.c / mszipd.c / qtmd.c: `if (x->error)
+return x->error`), until a file's offset lies below what the decompressor has WRITTEN so far and the folder is started over.
+What it has written is codec-specific: lzxd and mszipd hand over every frame / block, qtmd only when its window wraps
+(qtmd.c:420-428).  tests/golden/cab_sticky.json: four recipe cabinets whose file table has one offset moved far beyond its folder
+(in salvage mode the skip to it "succeeds" with nothing written: out of blocks reads as MSPACK_ERR_OK there), seven extraction
+orders each, with and without salvage mode, answered by the REAL cabd (tests/golden/make_cab_sticky_golden.py with oracle/_ref).
+  * `-m gpu`: through libmspack_hip.so; `-m "not gpu"`: the same driver code on the CPU stand-in for the batch ABI."""
+import hashlib
+import json
+import os
+import struct
+
+import pytest
+
+from libmspack_amd import api
+import cab_recipe as R
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cab_sticky.json")))
+
+
+def replay(v, L=None):
+    cab = R.base_cab(v["seed"], v["cut"])
+    struct.pack_into("<I", cab, R.file_entry_offsets(cab)[v["victim"]] + 4, 4521984)
+    cab = bytes(cab)
+    assert hashlib.md5(cab).hexdigest() == v["cab_md5"], "recipe no longer reproduces the golden cabinet"
+    for run in v["runs"]:
+        with api.Cab(cab, mem=True, L=L, salvage=run["salvage"]) as c:
+            assert c.open_error == 0
+            for k, (i, exp) in enumerate(zip(run["order"], run["results"])):
+                c.mem.outputs.clear()                    # (a call that fails before it opens its output leaves the previous one)
+                err, data = c.extract(i)
+                tag = "seed %d salvage %d order %s call %d (file %d)" % (v["seed"], run["salvage"], run["order"], k, i)
+                assert (err, len(data)) == (exp["err"], exp["n"]), (tag, err, len(data), exp)
+                assert hashlib.md5(data).hexdigest() == exp["md5"], tag
+
+
+def test_golden_holds_the_case():
+    """the Quantum cabinet whose second file starts in the folder's last window: after the failed call the reference writes nothing
+    for it either"""
+    v = [g for g in GOLD if g["cut"] == "last_window"][0]
+    r = [x for x in v["runs"] if x["salvage"] == 1 and x["order"] == [4, 5]][0]
+    assert [(x["err"], x["n"]) for x in r["results"]] == [(0, 0), (0, 0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", GOLD, ids=["seed%d" % g["seed"] for g in GOLD])
+def test_extract_after_failed_extract_gpu(built, v):
+    replay(v)
+
+
+@pytest.mark.parametrize("v", GOLD, ids=["seed%d" % g["seed"] for g in GOLD])
+def test_extract_after_failed_extract_host_logic_cpu(built, hostlogic, v):
+    replay(v, L=hostlogic)
