@@ -4,8 +4,8 @@ history, LZX, Quantum, stored) with random byte damage, truncation and header ed
 the plain and salvage modes: the reference's error code and every byte.  Needs the development container (oracle/_ref).
 LIMITS of the stand-in (test infrastructure): no MSPACK_HIP_UF_HARD_EOF and no MSZIP repair mode -- cabinets whose block chain ends in a
 read failure (truncation, bad checksums outside salvage mode) come back as "GPU batch decode failed" and are reported as such, not as
-driver bugs; those paths are covered on the GPU by tests/test_gpu_drivers.py.  What this fuzz found in round 4: DESIGN.md section 7,
-"a failed extract() and the reference's decompressor afterwards".
+driver bugs; those paths are covered on the GPU by tests/test_gpu_drivers.py.  What this fuzz found in round 4: DESIGN.md section 7
+(extract() after a failed extract(): fixed, tests/test_cab_sticky.py; salvage mode on damaged CFDATA headers: open).
     python tools/fuzz_drivers_cpu.py <seed> [cases]"""
 import ctypes, glob, os, subprocess, sys, zlib
 import numpy as np
