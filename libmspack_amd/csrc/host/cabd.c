@@ -1058,6 +1058,7 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
        * the codec's sticky error: the same code again, nothing written) */
       if (!failed) {
         unsigned int have = fol->good_len > file->offset ? fol->good_len - file->offset : 0;
+        if (file->offset > self->live_offset) self->live_offset = file->offset;      /* (the skip call's bytes were handed over) */
         if (have > filelen) have = filelen;
         end = file->offset + filelen;
         err = folder_status(fol, end, self->read_error, &failed);

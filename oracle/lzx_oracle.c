@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
+__thread int oracle_hard_eof_;          /* oracle_set_hard_eof(): the feeder's read FAILS at in_len (cabd.c:1322-1324) instead of ending */
+void oracle_set_hard_eof(int on) { oracle_hard_eof_ = on; }
 #include "oracle_huff.h"
 
 #define FRAME 32768u
@@ -33,7 +35,7 @@ typedef struct {
 static int rd_byte(bits_t *b, unsigned *v) {
   /* readbits.h:192-214: at EOF two zero bytes are fabricated once; after that ERR_READ */
   if (b->pos < b->in_len) { *v = b->in[b->pos++]; return 0; }
-  if (b->pos < b->in_len + 2) { b->pos++; *v = 0; return 0; }
+  if (!oracle_hard_eof_ && b->pos < b->in_len + 2) { b->pos++; *v = 0; return 0; }   /* (a FAILED read -- sys->read < 0 -- fabricates nothing: readbits.h:196-198) */
   b->err = ORC_READ; return 1;
 }
 static int ensure(bits_t *b, int n) {

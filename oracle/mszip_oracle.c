@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
+extern __thread int oracle_hard_eof_;   /* lzx_oracle.c: oracle_set_hard_eof() */
 #include "oracle_huff.h"
 
 #define FRAME 32768u
@@ -31,7 +32,7 @@ typedef struct {
 static int z_byte(zbits_t *b, unsigned *v) {
   if (b->pos <= b->in_len && (b->pos % b->bufsz == 0 || b->pos == b->in_len)) b->s_iptr = b->pos;   /* refill point */
   if (b->pos < b->in_len) { *v = b->in[b->pos++]; return 0; }
-  if (b->pos < b->in_len + 2) { b->pos++; *v = 0; return 0; }
+  if (!oracle_hard_eof_ && b->pos < b->in_len + 2) { b->pos++; *v = 0; return 0; }   /* (a FAILED read -- sys->read < 0 -- fabricates nothing: readbits.h:196-198) */
   b->err = ORC_READ; return 1;
 }
 static void z_store(zbits_t *b) { b->s_iptr = b->pos; b->s_bb = b->bb; b->s_bl = b->bl; }

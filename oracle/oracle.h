@@ -56,6 +56,10 @@ int oracle_lzx_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
                       int32_t e8_base, oracle_result *res);
 /* the same with LZX DELTA (is_delta: window 2^17..2^25, per-frame chunk size, extended match lengths)
  * and its reference data (lzxd_set_reference_data, lzxd.c:348-382) */
+/* For the NEXT decode calls of this thread: the feeder's read fails at in_len (sys->read returns < 0 -- a bad CFDATA block, cabd.c:1322-1324)
+ * instead of reporting the end of the input: MSPACK_ERR_READ at once, without the two zero bytes read_input fabricates at a clean end
+ * (readbits.h:192-208).  What MSPACK_HIP_UF_HARD_EOF tells the kernels.  0 switches it off again. */
+void oracle_set_hard_eof(int on);
 /* the reset points (frame indices) at which the last oracle_lzx_decode / oracle_lzxd_decode of THIS thread found a block still
  * open -- lzxd.c:423-431, where the reference warns through sys->message.  Returns how many there were (also beyond cap). */
 uint32_t oracle_lzx_open_resets(uint32_t *frames, uint32_t cap);

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "oracle.h"
+extern __thread int oracle_hard_eof_;   /* lzx_oracle.c: oracle_set_hard_eof() */
 
 #define FRAME 32768u
 
@@ -25,7 +26,7 @@ typedef struct {
 
 static int q_byte(qbits_t *b, unsigned *v) {
   if (b->pos < b->in_len) { *v = b->in[b->pos++]; return 0; }
-  if (b->pos < b->in_len + 2) { b->pos++; *v = 0; return 0; }
+  if (!oracle_hard_eof_ && b->pos < b->in_len + 2) { b->pos++; *v = 0; return 0; }   /* (a FAILED read -- sys->read < 0 -- fabricates nothing: readbits.h:196-198) */
   b->err = ORC_READ; return 1;
 }
 static int q_fill(qbits_t *b) {          /* one READ_BYTES: 16 bits, big-endian byte pair */

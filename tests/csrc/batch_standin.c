@@ -29,6 +29,7 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *
     const mspack_hip_unit *u = &units[i];
     mspack_hip_result *r = &results[i];
     oracle_result o;
+    uint32_t qtm_good = 0; int have_qtm_good = 0;
     const uint8_t *src = (const uint8_t *) in + u->in_off;
     uint8_t *dst = (uint8_t *) out + u->out_off;
     memset(&o, 0, sizeof(o));
@@ -37,8 +38,9 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *
       snprintf(g_err, sizeof(g_err), "unit outside arena"); return -1;
     }
     /* the frame table is a hint for the GPU's frame-parallel parse; results do not depend on it */
-    if (u->flags & ~(MSPACK_HIP_UF_FRAME_TABLE | (u->kind == MSPACK_HIP_KIND_LZX ? MSPACK_HIP_UF_LZX_LOG : 0u))) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
+    if (u->flags & ~(MSPACK_HIP_UF_FRAME_TABLE | MSPACK_HIP_UF_HARD_EOF | (u->kind == MSPACK_HIP_KIND_LZX ? MSPACK_HIP_UF_LZX_LOG : 0u))) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
     if (u->kind == 0) { r->err = 1; continue; }
+    oracle_set_hard_eof((u->flags & MSPACK_HIP_UF_HARD_EOF) != 0);
     switch (u->kind) {
     case MSPACK_HIP_KIND_LZX:
       oracle_lzx_decode(src, u->in_len, dst, u->out_len, u->out_len, u->out_len, u->window_bits, u->reset_frames,
@@ -59,12 +61,29 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *
       break;
     case MSPACK_HIP_KIND_QUANTUM:
       oracle_qtm_decode(src, u->in_len, dst, u->out_len, u->out_len, u->window_bits, &o);
+      if (o.err != 0 && u->out_len) {
+        /* good_len (mspack_hip.h): how far a SHORTER request would still have succeeded -- qtmd writes only when its window wraps
+         * and at the end of a call that succeeds, so the bytes it handed over say nothing about it: bisect with the oracle */
+        uint8_t *tmp = (uint8_t *) malloc((size_t) u->out_len + 64);
+        uint32_t lo = 0, hi = u->out_len;                        /* decode(lo) succeeds, decode(hi) fails */
+        while (tmp && hi - lo > 1) {
+          const uint32_t mid = lo + (hi - lo) / 2;
+          oracle_result t;
+          memset(&t, 0, sizeof(t));
+          oracle_qtm_decode(src, u->in_len, tmp, mid, mid, u->window_bits, &t);
+          if (t.err == 0) lo = mid; else hi = mid;
+        }
+        if (tmp) { oracle_result t; memset(&t, 0, sizeof(t)); oracle_qtm_decode(src, u->in_len, dst, lo, lo, u->window_bits, &t); }   /* the good bytes, in place */
+        free(tmp);
+        qtm_good = lo; have_qtm_good = 1;
+      }
       break;
     default:
       snprintf(g_err, sizeof(g_err), "stand-in: kind %d unsupported", u->kind); return -1;
     }
+    oracle_set_hard_eof(0);
     r->err = o.err; r->flags = o.flags; r->out_len = (uint32_t) o.out_len; r->in_used = (uint32_t) o.in_used;
-    r->good_len = (uint32_t) o.out_len; r->in_next = (uint32_t) o.in_next;
+    r->good_len = have_qtm_good ? qtm_good : (uint32_t) o.out_len; r->in_next = (uint32_t) o.in_next;
   }
   return 0;
 }

@@ -38,6 +38,25 @@ def main():
                                       results=[dict(err=e, n=len(b), md5=hashlib.md5(b).hexdigest()) for e, b in res]))
                 print(seed, salvage, order, [(e, len(b)) for e, b in res])
         gold.append(v)
+    # a damaged CFDATA block in the MIDDLE of a folder (bad checksum): the file behind it fails after its skip succeeded, the
+    # decompressor has then written up to that file's offset (+ what it flushed), and the file in FRONT of it starts the folder over
+    for seed, folder in ((7100, 2), (7125, 1), (7150, 0), (7214, 2), (7225, 1), (7230, 0)):   # Quantum, LZX, MSZIP; the last three: the first file lies in front of the damage
+        cab = F.base_cab(seed)
+        coff, = struct.unpack_from("<I", cab, 36 + 8 * folder)
+        cb0, = struct.unpack_from("<H", cab, coff + 4)
+        flip = coff + 8 + cb0 + 8 + 20                                    # byte 20 of the folder's second block
+        cab[flip] ^= 0x10
+        cab = bytes(cab)
+        a, b = 2 * folder, 2 * folder + 1
+        v = dict(seed=seed, victim=None, cut=None, flip=flip, cab_md5=hashlib.md5(cab).hexdigest(), runs=[])
+        for salvage in (0, 1):
+            for order in ([b, a], [a, b], [b, b, a], [b, a, b], list(range(8)), list(range(7, -1, -1))):
+                rc, res = helpers.ref_cab_extract(cab, order, cap=len(order) * 160000 + 4096, salvage=salvage)
+                assert rc == 0
+                v["runs"].append(dict(salvage=salvage, order=order,
+                                      results=[dict(err=e, n=len(bb), md5=hashlib.md5(bb).hexdigest()) for e, bb in res]))
+                print(seed, salvage, order, [(e, len(bb)) for e, bb in res])
+        gold.append(v)
     json.dump(gold, open(os.path.join(HERE, "cab_sticky.json"), "w"), indent=1)
 
 

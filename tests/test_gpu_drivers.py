@@ -15,7 +15,6 @@ import pytest
 import libmspack_amd as M
 from libmspack_amd import api
 
-pytestmark = pytest.mark.gpu
 VECS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "driver_cabs.json")))
 BASES = {v["tag"]: base64.b64decode(v["cab_b64"]) for v in VECS if "cab_b64" in v}
 
@@ -32,13 +31,12 @@ def cab_bytes(v):
     return bytes(b)
 
 
-@pytest.mark.parametrize("v", VECS, ids=[v["tag"] for v in VECS])
-def test_cab_driver_vs_reference(built, v):
+def replay(v, L=None):
     cab = cab_bytes(v)
     p = v["params"]
     for run in (v["runs"] or [None]):
         # the same in-memory mspack_system semantics the goldens were recorded with (api.MemSystem)
-        with api.Cab(cab, fix_mszip=p.get("fix_mszip", 0), salvage=p.get("salvage", 0), mem=True) as c:
+        with api.Cab(cab, fix_mszip=p.get("fix_mszip", 0), salvage=p.get("salvage", 0), mem=True, L=L) as c:
             assert c.open_error == v["open_err"], v["tag"]
             if run is None:
                 continue
@@ -52,6 +50,23 @@ def test_cab_driver_vs_reference(built, v):
                     assert len(data) == exp["n"] and hashlib.md5(data).hexdigest() == exp["md5"], tag
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("v", VECS, ids=[v["tag"] for v in VECS])
+def test_cab_driver_vs_reference(built, v):
+    replay(v)
+
+
+CPU_VECS = [v for v in VECS if not v["params"].get("fix_mszip")]      # (the stand-in has no MSZIP repair mode: those run on the GPU)
+
+
+@pytest.mark.parametrize("v", CPU_VECS, ids=[v["tag"] for v in CPU_VECS])
+def test_cab_driver_host_logic_cpu(built, hostlogic, v):
+    """the same goldens through the same driver code (csrc/host/cabd.c) on the CPU stand-in for the batch ABI (tests/csrc/
+    batch_standin.c: the oracle, incl. the feeder's failed reads -- MSPACK_HIP_UF_HARD_EOF): host logic without a GPU"""
+    replay(v, L=hostlogic)
+
+
+@pytest.mark.gpu
 def test_cab_any_order_24_permutations(built):
     """cabd_test.c:486-520: every ordering of 4 files from 2 folders gives identical contents."""
     import itertools
@@ -73,6 +88,7 @@ def test_cab_any_order_24_permutations(built):
                 assert err == 0 and d == exp[i], (perm, i)
 
 
+@pytest.mark.gpu
 def test_chm_driver(built):
     """CHM: LZX-21, reset interval 2 frames; listed order, reverse order, fast_find, interleaved
     (cf. libmspack/test/chmd_order.c:55-129), plus the section-0 system files."""
