@@ -60,6 +60,10 @@ struct chm_p {
 struct vdec {                     /* the reference's lzxd instance, replayed (chmd.c:989-1040)       */
   int alive, mode, serial, seek_pending;   /* mode 0: created at a reset-table entry, 1: at offset 0 with SpanInfo */
   off_t init, length, offset;     /* creation point, stream length it was created with, position    */
+  off_t dlen;                     /* the reference's d->length (chmd.c:1176): what extract() checks offsets and lengths against.
+                                     == length, except for a decoder created exactly AT the stream's stated end: lzxd_init then
+                                     gets an output length of 0, which means "not known" (lzxd.c:419, 458-461) -- it decodes
+                                     whatever frames follow, for as long as the input lasts */
   off_t decoded_end;              /* end of the last frame it has decoded: [offset, decoded_end) is stored
                                      up in its window and handed out without decoding (lzxd.c:397-408)  */
   uint64_t in_off;                /* compressed offset it was created at                            */
@@ -527,6 +531,13 @@ static int decode_intervals(struct chmd_p *self, struct chm_p *c, unsigned int f
     units[k].in_len = (uint32_t)((uint64_t) c->arena_len - off > 0xFFFFFFF0u ? 0xFFFFFFF0u : (uint64_t) c->arena_len - off);
     units[k].out_off = (uint64_t) k * (uint64_t) c->interval_bytes;
     units[k].out_len = (uint32_t) c->interval_bytes;
+    {
+      /* the stream ends where the (padded) UncompLen says: an interval that holds the end is as long as what is left of it --
+       * for an interval size that is no power of two the reference's padding (& -interval, chmd.c:1153-1157) is no multiple of
+       * it.  (Intervals wholly behind the stated end are only ever decoded by a decoder created AT it: unknown length, §vdec) */
+      const off_t at = (off_t)(first + k) * c->interval_bytes;
+      if (at < c->padded_len && c->padded_len - at < c->interval_bytes) units[k].out_len = (uint32_t)(c->padded_len - at);
+    }
     units[k].kind = MSPACK_HIP_KIND_LZX;
     units[k].window_bits = (uint8_t) c->window_bits;
     units[k].reset_frames = (uint16_t) c->fper;
@@ -584,7 +595,10 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
   /* the reference computes in `int` (chmd.c:1075,1114-1121): an interval beyond 2^31 wraps there */
   reset_interval = (off_t)(int)(unsigned int) reset_interval;
   if (reset_interval == 0 || reset_interval % FRAME) return MSPACK_ERR_DATAFORMAT;
-  if (reset_interval < 0 || reset_interval / FRAME > 65535) return MSPACK_ERR_DATAFORMAT;   /* ours: unit field width */
+  /* (an interval that wrapped negative passes the reference's checks and ends in lzxd_init(reset_interval < 0) == NULL:
+   *  MSPACK_ERR_NOMEMORY, lzxd.c:297-300, chmd.c:1183-1187) */
+  if (reset_interval < 0) return MSPACK_ERR_NOMEMORY;
+  if (reset_interval / FRAME > 65535) return MSPACK_ERR_DATAFORMAT;                          /* ours: unit field width */
   c->interval_bytes = reset_interval;
   c->fper = (unsigned int)(reset_interval / FRAME);
 
@@ -625,14 +639,22 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
     unsigned int nent = rd_le32(data + 4), esz = rd_le32(data + 8), toff = rd_le32(data + 0x0C);
     if (rd_le32(data + 0x20) == FRAME && (esz == 4 || esz == 8)) {
       off_t total = (off_t) rd_le64(data + 0x10);
-      uint64_t ni;
+      uint64_t ni, nt;
       c->padded_len = (total + reset_interval - 1) & -reset_interval;      /* chmd.c:1153-1157 */
-      ni = c->padded_len > 0 ? (uint64_t)(c->padded_len / reset_interval) : 0;
+      /* (intervals that hold bytes of the padded length: for an interval that is no power of two the reference's rounding
+       *  above does not give a multiple of it) */
+      ni = c->padded_len > 0 ? (uint64_t)((c->padded_len + reset_interval - 1) / reset_interval) : 0;
       if (ni > 0x7FFFFFFFu / c->fper) ni = 0x7FFFFFFFu / c->fper;
-      /* entries exist for the intervals whose first frame index is below NumEntries and inside the file */
-      if (ni && (c->ioff = (uint64_t *) sys->alloc(sys, (size_t) ni * sizeof(uint64_t)))) {
+      /* entries exist for the intervals whose first frame index is below NumEntries and inside the table's file -- whatever
+       * UncompLen says: the reference looks an entry up BEFORE it looks at the length (chmd.c:1146-1157), so a file that lies
+       * behind a dishonest UncompLen is answered from ITS interval (and then refused: lzxd_init with a negative length ->
+       * MSPACK_ERR_NOMEMORY, or "offset beyond the length" -> MSPACK_ERR_DECRUNCH), not from SpanInfo */
+      nt = (uint64_t) nent / c->fper + 1u;
+      { const uint64_t by_file = (uint64_t) sec->rtable->length / esz / c->fper + 1u; if (nt > by_file) nt = by_file; }
+      if (nt > 0x7FFFFFFFu / c->fper) nt = 0x7FFFFFFFu / c->fper;
+      if (nt && (c->ioff = (uint64_t *) sys->alloc(sys, (size_t) nt * sizeof(uint64_t)))) {
         unsigned int k;
-        for (k = 0; k < ni; k++) {
+        for (k = 0; k < nt; k++) {
           unsigned int entry = k * c->fper;
           unsigned int pos = toff + entry * esz;                              /* unsigned wrap as in chmd.c:1237 */
           if (entry >= nent || (off_t) pos > sec->rtable->length - (off_t) esz) break;
@@ -792,7 +814,9 @@ static int vdec_decode(struct chmd_p *self, struct chm_p *c, off_t A, off_t B, o
     unsigned int k0 = (unsigned int)(v->init / c->interval_bytes), k, k_hi;
     off_t total_frames = v->length / FRAME;     /* table mode: the length is padded to whole intervals */
     off_t kh = fe / c->fper;
-    k_hi = (kh >= (off_t) c->n_intervals) ? c->n_intervals - 1 : (unsigned int) kh;
+    /* (the intervals of THIS decoder's stream: c->n_intervals, but for the decoder of unknown length, struct vdec) */
+    const unsigned int nv = (unsigned int)((v->length + c->interval_bytes - 1) / c->interval_bytes);
+    k_hi = (kh >= (off_t) nv) ? nv - 1 : (unsigned int) kh;
     for (k = (unsigned int)(A / c->interval_bytes); k <= k_hi && (off_t) k * c->interval_bytes < v->length; k++) {
       if (k >= c->n_fast) { v->serial = 1; break; }
       if ((err = ensure_chunk(self, c, k, 0, NULL))) return err;
@@ -812,9 +836,9 @@ static int vdec_decode(struct chmd_p *self, struct chm_p *c, off_t A, off_t B, o
       if (fe >= total_frames) {
         /* the request reaches the end of the stream: the reference still enters one more (empty) frame,
          * at a reset point, and reads the header bit there -- which fails only if the input is exhausted */
-        if (c->n_intervals && c->n_intervals <= c->n_fast) {
-          if ((err = ensure_chunk(self, c, c->n_intervals - 1, 0, NULL))) return err;
-          if (c->ires[c->n_intervals - 1].flags & MSPACK_HIP_F_LOOKAHEAD_READ) { *good = v->length; return MSPACK_ERR_READ; }
+        if (nv && nv <= c->n_fast) {
+          if ((err = ensure_chunk(self, c, nv - 1, 0, NULL))) return err;
+          if (c->ires[nv - 1].flags & MSPACK_HIP_F_LOOKAHEAD_READ) { *good = v->length; return MSPACK_ERR_READ; }
         }
         if (B > v->length) { *good = v->length; return MSPACK_ERR_DECRUNCH; }         /* lzxd.c:758-761 */
       }
@@ -941,18 +965,20 @@ static int chmd_extract(struct mschm_decompressor *base, struct mschmd_file *fil
       off_t k0 = file->offset / c->interval_bytes;
       v->alive = 0;
       if (file->offset >= 0 && k0 < (off_t) c->n_fast) {
-        v->mode = 0; v->init = k0 * c->interval_bytes; v->length = c->padded_len; v->in_off = c->ioff[k0];
+        v->mode = 0; v->init = k0 * c->interval_bytes; v->length = v->dlen = c->padded_len; v->in_off = c->ioff[k0];
+        if (v->init > v->dlen) err = MSPACK_ERR_NOMEMORY;            /* lzxd_init(output_length < 0) == NULL (lzxd.c:297-300, chmd.c:1183-1187) */
+        else if (v->init == v->dlen) v->length = (off_t) c->n_fast * c->interval_bytes;    /* output_length 0: every interval the table has */
       }
       else if (c->span_err) err = c->span_err;                              /* chmd.c:1159-1166 */
-      else { v->mode = 1; v->init = 0; v->length = c->span_len; v->in_off = 0; }
+      else { v->mode = 1; v->init = 0; v->length = v->dlen = c->span_len; v->in_off = 0; }
       if (!err) { v->alive = 1; v->serial = (v->mode == 1); v->offset = v->decoded_end = v->init; v->seek_pending = 1; }
     }
     if (!err) {
-      if (file->offset > v->length) err = MSPACK_ERR_DECRUNCH;              /* chmd.c:1002-1005; the decoder lives on */
+      if (file->offset > v->dlen) err = MSPACK_ERR_DECRUNCH;                /* chmd.c:1002-1005; the decoder lives on */
       else if (v->seek_pending && sys->seek(infh, c->content_start + (off_t) v->in_off, MSPACK_SYS_SEEK_START))
         err = MSPACK_ERR_SEEK;                                              /* chmd.c:1008-1011; it lives on, too */
       else {
-        off_t length = file->length, maxlen = v->length - file->offset, good = 0;
+        off_t length = file->length, maxlen = v->dlen - file->offset, good = 0;
         v->seek_pending = 0;
         if (file->offset > v->offset) err = vdec_phase(self, c, v->offset, file->offset, &good);   /* skip */
         if (!err) {

@@ -115,6 +115,21 @@ c = base(4, seed=31, mutations=[["control_u32", 0x10, 3]])                  # wi
 add("lzx21-r2-badwindow", c, orders_for(len(c["files"]), 18)[:1])
 c = base(4, seed=31, mutations=[["control_u32", 0x08, 3]])                  # ControlData version 3
 add("lzx21-r2-badversion", c, orders_for(len(c["files"]), 19)[:1])
+# 13. (round 4, found by tools/fuzz_chm_cpu.py) an UncompLen that LIES: files behind the stated end.  The reference looks the
+# file's reset-table entry up before it looks at the length (chmd.c:1146-1157): a decoder created beyond the padded length gets a
+# negative output length (lzxd_init == NULL -> MSPACK_ERR_NOMEMORY), one created exactly AT it an output length of 0 = "not known"
+# (a request there is cut to one byte and succeeds), and a live decoder answers offsets beyond the length with MSPACK_ERR_DECRUNCH
+c = base(8, wb=17, seed=35, n_files=9, uncomp_len=3 * I64 - 9000)
+c["files"] = c["files"] + [["/zz-at-end.bin", 3 * I64, 700], ["/zz-one-more.bin", 3 * I64 + 700, 50]]
+n = len(c["files"])
+add("lzx17-r2-lying-uncomplen", c, orders_for(n, 21, extra=([n - 1], [n - 2], [n - 2, n - 1], [0, n - 2, 0, n - 1])))
+# 14. (round 4, fuzz) ControlData's reset interval disagrees with the stream's: 3 frames -- not a power of two, so that the
+# reference's rounding of UncompLen (& -interval) is no multiple of it -- and 65536 frames (2^31 bytes: negative as the int the
+# reference computes in, lzxd_init(reset_interval < 0) == NULL -> MSPACK_ERR_NOMEMORY)
+c = base(4, wb=17, rf=1, seed=37, n_files=8, mutations=[["control_u32", 0x0C, 3]])
+add("lzx17-r1-interval3", c, orders_for(len(c["files"]), 22))
+c = base(4, wb=17, rf=1, seed=37, n_files=8, mutations=[["control_u32", 0x0C, 65536]])
+add("lzx17-r1-interval-negative", c, orders_for(len(c["files"]), 23)[:2])
 # 12. BASELINE config 3: 1024 reset intervals (64 MiB), 96 files
 c = base(1024, seed=33, n_files=96)
 add("config3-1024-intervals", c, orders_for(len(c["files"]), 20)[:3])
