@@ -738,6 +738,9 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
   std::lock_guard<std::mutex> lock(cx.mu);
   hipError_t e;
   int rc = 0;
+  // (this thread's "last error" may be a leftover of an earlier call -- the library's own or the application's --: the
+  // hipGetLastError() checks behind the launches below must only see what THIS call did)
+  (void) hipGetLastError();
 #define TRY(call) do { e = (call); if (e != hipSuccess) { snprintf(errbuf, errcap, "%s: %s", #call, hipGetErrorString(e)); rc = -(int) e; goto done; } } while (0)
   static const bool trace = getenv("MSPACK_HIP_TRACE") != nullptr;
   auto tnow = []() { return std::chrono::steady_clock::now(); };
