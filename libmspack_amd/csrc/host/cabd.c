@@ -47,6 +47,8 @@ struct folder_p {
   struct out_store *store;
   unsigned int total;                 /* sum of the blocks' uncompressed sizes                     */
   unsigned int good_len;              /* bytes that decode without error                           */
+  unsigned int written;               /* bytes the codec handed to sys->write when asked for the whole folder (result.out_len):
+                                         for Quantum less than good_len -- it writes when its window wraps, qtmd.c:420-428 */
   unsigned int n_frames_good;         /* LZX: complete frames in good_len                          */
   int dec_err;                        /* MSPACK_ERR_* of the unit                                  */
   int read_err;                       /* what the feeder would have reported for ERR_READ          */
@@ -902,6 +904,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
       if (method >= 1 && method <= 3) {
         unsigned int g = res[k].good_len > gs[k].total ? gs[k].total : res[k].good_len;
         fp->good_len = g; fp->dec_err = res[k].err; fp->res_flags = res[k].flags;
+        fp->written = res[k].out_len > gs[k].total ? gs[k].total : res[k].out_len;
         if (units[k].flags & MSPACK_HIP_UF_MSZIP_LOG) {
           const unsigned char *lg = out_arena + units[k].out_off + (((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15);
           unsigned int cnt = rd_le32(lg), i;
@@ -912,7 +915,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
           }
         }
       }
-      else { fp->good_len = 0; fp->dec_err = MSPACK_ERR_DATAFORMAT; fp->res_flags = 0; }   /* cabd.c:1254 */
+      else { fp->good_len = 0; fp->written = 0; fp->dec_err = MSPACK_ERR_DATAFORMAT; fp->res_flags = 0; }   /* cabd.c:1254 */
       fp->n_frames_good = fp->good_len / CAB_BLOCKMAX;
       fp->decoded = 1;
     }
@@ -1062,6 +1065,16 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
         if (have > filelen) have = filelen;
         end = file->offset + filelen;
         err = folder_status(fol, end, self->read_error, &failed);
+        if (failed && (fol->base.comp_type & 0x0F) == MSCAB_COMP_QUANTUM) {
+          /* a Quantum call that fails has written what its window wraps flushed, not everything it decoded (qtmd.c:420-428; the
+           * wrap inside a match that crosses the window's end included, :358-390): what the codec wrote for the whole folder */
+          const unsigned int w = 1u << ((fol->base.comp_type >> 8) & 0x1F);
+          /* (a folder that decodes cleanly but is asked for more than it holds fails at the end of its input: the last window's
+           * bytes were never flushed) */
+          const unsigned int wr = fol->dec_err == MSPACK_ERR_OK ? fol->total / w * w : fol->written;
+          have = wr > file->offset ? wr - file->offset : 0;
+          if (have > filelen) have = filelen;
+        }
         if (write_slice(sys, fh, fol->dec + file->offset, have) != MSPACK_ERR_OK) err = MSPACK_ERR_WRITE;
       }
     }

@@ -46,7 +46,10 @@ LAST = []
 def mine(L, cab, order, **kw):
     with api.Cab(cab, mem=True, L=L, **kw) as c:
         if c.open_error: return c.open_error, []
-        r = [c.extract(i) if i < len(c.files) else (None, b"") for i in order]
+        r = []
+        for i in order:
+            c.mem.outputs.clear()               # (a call that fails before it opens its output leaves the previous one)
+            r.append(c.extract(i) if i < len(c.files) else (None, b""))
         LAST[:] = [m for m in c.mem.messages if b"GPU" in (m if isinstance(m, bytes) else m.encode())]
         L.mspack_hip_last_error.restype = ctypes.c_char_p
         if LAST: LAST.append(L.mspack_hip_last_error())
