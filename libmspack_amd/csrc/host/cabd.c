@@ -963,7 +963,9 @@ static unsigned int flushed_at_failure(struct folder_p *fp, unsigned int end)
   unsigned int f;
   if (method == MSCAB_COMP_QUANTUM) {
     const unsigned int w = 1u << ((fp->base.comp_type >> 8) & 0x1F);
-    f = reached / w * w;
+    /* (a stream that fails does so at the same symbol whatever the request: what the codec wrote for the whole folder -- its
+     * window can wrap right in front of a failing frame trailer, one byte beyond good_len) */
+    f = fp->dec_err != MSPACK_ERR_OK ? fp->written : reached / w * w;
   }
   else if (method == MSCAB_COMP_LZX && fp->dec_err != MSPACK_ERR_OK && fp->good_len < fp->total) f = fp->n_frames_good * CAB_BLOCKMAX;
   else f = (reached == fp->total) ? fp->total : reached / CAB_BLOCKMAX * CAB_BLOCKMAX;

@@ -5,7 +5,7 @@ return x->error`), until a file's offset lies below what the decompressor has WR
 What it has written is codec-specific: lzxd and mszipd hand over every frame / block, qtmd only when its window wraps
 (qtmd.c:420-428).  tests/golden/cab_sticky.json: four recipe cabinets whose file table has one offset moved far beyond its folder
 (in salvage mode the skip to it "succeeds" with nothing written: out of blocks reads as MSPACK_ERR_OK there), seven extraction
-orders each, and three cabinets with a damaged block in the middle of a folder, six orders each; with and without salvage mode, answered by the REAL cabd (tests/golden/make_cab_sticky_golden.py with oracle/_ref).
+orders each, and seven cabinets with damaged data inside a folder, six orders each; with and without salvage mode, answered by the REAL cabd (tests/golden/make_cab_sticky_golden.py with oracle/_ref).
   * `-m gpu`: through libmspack_hip.so; `-m "not gpu"`: the same driver code on the CPU stand-in for the batch ABI."""
 import hashlib
 import json
@@ -25,7 +25,7 @@ def replay(v, L=None):
     if v["victim"] is not None:
         struct.pack_into("<I", cab, R.file_entry_offsets(cab)[v["victim"]] + 4, 4521984)       # a file offset far beyond its folder
     else:
-        cab[v["flip"]] ^= 0x10                                                                    # a bad block in the middle of a folder
+        cab[v["flip"]] ^= v.get("flip_mask", 0x10)                                                # a bad block in the middle of a folder
     cab = bytes(cab)
     assert hashlib.md5(cab).hexdigest() == v["cab_md5"], "recipe no longer reproduces the golden cabinet"
     for run in v["runs"]:
@@ -36,8 +36,12 @@ def replay(v, L=None):
                 err, data = c.extract(i)
                 tag = "seed %d salvage %d order %s call %d (file %d)" % (v["seed"], run["salvage"], run["order"], k, i)
                 assert err == exp["err"], (tag, err, len(data), exp)
-                if err == 0 or v["victim"] is not None:          # (what a FAILING call leaves in its output file is compared for the
-                    assert len(data) == exp["n"] and hashlib.md5(data).hexdigest() == exp["md5"], tag     # cabinets without damaged data only)
+                if err != 0 and v["seed"] == 7214:
+                    # the one known difference in what a FAILING call leaves behind: qtmd first writes the tail of the match that ran
+                    # past the end of the previous call (qtmd.c:268-276; 2 bytes here), the batch ABI does not report token boundaries
+                    assert len(data) <= exp["n"], tag
+                    continue
+                assert len(data) == exp["n"] and hashlib.md5(data).hexdigest() == exp["md5"], tag
 
 
 def test_golden_holds_the_case():
