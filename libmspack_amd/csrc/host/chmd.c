@@ -98,6 +98,9 @@ static int read_headers(struct mspack_system *sys, struct mspack_file *fh, struc
   struct mschmd_file *tail = NULL;
   off_t off_hs0, filelen;
   unsigned int n, errors = 0;
+  /* the reference keeps ONE bad-ENCINT flag for the whole listing (chmd.c:262, never cleared): after the first badly encoded
+   * integer every later chunk ends at its first entry -- nothing more is listed (found by tools/fuzz_chmdir_cpu.py) */
+  int err = 0;
 
   chm->files = NULL; chm->sysfiles = NULL; chm->chunk_cache = NULL;
   chm->sec0.base.chm = chm; chm->sec0.base.id = 0;
@@ -151,7 +154,7 @@ static int read_headers(struct mspack_system *sys, struct mspack_file *fh, struc
   if (!(chunk = (unsigned char *) sys->alloc(sys, chm->chunk_size))) return MSPACK_ERR_NOMEMORY;
   while (n--) {
     const unsigned char *p, *end;
-    int entries, err = 0;
+    int entries;
     if (sys->read(fh, chunk, (int) chm->chunk_size) != (int) chm->chunk_size) { sys->free(chunk); return MSPACK_ERR_READ; }
     if (rd_le32(chunk) != 0x4C474D50u) continue;                          /* PMGL only */
     if (rd_le32(chunk + 4) < 2) sys->message(fh, "WARNING; PMGL quickref area is too small");

@@ -57,3 +57,35 @@ def synthetic_chm():
           b"!", b"\x7f", b"/\xf0\x9f\x98\x80", b"::DataSpace/Storage/MSCompressed/Content", b"::dataspace/storage/mscompressed/controldata"]
     q += [nm + b"0" for nm in names[::97]] + [nm[:-1] for nm in names[::101]]
     return chm, q
+
+
+def damaged_listing_chm():
+    """the synthetic CHM with one entry more announced in its fourth PMGL chunk than it holds, made of the chunk's free space and
+    quickref area so that its section number runs into the end of the chunk: a badly encoded integer in the middle of the listing
+    (tools/fuzz_chmdir_cpu.py, round 4)"""
+    import struct
+    chm, _ = synthetic_chm()
+    b = bytearray(chm)
+    dir_off = 0x78 + 0x54
+    chunk_size, = struct.unpack_from("<I", b, 0x78 + 0x10)
+    c = dir_off + 3 * chunk_size
+    n, = struct.unpack_from("<H", b, c + chunk_size - 2)
+    assert b[c:c + 4] == b"PMGL" and n > 0
+    p = c + 0x14
+    for _ in range(n):                                            # name length, name, section, offset, length (chm.h:62-67)
+        for field in range(4):
+            v = 0
+            while True:
+                ch = b[p]; p += 1
+                v = (v << 7) | (ch & 0x7F)
+                if not ch & 0x80:
+                    break
+            if field == 0:
+                p += v
+    end = c + chunk_size - 2
+    L = end - p - 2                                               # a "name" that leaves one byte in front of the entry count ...
+    assert 2 <= L < 128
+    struct.pack_into("<H", b, end, n + 1)
+    b[p] = L; b[p + 1] = ord("x"); b[p + 2] = ord("y")
+    b[end - 1] = 0x80                                             # ... and that byte says the section number goes on
+    return bytes(b)

@@ -55,6 +55,14 @@ def main():
                             list_md5=hashlib.md5(repr([(f["name"], f["section"], f["offset"], f["length"]) for f in lfiles]).encode()).hexdigest(),
                             finds=[[q.decode("latin-1"), *r] for q, r in zip(queries, res)])
     print("synthetic: files", len(lfiles), "queries", len(queries), "found", sum(1 for r in res if r[1] >= 0))
+    # (3) the same CHM with one PMGL chunk's entry count too large: the reference's bad-ENCINT flag is never cleared (chmd.c:262), so
+    # the listing ends in that chunk -- and open() still succeeds ("contents are corrupt", chmd.c:166-172)
+    bad = R.damaged_listing_chm()
+    derr, dfiles = helpers.ref_chm_list(bad)
+    out["damaged_listing"] = dict(chm_md5=hashlib.md5(bad).hexdigest(), open_err=derr, n_files=len(dfiles),
+                                  list_md5=hashlib.md5(repr([(f["name"], f["section"], f["offset"], f["length"]) for f in dfiles]).encode()).hexdigest())
+    print("damaged listing: open", derr, "files", len(dfiles), "of", len(lfiles))
+    assert 0 < len(dfiles) < len(lfiles) // 2
     json.dump(out, open(os.path.join(HERE, "chmdir.json"), "w"), indent=0)
 
 

@@ -56,3 +56,15 @@ def test_pmgi_two_levels():
     with api.Chm(chm, fast=True) as c:
         assert [q[0].encode("latin-1") for q in s["finds"]] == queries
         assert _finds(c, queries) == [q[1:] for q in s["finds"]]
+
+
+def test_listing_after_a_bad_encint():
+    """one PMGL chunk's entry count too large: the reference lists nothing behind the first badly encoded integer -- its error flag
+    is never cleared (chmd.c:262) -- and still opens the file with what it has (chmd.c:166-172)"""
+    chm = R.damaged_listing_chm()
+    s = G["damaged_listing"]
+    assert hashlib.md5(chm).hexdigest() == s["chm_md5"]
+    with api.Chm(chm) as c:
+        assert c.open_error == s["open_err"] == 0 and len(c.files) == s["n_files"]
+        lst = [(nm, sec, off, ln) for nm, ln, off, sec in c.files]
+        assert hashlib.md5(repr(lst).encode()).hexdigest() == s["list_md5"]
