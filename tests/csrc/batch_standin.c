@@ -6,8 +6,9 @@
  *
  * It provides the batch ABI of include/mspack_hip.h (host-buffer entry points only) on top of the CPU
  * oracle (oracle/liboracle.so): one oracle call per unit.  Supported: LZX units (CAB folders, CHM reset
- * intervals, E8 origin) and plain MSZIP / Quantum folder units without MSPACK_HIP_UF_* flags; anything
- * else makes the call fail, and the tests that need it run on the GPU.  The `-m gpu` parity tests never
+ * intervals, E8 origin, the reset log of MSPACK_HIP_UF_LZX_LOG), MSZIP and Quantum folder units, frame tables
+ * (ignored: the oracle is serial), the feeder's failed read (MSPACK_HIP_UF_HARD_EOF) and Quantum's good_len;
+ * NOT MSZIP repair mode -- that makes the call fail, and the tests that need it run on the GPU.  The `-m gpu` parity tests never
  * see this file: they load the real library. */
 #include <stdio.h>
 #include <string.h>

@@ -2,10 +2,10 @@
 batch ABI, tests/_build/libhostlogic_cpu.so) against the REAL reference driver (oracle/_ref): a synthetic four-folder cabinet (MSZIP with
 history, LZX, Quantum, stored) with random byte damage, truncation and header edits; for every file, in two extraction orders and in
 the plain and salvage modes: the reference's error code and every byte.  Needs the development container (oracle/_ref).
-LIMITS of the stand-in (test infrastructure): no MSPACK_HIP_UF_HARD_EOF and no MSZIP repair mode -- cabinets whose block chain ends in a
-read failure (truncation, bad checksums outside salvage mode) come back as "GPU batch decode failed" and are reported as such, not as
-driver bugs; those paths are covered on the GPU by tests/test_gpu_drivers.py.  What this fuzz found in round 4: DESIGN.md section 7
-(extract() after a failed extract(): fixed, tests/test_cab_sticky.py; salvage mode on damaged CFDATA headers: open).
+LIMIT of the stand-in (test infrastructure): no MSZIP repair mode -- that path is covered on the GPU by tests/test_gpu_drivers.py.
+What this fuzz found in round 4: DESIGN.md section 7 (extract() after a failed extract(), what a failing Quantum call leaves behind:
+fixed, tests/test_cab_sticky.py; two salvage-mode differences understood and left: qtmd's match tail in front of a failure, MSZIP
+blocks whose header lies about their uncompressed size).
     python tools/fuzz_drivers_cpu.py <seed> [cases]"""
 import ctypes, glob, os, subprocess, sys, zlib
 import numpy as np
