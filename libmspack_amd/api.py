@@ -281,24 +281,32 @@ class CabSet:
     """Several cabinets on ONE decompressor, joined with append()/prepend() like cabextract does
     (reference cabd.c:870-1064):  with CabSet([p1, p2, ...]) as s: s.append(0, 1); s.files(0); s.extract(f)"""
 
-    def __init__(self, srcs, fix_mszip=0, salvage=0):
-        self.L = _setup()
+    def __init__(self, srcs, fix_mszip=0, salvage=0, mem=False, L=None):
+        self.L = _setup(L)
         self._tmps = []
         self.paths = []
-        for src in srcs:
+        self.mem = MemSystem(self.L) if mem else None          # (mem=True: srcs are bytes, kept in an in-memory mspack_system)
+        for k, src in enumerate(srcs):
+            if self.mem:
+                self.mem.files[b"mem:in%d" % k] = bytes(src)
+                self.paths.append(b"mem:in%d" % k)
+                continue
             if isinstance(src, (bytes, bytearray)):
                 fd, tmp = tempfile.mkstemp(suffix=".cab")
                 os.write(fd, src); os.close(fd)
                 self._tmps.append(tmp)
                 src = tmp
             self.paths.append(os.fsencode(src))           # must outlive the cabinets (mspack.h:968-969)
-        self.d = self.L.mspack_create_cab_decompressor(None)
+        self.d = self.L.mspack_create_cab_decompressor(self.mem.ptr() if self.mem else None)
         if not self.d:
             raise RuntimeError("mspack_create_cab_decompressor failed")
         self.d.contents.set_param(self.d, MSCABD_PARAM_FIXMSZIP, fix_mszip)
         self.d.contents.set_param(self.d, MSCABD_PARAM_SALVAGE, salvage)
-        self.cabs = [self.d.contents.open(self.d, p) for p in self.paths]
-        self.open_errors = [0 if c else self.d.contents.last_error(self.d) for c in self.cabs]
+        self.cabs, self.open_errors = [], []
+        for p in self.paths:
+            c = self.d.contents.open(self.d, p)
+            self.cabs.append(c)
+            self.open_errors.append(0 if c else self.d.contents.last_error(self.d))      # (last_error() is the LAST call's)
 
     def _cab(self, i):
         return self.cabs[i] if i is not None and i >= 0 else None
@@ -325,6 +333,10 @@ class CabSet:
         return out
 
     def extract(self, fptr):
+        if self.mem:
+            self.mem.outputs.clear()
+            err = self.d.contents.extract(self.d, fptr, b"mem:out")
+            return err, bytes(self.mem.outputs.get(b"mem:out", b""))
         fd, out = tempfile.mkstemp(suffix=".out")
         os.close(fd)
         try:
