@@ -728,6 +728,8 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
   const int ignore_cksum = self->salvage || (self->fix_mszip && method == MSCAB_COMP_MSZIP);
   const int ignore_size = self->salvage;
   const size_t len0 = A->len;
+  uint32_t *qoff = NULL;               /* Quantum: where every block starts in the folder's stream (LZX / MSZIP: g->boff) */
+  unsigned int qn = 0;
   int err;
   g->len = 0; g->total = 0; g->read_err = MSPACK_ERR_OK; g->hard_eof = 0;
   g->nblk = 0; g->frames_ok = 1; g->tab_off = 0;
@@ -743,13 +745,16 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
     g->read_err = MSPACK_ERR_SEEK; g->hard_eof = 1; g->frames_ok = 0;
     return MSPACK_ERR_OK;
   }
-  r.quiet_cksum = self->fix_mszip && method == MSCAB_COMP_MSZIP && g->boff != NULL;
+  /* ignored checksums (salvage mode; MSZIP repair mode) are complained about when the reference READS the block -- in the
+   * extract() call whose decoding gets there, not when this driver gathers the cabinet's folders (rep_ck below) */
+  if (ignore_cksum && !g->boff) qoff = (uint32_t *) sys->alloc(sys, ((size_t) fol->base.num_blocks + 1) * sizeof(uint32_t));
+  r.quiet_cksum = ignore_cksum && (g->boff != NULL || qoff != NULL);
   while (r.block < fol->base.num_blocks) {
     unsigned int ulen = 0;
     r.block++;
     r.bad_cksum = 0;
     /* (a block, reassembled from the cabinets of a set or not, is at most CAB_INPUTBUF bytes: reader_block) */
-    if (!arena_room(sys, A, (size_t) CAB_INPUTBUF + 1 + 64 + 16)) { reader_close(self, &r); sys->free(g->boff); g->boff = NULL; A->len = len0; return MSPACK_ERR_NOMEMORY; }
+    if (!arena_room(sys, A, (size_t) CAB_INPUTBUF + 1 + 64 + 16)) { reader_close(self, &r); sys->free(g->boff); g->boff = NULL; sys->free(qoff); A->len = len0; return MSPACK_ERR_NOMEMORY; }
     r.input = A->p + A->len;
     if ((err = reader_block(self, &r, &ulen, ignore_cksum, ignore_size))) { g->read_err = err; g->hard_eof = 1; break; }
     if (r.bad_cksum) {
@@ -758,9 +763,10 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
       if (nw) {
         if (fol->ck_n) sys->copy(fol->rep_ck, nw, (size_t) fol->ck_n * sizeof(unsigned int));
         sys->free(fol->rep_ck); fol->rep_ck = nw;
-        fol->rep_ck[fol->ck_n++] = g->nblk;               /* (block index for now: turned into an output offset below) */
+        fol->rep_ck[fol->ck_n++] = g->boff ? g->nblk : qn;  /* (block index for now: turned into an output offset below) */
       }
     }
+    if (qoff) qoff[qn++] = (uint32_t)(A->len - g->in_off);
     if (g->boff) {
       if (g->total % CAB_BLOCKMAX) g->frames_ok = 0;          /* an earlier block was not a whole frame */
       g->boff[g->nblk++] = (uint32_t)(A->len - g->in_off);
@@ -771,19 +777,30 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
   }
   reader_close(self, &r);
   g->len = A->len - g->in_off;
-  if (fol->ck_n && g->boff) {
+  if (fol->ck_n && (g->boff || qoff)) {
     /* block i is read when the codec's refill reaches the input chunk it starts in; that refill happens while the block
      * that holds the chunk's first byte is being decoded (every block but the last decodes to 32 KiB) */
     const size_t q = (size_t)(self->buf_size > 0 ? self->buf_size : 4096);
+    const uint32_t *const off = g->boff ? g->boff : qoff;
     unsigned int i;
     for (i = 0; i < fol->ck_n; i++) {
       const unsigned int b = fol->rep_ck[i];
-      const size_t chunk_start = ((size_t) g->boff[b] / q) * q;
+      const size_t chunk_start = ((size_t) off[b] / q) * q;
       unsigned int t = b;
-      while (t > 0 && (size_t) g->boff[t] > chunk_start) t--;
+      while (t > 0 && (size_t) off[t] > chunk_start) t--;
       fol->rep_ck[i] = t * CAB_BLOCKMAX;
+      if (method == MSCAB_COMP_QUANTUM && t < b) {
+        /* lzxd and mszipd decode a whole frame / block before they hand any of it over: its first byte asked for is enough.
+         * qtmd decodes as far as it is asked: WHERE in block t -- when it has used the block's input up to the chunk, taken
+         * as the same share of the block's output (an estimate: which extract() call says it can be off when a file ends
+         * right there) */
+        const size_t clen = (size_t) off[t + 1] - off[t];
+        const size_t ulen = g->total - (size_t) t * CAB_BLOCKMAX < CAB_BLOCKMAX ? g->total - (size_t) t * CAB_BLOCKMAX : CAB_BLOCKMAX;
+        if (clen) fol->rep_ck[i] += (unsigned int)((chunk_start - off[t]) * ulen / clen);
+      }
     }
   }
+  sys->free(qoff);
   if (!g->hard_eof) g->read_err = self->salvage ? MSPACK_ERR_OK : MSPACK_ERR_DATAFORMAT;  /* ran out of blocks */
   else {
     /* the codec pulls buf_size bytes per read; a read that reaches the bad block fails as a whole,
@@ -1033,7 +1050,8 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
   /* What the codec would have said on the way: mszipd in repair mode reports every block it repairs when it decodes it
    * (mszipd.c:420-433), i.e. when the first byte of that block is asked for -- by this file, or by the skip to its offset.
    * The reference's decompressor starts over (and says it all again) for another folder or an earlier offset. */
-  if ((fol->rep_n || fol->ck_n) && filelen) {
+  if (filelen && self->live_failed) ;       /* (the codec's sticky error: it reads nothing more and says nothing more) */
+  else if ((fol->rep_n || fol->ck_n) && filelen) {
     const unsigned int end = file->offset + filelen;
     if (self->msg_folder != fol || self->msg_offset > file->offset) { self->msg_folder = fol; self->msg_next = 0; self->msg_next_ck = 0; }
     for (;;) {

@@ -61,3 +61,27 @@ def test_extract_after_failed_extract_gpu(built, v):
 @pytest.mark.parametrize("v", GOLD, ids=["seed%d" % g["seed"] for g in GOLD])
 def test_extract_after_failed_extract_host_logic_cpu(built, hostlogic, v):
     replay(v, L=hostlogic)
+
+
+MSG_GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cab_salvage_messages.json")))
+
+
+@pytest.mark.parametrize("g", MSG_GOLD, ids=["seed%d" % g["seed"] for g in MSG_GOLD])
+def test_salvage_checksum_warnings_come_with_the_call_that_reads_the_block_cpu(built, hostlogic, g):
+    """salvage mode ignores CFDATA checksums and says "WARNING; bad block checksum found" instead -- the reference when its decoding
+    reads the block (cabd.c:1408-1421), this driver gathers a cabinet's folders in one go and must say it in the same extract() call
+    all the same (found by tools/fuzz_cab_messages_cpu.py: it used to say all of them in the first call); a decompressor in its error
+    state reads nothing and says nothing.  tests/golden/cab_salvage_messages.json: the real cabd's count per call."""
+    cab = R.base_cab(g["seed"]); cab[g["flip"]] ^= 0x10; cab = bytes(cab)
+    assert hashlib.md5(cab).hexdigest() == g["cab_md5"]
+    for run in g["runs"]:
+        with api.Cab(cab, mem=True, L=hostlogic, salvage=1) as c:
+            assert c.open_error == 0
+            got, errs = [], []
+            for i in run["order"]:
+                del c.mem.messages[:]
+                c.mem.outputs.clear()
+                err, _ = c.extract(i)
+                errs.append(err)
+                got.append(sum(1 for m in c.mem.messages if b"bad block checksum" in m))
+            assert errs == run["errs"] and got == run["warnings"], (g["seed"], run["order"], errs, got, run)
