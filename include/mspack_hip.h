@@ -225,10 +225,16 @@ void mspack_hip_host_path_stats(double *ms4, int reset);
 /* ---- optional: page-lock a caller's input arena ---------------------------------------------------------
  * The host-buffer entry points copy their input with the runtime's pageable path unless the caller's buffer is
  * page-locked; for an arena that was just written (the C drivers' gather) that path runs at 5-6 GB/s.  mspack_hip_pin()
- * page-locks [p, p + bytes) (whole pages around it) so that those copies are plain DMA; mspack_hip_unpin(p) releases it --
- * before the memory is freed.  Both are advice: pin returns 0 when the range is locked now, a non-zero code when it is not
- * (no device, already locked, the runtime refuses) and the calls work either way.  (Output buffers are handled inside
- * mspack_hip_decode_batch itself, chunk by chunk; a buffer that is used for many calls is better locked by its owner.) */
+ * page-locks the WHOLE PAGES INSIDE [p, p + bytes) so that copies out of them are plain DMA; mspack_hip_unpin(p) releases
+ * them -- before the memory is freed.  Never a byte outside the caller's range: the runtime treats every host address inside
+ * a locked range as part of it, and a copy that starts inside one and ends behind it fails (hipErrorInvalidValue) -- with
+ * outward rounding that happened to whatever the allocator had placed beside the arena (round 4's intermittent "GPU batch
+ * decode failed").  A buffer that starts and ends on page boundaries is locked completely; the entry
+ * points cut their copies at the boundaries of the ranges locked through this call.  A caller who locks memory with
+ * hipHostRegister() directly must follow the same rule: the locked range has to contain every byte of the in / out buffers
+ * it overlaps.  Both calls are advice: pin returns 0 when the range is locked now, a non-zero code when it is not (no device,
+ * already locked, less than a page, the runtime refuses) and the entry points work either way.  (Output buffers are handled
+ * inside mspack_hip_decode_batch itself, chunk by chunk; a buffer that is used for many calls is better locked by its owner.) */
 int  mspack_hip_pin(const void *p, size_t bytes);
 void mspack_hip_unpin(const void *p);
 

@@ -46,7 +46,7 @@ def build_hip(force=False):
     hip_dir = os.path.join(CSRC, "hip")
     host_dir = os.path.join(CSRC, "host")
     srcs = _walk(hip_dir, (".hip", ".hpp")) + _walk(host_dir, (".c", ".h")) + \
-        _walk(os.path.join(ROOT, "include"), (".h",))
+        _walk(os.path.join(ROOT, "include"), (".h",)) + [os.path.join(CSRC, "exports.map")]
     if not (force or _newer(HIP_SO, srcs)):
         return HIP_SO
     objs = []
@@ -57,7 +57,8 @@ def build_hip(force=False):
     shim_o = os.path.join(hip_dir, "shim.o")
     _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
           "-I", os.path.join(ROOT, "include"), "-c", os.path.join(hip_dir, "shim.hip"), "-o", shim_o])
-    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO, shim_o] + objs + ["-lpthread"])
+    _run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO, shim_o] + objs +
+         ["-lpthread", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")])
     return HIP_SO
 
 

@@ -33,7 +33,6 @@
 // so a source inside the reference data is an ordinary linear copy).
 #include "wave_common.hpp"
 #include "spec_queue.hpp"
-#include "tile_resolve.hpp"
 
 #define LZX_FRAME 32768u
 #undef LZX_MAIN_P
@@ -217,9 +216,6 @@ struct LzxDec {
 };
 
 __device__ __forceinline__ u32 lzx_read_lens_spec(LzxDec &d, u8 *lens, u32 first, u32 last);
-#if defined(LZX_PARSE_ONLY) && defined(LZX_HDR_LANES)
-__device__ __forceinline__ u32 lzx_hdr_lanes(LzxDec &d, u8 *lens, u32 first, u32 last);
-#endif
 
 // lzxd_read_lens (lzxd.c:138-183).  Every length is a delta against the previous block's lens[x], but
 // the tokens of one call never depend on each other: far from the end of the input they are decoded
@@ -238,13 +234,7 @@ __device__ __forceinline__ bool lzx_read_lens(LzxDec &d, u8 *lens, u32 first, u3
     d.err = ERR_DECRUNCH; return false;                       // incl. the all-zero pretree
   }
   HT(0);
-#ifndef LZX_NO_SPEC
-#if defined(LZX_PARSE_ONLY) && defined(LZX_HDR_LANES)      /* (an experiment that lost: see lzx_read_lens_lanes) */
-  if (!d.careful) first = lzx_hdr_lanes(d, lens, first, last);       // (an experiment: every lane its own stretch of the header)
-#else
   if (!d.careful) first = lzx_read_lens_spec(d, lens, first, last);
-#endif
-#endif
   for (u32 x = first; x < last; ) {
     d.need(32);
     int z = d.decode_sym<LZX_PRE_P>(sh->pre_tab, sh->pre_sorted, d.hr_pre);
@@ -438,120 +428,11 @@ __device__ void lzx_copy_match_odd(u8 *out, u32 P, u32 wpos, u32 wsize, u32 off,
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// The steady-state token loop (lzxd.c:538-651), far from the end of the input: no EOF bookkeeping
-// at all.  Everything hot is held in locals for the duration of the run; the loop hands over to
-// the generic (EOF-exact) loop in lzx_decode_unit as soon as the input window gets within 64 bytes
-// of in_len -- always at a token boundary, where the reference's bits_left is a pure function of
-// the bit position (see LzxDec::sym_ensure).
-// ---------------------------------------------------------------------------------------------------
+// what a steady-state run (lzx_run_spec / lzx_run_spec2 below) ends with: the run is through, the generic (EOF-exact) loop of
+// lzx_decode_unit takes over -- always at a token boundary, where the reference's bits_left is a pure function of the bit
+// position (LzxDec::sym_ensure) --, or the stream is bad
 enum { LZX_RUN_DONE = 0, LZX_RUN_SWITCH = 1, LZX_RUN_FAIL = 2 };
 
-template <bool ALIGNED>
-__device__ __forceinline__ int lzx_run_fast(LzxDec &d, LzxState &s, const u32 run_end, const u32 wbase)
-{
-  const LzxShared *sh = d.sh;
-  const u32 lane = d.lane;
-  u8 *const out = d.out;
-  u64 bb = d.bb; int bl = d.bl;
-  u32 wi = d.w.wi, cur = d.w.cur, nxt = d.w.nxt;
-  u32 P = d.P, lit_n = d.lit_n, lit_buf = d.lit_buf;
-  u32 R0 = s.R0, R1 = s.R1, R2 = s.R2;
-  const u32 wsize = s.wsize, offset_written = s.offset;
-  // first dword index at which the window is within 64 bytes of the end of the input
-  const u32 room = (d.w.in_len > d.w.origin + 64u) ? (d.w.in_len - d.w.origin - 64u) : 0u;
-  const u32 wi_limit = room >> 2;
-  int rc = LZX_RUN_DONE;
-
-#define FAST_REFILL()                                                              \
-  do {                                                                             \
-    u32 dw_ = rdl(cur, wi & 63u);                                                  \
-    wi++;                                                                          \
-    bb |= (u64)((dw_ << 16) | (dw_ >> 16)) << (32 - bl);                           \
-    bl += 32;                                                                      \
-    if ((wi & 63u) == 0u) { cur = nxt; d.w.wi = wi; nxt = d.w.load_chunk((wi >> 6) + 1u, lane); } \
-  } while (0)
-#define FAST_FLUSH()                                                               \
-  do { if (lit_n) { if (lane < lit_n) out[P - lit_n + lane] = (u8) lit_buf; lit_n = 0; } } while (0)
-#define FAST_FAIL(code) do { d.err = (code); rc = LZX_RUN_FAIL; goto out; } while (0)
-
-  while (P < run_end) {
-    if (bl <= 32) {
-      if (wi >= wi_limit) { rc = LZX_RUN_SWITCH; break; }
-      FAST_REFILL();
-    }
-    u32 e = rfl((u32) sh->main_tab[(u32)(bb >> (64 - LZX_MAIN_P))]);
-    if (e == 0) {
-      e = huff_long<LZX_MSH>(d.hr_main, sh->main_sorted, (u32)(bb >> 48), lane);
-      if (e == 0) FAST_FAIL(ERR_DECRUNCH);
-    }
-    { u32 l = e >> LZX_MSH; bb <<= l; bl -= (int) l; }
-    u32 sym = e & LZX_MMASK;
-    if (sym < 256u) {
-      lit_buf = wrl(lit_buf, sym, lit_n);
-      lit_n++; P++;
-      if (lit_n == WAVE) { if (true) out[P - WAVE + lane] = (u8) lit_buf; lit_n = 0; }
-      continue;
-    }
-    u32 m = sym - 256u, slot = m >> 3, len = (m & 7u) + 2u, off;
-    if ((m & 7u) == 7u) {
-      if (s.length_empty) FAST_FAIL(ERR_DECRUNCH);
-      u32 f = rfl((u32) sh->len_tab[(u32)(bb >> (64 - LZX_LEN_P))]);
-      if (f == 0) {
-        f = huff_long(d.hr_len, sh->len_sorted, (u32)(bb >> 48), lane);
-        if (f == 0) FAST_FAIL(ERR_DECRUNCH);
-      }
-      { u32 l = f >> 10; bb <<= l; bl -= (int) l; }
-      len += f & 1023u;
-    }
-    if (slot < 3u) {
-      if (slot == 0u) off = R0;
-      else if (slot == 1u) { off = R1; R1 = R0; R0 = off; }
-      else { off = R2; R2 = R0; R0 = off; }
-    }
-    else {
-      u32 extra = slot < 4u ? 0u : (slot < 36u ? (slot >> 1) - 1u : 17u);
-      u32 base = slot < 4u ? slot : (slot < 36u ? ((2u + (slot & 1u)) << extra) : ((slot - 34u) << 17));
-      off = base - 2u;
-      if (bl <= 32) {
-        // mid-token refill: if it enters the last 64 bytes, finish this token and hand over
-        if (wi >= wi_limit) rc = LZX_RUN_SWITCH;
-        FAST_REFILL();
-      }
-      if (ALIGNED && extra >= 3u) {
-        if (extra > 3u) { u32 nb = extra - 3u; off += (u32)(bb >> (64 - nb)) << 3; bb <<= nb; bl -= (int) nb; }
-        u32 a = rfl((u32) sh->ali_tab[(u32)(bb >> (64 - LZX_ALI_P))]);
-        if (a == 0) FAST_FAIL(ERR_DECRUNCH);                 // aligned codes are <= 7 bits: never long
-        { u32 l = a >> 10; bb <<= l; bl -= (int) l; }
-        off += a & 1023u;
-      }
-      else if (extra) { off += (u32)(bb >> (64 - extra)); bb <<= extra; bl -= (int) extra; }
-      R2 = R1; R1 = R0; R0 = off;
-    }
-    u32 wp = P - wbase;
-    if (P + len > run_end) FAST_FAIL(ERR_DECRUNCH);          // lzxd.c:678-693
-    if (wp + len > wsize) FAST_FAIL(ERR_DECRUNCH);           // lzxd.c:613
-    if (LZX_BAD_SOURCE(off, wp, offset_written, s.ref_size, wsize)) FAST_FAIL(ERR_DECRUNCH);
-#ifndef LZX_EXP_NOCOPY
-    FAST_FLUSH();
-    if (off != 0u && off <= wsize) lzx_copy_match(out, P, off, len, lane);
-    else { if (lane == 0) lzx_copy_match_odd(out, P, wp, wsize, off, len); }
-#else
-    lit_n = 0;
-#endif
-    P += len;
-    if (rc != LZX_RUN_DONE) break;
-  }
-out:
-  d.bb = bb; d.bl = bl; d.w.wi = wi; d.w.cur = cur; d.w.nxt = nxt;
-  d.P = P; d.lit_n = lit_n; d.lit_buf = lit_buf;
-  s.R0 = R0; s.R1 = R1; s.R2 = R2;
-  if (wi >= wi_limit) d.near_end = true;
-  return rc;
-#undef FAST_REFILL
-#undef FAST_FLUSH
-#undef FAST_FAIL
-}
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -1747,182 +1628,6 @@ __device__ __forceinline__ bool lzx_build_sub(LzxShared *sh, const HuffRegs &hr,
     if (WANT1) { const u32 x2_ = q_[1]; w1_ = (u32) __builtin_amdgcn_alignbit(x1_, x2_, a_); } \
   }
 
-#ifdef LZX_HDR_LANES
-// ---------------------------------------------------------------------------------------------------
-// lzx_read_lens_lanes -- lzxd_read_lens (lzxd.c:138-183) with the lane parser's scheme (parse tasks only).
-// lzx_read_lens_spec decodes 64 bit positions per round and follows the ~13 real tokens among them with one v_readlane hop
-// each: ~70 rounds of ~1300 cycles for a block header's ~900 pretree tokens, 89 of a parse task's ~670 microseconds.
-// Here the header's bits are staged (sh->stage: free until the frame's tokens are parsed) and cut into stretches of
-// LZX_HDR_S bits, one per lane: a first walk from LZX_HDR_LEAD bits in front of the stretch finds the lane's exit (a walk
-// that starts inside a token falls into step with the real chain after a few tokens: pretree codes are short), then every
-// lane walks from its left neighbour's exit, counting the lengths its tokens set (1, or a run of 4..51), until no entry
-// moves; a prefix sum gives every lane its first index x, and the last walk rewrites lens[x .. x + y) token by token.  The
-// run ends at the first token whose x has reached `last` (tokens are read only while x < last, lzxd.c:148; a run may
-// overshoot, it is not clipped, :159).  A token the pretree does not hold ends the consistent prefix: the scalar loop of
-// lzx_read_lens takes (and judges) it, as it takes everything within 56 bytes of the end of the input.
-// Returns the index the scalar loop continues from; the decoder stands behind the last token taken.
-// MEASURED AND NOT SHIPPED (round 4, profiles/round4_header_lanes_experiment.txt; build with -DLZX_HDR_LANES): bit-exact as a real
-// call, but a block header is too short for the scheme -- ~300 tokens per run, 5-7 per lane, so the sync rounds are most of the
-// steps and every step is a chain of dependent LDS reads: header decode 143 us per frame against 89 with lzx_read_lens_spec.
-// ---------------------------------------------------------------------------------------------------
-#define LZX_HDR_S 32u
-#define LZX_HDR_LEAD 40u
-#define LZX_HDR_ROUNDS 6u
-struct PreTok { u32 tot, y, zz; bool zero, unk; };
-// one pretree token at the bits (w0, w1), every lane its own.  The rare parts -- a code longer than the direct table, the second
-// symbol of a "same" run -- are behind wave-uniform branches (any ACTIVE lane needs them): a step is then two dependent LDS
-// reads (the staged bits, the direct table) instead of five.
-__device__ __forceinline__ PreTok lzx_pre_token(const LzxShared *sh, const bool act, const u32 *plim, const u32 pre_fov, const u32 w0, const u32 w1)
-{
-  PreTok t;
-  u64 r = ((u64) w0 << 32) | w1;
-  u32 e = sh->pre_tab[w0 >> (32 - LZX_PRE_P)];
-  if (ballot(act && e == 0u)) {
-    const u32 peek16 = w0 >> 16;
-    u32 ln = LZX_PRE_P + 1u;
-#pragma unroll
-    for (int l = LZX_PRE_P + 1; l <= 16; l++) ln += (peek16 >= plim[l - LZX_PRE_P - 1]) ? 1u : 0u;
-    const u32 lq = ln <= 16u ? ln : 0u;
-    const u32 fo = (u32) __builtin_amdgcn_ds_bpermute((int)(lq << 2), (int) pre_fov);
-    u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
-    if (idx >= 20u) idx = 0;
-    const u32 ls = sh->pre_sorted[idx];
-    if (e == 0u && lq != 0u) e = ls | (lq << 10);
-  }
-  t.unk = (e == 0u);
-  const u32 z = e & 1023u;
-  u32 tot = e >> 10;
-  r <<= tot;
-  const u32 nb = z == 17u ? 4u : (z == 18u ? 5u : (z == 19u ? 1u : 0u));
-  const u32 xb = nb ? (u32)(r >> (64u - nb)) : 0u;
-  r <<= nb; tot += nb;
-  t.y = z == 17u ? 4u + xb : (z == 18u ? 20u + xb : (z == 19u ? 4u + xb : 1u));
-  t.zz = z;
-  if (ballot(act && z == 19u)) {
-    const u32 e2 = sh->pre_tab[(u32)(r >> (64 - LZX_PRE_P))];       // second symbol of a "same" run
-    if (z == 19u) { t.unk = t.unk || e2 == 0u; tot += e2 >> 10; t.zz = e2 & 1023u; }   // (a long second code: the scalar loop)
-  }
-  t.zero = z == 17u || z == 18u;
-  t.tot = tot;
-  return t;
-}
-
-// (a real call with everything by value: inlined into the block header's three call sites the function was not only large but
-// WRONG on the hardware -- right on the emulator and in every build that added code around it --, and a decoder passed by
-// reference lives in scratch memory from then on)
-struct HdrLanes { u32 X, B, moved; };
-#ifndef LZX_HDR_INLINE
-__device__ __attribute__((noinline))
-#else
-__device__ __forceinline__
-#endif
-HdrLanes lzx_read_lens_lanes(LzxShared *sh, const u8 *unit, const u32 unit_len, const u32 B_, const u32 pre_limv, const u32 pre_fov,
-                             u8 *lens, const u32 first, const u32 last_, const u32 lane)
-{
-  const u32 last = rfl(last_);
-  u32 X = rfl(first);
-  const u32 in_limit = unit_len > 56u ? (unit_len - 56u) * 8u : 0u;        // bits from the unit's first byte, like B
-  u32 B = rfl(B_);
-  u32 plim[16 - LZX_PRE_P];
-#pragma unroll
-  for (int l = LZX_PRE_P + 1; l <= 16; l++) plim[l - LZX_PRE_P - 1] = rdl(pre_limv, (u32) l);
-  bool moved = false, stop = false;
-  while (!stop && X < last && B + 64u < in_limit) {
-    // ---- stage the input from the dword that holds bit B (16-bit words pre-swapped: a plain MSB-first bit string) ----
-    const u32 sb_byte = (B >> 5) << 2, sb_bit = sb_byte * 8u;
-    const u32 b0 = B - sb_bit;
-    u32 e0 = b0 + 64u * LZX_HDR_S; if (e0 > in_limit - sb_bit) e0 = in_limit - sb_bit;
-    {
-      const u32 nck = (e0 + 128u + 2047u) >> 11;               // a token that starts below e0 ends below e0 + 37
-      InWindow ws; ws.unit = unit; ws.in_len = unit_len; ws.eofs = 0u; ws.origin = sb_byte; ws.wi = 0u; ws.cur = 0u; ws.nxt = 0u;
-#pragma unroll
-      for (int c = 0; c < 2; c++) {                            // (64 x 32 bits + 31 + 128: at most two chunks)
-        const u32 v = (u32) c < nck ? ws.load_chunk((u32) c, lane) : 0u;
-        sh->stage[(u32) c * 64u + lane] = SWAP16(v);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const u32 nl = (e0 - b0 + LZX_HDR_S - 1u) / LZX_HDR_S;     // >= 1
-    const u32 rstart = b0 + lane * LZX_HDR_S;
-    u32 rend = rstart + LZX_HDR_S; if (rend > e0) rend = e0;
-    u32 entry = (lane == 0u || rstart < b0 + LZX_HDR_LEAD) ? b0 : rstart - LZX_HDR_LEAD;
-    u32 n = 0, ny = 0, exitp = entry, stop_at = 0;
-    bool dead = false, changed = lane < nl;
-    for (u32 round = 0; ; ) {
-      u32 p = entry, cnt = 0, cy = 0, sa = 0;
-      bool dd = false;
-      for (;;) {
-        const bool act = changed && p < rend;
-        if (!ballot(act)) break;
-        STAGE_BITS(act ? p : 0u, w0, w1, true)
-        const PreTok t = lzx_pre_token(sh, act, plim, pre_fov, w0, w1);
-        const bool ok = act && !t.unk, die = act && t.unk;
-        dd = dd || die; sa = die ? p : sa;
-        cnt += ok ? 1u : 0u; cy += ok ? t.y : 0u;
-        p = die ? rend : p + (ok ? t.tot : 0u);
-      }
-      if (changed) { n = cnt; ny = cy; exitp = p; dead = dd; stop_at = sa; }
-      round++;
-      const u32 pe = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) exitp);
-      const u32 ne = lane == 0u ? b0 : pe;
-      changed = lane < nl && ne != entry;
-      entry = ne;
-      if (!ballot(changed) || round >= LZX_HDR_ROUNDS) break;
-    }
-    // ---- the consistent prefix: lanes < mm (lane 0 always is: it starts at a real token) ----
-    u32 m = nl;
-    { const u64 chm = ballot(changed); if (chm) m = (u32) __ffsll((long long) chm) - 1u; }
-    u32 mm = m, dl = 0;
-    bool hit = false;
-    { const u64 dm = ballot(dead && lane < m); if (dm) { dl = (u32) __ffsll((long long) dm) - 1u; mm = dl + 1u; hit = true; } }
-    if (mm == 0u) break;
-    const u32 cvn = lane < mm ? n : 0u, cvy = lane < mm ? ny : 0u;
-    const u32 incly = wave_incl_scan(cvy);
-    // ---- last walk: every token rewrites its own lens[x .. x + y) ----
-    u32 p = entry, i = 0, x = X + incly - cvy, endp = 0;
-    bool ended = false;
-    for (;;) {
-      const bool on = i < cvn && !ended;
-      if (!ballot(on)) break;
-      STAGE_BITS(on ? p : 0u, w0, w1, true)
-      const PreTok t = lzx_pre_token(sh, on, plim, pre_fov, w0, w1);
-      if (on && x >= last) { ended = true; endp = p; }             // lengths are read only while x < last (lzxd.c:148)
-      else if (on) {
-        int nv = 0;
-        if (!t.zero) { nv = (int)(u32) lens[x] - (int) t.zz; if (nv < 0) nv += 17; }
-        for (u32 k = 0; k < t.y; k++) lens[x + k] = (u8) nv;     // (a run may overshoot `last`: it is not clipped, lzxd.c:159)
-        x += t.y; p += t.tot; i++;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // (the next pass restages; lens[] is read by the next call)
-    moved = true;
-    // the first token (in stream order) that found x >= last ends the run: every lane to its right marks its own first token
-    const u64 em = ballot(lane < mm && ended);
-    const u32 xend = rdl(incly, mm - 1u) + X;                     // index behind the prefix's last token
-    if (em) {
-      const u32 le = (u32) __ffsll((long long) em) - 1u;
-      B = sb_bit + rdl(endp, le);
-      X = rdl(x, le);                                             // >= last
-      stop = true;
-    }
-    else {
-      X = xend;
-      if (hit) { B = sb_bit + rdl(stop_at, dl); stop = true; }
-      else B = sb_bit + rdl(exitp, mm - 1u);
-    }
-  }
-  HdrLanes res; res.X = X; res.B = B; res.moved = moved ? 1u : 0u;
-  return res;
-}
-
-__device__ __forceinline__ u32 lzx_hdr_lanes(LzxDec &d, u8 *lens, u32 first, u32 last)
-{
-  const HdrLanes r = lzx_read_lens_lanes(d.sh, d.w.unit, d.w.in_len, rfl(d.w.origin) * 8u + rfl(d.cons_bits()), d.hr_pre.limv, d.hr_pre.fov,
-                                         lens, first, last, d.lane);
-  if (rfl(r.moved)) lzx_seek_bit(d, rfl(r.B));
-  return rfl(r.X);
-}
-#endif  /* LZX_HDR_LANES */
 
 // One token at the bits (w0, w1), every lane its own: main-tree entry (codes beyond the direct table resolved for all
 // lanes at once when any lane has one), length footer, offset bits, aligned-offset symbol.  Everything is computed for
@@ -2560,11 +2265,7 @@ __device__ __forceinline__ u32 lzx_chain_wait(const u32 *p, const bool)
   return ch;
 }
 
-#ifndef LZX_RESOLVE_TILE
-#define LZX_RESOLVE_TILE 0          /* 1: every resolve task copies through the LDS tile (tile_resolve.hpp); 2: only the tasks of
-                                       units that are one chain of frames (`merged`); 0: spec_queue.hpp everywhere */
-#endif
-union LzxResolveLds { SpecQueueLds q; TileLds t; };
+union LzxResolveLds { SpecQueueLds q; };
 __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_arena, LzxFrameRec *urecs, const uint2 *pool_base, LzxResolveLds *rl,
                                  const bool merged)
 {
@@ -2617,56 +2318,7 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
     n_rec = rfl(rec->n_tokens); bytes = rfl(rec->bytes_done); end_bit = rfl(rec->end_bit);
     bad = rfl(rec->frame_start_bit) != prev_end || rfl(rec->block_length) != fsz || bytes > fsz || n_rec > REC_CHUNK * REC_CHUNKS;
   }
-  const bool use_tile = LZX_RESOLVE_TILE == 1 || (LZX_RESOLVE_TILE == 2 && merged);
-  if (!bad && use_tile) {
-    // ---- the copies through the LDS tile (tile_resolve.hpp): a batch of 64 matches per pass, chains collapsed ----
-    TileLds *const tl = &rl->t;
-    const u32 ne = rfl(rec->n_edge);
-    for (u32 i = lane; i < ne; i += WAVE)
-      if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
-    tr_clear_map(*tl, lane);
-    TileState T;
-    T.T0 = 0; T.hi = 0; T.live = false;
-    u32 th = 0;
-    uint2 cur = make_uint2(0u, 0u), nxt = cur;
-    if (th + lane < n_rec) cur = tr_gld(MREC(th + lane));
-    if (th + 64u + lane < n_rec) nxt = tr_gld(MREC(th + 64u + lane));
-    while (th < n_rec && !bad) {
-      u32 n = n_rec - th; if (n > 64u) n = 64u;
-      const u32 opos = cur.x, olen = (cur.y >> 2) & 511u, which = cur.y & 3u, c1 = cur.y >> 11;
-      // the tile: every record of the batch has to start inside it
-      {
-        const u32 p_first = rdl(opos, 0u), p_last = rdl(opos, n - 1u);
-        if (p_first < frame_pos || p_last < p_first || p_last >= frame_pos + bytes) { bad = true; break; }    // (a record list no parse wave wrote)
-        if (T.live && p_last - T.T0 >= TR_TILE && p_first - T.T0 >= 16u) { tr_flush(*tl, out, T.T0, T.hi, lane); T.live = false; }
-        if (!T.live) { T.T0 = p_first & ~15u; T.hi = T.T0; tr_fill(*tl, out, T.T0, frame_pos + fsz, lane); T.live = true; }
-        if (p_last - T.T0 >= TR_TILE) n = (u32) __popcll(ballot(lane < n && opos - T.T0 < TR_TILE));            // (>= 1: the first one does)
-      }
-      PH(10);
-      const bool ism = lane < n;
-      u32 vmoff;
-      if (!lzx_front_batch(ism, lane, opos, olen, which, c1, R0, R1, R2, frame_pos, wbase, wsize, vmoff)) { bad = true; break; }
-      {
-        // what the tile takes for granted: records in position order, inside the bytes the parse wave stored
-        const u32 nextp = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane + 1u) & 63u) << 2), (int) opos);
-        if (ballot(ism && (olen < 2u || olen > 257u || opos + olen > frame_pos + bytes || (lane + 1u < n && opos + olen > nextp) || opos < T.hi))) { bad = true; break; }
-      }
-      PH(9);
-      if (tr_batch(*tl, out, T.T0, frame_pos, true, true, ism, false, opos, olen, vmoff, lane)) { bad = true; break; }   // (nothing is deferred here)
-      T.hi = rdl(opos + olen, n - 1u);
-      PH(11);
-      th += n;
-      if (n == 64u) { cur = nxt; nxt = make_uint2(0u, 0u); if (th + 64u + lane < n_rec) nxt = tr_gld(MREC(th + 64u + lane)); }
-      else {                                                     // (a batch cut at the tile's end)
-        cur = make_uint2(0u, 0u); nxt = cur;
-        if (th + lane < n_rec) cur = tr_gld(MREC(th + lane));
-        if (th + 64u + lane < n_rec) nxt = tr_gld(MREC(th + 64u + lane));
-      }
-    }
-    if (T.live && !bad) tr_flush(*tl, out, T.T0, T.hi, lane);
-    PH(10);
-  }
-  else if (!bad) {
+  if (!bad) {
     // ---- the literals of the frame's first cache line ----
     const u32 ne = rfl(rec->n_edge);
     for (u32 i = lane; i < ne; i += WAVE)
@@ -2970,12 +2622,10 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
 #endif
           while (d.P < run_end) {
             if (respec && !d.careful && !d.near_end) {
-#if !defined(LZX_NO_SPEC) && !defined(LZX_DELTA)
+#ifndef LZX_DELTA
               int rc = aligned ? lzx_run_spec2<true>(d, s, run_end, wbase) : lzx_run_spec2<false>(d, s, run_end, wbase);
-#elif !defined(LZX_NO_SPEC)
-              int rc = aligned ? lzx_run_spec<true>(d, s, run_end, wbase) : lzx_run_spec<false>(d, s, run_end, wbase);
 #else
-              int rc = aligned ? lzx_run_fast<true>(d, s, run_end, wbase) : lzx_run_fast<false>(d, s, run_end, wbase);
+              int rc = aligned ? lzx_run_spec<true>(d, s, run_end, wbase) : lzx_run_spec<false>(d, s, run_end, wbase);
 #endif
               if (rc == LZX_RUN_FAIL) { fail = true; break; }
               if (d.P >= run_end) break;

@@ -966,8 +966,7 @@ __device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
 
 // recs / toks: the parse waves' records and tokens for this launch (NULL: none), indexed by frame slot
 __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
-                                  mspack_hip_result *res, MszipShared *sh, const ZipBlockRec *recs, const uint2 *toks,
-                                  const bool wait_recs = false)
+                                  mspack_hip_result *res, MszipShared *sh, const ZipBlockRec *recs, const uint2 *toks)
 {
   const u32 lane = threadIdx.x;
   ZipDec d;
@@ -1033,13 +1032,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
     if (use_recs && blk < nblk) {
       // a parse wave's record for this block?  adopt it if it was parsed from exactly this bit position
       const ZipBlockRec *rc_ = &recs[u.frame_base + blk];
-      u32 st_ = 0;
-      if (wait_recs) {
-        // (mspack_mszip_pipe: the block's parse task has an earlier ticket, so a live wave holds it or it is done)
-        while ((st_ = zip_status_load(&rc_->status)) == 0u) __builtin_amdgcn_s_sleep(8);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      else st_ = rfl(rc_->status);
+      const u32 st_ = rfl(rc_->status);       // (the parse kernel ran before this one)
       // (and only where the parse wave put the literals: every earlier block of the folder a full one)
       if (st_ == 1u && rfl(rc_->start_bit) == d.w.origin * 8u + d.cons_bits() && d.B == blk * ZIP_FRAME &&
           zip_run_tokens(d, toks, rc_->chunk, rc_->n_tokens, rc_->total_out)) {

@@ -11,7 +11,6 @@
 #include <array>
 #include "wave_common.hpp"
 #include "spec_queue.hpp"
-#include "tile_resolve.hpp"
 // lzx_kernel.hpp is compiled twice: plain LZX (CAB, CHM) and LZX DELTA (OAB) -- see its header
 namespace lzxn {
 #include "lzx_kernel.hpp"
@@ -338,67 +337,6 @@ void mspack_decode_mszip(const mspack_hip_unit *units, const u32 *order, u32 n_u
   const mspack_hip_unit u = units[ui];
   mszip_decode_unit(u, in_arena, out_arena, &results[ui], &sh, (const ZipBlockRec *) recs, toks);
 }
-// ---------------------------------------------------------------------------------------------------
-// mspack_mszip_pipe -- block parse tasks and folder tasks of a launch's MSZIP units from ONE ticket counter (the scheme of
-// mspack_lzx_pipe): tickets [0, n_slots) are P(block slot) -- block-major (all first blocks, all second blocks, ...) when
-// every unit has the same number of blocks, else in slot order --, tickets [n_slots, n_slots + n_units) are F(unit) in
-// launch order: mszip_decode_unit, which waits for each block's record (its parse task has an earlier ticket, so a live
-// wave holds it or it is done), commits it, and decodes whatever no record covers the serial way.  A folder's first
-// blocks are committed while its later ones are still being parsed; no kernel boundary between parse and commit.
-// Where the folder's wave decodes serially it writes only output that belongs to blocks whose records it has already
-// waited for (a block's bytes lie at or below its index * 32 KiB), so no parse wave's literals can arrive afterwards.
-// ---------------------------------------------------------------------------------------------------
-__device__ __attribute__((noinline)) void mszip_pipe_task_parse(const mspack_hip_unit *up, const u32 b, const u8 *in_arena, u8 *out_arena,
-                                                                lzxn::LzxFrameRec *recs, uint2 *toks, u32 *pool_head, const u32 pool_chunks, MszipShared *sh)
-{
-  const mspack_hip_unit u = *up;
-  RecPool rp; rp.base = toks; rp.head = pool_head; rp.cap = pool_chunks;
-  zip_parse_block(u, b, in_arena, out_arena, (ZipBlockRec *) &recs[u.frame_base + b], rp, sh);
-}
-__device__ __attribute__((noinline)) void mszip_pipe_task_folder(const mspack_hip_unit *up, const u8 *in_arena, u8 *out_arena,
-                                                                 mspack_hip_result *res, const lzxn::LzxFrameRec *recs, const uint2 *toks,
-                                                                 MszipShared *sh)
-{
-  const mspack_hip_unit u = *up;
-  mszip_decode_unit(u, in_arena, out_arena, res, sh, (const ZipBlockRec *) recs, toks, true);
-}
-static_assert(sizeof(MszipShared) <= 10240, "16 waves per CU");
-
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
-void mspack_mszip_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
-                       const u8 *in_arena, u8 *out_arena, mspack_hip_result *results,
-                       const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks, u32 pool_chunks)
-{
-  __shared__ MszipShared sh;
-  const u32 lane = threadIdx.x;
-  const u32 Fmax = rfl(ctl[0]), Fmin = rfl(ctl[1]);
-  const u32 F = (Fmax != 0u && Fmax == Fmin && n_units * Fmax == n_slots) ? Fmax : 0u;
-  const u32 T = n_slots + n_units;
-  for (;;) {
-    u32 t = 0;
-    if (lane == 0) t = atomicAdd(&ctl[2], 1u);
-    t = rfl(t);
-    if (t >= T) break;
-    if (t < n_slots) {
-      u32 ui, b;
-      if (F) { ui = rfl(order ? order[t % n_units] : t % n_units); b = t / n_units; }
-      else {
-        const u32 slot = slot_lo + t;
-        ui = rfl(frame_unit[slot]);
-        if (ui == 0xFFFFFFFFu) continue;
-        b = slot - rfl(units[ui].frame_base);
-      }
-      mszip_pipe_task_parse(&units[ui], b, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh);
-    }
-    else {
-      const u32 j = t - n_slots;
-      const u32 ui = rfl(order ? order[j] : j);
-      if (rfl((u32) units[ui].kind) != MSPACK_HIP_KIND_MSZIP) continue;
-      mszip_pipe_task_folder(&units[ui], in_arena, out_arena, &results[ui], recs, toks, &sh);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the next task reuses the LDS
-  }
-}
 static_assert(sizeof(ZipBlockRec) == sizeof(lzxn::LzxFrameRec), "MSZIP and LZX share the work scratch");
 
 __global__ __launch_bounds__(64)
@@ -450,41 +388,61 @@ static int fail(hipError_t e, const char *what) {
 // that carry a frame table get their frames parsed by one wave each first (slots [slot_lo, slot_lo + n_slots)
 // of the work scratch belong to this launch).
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
-static const bool g_mszip_pipe = getenv("MSPACK_HIP_MSZIP_PIPE") != nullptr;         // experiments: mspack_mszip_pipe instead of parse + folder kernels
 // persistent waves of mspack_lzx_pipe: as many as the device holds at once (nothing depends on that number being right)
 // (cached per device: mspack_hip_decode_batch_multi runs one host thread per device)
-static unsigned pipe_waves_for(int which)
+static unsigned lzx_pipe_waves()
 {
   static std::mutex mu;
-  static unsigned cache[2][MSPK_MAX_DEV_CACHE] = { { 0 } };
+  static unsigned cache[MSPK_MAX_DEV_CACHE] = { 0 };
   int dev = 0, per_cu = 0; hipDeviceProp_t pr;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MSPK_MAX_DEV_CACHE) return 4096u;
   std::lock_guard<std::mutex> lock(mu);
-  if (!cache[which][dev]) {
+  if (!cache[dev]) {
     if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 4096u;
-    hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_lzx_pipe, 64, 0)
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_mszip_pipe, 64, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mspack_lzx_pipe, 64, 0);
     if (e != hipSuccess || per_cu < 1) per_cu = 16;
-    if (which == 0) { const char *ev = getenv("MSPACK_HIP_PIPE_WAVES_PER_CU"); if (ev && atoi(ev) > 0) per_cu = atoi(ev); }
-    cache[which][dev] = (unsigned) pr.multiProcessorCount * (unsigned) per_cu;
+    { const char *ev = getenv("MSPACK_HIP_PIPE_WAVES_PER_CU"); if (ev && atoi(ev) > 0) per_cu = atoi(ev); }
+    cache[dev] = (unsigned) pr.multiProcessorCount * (unsigned) per_cu;
   }
-  return cache[which][dev];
+  return cache[dev];
 }
-static unsigned lzx_pipe_waves() { return pipe_waves_for(0); }
-static unsigned mszip_pipe_waves() { return pipe_waves_for(1); }
-static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
-                        const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
-                        size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true, unsigned launch_ix = 0,
-                        size_t n_rec_slots = (size_t) -1, bool alone = true)
+// a kernel launch whose status is RETURNED (hipLaunchKernelGGL leaves it in the thread's "last error", which is whoever's:
+// an application's stale error made round 4's entry points fail, and clearing it on entry was the application's to do)
+#include <tuple>
+#include <utility>
+template <typename... P, typename... A>
+static hipError_t launch(void (*kernel)(P...), dim3 grid, dim3 block, hipStream_t st, A... a)
+{
+  static_assert(sizeof...(P) == sizeof...(A), "one argument per kernel parameter");
+  std::tuple<P...> vals{ (P) a... };
+#ifdef MSPACK_WAVE_EMU             /* tests/emu: the kernel is a host function, a launch runs it on the emulator's wave threads */
+  (void) st;
+  emu_launch(grid, block, [=]() { std::apply(kernel, vals); });
+  return hipSuccess;
+#else
+  void *args[sizeof...(P)];
+  size_t i = 0;
+  std::apply([&](auto &... v) { ((args[i++] = (void *) &v), ...); }, vals);
+  return hipLaunchKernel((const void *) kernel, grid, block, args, 0, st);
+#endif
+}
+#define LK(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+
+static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
+                              const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
+                              size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true, unsigned launch_ix = 0,
+                              size_t n_rec_slots = (size_t) -1)
 {
   if (n_rec_slots == (size_t) -1) n_rec_slots = n_frames_total;
-  if (n == 0) return;
+  if (n == 0) return hipSuccess;
   const dim3 grid((unsigned) n), block(64);
+  const u8 *const in = (const u8 *) d_in;
+  u8 *const out = (u8 *) d_out;
+  static const u32 hdr_init[8] = { 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u };
   switch (kind) {
   case MSPACK_HIP_KIND_LZX: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total, n_rec_slots);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
-    static const u32 hdr_init[8] = { 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u };
     // launches of one batch that run on different streams (host path, several chunks) have their own control words, and
     // their own part of the record pool: the part that belongs to their frame slots
     u32 *hdr = L.hdr + 8u * (launch_ix & 15u);
@@ -492,70 +450,54 @@ static void launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uin
     const u32 pool_chunks = (u32)(n_slots * REC_POOL_PER_SLOT);
     if (frames) {
       // one dependency-driven launch: parse and resolve tasks from a ticket counter (mspack_lzx_pipe)
-      hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
-      hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
-      hipLaunchKernelGGL(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, 0, st, d_units, d_order, (u32) n, L.frame_unit,
-                         L.recs, hdr);
+      LK(hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st));
+      LK(hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st));
+      LK(launch(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr));
       const size_t tickets = 2u * n_slots;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
-      hipLaunchKernelGGL(mspack_lzx_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
-                         (const u8 *) d_in, (u8 *) d_out, d_results, L.meta, (const u32 *) L.frame_unit, hdr, L.recs, pool, pool_chunks);
+      LK(launch(mspack_lzx_pipe, dim3(waves), block, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots, in, out, d_results,
+                L.meta, L.frame_unit, hdr, L.recs, pool, pool_chunks));
       // what the pipe leaves: the last bytes of every unit's input (the EOF-exact reader's), the look-ahead frame, frames
       // that are not one regular block, errors, E8, the results -- the unit kernel, resuming where each unit's chain of frames ended
-      hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                         d_results, L.meta, (const lzxn::LzxFrameRec *) L.recs, (const uint2 *) pool, 1u);
+      LK(launch(mspack_decode_lzx, grid, block, st, d_units, d_order, (u32) n, in, out, d_results, L.meta, L.recs, pool, 1u));
       break;
     }
-    hipLaunchKernelGGL(mspack_decode_lzx, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results, d_fm ? L.meta : nullptr, (const lzxn::LzxFrameRec *) nullptr, (const uint2 *) nullptr, 0u);
+    LK(launch(mspack_decode_lzx, grid, block, st, d_units, d_order, (u32) n, in, out, d_results, d_fm ? L.meta : (int32_t *) nullptr,
+              (const lzxn::LzxFrameRec *) nullptr, (const uint2 *) nullptr, 0u));
     break; }
   case MSPACK_HIP_KIND_LZX_DELTA:
-    hipLaunchKernelGGL(mspack_decode_lzxd, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results, (int32_t *) d_fm); break;
+    LK(launch(mspack_decode_lzxd, grid, block, st, d_units, d_order, (u32) n, in, out, d_results, (int32_t *) d_fm)); break;
   case MSPACK_HIP_KIND_MSZIP: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total, n_rec_slots);
     const bool frames = d_fm != nullptr && n_slots != 0 && !g_no_frames && frame_tables;
     uint2 *pool = nullptr;
     u32 pool_chunks = 0;
     if (frames) {
-      static const u32 hdr_init[8] = { 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u };
+      // one parse wave per CFDATA block first (mszip_kernel.hpp: "Block-level parse parallelism"); a pipe of the LZX kind
+      // was measured slower here (profiles/round3_mszip.txt: the blocks' parse tasks do not depend on each other)
       u32 *hdr = L.hdr + 8u * (16u + (launch_ix & 15u));
       pool = L.pool + slot_lo * REC_SLOT_RECORDS;
       pool_chunks = (u32)(n_slots * REC_POOL_PER_SLOT);
-      hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st);
-      hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st);
-      hipLaunchKernelGGL(mspack_lzx_frame_map, grid, block, 0, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr,
-                         (u32) MSPACK_HIP_KIND_MSZIP);
-      if (g_mszip_pipe) {
-        // (experiment, MSPACK_HIP_MSZIP_PIPE=1) one dependency-driven launch: block parse tasks and folder tasks from a
-        // ticket counter.  Measured slower than the two kernels below: 4096 one-block units 2.10 ms against 1.79,
-        // 512 x 8 blocks 3.63 against 3.52 (profiles/round3_mszip.txt) -- the blocks' parse tasks do not depend on each
-        // other, so the kernel boundary costs one tail only, while the hand-off costs a release per block and the two
-        // roles share one register budget (parse alone: 62 VGPRs; in the pipe kernel 120)
-        const size_t tickets = n_slots + n;
-        const unsigned waves = (unsigned) std::min<size_t>(tickets, mszip_pipe_waves());
-        hipLaunchKernelGGL(mspack_mszip_pipe, dim3(waves), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots,
-                           (const u8 *) d_in, (u8 *) d_out, d_results, (const u32 *) L.frame_unit, hdr, L.recs, pool, pool_chunks);
-        break;
-      }
-      hipLaunchKernelGGL(mspack_mszip_parse, dim3((unsigned) n_slots), block, 0, st, d_units, d_order, (u32) n, (u32) slot_lo,
-                         (u32) n_slots, (const u8 *) d_in, (u8 *) d_out, (const u32 *) L.frame_unit, hdr, L.recs, pool, pool_chunks);
+      LK(hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st));
+      LK(hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st));
+      LK(launch(mspack_lzx_frame_map, grid, block, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr, (u32) MSPACK_HIP_KIND_MSZIP));
+      LK(launch(mspack_mszip_parse, dim3((unsigned) n_slots), block, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots, in, out,
+                L.frame_unit, hdr, L.recs, pool, pool_chunks));
     }
-    hipLaunchKernelGGL(mspack_decode_mszip, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results, frames ? (const lzxn::LzxFrameRec *) L.recs : nullptr, (const uint2 *) pool);
+    LK(launch(mspack_decode_mszip, grid, block, st, d_units, d_order, (u32) n, in, out, d_results,
+              frames ? L.recs : (lzxn::LzxFrameRec *) nullptr, pool));
     break; }
   case MSPACK_HIP_KIND_QUANTUM:
-    hipLaunchKernelGGL(mspack_decode_qtm, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results); break;
+    LK(launch(mspack_decode_qtm, grid, block, st, d_units, d_order, (u32) n, in, out, d_results)); break;
   case MSPACK_HIP_KIND_LZSS:
-    hipLaunchKernelGGL(mspack_decode_lzss, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results); break;
+    LK(launch(mspack_decode_lzss, grid, block, st, d_units, d_order, (u32) n, in, out, d_results)); break;
   case MSPACK_HIP_KIND_KWAJ_LZH:
-    hipLaunchKernelGGL(mspack_decode_kwaj_lzh, grid, block, 0, st, d_units, d_order, (u32) n, (const u8 *) d_in, (u8 *) d_out,
-                       d_results); break;
+    LK(launch(mspack_decode_kwaj_lzh, grid, block, st, d_units, d_order, (u32) n, in, out, d_results)); break;
   default: break;
   }
+  return hipSuccess;
 }
+#undef LK
 
 extern "C" {
 
@@ -612,9 +554,8 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
   // order list per codec and a one-bit mask (what the host-buffer entry points below do).
   for (unsigned k = 1; k <= 6; k++)
     if (kind_mask & (1u << k))
-      launch_kind(k, d_units, d_order, n_units, d_in, d_out, d_results, d_frame_scratch, n_frames_total, 0, n_frames_total,
-                  (hipStream_t) stream, (kind_mask & MSPACK_HIP_MASK_FRAME_TABLES) != 0u);
-  CK(hipGetLastError());
+      CK(launch_kind(k, d_units, d_order, n_units, d_in, d_out, d_results, d_frame_scratch, n_frames_total, 0, n_frames_total,
+                     (hipStream_t) stream, (kind_mask & MSPACK_HIP_MASK_FRAME_TABLES) != 0u));
   return 0;
 }
 
@@ -724,6 +665,52 @@ static inline size_t unit_frames(const mspack_hip_unit &u) {
   return 0u;
 }
 
+// ---- page-locked host ranges and the copies that touch them ---------------------------------------------------------
+// ROOT CAUSE of round 4's intermittent "GPU batch decode failed ... invalid argument" (DESIGN.md sec. 8h):
+// the runtime treats EVERY host address inside a registered range as that registration's memory, and a copy whose host
+// side starts inside a registration and ends beyond it is refused with hipErrorInvalidValue.  Rounds 3-4 rounded their
+// registrations OUTWARD to whole pages, so the first and last page also held whatever the allocator had put next to the
+// caller's buffer -- e.g. this file's own std::vector<> of launch orders, 4 KiB that began in the arena's last page and
+// ended behind it (glibc serves a 24 MiB arena from the brk heap once an mmap'd block of that size has been freed: the
+// SECOND decompressor of a process).  Rules since:
+//   (1) a registration never holds a byte outside the range its owner passed (whole pages INSIDE it);
+//   (2) every copy between the device and host memory is cut at the boundaries of the registrations this library made
+//       (mspack_hip_pin's registry + the call's own), so that no piece straddles one.
+struct PinRange { uintptr_t ra, rb; const void *user; };
+static std::mutex g_pin_mu;
+static std::vector<PinRange> g_pins;
+static const uintptr_t MSPK_PAGE = 4096u;
+static inline bool inner_pages(const void *p, size_t bytes, uintptr_t &ra, uintptr_t &rb) {
+  ra = ((uintptr_t) p + MSPK_PAGE - 1u) & ~(MSPK_PAGE - 1u);
+  rb = ((uintptr_t) p + bytes) & ~(MSPK_PAGE - 1u);
+  return rb > ra;
+}
+// the boundaries of known registrations strictly inside (lo, hi), ascending
+static void pin_cuts(uintptr_t lo, uintptr_t hi, const PinRange *extra, int n_extra, std::vector<uintptr_t> &cuts) {
+  cuts.clear();
+  auto add = [&](const PinRange &r) { if (r.ra > lo && r.ra < hi) cuts.push_back(r.ra); if (r.rb > lo && r.rb < hi) cuts.push_back(r.rb); };
+  { std::lock_guard<std::mutex> lock(g_pin_mu); for (const PinRange &r : g_pins) add(r); }
+  for (int i = 0; i < n_extra; i++) add(extra[i]);
+  std::sort(cuts.begin(), cuts.end());
+}
+// hipMemcpyAsync with the HOST side cut at registration boundaries
+static hipError_t copy_cut(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t st,
+                           const PinRange *extra = nullptr, int n_extra = 0) {
+  if (!n) return hipSuccess;
+  const uintptr_t h = kind == hipMemcpyHostToDevice ? (uintptr_t) src : (uintptr_t) dst;
+  std::vector<uintptr_t> cuts;
+  pin_cuts(h, h + n, extra, n_extra, cuts);
+  uintptr_t at = h;
+  for (size_t i = 0; i <= cuts.size(); i++) {
+    const uintptr_t to = i < cuts.size() ? cuts[i] : h + n;
+    if (to <= at) continue;
+    const hipError_t e = hipMemcpyAsync((char *) dst + (at - h), (const char *) src + (at - h), to - at, kind, st);
+    if (e != hipSuccess) return e;
+    at = to;
+  }
+  return hipSuccess;
+}
+
 // `sel` lists the unit indices this device handles (NULL = all n_sel units).  host_out != NULL: outputs are
 // copied back into it; dev_out != NULL: the caller's DEVICE buffer receives them (out_off relative to it).
 // per_unit_back: copy the outputs back unit by unit (a sharded call whose shards' output spans interleave)
@@ -738,9 +725,6 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
   std::lock_guard<std::mutex> lock(cx.mu);
   hipError_t e;
   int rc = 0;
-  // (this thread's "last error" may be a leftover of an earlier call -- the library's own or the application's --: the
-  // hipGetLastError() checks behind the launches below must only see what THIS call did)
-  (void) hipGetLastError();
 #define TRY(call) do { e = (call); if (e != hipSuccess) { snprintf(errbuf, errcap, "%s: %s", #call, hipGetErrorString(e)); rc = -(int) e; goto done; } } while (0)
   static const bool trace = getenv("MSPACK_HIP_TRACE") != nullptr;
   auto tnow = []() { return std::chrono::steady_clock::now(); };
@@ -883,7 +867,10 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     TRY(grow(cx.d_order, n_sel * sizeof(uint32_t), false));
     TRY(grow(cx.d_res, n_sel * sizeof(mspack_hip_result), false));
     TRY(grow(cx.d_fm, lzx_scratch(nullptr, n_frames, n_rec_slots).bytes, false));
-    TRY(grow(cx.h_stage, n_sel * sizeof(mspack_hip_result), true));
+    // (pinned staging: the results, and room for the few output bytes that lie outside every page-locked range -- below)
+    const size_t stage_res = (n_sel * sizeof(mspack_hip_result) + 255u) & ~(size_t) 255u;
+    const size_t STAGE_PIECE = 8192u, STAGE_SLOTS = 4u * MSPK_MAX_CHUNKS;
+    TRY(grow(cx.h_stage, stage_res + STAGE_PIECE * STAGE_SLOTS, true));
     u8 *const d_in = (u8 *) cx.d_in.p;
     u8 *const d_out = dev_out ? (u8 *) dev_out : (u8 *) cx.d_out.p;
     mspack_hip_unit *const d_units = (mspack_hip_unit *) cx.d_units.p;
@@ -909,77 +896,107 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     // copies and the first launches run), after which chunk c's D2H is a plain DMA that starts the moment chunk c's
     // launches have ended, next to the H2D of later chunks (PCIe is full duplex).  The pages are released before the
     // call returns.  A buffer that cannot be registered (already pinned by its owner, or the runtime refuses) is
-    // copied the ordinary way.
+    // copied the ordinary way.  Only whole pages INSIDE the bytes this call writes are locked (see PinRange above); what is
+    // left over at the two ends of the span (less than a page each; nothing for a page-aligned buffer such as the C
+    // drivers') goes through the pinned staging buffer and is copied into place at the end.
     std::atomic<size_t> issued{0};                       // chunks whose ev_done has been recorded
     std::atomic<bool> stop{false};
     hipError_t back_err = hipSuccess;
     double pin_ms = 0.0, unpin_ms = 0.0;
     std::thread back;
-    struct Pins {                                          // page-locked ranges of the caller's buffer
-      char *p[MSPK_MAX_CHUNKS]; int n = 0;
-      void release() { for (int i = 0; i < n; i++) hipHostUnregister(p[i]); n = 0; }
+    struct Pins {                                          // page-locked ranges of the caller's buffers (this call's own)
+      PinRange r[MSPK_MAX_CHUNKS + 1]; int n = 0;
+      bool lock(uintptr_t ra, uintptr_t rb) {
+        if (rb <= ra || n >= MSPK_MAX_CHUNKS + 1) return false;
+        if (hipHostRegister((void *) ra, rb - ra, hipHostRegisterDefault) != hipSuccess) { (void) hipGetLastError(); return false; }
+        r[n].ra = ra; r[n].rb = rb; r[n].user = nullptr; n++;
+        return true;
+      }
+      void release() { for (int i = 0; i < n; i++) if (hipHostUnregister((void *) r[i].ra) != hipSuccess) (void) hipGetLastError(); n = 0; }
       ~Pins() { if (n) { hipDeviceSynchronize(); release(); } }      // (an error path: nothing may still be writing them)
-    } pins;
+    } pins, pins_in;
+    struct Staged { void *host; size_t off, n; };
+    std::vector<Staged> staged;                            // (written by the thread that issues the copies back, read after it)
+    staged.reserve(STAGE_SLOTS);
+    // one span of the output, device -> caller's memory on st_out: cut at the boundaries of every registration this library
+    // knows; pieces outside all of them that are small go through the pinned staging buffer (no pageable copy in the way)
+    auto copy_out = [&](uintptr_t lo, uintptr_t hi, const u8 *d_src) -> hipError_t {
+      std::vector<uintptr_t> cuts;
+      pin_cuts(lo, hi, pins.r, pins.n, cuts);
+      uintptr_t at = lo;
+      for (size_t i = 0; i <= cuts.size(); i++) {
+        const uintptr_t to = i < cuts.size() ? cuts[i] : hi;
+        if (to <= at) continue;
+        bool locked = false;
+        for (int k = 0; k < pins.n && !locked; k++) locked = at >= pins.r[k].ra && to <= pins.r[k].rb;
+        hipError_t ce;
+        if (!locked && pins.n && to - at <= STAGE_PIECE && staged.size() < STAGE_SLOTS) {
+          const size_t off = stage_res + STAGE_PIECE * staged.size();
+          ce = hipMemcpyAsync((char *) cx.h_stage.p + off, d_src + (at - lo), to - at, hipMemcpyDeviceToHost, st_out);
+          staged.push_back(Staged{ (void *) at, off, (size_t)(to - at) });
+        }
+        else ce = hipMemcpyAsync((void *) at, d_src + (at - lo), to - at, hipMemcpyDeviceToHost, st_out);
+        if (ce != hipSuccess) return ce;
+        at = to;
+      }
+      return hipSuccess;
+    };
     struct Joiner { std::thread &t; std::atomic<bool> &stop; ~Joiner() { if (t.joinable()) { stop.store(true); t.join(); } } } joiner{back, stop};
-    static const bool pin_out = env_int("MSPACK_HIP_PIN_OUT", 1, 0, 1) != 0;
+    // (LZX DELTA units read their reference data out of the caller's output buffer while this call runs: no locking of it then)
+    bool refs_in_out = false;
+    for (size_t i = 0; i < n_sel && !refs_in_out; i++) refs_in_out = local[i].kind == MSPACK_HIP_KIND_LZX_DELTA && local[i].ref_len != 0u;
+    static const bool pin_out_env = env_int("MSPACK_HIP_PIN_OUT", 1, 0, 1) != 0;
+    const bool pin_out = pin_out_env && !refs_in_out;
     // The INPUT is not locked here by default (MSPACK_HIP_PIN_IN=1 does it, one range per call): for a caller's warm buffer the
     // runtime's pageable path is as fast as the lock costs (to the host 7.4 -> 8.1 ms on the headline batch); for an arena that was
     // just written -- the C drivers' gather -- it runs at 5-6 GB/s, and those callers lock their arena themselves (mspack_hip_pin).
     static const bool pin_in = env_int("MSPACK_HIP_PIN_IN", 0, 0, 1) != 0;
-    Pins pins_in;
     bool back_started = false;
     if (host_out && !one) try {
       back = std::thread([&]() {
         hipError_t be = hipSetDevice(dev);
-        const uintptr_t PG = 4096u, base = (uintptr_t) host_out;
+        const uintptr_t base = (uintptr_t) host_out;
+        uintptr_t span_a, span_b;                            // the whole pages inside the bytes this call writes
+        const bool any = inner_pages((const void *)(base + out_lo), out_span, span_a, span_b);
         for (size_t ci = 0; ci < chunks.size() && be == hipSuccess; ci++) {
           const Chunk &c = chunks[ci];
-          // chunk ci's pages: from the first page boundary inside it (chunk 0: the page its first byte is in) to the
-          // first page boundary at or after its end -- disjoint from its neighbours' ranges
-          uintptr_t ra = base + c.out_lo, rb = base + c.out_hi;
-          ra = ci == 0 ? (ra & ~(PG - 1u)) : ((ra + PG - 1u) & ~(PG - 1u));
-          rb = (rb + PG - 1u) & ~(PG - 1u);
+          // chunk ci's pages: from the first page boundary at or behind its first byte to the first one at or behind its
+          // end (the last chunk: the last one inside the span) -- disjoint from its neighbours' ranges
+          uintptr_t ra = (base + c.out_lo + MSPK_PAGE - 1u) & ~(MSPK_PAGE - 1u), rb = (base + c.out_hi + MSPK_PAGE - 1u) & ~(MSPK_PAGE - 1u);
+          if (ra < span_a) ra = span_a;
+          if (rb > span_b || ci + 1 == chunks.size()) rb = span_b;
           auto r0 = tnow();
-          if (pin_out && rb > ra && hipHostRegister((void *) ra, rb - ra, hipHostRegisterDefault) == hipSuccess)
-            pins.p[pins.n++] = (char *) ra;
-          else
-            (void) hipGetLastError();
+          if (pin_out && any) pins.lock(ra, rb);
           pin_ms += tms(r0, tnow());
           while (issued.load(std::memory_order_acquire) <= ci) { if (stop.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
           be = hipStreamWaitEvent(st_out, cx.ev_done[ci], 0);
-          // (the bytes of chunk ci below its first page boundary lie in the previous chunk's range: a copy of their own)
-          uintptr_t lo = base + c.out_lo, hi = base + c.out_hi, cut = std::min(std::max(lo, ra), hi);
-          if (be == hipSuccess && cut > lo)
-            be = hipMemcpyAsync((void *) lo, d_out + (c.out_lo - out_lo), cut - lo, hipMemcpyDeviceToHost, st_out);
-          if (be == hipSuccess && hi > cut)
-            be = hipMemcpyAsync((void *) cut, d_out + (c.out_lo - out_lo) + (cut - lo), hi - cut, hipMemcpyDeviceToHost, st_out);
+          if (be == hipSuccess) be = copy_out(base + c.out_lo, base + c.out_hi, d_out + (c.out_lo - out_lo));
         }
         back_err = be;
       });
       back_started = true;
     } catch (...) { back_started = false; }      // (no helper thread: the copies back are issued below, in this thread)
     if (pin_in && in_span >= ((size_t) 4 << 20)) {
-      // (ONE range, every page the copies below read: the chunks' input ranges may overlap -- frame tables behind the streams)
-      const uintptr_t PG = 4096u, ra = ((uintptr_t) in + in_lo) & ~(PG - 1u), rb = ((uintptr_t) in + in_hi + PG - 1u) & ~(PG - 1u);
-      if (hipHostRegister((void *) ra, rb - ra, hipHostRegisterDefault) == hipSuccess) pins_in.p[pins_in.n++] = (char *) ra;
-      else (void) hipGetLastError();
+      // (ONE range, the whole pages inside what the copies below read: the chunks' input ranges may overlap -- frame tables
+      // behind the streams)
+      uintptr_t ra, rb;
+      if (inner_pages((const char *) in + in_lo, in_span, ra, rb)) pins_in.lock(ra, rb);
     }
     for (size_t ci = 0; ci < chunks.size(); ci++) {
       const Chunk &c = chunks[ci];
       hipStream_t st = one ? cx.st[0] : cx.st[2 + ci % n_comp];
-      TRY(hipMemcpyAsync(d_in + (c.in_lo - in_lo), (const char *) in + c.in_lo, (size_t)(c.in_hi - c.in_lo),
-                         hipMemcpyHostToDevice, st_in));
+      TRY(copy_cut(d_in + (c.in_lo - in_lo), (const char *) in + c.in_lo, (size_t)(c.in_hi - c.in_lo), hipMemcpyHostToDevice, st_in,
+                   pins_in.r, pins_in.n));
       if (host_out)
         for (size_t i = c.a; i < c.b; i++)               // LZX DELTA reference data sits below the unit's output
           if (local[i].ref_len && local[i].kind == MSPACK_HIP_KIND_LZX_DELTA)
-            TRY(hipMemcpyAsync(d_out + local[i].out_off - local[i].ref_len,
-                               (const char *) host_out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
-                               hipMemcpyHostToDevice, st_in));
+            TRY(copy_cut(d_out + local[i].out_off - local[i].ref_len,
+                         (const char *) host_out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
+                         hipMemcpyHostToDevice, st_in));
       if (!one) { TRY(hipEventRecord(cx.ev_in[ci], st_in)); TRY(hipStreamWaitEvent(st, cx.ev_in[ci], 0)); }
       for (unsigned k = 1; k <= 6; k++)
-        launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
-                    c.has_ftab, (unsigned) ci, n_rec_slots, one);
-      TRY(hipGetLastError());
+        TRY(launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
+                        c.has_ftab, (unsigned) ci, n_rec_slots));
       TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
       if (!one) { TRY(hipEventRecord(cx.ev_done[ci], st)); issued.store(ci + 1, std::memory_order_release); }
     }
@@ -988,21 +1005,20 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     if (host_out && one) {
       const Chunk &c = chunks[0];
       if (monotone)
-        TRY(hipMemcpyAsync((char *) host_out + c.out_lo, d_out + (c.out_lo - out_lo), (size_t)(c.out_hi - c.out_lo),
-                           hipMemcpyDeviceToHost, st_out));
+        TRY(copy_out((uintptr_t) host_out + c.out_lo, (uintptr_t) host_out + c.out_hi, d_out + (c.out_lo - out_lo)));
       else
-        for (size_t i = c.a; i < c.b; i++)
-          TRY(hipMemcpyAsync((char *) host_out + out_lo + local[i].out_off, d_out + local[i].out_off,
-                             (size_t) local[i].out_len + ((local[i].flags & (MSPACK_HIP_UF_MSZIP_LOG | MSPACK_HIP_UF_LZX_LOG)) ? (size_t) unit_above(local[i]) : 0u),   // (a unit's log lies behind its slack)
-                             hipMemcpyDeviceToHost, st_out));
+        for (size_t i = c.a; i < c.b; i++) {
+          const size_t nb = (size_t) local[i].out_len + ((local[i].flags & (MSPACK_HIP_UF_MSZIP_LOG | MSPACK_HIP_UF_LZX_LOG)) ? (size_t) unit_above(local[i]) : 0u);   // (a unit's log lies behind its slack)
+          const uintptr_t lo = (uintptr_t) host_out + out_lo + local[i].out_off;
+          TRY(copy_out(lo, lo + nb, d_out + local[i].out_off));
+        }
     }
     if (host_out && !one && !back_started) {
       // (the helper thread could not be created: plain copies, chunk by chunk, behind each chunk's launches)
       for (size_t ci = 0; ci < chunks.size(); ci++) {
         const Chunk &c = chunks[ci];
         TRY(hipStreamWaitEvent(st_out, cx.ev_done[ci], 0));
-        TRY(hipMemcpyAsync((char *) host_out + c.out_lo, d_out + (c.out_lo - out_lo), (size_t)(c.out_hi - c.out_lo),
-                           hipMemcpyDeviceToHost, st_out));
+        TRY(copy_out((uintptr_t) host_out + c.out_lo, (uintptr_t) host_out + c.out_hi, d_out + (c.out_lo - out_lo)));
       }
     }
     if (back.joinable()) {
@@ -1010,6 +1026,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       if (back_err != hipSuccess) TRY(back_err);
     }
     for (int i = 0; i < cx.ns; i++) TRY(hipStreamSynchronize(cx.st[i]));
+    for (const Staged &sg : staged) memcpy(sg.host, (const char *) cx.h_stage.p + sg.off, sg.n);
     { auto r0 = tnow(); pins.release(); pins_in.release(); unpin_ms = tms(r0, tnow()); }
     for (size_t i = 0; i < n_sel; i++) {
       results[idx[i]] = h_res[i];
@@ -1115,28 +1132,28 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
   return 0;
 }
 
-// page-locked caller arenas (mspack_hip_pin / _unpin): user pointer -> the page-aligned base that was registered
-static std::mutex g_pin_mu;
-static std::vector<std::pair<const void *, void *>> g_pins;
+// page-locked caller arenas (mspack_hip_pin / _unpin): the whole pages INSIDE [p, p + bytes) -- never a byte that is not the
+// caller's (PinRange above).  A buffer that starts and ends on page boundaries is locked completely (the C drivers' arenas do:
+// mspack_arena_alloc); of any other one the bytes before the first and behind the last boundary are copied the pageable way.
 int mspack_hip_pin(const void *p, size_t bytes)
 {
-  if (!p || !bytes) return -1;
-  const uintptr_t PG = 4096u, ra = (uintptr_t) p & ~(PG - 1u), rb = ((uintptr_t) p + bytes + PG - 1u) & ~(PG - 1u);
+  uintptr_t ra, rb;
+  if (!p || !bytes || !inner_pages(p, bytes, ra, rb)) return -1;
   const hipError_t e = hipHostRegister((void *) ra, rb - ra, hipHostRegisterPortable);       // (every device of the process: _multi)
   if (e != hipSuccess) { (void) hipGetLastError(); return (int) e; }
   std::lock_guard<std::mutex> lock(g_pin_mu);
-  g_pins.emplace_back(p, (void *) ra);
+  g_pins.push_back(PinRange{ ra, rb, p });
   return 0;
 }
 void mspack_hip_unpin(const void *p)
 {
-  void *base = nullptr;
+  uintptr_t base = 0;
   {
     std::lock_guard<std::mutex> lock(g_pin_mu);
     for (size_t i = 0; i < g_pins.size(); i++)
-      if (g_pins[i].first == p) { base = g_pins[i].second; g_pins.erase(g_pins.begin() + (long) i); break; }
+      if (g_pins[i].user == p) { base = g_pins[i].ra; g_pins.erase(g_pins.begin() + (long) i); break; }
   }
-  if (base && hipHostUnregister(base) != hipSuccess) (void) hipGetLastError();
+  if (base && hipHostUnregister((void *) base) != hipSuccess) (void) hipGetLastError();
 }
 
 void mspack_hip_host_path_stats(double *ms4, int reset)

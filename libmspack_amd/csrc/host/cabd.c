@@ -147,7 +147,7 @@ static char *read_cstring(struct mspack_system *sys, struct mspack_file *fh, int
 }
 
 static void free_folder_cache(struct mspack_system *sys, struct folder_p *f) {
-  if (f->store && --f->store->refs == 0) { sys->free(f->store->base); sys->free(f->store); }
+  if (f->store && --f->store->refs == 0) { mspack_arena_free(sys, f->store->base); sys->free(f->store); }
   f->store = NULL; f->dec = NULL; f->decoded = 0;
   sys->free(f->rep); f->rep = NULL; f->rep_n = 0;
   sys->free(f->rep_ck); f->rep_ck = NULL; f->ck_n = 0;
@@ -536,7 +536,7 @@ static int cabd_merge(struct mscab_decompressor *base, struct mscabd_cabinet *lc
     if (self->st_active && (self->st.folder == rfol || self->st.folder == lfol)) stored_reset(self);
     if (self->last_folder == rfol) self->last_folder = NULL;
     if (self->live_folder == rfol || self->live_folder == lfol) self->live_folder = NULL;     /* (the merged folder is decoded anew) */
-    if (self->msg_folder == rfol) self->msg_folder = NULL;
+    if (self->msg_folder == rfol || self->msg_folder == lfol) self->msg_folder = NULL;       /* (and says everything again) */
     sys->free(rfol);
   }
   /* every cabinet of the set shows the same lists */
@@ -699,7 +699,7 @@ static int arena_room(struct mspack_system *sys, struct in_arena *a, size_t need
   if (ncap < a->len + need) ncap = a->len + need;
   if (!(n = (unsigned char *) mspack_arena_alloc(sys, ncap))) return 0;
   if (a->len) sys->copy(a->p, n, a->len);
-  sys->free(a->p);
+  mspack_arena_free(sys, a->p);
   a->p = n; a->cap = ncap;
   return 1;
 }
@@ -730,7 +730,11 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
   const size_t len0 = A->len;
   uint32_t *qoff = NULL;               /* Quantum: where every block starts in the folder's stream (LZX / MSZIP: g->boff) */
   unsigned int qn = 0;
+  unsigned int *bad = NULL, bad_n = 0, bad_cap = 0;   /* blocks whose checksum was ignored: indices here, published to the
+                                                         folder as output offsets once the chain has been walked */
   int err;
+  /* (a folder that is gathered again -- the batch it was in failed -- starts its list afresh) */
+  sys->free(fol->rep_ck); fol->rep_ck = NULL; fol->ck_n = 0;
   g->len = 0; g->total = 0; g->read_err = MSPACK_ERR_OK; g->hard_eof = 0;
   g->nblk = 0; g->frames_ok = 1; g->tab_off = 0;
   if (!arena_room(sys, A, 16 + 64 + 32)) return MSPACK_ERR_NOMEMORY;
@@ -754,17 +758,20 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
     r.block++;
     r.bad_cksum = 0;
     /* (a block, reassembled from the cabinets of a set or not, is at most CAB_INPUTBUF bytes: reader_block) */
-    if (!arena_room(sys, A, (size_t) CAB_INPUTBUF + 1 + 64 + 16)) { reader_close(self, &r); sys->free(g->boff); g->boff = NULL; sys->free(qoff); A->len = len0; return MSPACK_ERR_NOMEMORY; }
+    if (!arena_room(sys, A, (size_t) CAB_INPUTBUF + 1 + 64 + 16)) { reader_close(self, &r); sys->free(g->boff); g->boff = NULL; sys->free(qoff); sys->free(bad); A->len = len0; return MSPACK_ERR_NOMEMORY; }
     r.input = A->p + A->len;
     if ((err = reader_block(self, &r, &ulen, ignore_cksum, ignore_size))) { g->read_err = err; g->hard_eof = 1; break; }
     if (r.bad_cksum) {
       /* said when the reference would say it (cabd_extract): remember the block */
-      unsigned int *nw = (unsigned int *) sys->alloc(sys, ((size_t) fol->ck_n + 1) * sizeof(unsigned int));
-      if (nw) {
-        if (fol->ck_n) sys->copy(fol->rep_ck, nw, (size_t) fol->ck_n * sizeof(unsigned int));
-        sys->free(fol->rep_ck); fol->rep_ck = nw;
-        fol->rep_ck[fol->ck_n++] = g->boff ? g->nblk : qn;  /* (block index for now: turned into an output offset below) */
+      if (bad_n == bad_cap) {
+        const unsigned int ncap = bad_cap ? bad_cap * 2 : 16;
+        unsigned int *nw = (unsigned int *) sys->alloc(sys, (size_t) ncap * sizeof(unsigned int));
+        if (nw) {
+          if (bad_n) sys->copy(bad, nw, (size_t) bad_n * sizeof(unsigned int));
+          sys->free(bad); bad = nw; bad_cap = ncap;
+        }
       }
+      if (bad_n < bad_cap) bad[bad_n++] = g->boff ? g->nblk : qn;
     }
     if (qoff) qoff[qn++] = (uint32_t)(A->len - g->in_off);
     if (g->boff) {
@@ -777,18 +784,18 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
   }
   reader_close(self, &r);
   g->len = A->len - g->in_off;
-  if (fol->ck_n && (g->boff || qoff)) {
+  if (bad_n && (g->boff || qoff)) {
     /* block i is read when the codec's refill reaches the input chunk it starts in; that refill happens while the block
      * that holds the chunk's first byte is being decoded (every block but the last decodes to 32 KiB) */
     const size_t q = (size_t)(self->buf_size > 0 ? self->buf_size : 4096);
     const uint32_t *const off = g->boff ? g->boff : qoff;
     unsigned int i;
-    for (i = 0; i < fol->ck_n; i++) {
-      const unsigned int b = fol->rep_ck[i];
+    for (i = 0; i < bad_n; i++) {
+      const unsigned int b = bad[i];
       const size_t chunk_start = ((size_t) off[b] / q) * q;
       unsigned int t = b;
       while (t > 0 && (size_t) off[t] > chunk_start) t--;
-      fol->rep_ck[i] = t * CAB_BLOCKMAX;
+      bad[i] = t * CAB_BLOCKMAX;
       if (method == MSCAB_COMP_QUANTUM && t < b) {
         /* lzxd and mszipd decode a whole frame / block before they hand any of it over: its first byte asked for is enough.
          * qtmd decodes as far as it is asked: WHERE in block t -- when it has used the block's input up to the chunk, taken
@@ -796,10 +803,12 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
          * right there) */
         const size_t clen = (size_t) off[t + 1] - off[t];
         const size_t ulen = g->total - (size_t) t * CAB_BLOCKMAX < CAB_BLOCKMAX ? g->total - (size_t) t * CAB_BLOCKMAX : CAB_BLOCKMAX;
-        if (clen) fol->rep_ck[i] += (unsigned int)((chunk_start - off[t]) * ulen / clen);
+        if (clen) bad[i] += (unsigned int)((chunk_start - off[t]) * ulen / clen);
       }
     }
+    fol->rep_ck = bad; fol->ck_n = bad_n; bad = NULL;
   }
+  sys->free(bad);
   sys->free(qoff);
   if (!g->hard_eof) g->read_err = self->salvage ? MSPACK_ERR_OK : MSPACK_ERR_DATAFORMAT;  /* ran out of blocks */
   else {
@@ -847,7 +856,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   if (A.cap > ((size_t) 256 << 20)) A.cap = (size_t) 256 << 20;
   A.cap += n * 96 + 65536;
   A.p = (unsigned char *) mspack_arena_alloc(sys, A.cap);
-  if (!gs || !units || !res || !A.p) { sys->free(gs); sys->free(units); sys->free(res); sys->free(A.p); return MSPACK_ERR_NOMEMORY; }
+  if (!gs || !units || !res || !A.p) { sys->free(gs); sys->free(units); sys->free(res); mspack_arena_free(sys, A.p); return MSPACK_ERR_NOMEMORY; }
   n = 0;
   for (fo = cab->base.folders; fo; fo = fo->next) {
     struct folder_p *fp = (struct folder_p *) fo;
@@ -863,7 +872,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     n++;
   }
   if (!err && !arena_room(sys, &A, 64)) err = MSPACK_ERR_NOMEMORY;
-  if (err) { for (k = 0; k < n; k++) sys->free(gs[k].boff); sys->free(gs); sys->free(units); sys->free(res); sys->free(A.p); return err; }
+  if (err) { for (k = 0; k < n; k++) sys->free(gs[k].boff); sys->free(gs); sys->free(units); sys->free(res); mspack_arena_free(sys, A.p); return err; }
   memset(A.p + A.len, 0, 64);
 
   /* the units: where gather_folder put their input, one stretch of the output arena each */
@@ -895,7 +904,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     memset(res, 0, n * sizeof(*res));
     if (nhip) {
       /* the arena was written a moment ago: page-locked, its copy to the device is plain DMA (mspack_hip.h; advice only) */
-      const int pinned = A.len >= ((size_t) 4 << 20) && mspack_hip_pin(A.p, A.len + 64) == 0;
+      const int pinned = A.len >= ((size_t) 4 << 20) && mspack_hip_pin(A.p, mspack_arena_room(A.len + 64)) == 0;
       /* kinds other than 1..3 are answered with MSPACK_ERR_ARGS by the kernels; fix them up below */
       rc = (self->devices > 1)
         ? mspack_hip_decode_batch_multi(units, n, A.p, A.len + 64, out_arena, out_bytes + 64, res, self->devices)
@@ -926,6 +935,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
           const unsigned char *lg = out_arena + units[k].out_off + (((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15);
           unsigned int cnt = rd_le32(lg), i;
           if (cnt > (unsigned int) units[k].e8_base) cnt = (unsigned int) units[k].e8_base;
+          sys->free(fp->rep); fp->rep = NULL; fp->rep_n = 0;
           if (cnt && (fp->rep = (unsigned int *) sys->alloc(sys, (size_t) cnt * 2 * sizeof(unsigned int)))) {
             for (i = 0; i < 2 * cnt; i++) fp->rep[i] = rd_le32(lg + 4 + 4 * (size_t) i);
             fp->rep_n = cnt;
@@ -940,7 +950,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     else if (store) sys->free(store);
   }
   for (k = 0; k < n; k++) sys->free(gs[k].boff);
-  sys->free(gs); sys->free(units); sys->free(res); sys->free(A.p); sys->free(out_arena);
+  sys->free(gs); sys->free(units); sys->free(res); mspack_arena_free(sys, A.p); mspack_arena_free(sys, out_arena);
   return err;
 }
 
@@ -1034,7 +1044,7 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
   /* one decompression state per decompressor: another folder ends the stored folder's stream */
   if (self->last_folder != fol) stored_reset(self);
   self->last_folder = fol;
-  if ((fol->base.comp_type & 0x0F) == MSCAB_COMP_NONE) { self->live_folder = NULL; return stored_extract(self, fol, file, filelen, filename); }
+  if ((fol->base.comp_type & 0x0F) == MSCAB_COMP_NONE) { self->live_folder = NULL; self->msg_folder = NULL; return stored_extract(self, fol, file, filelen, filename); }
 
   if (!fol->decoded) {
     int err = decode_cabinet(self, (struct cab_p *) fol->data.cab, fol);

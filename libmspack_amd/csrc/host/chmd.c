@@ -558,9 +558,9 @@ static int decode_intervals(struct chmd_p *self, struct chm_p *c, unsigned int f
 
 static void free_sec1(struct mspack_system *sys, struct chm_p *c) {
   unsigned int i;
-  if (c->chunks) for (i = 0; i < c->n_chunks; i++) sys->free(c->chunks[i].buf);
+  if (c->chunks) for (i = 0; i < c->n_chunks; i++) mspack_arena_free(sys, c->chunks[i].buf);
   if (c->arena_pinned) { mspack_hip_unpin(c->arena); c->arena_pinned = 0; }
-  sys->free(c->chunks); sys->free(c->arena); sys->free(c->ioff); sys->free(c->ires); sys->free(c->s_buf);
+  sys->free(c->chunks); mspack_arena_free(sys, c->arena); sys->free(c->ioff); sys->free(c->ires); mspack_arena_free(sys, c->s_buf);
   c->chunks = NULL; c->arena = NULL; c->ioff = NULL; c->ires = NULL; c->s_buf = NULL; c->sec1_state = 0;
   c->n_chunks = 0; c->s_valid = 0;
 }
@@ -701,7 +701,7 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
   }
 
   /* every batch of this CHM reads the arena: page-locked once, its copies to the device are plain DMA (advice only) */
-  if (!c->arena_pinned && arena_alloc >= ((size_t) 4 << 20)) c->arena_pinned = mspack_hip_pin(c->arena, arena_alloc) == 0;
+  if (!c->arena_pinned && arena_alloc >= ((size_t) 4 << 20)) c->arena_pinned = mspack_hip_pin(c->arena, mspack_arena_room(arena_alloc)) == 0;
 
   /* fast-result bookkeeping */
   if (c->n_fast) {
@@ -734,14 +734,14 @@ static int ensure_chunk(struct chmd_p *self, struct chm_p *c, unsigned int k, in
       for (i = 0; i < c->n_chunks; i++)
         if (c->chunks[i].buf) { used += each; if (&c->chunks[i] != ch && (!lru || c->chunks[i].stamp < lru->stamp)) lru = &c->chunks[i]; }
       if (used + each <= budget || !lru) break;
-      sys->free(lru->buf); lru->buf = NULL;
+      mspack_arena_free(sys, lru->buf); lru->buf = NULL;
     }
   }
   if (!(ch->buf = (unsigned char *) mspack_arena_alloc(sys, (size_t) count * (size_t) c->interval_bytes + 128))) return MSPACK_ERR_NOMEMORY;
   err = decode_intervals(self, c, first, count, 0, ch->buf, &c->ires[first]);
-  if (err) { sys->free(ch->buf); ch->buf = NULL; return err; }
+  if (err) { mspack_arena_free(sys, ch->buf); ch->buf = NULL; return err; }
   ch->res_valid = 1;
-  if (!need_buf && count * (size_t) c->interval_bytes > ((size_t) mspack_hip_cache_mb() << 20)) { sys->free(ch->buf); ch->buf = NULL; }
+  if (!need_buf && count * (size_t) c->interval_bytes > ((size_t) mspack_hip_cache_mb() << 20)) { mspack_arena_free(sys, ch->buf); ch->buf = NULL; }
   return MSPACK_ERR_OK;
 }
 
@@ -765,7 +765,7 @@ static int ensure_serial(struct chmd_p *self, struct chm_p *c, off_t need)
   cover = (cover + FRAME - 1) & ~(off_t)(FRAME - 1);
   if (cover >= full) cover = full;
   if (cover > 0xFFFF0000LL) return MSPACK_ERR_DATAFORMAT;                /* ours: 32-bit unit length */
-  sys->free(c->s_buf); c->s_buf = NULL; c->s_valid = 0;
+  mspack_arena_free(sys, c->s_buf); c->s_buf = NULL; c->s_valid = 0;
   /* (one log entry per reset point the span can reach, the look-ahead frame's included) */
   log_cap = (unsigned int)(cover / c->interval_bytes) + 2u;
   log_off = ((size_t) cover + 32768 + 15) & ~(size_t) 15;
@@ -913,7 +913,7 @@ static int vdec_emit(struct chmd_p *self, struct chm_p *c, struct mspack_file *f
       unsigned char *tmp = (unsigned char *) mspack_arena_alloc(sys, (size_t) cnt * (size_t) c->interval_bytes + 128);
       err = (!r2 || !tmp) ? MSPACK_ERR_NOMEMORY : decode_intervals(self, c, k, cnt, v->init, tmp, r2);
       if (!err) err = write_slice(sys, fh, tmp + (from - (off_t) k * c->interval_bytes), (size_t)(stop - from));
-      sys->free(r2); sys->free(tmp);
+      sys->free(r2); mspack_arena_free(sys, tmp);
       if (err) return err;
     }
     else if ((err = write_slice(sys, fh, ch->buf + (from - (off_t) cfirst * c->interval_bytes), (size_t)(stop - from)))) return err;

@@ -12,11 +12,14 @@
 extern struct mspack_system *mspack_default_system;
 int mspack_valid_system(struct mspack_system *sys);
 int mspack_sys_filelen(struct mspack_system *system, struct mspack_file *file, off_t *length);
-/* sys->alloc for a batch's input / output arena: the same call, plus -- on Linux, for arenas of several MiB -- the advice
- * that the fresh pages behind it may be huge ones (madvise MADV_HUGEPAGE: the arenas are written once, front to back, by
- * sys->read or the copy back from the device, and 4 KiB faults were most of that time).  Advice only: the bytes, the
- * pointer and the caller's allocator are untouched; ignored where the kernel does not offer it. */
+/* A batch's input / output arena: memory from sys->alloc that starts on a page boundary and is whole pages long
+ * (mspack_arena_room(bytes) of them), so that mspack_hip_pin(arena, mspack_arena_room(bytes)) page-locks exactly the arena;
+ * released with mspack_arena_free(), never with sys->free directly.  On Linux, arenas of several MiB also carry the advice
+ * that the fresh pages behind them may be huge ones (madvise MADV_HUGEPAGE: the arenas are written once, front to back, by
+ * sys->read or the copy back from the device, and 4 KiB faults were most of that time). */
 void *mspack_arena_alloc(struct mspack_system *sys, size_t bytes);
+void mspack_arena_free(struct mspack_system *sys, void *arena);
+size_t mspack_arena_room(size_t bytes);
 
 static inline unsigned int rd_le16(const unsigned char *p) { return (unsigned int) p[0] | ((unsigned int) p[1] << 8); }
 static inline unsigned int rd_le32(const unsigned char *p) {

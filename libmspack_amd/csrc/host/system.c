@@ -9,19 +9,38 @@
 #include <sys/mman.h>
 #endif
 
+/* A batch's input / output arena: sys->alloc'd memory whose first byte lies on a page boundary and whose room is whole pages,
+ * so that mspack_hip_pin() can page-lock ALL of it and nothing else -- a lock never holds a byte that is not the arena's
+ * (include/mspack_hip.h: mspack_hip_pin; DESIGN.md sec. 8h: what happened when one did).  The block sys->alloc returned is
+ * remembered in the word below the arena; mspack_arena_free() hands that block back to sys->free. */
+#define ARENA_PAGE ((size_t) 4096)
 void *mspack_arena_alloc(struct mspack_system *sys, size_t bytes) {
-  void *p = sys->alloc(sys, bytes);
+  const size_t room = (bytes + ARENA_PAGE - 1) & ~(ARENA_PAGE - 1);
+  unsigned char *raw, *p;
+  if (room < bytes || room + ARENA_PAGE + sizeof(void *) < room) return NULL;
+  if (!(raw = (unsigned char *) sys->alloc(sys, room + ARENA_PAGE + sizeof(void *)))) return NULL;
+  p = (unsigned char *)(((uintptr_t) raw + sizeof(void *) + ARENA_PAGE - 1) & ~(uintptr_t)(ARENA_PAGE - 1));
+  memcpy(p - sizeof(void *), &raw, sizeof(void *));
 #if defined(__linux__) && defined(MADV_HUGEPAGE)
-  static int on = -1;                 /* MSPACK_ARENA_HUGEPAGES=0 turns the advice off */
-  if (on < 0) { const char *e = getenv("MSPACK_ARENA_HUGEPAGES"); on = !(e && e[0] == '0'); }
-  if (on && p && bytes >= ((size_t) 4 << 20)) {
-    const uintptr_t H = (uintptr_t) 2 << 20;
-    const uintptr_t a = ((uintptr_t) p + H - 1) & ~(H - 1), b = ((uintptr_t) p + bytes) & ~(H - 1);
-    if (b > a) (void) madvise((void *) a, (size_t)(b - a), MADV_HUGEPAGE);       /* (whole 2 MiB pages inside the block only) */
+  {
+    static int on = -1;                 /* MSPACK_ARENA_HUGEPAGES=0 turns the advice off */
+    if (on < 0) { const char *e = getenv("MSPACK_ARENA_HUGEPAGES"); on = !(e && e[0] == '0'); }
+    if (on && room >= ((size_t) 4 << 20)) {
+      const uintptr_t H = (uintptr_t) 2 << 20;
+      const uintptr_t a = ((uintptr_t) p + H - 1) & ~(H - 1), b = ((uintptr_t) p + room) & ~(H - 1);
+      if (b > a) (void) madvise((void *) a, (size_t)(b - a), MADV_HUGEPAGE);       /* (whole 2 MiB pages inside the block only) */
+    }
   }
 #endif
   return p;
 }
+void mspack_arena_free(struct mspack_system *sys, void *arena) {
+  void *raw;
+  if (!arena) return;
+  memcpy(&raw, (unsigned char *) arena - sizeof(void *), sizeof(void *));
+  sys->free(raw);
+}
+size_t mspack_arena_room(size_t bytes) { return (bytes + ARENA_PAGE - 1) & ~(ARENA_PAGE - 1); }
 
 int mspack_version(int entity) {
   switch (entity) {

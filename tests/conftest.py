@@ -13,6 +13,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order: the driver runs `pytest -m gpu -x`, so a failure in a container / driver test
+# must not hide the codec-level oracle parity behind it.  Codec parity first (known-answer vectors, then LZX, MSZIP, Quantum
+# against the oracle), then the host-buffer path and the fuzz sweeps, then the object API's drivers and containers, the
+# slow shapes last.  Within a module the order is the file's.
+_ORDER = ["test_gpu_kat", "test_gpu_lzx", "test_gpu_lzx_frames", "test_gpu_lzx_log", "test_gpu_lzxd", "test_gpu_mszip",
+          "test_gpu_mszip_blocks", "test_gpu_qtm", "test_szdd_kwaj", "test_oab", "test_gpu_hostpath", "test_gpu_fuzz",
+          "test_gpu_messages", "test_gpu_drivers", "test_chm_extract", "test_chmdir", "test_chm_messages", "test_cab_sticky",
+          "test_cabsets", "test_config2_cab", "test_gpu_reference_suites", "test_api_bench", "test_gpu_bench_line",
+          "test_gpu_large_files"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    rank = {m: i for i, m in enumerate(_ORDER)}
+
+    def key(it):
+        mod = os.path.splitext(os.path.basename(str(it.fspath)))[0]
+        return rank.get(mod, len(_ORDER) // 2)
+    items.sort(key=key)           # (stable: a module's tests keep their order)
+
+
 @pytest.fixture(scope="session")
 def built():
     """Build (or reuse) the native libraries once per session."""
