@@ -38,6 +38,12 @@ extern "C" {
                                        the room available, the result's out_len what the stream produced.  The
                                        4096 bytes below out_off belong to the unit (its window pre-fill).        */
 #define MSPACK_HIP_KIND_KWAJ_LZH 6   /* lzh_decompress (kwajd.c:432-563): KWAJ method 3; same conventions         */
+#define MSPACK_HIP_KIND_XORSUM   7   /* cabd_checksum(data, bytes, 0) (cabd.c:1462-1479): the checksum of ONE CFDATA block's
+                                       payload -- the XOR of its little-endian dwords and the reference's odd big-endian tail of
+                                       bytes & 3 bytes.  Decodes nothing: out_len must be 0, no output region; the checksum comes
+                                       back in result.in_next (err 0, in_used = in_len).  The cabinet driver puts one such unit
+                                       per block part into the batch that decodes the folders: the bytes are in HBM anyway, and
+                                       it compares with the CFDATA headers (cabd.c:1411-1417) when the results are back        */
 
 #define MSPACK_HIP_MASK_FRAME_TABLES 0x80000000u   /* mspack_hip_decode_batch_device(kind_mask): see there */
 

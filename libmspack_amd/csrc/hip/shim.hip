@@ -371,6 +371,41 @@ void mspack_decode_kwaj_lzh(const mspack_hip_unit *units, const u32 *order, u32 
   kwaj_lzh_decode_unit(u, in_arena, out_arena, &results[ui], &sh);
 }
 
+// cabd_checksum (cabd.c:1462-1479) of a unit's input bytes with seed 0 -> result.in_next.  The XOR of the unit's dwords taken
+// at its own (byte) alignment equals the byte-aligned window of the XORs of the ALIGNED dwords around it -- alignbyte is
+// linear over XOR --, so every lane XORs aligned dwords (coalesced), and the two ends are fixed up once.
+__global__ __launch_bounds__(64)
+void mspack_xorsum(const mspack_hip_unit *units, const u32 *order, u32 n_units, const u8 *in_arena, mspack_hip_result *results)
+{
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_XORSUM, ui)) return;
+  const mspack_hip_unit u = units[ui];
+  const u32 lane = threadIdx.x;
+  const u8 *p = in_arena + u.in_off;
+  const u32 nd = u.in_len >> 2, sh = (u32)((size_t) p & 3u);
+  const u32 *w = (const u32 *)(p - sh);                  // aligned dwords; w[nd] exists (the arena's slack) when sh != 0
+  u32 a = 0;
+  for (u32 j = lane; j < nd; j += WAVE) a ^= w[j];
+  for (int o = 32; o >= 1; o >>= 1) a ^= (u32) __builtin_amdgcn_ds_bpermute((int)(((lane ^ (u32) o) & 63u) << 2), (int) a);
+  if (lane == 0) {
+    u32 sum = a;
+    if (sh && nd) {
+      const u32 b = a ^ w[0] ^ w[nd];                     // the XOR of w[1 .. nd]
+      sum = __builtin_amdgcn_alignbyte(b, a, sh);
+    }
+    const u8 *t = p + (size_t) nd * 4u;
+    u32 tail = 0;
+    switch (u.in_len & 3u) {
+    case 3: tail |= (u32) *t++ << 16;   /* fall through */
+    case 2: tail |= (u32) *t++ << 8;    /* fall through */
+    case 1: tail |= *t;
+    }
+    mspack_hip_result r;
+    r.err = ERR_OK; r.flags = 0; r.out_len = 0; r.in_used = u.in_len; r.good_len = 0; r.in_next = sum ^ tail;
+    results[ui] = r;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Host side of the C ABI.
 // ---------------------------------------------------------------------------------------------------
@@ -493,6 +528,8 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
     LK(launch(mspack_decode_lzss, grid, block, st, d_units, d_order, (u32) n, in, out, d_results)); break;
   case MSPACK_HIP_KIND_KWAJ_LZH:
     LK(launch(mspack_decode_kwaj_lzh, grid, block, st, d_units, d_order, (u32) n, in, out, d_results)); break;
+  case MSPACK_HIP_KIND_XORSUM:
+    LK(launch(mspack_xorsum, grid, block, st, d_units, d_order, (u32) n, in, d_results)); break;
   default: break;
   }
   return hipSuccess;
@@ -548,11 +585,11 @@ int mspack_hip_decode_batch_device(const mspack_hip_unit *d_units, const uint32_
 {
   (void) in_bytes; (void) out_bytes;
   if (n_units == 0) return 0;
-  if ((kind_mask & 0x7Eu) == 0) kind_mask |= 0x7Eu;     // bit k = units of kind k may be present
+  if ((kind_mask & 0xFEu) == 0) kind_mask |= 0xFEu;     // bit k = units of kind k may be present
   // the caller's unit table lives on the device, so the kinds cannot be compacted here: every codec in the
   // mask gets the whole grid and blocks of other kinds leave at once.  Callers with mixed batches pass one
   // order list per codec and a one-bit mask (what the host-buffer entry points below do).
-  for (unsigned k = 1; k <= 6; k++)
+  for (unsigned k = 1; k <= MSPACK_HIP_KIND_XORSUM; k++)
     if (kind_mask & (1u << k))
       CK(launch_kind(k, d_units, d_order, n_units, d_in, d_out, d_results, d_frame_scratch, n_frames_total, 0, n_frames_total,
                      (hipStream_t) stream, (kind_mask & MSPACK_HIP_MASK_FRAME_TABLES) != 0u));
@@ -744,7 +781,14 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     mspack_hip_unit &u = local[i];
     u = units[idx[i]];
     if (u.kind != MSPACK_HIP_KIND_LZX_DELTA && !(u.kind == MSPACK_HIP_KIND_LZX && (u.flags & MSPACK_HIP_UF_LZX_LOG))) u.ref_len = 0;
-    if (u.kind > 6) { snprintf(errbuf, errcap, "unit %u: unknown kind %u", idx[i], u.kind); return -1; }
+    if (u.kind > MSPACK_HIP_KIND_XORSUM) { snprintf(errbuf, errcap, "unit %u: unknown kind %u", idx[i], u.kind); return -1; }
+    if (u.kind == MSPACK_HIP_KIND_XORSUM) {                // reads its input, owns no output
+      if (u.out_len) { snprintf(errbuf, errcap, "unit %u: a checksum unit has no output", idx[i]); return -1; }
+      if (u.in_off + u.in_len > in_bytes) { snprintf(errbuf, errcap, "unit outside arena"); return -1; }
+      in_lo = std::min<uint64_t>(in_lo, u.in_off); in_hi = std::max<uint64_t>(in_hi, u.in_off + u.in_len);
+      in_sum += u.in_len;
+      continue;
+    }
     // kind 0 = "no codec": the unit is carried along, no kernel takes it, its result says MSPACK_ERR_ARGS
     const uint64_t below = unit_below(u);
     if (below > u.out_off) { snprintf(errbuf, errcap, "unit's lower region outside arena"); return -1; }
@@ -772,6 +816,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     if (pass == 0) n_rec_slots = n_frames;
   }
   in_lo &= ~15ull;                                     // keep the units' alignment
+  if (out_lo > out_hi) out_lo = out_hi = 0;            // (checksum units only: nothing is written)
   if (dev_out) out_lo = 0;                             // the caller's device buffer is addressed as is
   const size_t in_span = (size_t)(in_hi - in_lo), out_span = (size_t)(out_hi - out_lo);
 
@@ -829,6 +874,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     // per chunk: spans, per-kind launch lists (longest compressed unit first: the slowest chain starts first)
     std::vector<uint32_t> order(n_sel);
     size_t op = 0;
+    uint64_t ci_prev_hi = out_lo == ~0ull ? 0 : out_lo;
     for (Chunk &c : chunks) {
       c.in_lo = ~0ull; c.in_hi = 0; c.out_lo = ~0ull; c.out_hi = 0;
       c.fm_lo = ~(size_t) 0; c.fm_n = 0; c.has_ftab = false;
@@ -842,12 +888,15 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
           c.fm_lo = std::min<size_t>(c.fm_lo, u.frame_base);          // (the chunk's table units' slots are contiguous)
           c.fm_n += unit_frames(u);
         }
+        if (u.kind == MSPACK_HIP_KIND_XORSUM) continue;
         c.out_lo = std::min<uint64_t>(c.out_lo, u.out_off - unit_below(u));
         c.out_hi = std::max<uint64_t>(c.out_hi, u.out_off + u.out_len + unit_above(u));
       }
+      if (c.out_lo > c.out_hi) c.out_lo = c.out_hi = (ci_prev_hi);         // (a chunk of checksum units only: an empty span)
+      ci_prev_hi = c.out_hi;
       if (c.fm_lo == ~(size_t) 0) c.fm_lo = 0;
       c.in_lo &= ~15ull;
-      for (unsigned k = 1; k <= 6; k++) {
+      for (unsigned k = 1; k <= MSPACK_HIP_KIND_XORSUM; k++) {
         c.order_off[k] = op;
         for (size_t i = c.a; i < c.b; i++) if (local[i].kind == k) order[op++] = (uint32_t) i;
         c.order_n[k] = op - c.order_off[k];
@@ -857,7 +906,8 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     }
     for (size_t i = 0; i < n_sel; i++) {
       if (unit_has_ftab(local[i])) local[i].in_chunk -= (uint32_t)(in_lo >> 2);      // in_lo is a multiple of 16
-      local[i].in_off -= in_lo; local[i].out_off -= out_lo;
+      local[i].in_off -= in_lo;
+      if (local[i].kind != MSPACK_HIP_KIND_XORSUM) local[i].out_off -= out_lo;
     }
 
     // ---- buffers (persistent) ----
@@ -994,7 +1044,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
                          (const char *) host_out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
                          hipMemcpyHostToDevice, st_in));
       if (!one) { TRY(hipEventRecord(cx.ev_in[ci], st_in)); TRY(hipStreamWaitEvent(st, cx.ev_in[ci], 0)); }
-      for (unsigned k = 1; k <= 6; k++)
+      for (unsigned k = 1; k <= MSPACK_HIP_KIND_XORSUM; k++)
         TRY(launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
                         c.has_ftab, (unsigned) ci, n_rec_slots));
       TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
@@ -1105,8 +1155,9 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
     uint64_t prev_hi = 0;
     for (size_t i = 0; i < n_units && ascending; i++) {
       const mspack_hip_unit &u = units[idx[i]];
+      if (u.kind == MSPACK_HIP_KIND_XORSUM) continue;       // (no output)
       const uint64_t lo = u.out_off - std::min<uint64_t>(u.out_off, unit_below(u)), hi = u.out_off + u.out_len + unit_above(u);
-      if (i && lo < prev_hi) ascending = false;
+      if (lo < prev_hi) ascending = false;
       prev_hi = std::max(prev_hi, hi);
     }
   }

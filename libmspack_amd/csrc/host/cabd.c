@@ -53,6 +53,8 @@ struct folder_p {
   int dec_err;                        /* MSPACK_ERR_* of the unit                                  */
   int read_err;                       /* what the feeder would have reported for ERR_READ          */
   int hard_eof;                       /* the block chain ended with a read failure, not cleanly    */
+  int cksum_on_host;                  /* a block of this folder failed its checksum on the device (below): gather it again, checksums
+                                         verified while the blocks are read -- the chain then ends AT the bad block as the reference's does */
   unsigned int res_flags;
   /* MSZIP repair mode (MSCABD_PARAM_FIXMSZIP): the blocks the codec repaired, in stream order: rep[2 i] = output offset of
    * the block, rep[2 i + 1] = bytes lost (what mszipd tells sys->message, mszipd.c:427) */
@@ -70,7 +72,17 @@ struct cab_p {
 };
 /* the CFDATA feeder of one folder (the subset of the reference's mscabd_decompress_state, cab.h:95-110,
  * that cabd_sys_read_block works on) */
+/* CFDATA checksums verified ON THE DEVICE (cabd.c:1411-1417): the folders' payloads go to HBM for decoding
+ * anyway, so the gather only notes every block part that carries a checksum -- where its payload lies in the input arena and
+ * what the XOR of its dwords must be (the stored checksum with the header's cbData / cbUncomp word folded back out) -- and the batch
+ * carries one MSPACK_HIP_KIND_XORSUM unit per part.  A part that fails makes its folder be gathered again the reference's way
+ * (folder_p.cksum_on_host): rare, and then exact.  Not used where checksums are ignored and only talked about (salvage mode,
+ * MSZIP repair mode): when the warning is said depends on the read order there. */
+struct ck_part { size_t off; uint32_t len, want; unsigned int owner; };
+struct ck_list { struct ck_part *p; size_t n, cap; int failed; };
 struct blk_reader {
+  struct ck_list *defer;              /* note the parts' checksums here instead of verifying them (gather only)          */
+  size_t defer_base; unsigned int defer_owner;   /* arena offset of input[0]; index of the folder in the batch          */
   int quiet_cksum, bad_cksum;          /* do not say "bad block checksum" now: the caller notes it (bad_cksum) and says it later */
   struct folder_p *folder;
   struct fseg *seg;                   /* cabinet the next block header is read from                */
@@ -590,7 +602,21 @@ static int reader_block(struct cabd_p *self, struct blk_reader *r, unsigned int 
     if (full > CAB_INPUTMAX && (!ignore_size || full > CAB_INPUTMAX_SALVAGE)) return MSPACK_ERR_DATAFORMAT;
     if (ulen > CAB_BLOCKMAX && !ignore_size) return MSPACK_ERR_DATAFORMAT;
     if (sys->read(r->fh, r->input + r->i_end, (int) len) != (int) len) return MSPACK_ERR_READ;
-    if ((cksum = rd_le32(hdr))) {                         /* every part carries its own checksum */
+    if ((cksum = rd_le32(hdr)) && r->defer && !ignore_cksum) {
+      struct ck_list *L = r->defer;
+      if (L->n == L->cap) {
+        const size_t ncap = L->cap ? L->cap * 2 : 1024;
+        struct ck_part *np = (struct ck_part *) sys->alloc(sys, ncap * sizeof(*np));
+        if (np) { if (L->n) sys->copy(L->p, np, L->n * sizeof(*np)); sys->free(L->p); L->p = np; L->cap = ncap; }
+        else L->failed = 1;
+      }
+      if (L->n < L->cap) {
+        L->p[L->n].off = r->defer_base + r->i_end; L->p[L->n].len = len;
+        L->p[L->n].want = cksum ^ rd_le32(hdr + 4);       /* (cab_checksum over one whole dword is an XOR) */
+        L->p[L->n].owner = r->defer_owner; L->n++;
+      }
+    }
+    else if (cksum) {                                     /* every part carries its own checksum */
       unsigned int sum = cab_checksum(r->input + r->i_end, len, 0);
       if (cab_checksum(hdr + 4, 4, sum) != cksum) {
         if (!ignore_cksum) return MSPACK_ERR_CHECKSUM;
@@ -719,7 +745,7 @@ struct gathered {
 /* walk the CFDATA chain of one folder (reference cabd.c:1283-1345 + 1362-1459), following it through
  * the cabinets of a set.  Returns MSPACK_ERR_OPEN / SEEK / NOMEMORY when nothing could be started (the arena is as it
  * was); every later failure ends the chain and is recorded as the feeder's error (g->read_err, g->hard_eof). */
-static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_arena *A)
+static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_arena *A, struct ck_list *ck, unsigned int owner)
 {
   struct mspack_system *sys = self->system;
   struct folder_p *fol = g->fol;
@@ -760,6 +786,8 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
     /* (a block, reassembled from the cabinets of a set or not, is at most CAB_INPUTBUF bytes: reader_block) */
     if (!arena_room(sys, A, (size_t) CAB_INPUTBUF + 1 + 64 + 16)) { reader_close(self, &r); sys->free(g->boff); g->boff = NULL; sys->free(qoff); sys->free(bad); A->len = len0; return MSPACK_ERR_NOMEMORY; }
     r.input = A->p + A->len;
+    r.defer = (ck && !ignore_cksum && !fol->cksum_on_host && !ck->failed) ? ck : NULL;
+    r.defer_base = A->len; r.defer_owner = owner;
     if ((err = reader_block(self, &r, &ulen, ignore_cksum, ignore_size))) { g->read_err = err; g->hard_eof = 1; break; }
     if (r.bad_cksum) {
       /* said when the reference would say it (cabd_extract): remember the block */
@@ -842,21 +870,21 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   mspack_hip_unit *units;
   mspack_hip_result *res;
   struct in_arena A = { NULL, 0, 0 };
+  struct ck_list ck = { NULL, 0, 0, 0 };
   unsigned char *out_arena = NULL;
-  size_t n = 0, k, out_bytes = 0, budget = (size_t) self->cache_mb << 20, used = 0;
-  int err = MSPACK_ERR_OK, rc;
+  size_t n = 0, k, out_bytes = 0, budget = (size_t) self->cache_mb << 20, used = 0, nu;
+  int err = MSPACK_ERR_OK, rc, again = 0;
 
   for (fo = cab->base.folders; fo; fo = fo->next) n++;
   gs = (struct gathered *) sys->alloc(sys, n * sizeof(*gs));
-  units = (mspack_hip_unit *) sys->alloc(sys, n * sizeof(*units));
-  res = (mspack_hip_result *) sys->alloc(sys, n * sizeof(*res));
+  units = NULL; res = NULL;                              /* (sized once the gather knows how many checksum units ride along) */
   /* (first guess for the arena: the cabinet's stated length, within reason -- it grows when that was wrong or the folders
    *  go on in other cabinets) */
   A.cap = (size_t) cab->base.length;
   if (A.cap > ((size_t) 256 << 20)) A.cap = (size_t) 256 << 20;
   A.cap += n * 96 + 65536;
   A.p = (unsigned char *) mspack_arena_alloc(sys, A.cap);
-  if (!gs || !units || !res || !A.p) { sys->free(gs); sys->free(units); sys->free(res); mspack_arena_free(sys, A.p); return MSPACK_ERR_NOMEMORY; }
+  if (!gs || !A.p) { sys->free(gs); mspack_arena_free(sys, A.p); return MSPACK_ERR_NOMEMORY; }
   n = 0;
   for (fo = cab->base.folders; fo; fo = fo->next) {
     struct folder_p *fp = (struct folder_p *) fo;
@@ -865,18 +893,33 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     if ((fo->comp_type & 0x0F) == MSCAB_COMP_NONE || fp->merge_prev) continue;   /* streamed / not extractable */
     if (fp != want && used + est > budget) continue;
     gs[n].fol = fp;
-    err = gather_folder(self, &gs[n], &A);
+    {
+      const size_t ck_mark = ck.n;
+      err = gather_folder(self, &gs[n], &A, &ck, (unsigned int) n);
+      if (err) ck.n = ck_mark;                             /* (the arena was rolled back: so are the parts noted in it) */
+    }
     if (err == MSPACK_ERR_OPEN && fp != want) { err = MSPACK_ERR_OK; continue; }   /* that folder stays undecoded */
     if (err) break;
     used += est;
     n++;
   }
   if (!err && !arena_room(sys, &A, 64)) err = MSPACK_ERR_NOMEMORY;
-  if (err) { for (k = 0; k < n; k++) sys->free(gs[k].boff); sys->free(gs); sys->free(units); sys->free(res); mspack_arena_free(sys, A.p); return err; }
+  if (ck.failed) ck.n = 0;             /* (the list could not grow: those folders verified on the host from then on -- none deferred twice) */
+  nu = n + ck.n;
+  if (!err) {
+    units = (mspack_hip_unit *) sys->alloc(sys, (nu ? nu : 1) * sizeof(*units));
+    res = (mspack_hip_result *) sys->alloc(sys, (nu ? nu : 1) * sizeof(*res));
+    if (!units || !res) err = MSPACK_ERR_NOMEMORY;
+  }
+  if (err) { for (k = 0; k < n; k++) sys->free(gs[k].boff); sys->free(gs); sys->free(units); sys->free(res); sys->free(ck.p); mspack_arena_free(sys, A.p); return err; }
   memset(A.p + A.len, 0, 64);
 
   /* the units: where gather_folder put their input, one stretch of the output arena each */
-  memset(units, 0, n * sizeof(*units));
+  memset(units, 0, nu * sizeof(*units));
+  for (k = 0; k < ck.n; k++) {                             /* the block parts' checksums (mspack_hip.h: MSPACK_HIP_KIND_XORSUM) */
+    units[n + k].kind = MSPACK_HIP_KIND_XORSUM;
+    units[n + k].in_off = ck.p[k].off; units[n + k].in_len = ck.p[k].len;
+  }
   for (k = 0; k < n; k++) {
     struct folder_p *fp = gs[k].fol;
     int method = fp->base.comp_type & 0x0F;
@@ -901,20 +944,25 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   else {
     size_t nhip = 0;
     for (k = 0; k < n; k++) if (units[k].kind != 0) nhip++;
-    memset(res, 0, n * sizeof(*res));
+    memset(res, 0, nu * sizeof(*res));
     if (nhip) {
       /* the arena was written a moment ago: page-locked, its copy to the device is plain DMA (mspack_hip.h; advice only) */
       const int pinned = A.len >= ((size_t) 4 << 20) && mspack_hip_pin(A.p, mspack_arena_room(A.len + 64)) == 0;
       /* kinds other than 1..3 are answered with MSPACK_ERR_ARGS by the kernels; fix them up below */
       rc = (self->devices > 1)
-        ? mspack_hip_decode_batch_multi(units, n, A.p, A.len + 64, out_arena, out_bytes + 64, res, self->devices)
-        : mspack_hip_decode_batch(units, n, A.p, A.len + 64, out_arena, out_bytes + 64, res);
+        ? mspack_hip_decode_batch_multi(units, nu, A.p, A.len + 64, out_arena, out_bytes + 64, res, self->devices)
+        : mspack_hip_decode_batch(units, nu, A.p, A.len + 64, out_arena, out_bytes + 64, res);
       if (pinned) mspack_hip_unpin(A.p);
       if (rc) {
         sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error());
         err = MSPACK_ERR_DECRUNCH;
       }
     }
+  }
+  if (!err) {
+    /* a block part whose payload is not what its header says: that folder is gathered again, the reference's way */
+    for (k = 0; k < ck.n; k++)
+      if (res[n + k].err != MSPACK_ERR_OK || res[n + k].in_next != ck.p[k].want) { gs[ck.p[k].owner].fol->cksum_on_host = 1; again = 1; }
   }
   if (!err && n) {
     /* the output arena stays: every folder's decoded bytes are where the batch put them (no copy per folder) */
@@ -924,6 +972,11 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     for (k = 0; k < n && !err; k++) {
       struct folder_p *fp = gs[k].fol;
       int method = fp->base.comp_type & 0x0F;
+      if (fp->cksum_on_host && ck.n) {                     /* (flagged just now?  It was decoded past a bad block: not kept) */
+        size_t j; int mine = 0;
+        for (j = 0; j < ck.n && !mine; j++) mine = ck.p[j].owner == (unsigned int) k;
+        if (mine) continue;
+      }
       fp->total = gs[k].total; fp->read_err = gs[k].read_err; fp->hard_eof = gs[k].hard_eof;
       fp->store = store; store->refs++;
       fp->dec = out_arena + units[k].out_off;
@@ -950,7 +1003,9 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     else if (store) sys->free(store);
   }
   for (k = 0; k < n; k++) sys->free(gs[k].boff);
-  sys->free(gs); sys->free(units); sys->free(res); mspack_arena_free(sys, A.p); mspack_arena_free(sys, out_arena);
+  sys->free(gs); sys->free(units); sys->free(res); sys->free(ck.p); mspack_arena_free(sys, A.p); mspack_arena_free(sys, out_arena);
+  /* (the folders flagged above defer nothing the second time: one more round at most) */
+  if (!err && again) return decode_cabinet(self, cab, want);
   return err;
 }
 

@@ -88,6 +88,8 @@ int oracle_lzss_decode(const uint8_t *in, size_t in_len, int mode, uint8_t *out,
 int oracle_kwaj_lzh_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, oracle_result *res);
 
 int oracle_huff_accepts(const uint8_t *lens, int nsyms, int tablebits);
+/* cabd_checksum (cabd.c:1462-1479): the CFDATA checksum of `bytes` bytes with seed `cksum` (cab_oracle.c) */
+uint32_t oracle_cab_checksum(const uint8_t *data, size_t bytes, uint32_t cksum);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,11 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *
     /* the frame table is a hint for the GPU's frame-parallel parse; results do not depend on it */
     if (u->flags & ~(MSPACK_HIP_UF_FRAME_TABLE | MSPACK_HIP_UF_HARD_EOF | (u->kind == MSPACK_HIP_KIND_LZX ? MSPACK_HIP_UF_LZX_LOG : 0u))) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
     if (u->kind == 0) { r->err = 1; continue; }
+    if (u->kind == MSPACK_HIP_KIND_XORSUM) {                     /* a CFDATA block's checksum (cabd.c:1462-1479) */
+      if (u->out_len) { snprintf(g_err, sizeof(g_err), "a checksum unit has no output"); return -1; }
+      r->in_used = u->in_len; r->in_next = oracle_cab_checksum(src, u->in_len, 0);
+      continue;
+    }
     oracle_set_hard_eof((u->flags & MSPACK_HIP_UF_HARD_EOF) != 0);
     switch (u->kind) {
     case MSPACK_HIP_KIND_LZX:

@@ -25,7 +25,7 @@ class OracleResult(C.Structure):
 def _build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in
-            ("lzx_oracle.c", "mszip_oracle.c", "qtm_oracle.c", "lzss_oracle.c", "oracle.h", "oracle_huff.h")]
+            ("lzx_oracle.c", "mszip_oracle.c", "qtm_oracle.c", "lzss_oracle.c", "cab_oracle.c", "oracle.h", "oracle_huff.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -51,8 +51,43 @@ def oracle():
         lib.oracle_lzxd_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint64,
                                            C.c_uint64, C.c_int, C.c_int, C.c_int32, C.c_int, C.c_char_p, C.c_size_t,
                                            C.POINTER(OracleResult)]
+        lib.oracle_cab_checksum.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
+        lib.oracle_cab_checksum.restype = C.c_uint32
         _oracle = lib
     return _oracle
+
+
+def oracle_cab_checksum(data, seed=0):
+    """cabd_checksum (cabd.c:1462-1479) of `data` with seed `seed`"""
+    return int(oracle().oracle_cab_checksum(bytes(data), len(data), seed))
+
+
+def cab_blocks_with_checksums(cab):
+    """[(stored checksum, the 4 header bytes cbData|cbUncomp, payload)] of every CFDATA block of a single cabinet"""
+    files_off, = struct.unpack_from("<I", cab, 0x10)
+    nfolders, _nfiles, flags = struct.unpack_from("<HHH", cab, 0x1A)
+    p, fres, dres = 0x24, 0, 0
+    if flags & 4:
+        hres, fres, dres = struct.unpack_from("<HBB", cab, p)
+        p += 4 + hres
+    for bit in (1, 2):
+        if flags & bit:
+            for _ in range(2):
+                p = cab.index(b"\0", p) + 1
+    out = []
+    for _ in range(nfolders):
+        doff, nblocks, _ct = struct.unpack_from("<IHH", cab, p)
+        p += 8 + fres
+        q = doff
+        for _b in range(nblocks):
+            if q + 8 > len(cab):
+                break
+            csum, cb, _cu = struct.unpack_from("<IHH", cab, q)
+            if q + 8 + dres + cb > len(cab):
+                break
+            out.append((csum, cab[q + 4:q + 8], cab[q + 8 + dres:q + 8 + dres + cb]))
+            q += 8 + dres + cb
+    return out
 
 
 def oracle_lzx(data, out_bytes, window_bits, reset_frames=0, length=None, e8_base=0):

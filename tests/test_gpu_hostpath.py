@@ -401,3 +401,34 @@ def test_copies_are_cut_at_pin_boundaries(built):
         finally:
             L.mspack_hip_unpin(p_in)
             L.mspack_hip_unpin(p_out)
+
+
+def test_xorsum_units_vs_oracle(built):
+    """MSPACK_HIP_KIND_XORSUM (cabd_checksum, cabd.c:1462-1479) against the oracle's restatement: payloads at every byte alignment
+    and of every length residue (the odd big-endian tail), empty and maximal blocks, alone and riding along a batch that decodes
+    (checksum units own no output; the decode units' bytes must be untouched by them)."""
+    from helpers import oracle_cab_checksum
+    rng = np.random.default_rng(77)
+    lens = [0, 1, 2, 3, 4, 5, 7, 8, 255, 256, 257, 4095, 32768 + 6144] + [int(x) for x in rng.integers(1, 40000, 300)]
+    arena = rng.integers(0, 256, sum(lens) + 4 * len(lens) + 128, dtype=np.uint8)
+    offs, pos = [], 0
+    for i, ln in enumerate(lens):
+        pos += i % 4                                   # (every alignment)
+        offs.append(pos); pos += ln
+    u = np.zeros(len(lens), dtype=M.UNIT_DTYPE)
+    u["kind"] = 7; u["in_off"] = offs; u["in_len"] = lens
+    out, res = M.decode_batch(u, arena, 64)
+    for i, (o, ln) in enumerate(zip(offs, lens)):
+        assert res["err"][i] == 0 and int(res["in_next"][i]) == oracle_cab_checksum(arena[o:o + ln].tobytes()), (i, o, ln)
+    # the same units mixed into a decoding batch, unit table shuffled
+    units, marena, out_bytes, items = mixed_batch(n_each=8, seed=3)
+    big = np.concatenate([marena, arena])
+    u2 = u.copy(); u2["in_off"] += marena.size
+    allu = np.concatenate([units, u2])
+    perm = rng.permutation(len(allu))
+    out, res = M.decode_batch(allu[perm], big, out_bytes)
+    inv = np.argsort(perm)
+    check(units, out, res[inv][:len(units)], items)
+    for i, (o, ln) in enumerate(zip(offs, lens)):
+        r = res[inv][len(units) + i]
+        assert r["err"] == 0 and int(r["in_next"]) == oracle_cab_checksum(arena[o:o + ln].tobytes()), (i, o, ln)

@@ -38,3 +38,34 @@ def test_published_md5s():
             assert k["ref_md5"] == want[k["method"]]
             seen += 1
     assert seen == 3
+
+
+def test_cab_checksum_on_reference_cabinets():
+    """oracle/cab_oracle.c (cabd_checksum, cabd.c:1462-1479) pinned on DATA: every CFDATA block that carries a checksum in the
+    reference's own test cabinets -- Microsoft-made files among them -- stores what the restatement computes: the payload with
+    seed 0, then the header's cbData / cbUncomp word with that as the seed (cabd.c:1411-1417).  (Files the reference's tests
+    damaged on purpose are skipped when their tables do not parse; at least 20 blocks must check out, with payload lengths of every residue mod 4.)"""
+    import glob
+    import os
+    import helpers
+    root = os.path.join(os.path.dirname(__file__), "golden")            # ref_fixtures/ (libmspack's tests), cabsets/ (cabextract's split set)
+    good = bad = 0
+    odd_lengths = set()
+    for f in sorted(glob.glob(os.path.join(root, "**", "*.cab"), recursive=True)):
+        cab = open(f, "rb").read()
+        if cab[:4] != b"MSCF":
+            continue
+        try:
+            blocks = helpers.cab_blocks_with_checksums(cab)
+        except Exception:
+            continue
+        for csum, hdr4, payload in blocks:
+            if csum == 0:
+                continue
+            if helpers.oracle_cab_checksum(hdr4, helpers.oracle_cab_checksum(payload, 0)) == csum:
+                good += 1
+                odd_lengths.add(len(payload) & 3)
+            else:
+                bad += 1
+    assert good >= 20 and bad <= good // 5, (good, bad)             # (a few fixtures have deliberately bad blocks)
+    assert odd_lengths == {0, 1, 2, 3}, odd_lengths                  # every form of the odd tail was exercised
