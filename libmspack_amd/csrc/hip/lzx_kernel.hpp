@@ -2357,8 +2357,16 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
         if (!lzx_front_batch(ism, lane, opos, olen, which, c1, R0, R1, R2, frame_pos, wbase, wsize, vmoff)) { bad = true; break; }
         PH(9);
         // (3) queue the copies (cf. lzx_commit_batch)
-        {
-          const u32 newP = rdl(opos + olen, n - 1u);
+        const u32 newP = rdl(opos + olen, n - 1u);
+        if (spq_is_run(ism, n, opos, olen, vmoff, lane)) {
+          // the batch is one run (spec_queue.hpp): everything below it final, then stores only
+          const u32 rs = rdl(opos, 0u);
+          spq_resolve(*spq, Q, out, rs, true, lane);
+          spq_fill_run(out, rs, newP, rdl(vmoff, 0u), lane);
+          Q.Pf = newP;
+          PH(11);
+        }
+        else {
           u64 mq = mm;
           if (Q.mcount + (u32) __popcll(mq) > SPQ_CAP) spq_resolve(*spq, Q, out, rdl(opos, 0u), true, lane);
           bool im = ism;

@@ -850,8 +850,16 @@ __device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *pool_base
       const u32 newP = rdl(opos + olen, n - 1u);
       u64 mm = ballot(valid);
       bool ism = valid;
-      if (Q.mcount + n > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
-      for (;;) {
+      if (spq_is_run(valid, n, opos, olen, dist, lane)) {
+        // the batch is one run (spec_queue.hpp): everything below it final, then stores only
+        const u32 rs = rdl(opos, 0u);
+        spq_resolve(sh->spq, Q, out, rs, true, lane);
+        spq_fill_run(out, rs, newP, rdl(dist, 0u), lane);
+        Q.Pf = newP;
+        mm = 0ull;
+      }
+      else if (Q.mcount + n > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
+      while (mm) {
         const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
         const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
         if (fit) {

@@ -184,6 +184,65 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
   if (fin) { q.Pf = P; q.mcount = 0; q.ja = 0; }
 }
 
+// ---- runs ----------------------------------------------------------------------------------------------------------
+// A batch of matches that follow each other without a literal in between and share ONE offset is a RUN [s, e):
+//     out[b] = out[b - off]   for all b in [s, e)     ==     out[b] = out[s - off + (b - s) mod off]
+// -- every source lies below s.  So once everything below s is final the run has no dependency inside it, however long it is:
+// no memory round trip per 256 bytes (the position-space passes above: ~1.4 us per group, 170 MB/s for ONE folder), just
+// stores.  That is what long stretches of zeros and of repeated records look like after LZ77 with a maximal match length
+// of 257 / 258 (lzxd.c:588, mszipd.c:62-66) -- the reference's own large-files.test (a 64-byte line repeated for 2 GiB:
+// ~127 matches of 257 bytes at offset 64 per frame) is the pure case.  
+#ifndef SPQ_RUN_MIN
+#define SPQ_RUN_MIN 512u            /* a batch takes the run path when it spans at least this many bytes */
+#endif
+__device__ __forceinline__ bool spq_is_run(const bool ism, const u32 n, const u32 opos, const u32 olen, const u32 off, const u32 lane)
+{
+  if (n < 2u) return false;
+  const u32 s = rdl(opos, 0u), e = rdl(opos + olen, n - 1u), off0 = rdl(off, 0u);
+  if (e - s < SPQ_RUN_MIN || off0 == 0u || off0 > s) return false;
+  const u32 nextp = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane + 1u) & 63u) << 2), (int) opos);
+  return !ballot(ism && (off != off0 || (lane + 1u < n && opos + olen != nextp)));
+}
+// write the run [s, e) with period `off` (everything below s is final in memory); stores at or above `clip` are dropped
+__device__ __forceinline__ void spq_fill_run(u8 *const out, const u32 s, const u32 e, const u32 off, const u32 lane,
+                                             const u32 clip = 0xFFFFFFFFu)
+{
+  const u8 *const src = out + (s - off);
+#if defined(SPQ_RUN_TRACE) && defined(MSPACK_WAVE_EMU)     /* emulator analysis builds: which runs took this path */
+  if (lane == 0) fprintf(stderr, "spq_fill_run: [%u, %u) period %u\n", s, e, off);
+#endif
+  if (off <= 64u) {
+    // the whole period sits in one register across the wave: byte (b - s) mod off comes from a lane, not from memory
+    u32 k = lane % off;                                  // (one division per run)
+    const u32 pat = (u32) gld(src + k);
+    const u32 step = 64u % off;
+    for (u32 cb = s; cb < e; cb += 64u) {
+      const u32 b = cb + lane;
+      const u32 v = (u32) __builtin_amdgcn_ds_bpermute((int)(k << 2), (int) pat);
+      if (b < e && b < clip) gst(out + b, (u8) v);
+      k += step; if (k >= off) k -= off;
+    }
+  }
+  else {
+    // sources below s, all of them final: eight chunks' loads in flight at once, then their stores
+    u32 k = lane;                                        // (b - s) mod off for b = cb + lane; lane < 64 < off
+    for (u32 cb = s; cb < e; cb += 512u) {
+      u32 val[8], kk = k;
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        val[g] = (cb + 64u * g + lane < e) ? (u32) gld(src + kk) : 0u;
+        kk += 64u; if (kk >= off) kk -= off;
+      }
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        const u32 b = cb + 64u * g + lane;
+        if (b < e && b < clip) gst(out + b, (u8) val[g]);
+      }
+      k = kk;
+    }
+  }
+}
+
 // one lane-parallel push: lanes with `ism` hold matches of ranks 0..n-1 in position order
 __device__ __forceinline__ void spq_push(SpecQueueLds &l, SpecQueue &q, const bool ism, const u32 rank,
                                          const u32 n, const u32 pos, const u32 off, const u32 len)
