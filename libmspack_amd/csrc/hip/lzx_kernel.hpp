@@ -1358,8 +1358,13 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
 // block's, lzxd.c:138-183: a chain, but a short one -- one header per link), reads its own block header, publishes
 // its code lengths, builds the tables and parses the frame's tokens with every lane walking its own stretch of the bits
 // (lzx_parse_emit): literals go straight to the output, matches become 8-byte records in the launch's record pool.
-// The parse works on the guess that every frame holds exactly ONE verbatim / aligned block that begins where the frame
-// begins -- what encoders do -- and gives up silently otherwise.  A resolve task per frame (lzx_pipe_resolve) then
+// Rounds 2-4 parsed on the guess that every frame holds exactly ONE verbatim / aligned block that begins where the frame
+// begins -- what this build's own encoder writes.  Microsoft's encoder does not: the reference's large-files cabinets hold
+// blocks of megabytes (8 384 624 bytes, 7 379 562 ...), so their frames lie INSIDE a block, and the guess failed for every
+// frame of every real cabinet tried (they all took the serial path: 180 MB/s).  Round 5: the chain from frame to frame is
+// "code lengths + what is left of the open block"; a frame inside a block inherits both and has no header to read, a frame
+// that holds a block's end parses up to it, reads the next header there and goes on with the new tables (lzx_pipe_parse).
+// Stored blocks, a block that ends where nothing can be parsed, damage: the task gives up silently.  A resolve task per frame (lzx_pipe_resolve) then
 // turns the records into copies in stream order: R0-R2, the reference's checks, the match queue.  Whatever the tasks
 // do not cover -- the last bytes of the input, a frame with several blocks, stored blocks, a damaged stream, a wrong
 // table -- ends the unit's chain there (rs_* in the unit's first record) and is decoded by the serial path
@@ -1376,7 +1381,10 @@ struct __align__(16) LzxFrameRec {
   u32 prog;                         /* mspack_lzx_pipe, while status is 2: match records | output bytes << 15 that are in memory
                                        already (published after every pass of lzx_parse_emit but the last) */
   u8 ali_len[8];
-  u8 pad1[8];
+  u32 rem_out;                      /* lzx_pipe_parse: bytes of the block that is open BEHIND this frame (0: the next frame starts with a
+                                       block header).  Published with the code lengths (status 2): the next frame's task inherits both */
+  u32 run_rem;                      /* what a decoder that goes on INSIDE this frame (a record that ends early) has as block_remaining
+                                       at the frame's first byte, counting the block the record ends in as if it had begun there */
   u8 main_len[LZX_MAIN_SYMS + 16];
   u8 len_len[LZX_LEN_SYMS + 70];
   /* ---- mspack_lzx_pipe (lzx_pipe_parse / lzx_pipe_commit) ---- */
@@ -1709,8 +1717,14 @@ template <bool ALIGNED>
 __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empty, const u32 start_bit, const u32 frame_end_bit,
                                                u8 *const fout, const u32 frame_pos, const u32 frame_size, const u32 edge_n,
                                                LzxFrameRec *rec, RecWriter &W, u32 &n_rec, u32 &end_bit, u32 &bytes_done,
-                                               const bool two_level, const bool stream)
+                                               const bool two_level, const bool stream, const u32 plimit, const bool first_seg,
+                                               u32 &emask)
 {
+  // emask: lanes 0-3 hold the edge literals' position mask between the calls (its LDS words are the table builder's counters)
+  // n_rec / bytes_done: in and out -- a frame that holds the end of one block and the beginning of the next is parsed in two
+  // calls (lzx_pipe_parse), each with its own tables, the second one going on where the first one stopped; plimit: the frame
+  // position the call may not pass (the end of its block or of the frame: a match that crosses either is the serial path's to
+  // report, lzxd.c:678-693)
   LzxShared *sh = d.sh;
   const u32 lane = d.lane;
   const u32 in_limit = d.w.in_len > 56u ? (d.w.in_len - 56u) * 8u : 0u;
@@ -1721,14 +1735,16 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
 #pragma unroll
   for (int l = LZX_LEN_P + 1; l <= 16; l++) llim[l - LZX_LEN_P - 1] = rdl(d.hr_len.limv, (u32) l);
   const u32 main_fov = d.hr_main.fov, len_fov = d.hr_len.fov;
-  u32 tt = 0, B = rfl(start_bit), P = 0;                       // records written, next bit, bytes of the frame done
+  u32 tt = rfl(n_rec), B = rfl(start_bit), P = rfl(bytes_done);   // records written, next bit, bytes of the frame done
   bool stop = false;
-  if (lane < 4u) sh->cnt[lane] = 0u;                           // the edge literals' positions (128 bits)
+  if (lane < 4u) sh->cnt[lane] = first_seg ? 0u : emask;       // the edge literals' positions (128 bits)
 #ifdef LZX_LIT_RING
-  u32 lit_flushed = edge_n;                                    // literals below this position have left the ring (a multiple of 16)
+  // literals below this position have left the ring (a multiple of 16).  (A second call starts with the first whole row at or
+  // above P: the literals in front of it are stored on their own -- the row they lie in holds the first call's bytes)
+  u32 lit_flushed = first_seg ? edge_n : (((P + 15u) & ~15u) > edge_n ? ((P + 15u) & ~15u) : edge_n);
 #endif
 
-  while (!stop && B < Eall && P < frame_size) {
+  while (!stop && B < Eall && P < plimit) {
     PHE0();
     // ---- stage the input from the dword that holds bit B ----
     const u32 sb_byte = (B >> 5) << 2, sb_bit = sb_byte * 8u;
@@ -1839,12 +1855,12 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     u32 p = entry, i = 0, pos = P + inclb - cvb, j = tt + inclm - cvm;
     bool cross = false;
     for (;;) {
-      const bool on = i < my_n && pos < frame_size && !cross;
+      const bool on = i < my_n && pos < plimit && !cross;
       if (!ballot(on)) break;
       STAGE_BITS(on ? p : 0u, w0, w1, true)
       const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
       const bool lit = on && !t.is_match;
-      const bool crs = on && t.is_match && pos + t.olen > frame_size;   // lzxd.c:678-693: the serial path reports it
+      const bool crs = on && t.is_match && pos + t.olen > plimit;   // lzxd.c:678-693: the serial path reports it
       const bool mt = on && t.is_match && !crs;
       if (lit) {
         if (pos >= edge_n) gst_stream(fout + pos, (u8) t.sym);
@@ -1882,8 +1898,9 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     if (segc > 8u) segc = 8u;                                     // (a stretch of more than 8 segments: the last one is long)
     const u32 seginc = wave_incl_scan(segc);
     const u32 T = rdl(seginc, 63u);
-    // (512 bytes of scratch: the sorted symbols are not needed once the second-level table stands; else the code lengths' room)
-    u8 *const owner = two_level ? (u8 *) sh->main_sorted : sh->main_len;
+    // (512 bytes of scratch: the sorted symbols are not needed once the second-level table stands
+    // -- or, without one, the block header's input window: NOT the code lengths, a later header of this frame works on them)
+    u8 *const owner = two_level ? (u8 *) sh->main_sorted : (u8 *) sh->inbuf;
     for (u32 q = 0; q < segc; q++) owner[seginc - segc + q] = (u8) lane;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const u32 info0 = entry | (n << 16), info1 = P + inclb - cvb, info2 = tt + inclm - cvm, info3 = (seginc - segc) | (segc << 16);
@@ -1907,13 +1924,13 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       u32 p = ca & 0xFFFFu, i = 0, pos = i1_ + (k == 0u ? 0u : ca >> 16), j = i2_ + cmk;
       bool cross = false;
       for (;;) {
-        const bool on = i < ntok && pos < frame_size && !cross;
+        const bool on = i < ntok && pos < plimit && !cross;
         if (!ballot(on)) break;
         LZX_MARK("emit_last_step_begin");
         STAGE_BITS(on ? p : 0u, w0, w1, true)
         const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
         const bool lit = on && !t.is_match;
-        const bool crs = on && t.is_match && pos + t.olen > frame_size;   // lzxd.c:678-693: the serial path reports it
+        const bool crs = on && t.is_match && pos + t.olen > plimit;   // lzxd.c:678-693: the serial path reports it
         const bool mt = on && t.is_match && !crs;
         if (lit) {
 #ifdef LZX_LIT_RING
@@ -1981,7 +1998,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     // match records below tt -- is published now, so that the unit's commit task works on this frame while its later passes
     // are still being parsed (lzx_pipe_commit).  The edge literals all lie in the first 128 bytes: their mask is complete
     // once P has passed them.
-    if (stream && !stop && B < Eall && P < frame_size && P >= 128u && tt <= 0x7FFFu) {
+    if (stream && !stop && B < Eall && P < plimit && P >= 128u && tt <= 0x7FFFu) {
       if (lane < 4u) rec->edge_mask[lane] = sh->cnt[lane];
       lzx_status_publish(&rec->prog, tt | (P << 15), lane);
 #ifdef MSPACK_WAVE_EMU
@@ -2000,7 +2017,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     if (b0 + lane < P) gst(fout + b0 + lane, ((const u8 *) sh->litring)[(b0 + lane) & (LZX_LIT_RING - 1u)]);
   }
 #endif
-  if (lane < 4u) rec->edge_mask[lane] = sh->cnt[lane];
+  if (lane < 4u) { emask = sh->cnt[lane]; rec->edge_mask[lane] = emask; }
   n_rec = tt; end_bit = B; bytes_done = P;
 }
 #endif  /* LZX_PARSE_ONLY */
@@ -2058,6 +2075,8 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   const bool first = rf ? (f % rf) == 0u : f == 0u;
   PHDECL();
   PH0();
+  // ---- the state in front of the frame: the code lengths of the last block header and what is left of that block ----
+  u32 rem = 0, btype = 0;
   if (first) lzx_reset_state(d, s);
   else {
     const LzxFrameRec *pr = rec - 1;
@@ -2075,13 +2094,15 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
     // (1056 bytes, a dword per lane and step)
     for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) ((u32 *) sh->main_len)[i] = gld((const u32 *) pr->main_len + i);
     for (u32 i = lane; i < (LZX_LEN_SYMS + 70) / 4u; i += WAVE) ((u32 *) sh->len_len)[i] = gld((const u32 *) pr->len_len + i);
+    if (lane < 8u) sh->ali_len[lane] = gld(&pr->ali_len[lane]);
+    rem = rfl(gld(&pr->rem_out)); btype = rfl(gld(&pr->block_type));
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
   PH(0);
-  // ---- the header the frame table points at ----
+  // ---- where the frame table says the frame begins ----
   const u32 fo = rfl(ftab[f]);
   bool ok = !(fo >= u.in_len || u.in_len - fo <= 64u);         // the last bytes of the input belong to the EOF-exact reader
-  u32 hdr_start = 0, intel = 0;
+  u32 intel = 0;
   if (ok) {
     d.w.seek(fo, lane);
     d.bb = 0; d.bl = 0; d.rbl = 0; d.near_end = false; d.careful = false; d.err = 0;
@@ -2092,65 +2113,104 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
       intel = (hi << 16) | lo;
     }
   }
-  if (ok) {
-    hdr_start = fo * 8u + d.cons_bits();
-    s.block_type = 0;
-    ok = lzx_block_header(d, s, false) && !d.careful && !d.near_end;
-  }
+  if (!ok || (rem != 0u && btype != 1u && btype != 2u)) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
   u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
-  if (ok) ok = (s.block_type == 1u || s.block_type == 2u) && s.block_length == fsz;    // one block per frame, or no guess
-  if (!ok) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
-  const u32 start_bit = rfl(d.w.origin) * 8u + rfl(d.cons_bits());                // the frame's first token
-  PH(1);
-  for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) gst((u32 *) rec->main_len + i, ((const u32 *) sh->main_len)[i]);
-  for (u32 i = lane; i < (LZX_LEN_SYMS + 70) / 4u; i += WAVE) gst((u32 *) rec->len_len + i, ((const u32 *) sh->len_len)[i]);
-  if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
-  if (lane == 0) {
-    rec->n_tokens = 0; rec->hdr_start_bit = hdr_start; rec->end_bit = start_bit;
-    rec->block_type = s.block_type; rec->block_length = s.block_length;
-    rec->flags = (sh->main_len[0xE8] != 0 ? 2u : 0u);
-    rec->frame_start_bit = fo * 8u; rec->intel_filesize = intel; rec->bytes_done = 0; rec->prog = 0;
-    // the frame's first bytes up to the next 128-byte line: another wave may be writing that line (see lzx_parse_emit)
-    const u32 en_ = (128u - (u32)((size_t)(out_arena + u.out_off + (size_t) f * LZX_FRAME) & 127u)) & 127u;
-    rec->n_edge = en_ < fsz ? en_ : fsz;
-  }
-  lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);        // the next frame's wave may go on
-  PH(2);
-  // ---- tables + tokens (cf. lzx_parse_frame): length and aligned trees first, the main tree last -- its second level
-  // takes the room of the code lengths ----
-  bool tables = true, two_level = false;
-  {
-    const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, lane, false);
-    tables = r != 1;
-    s.length_empty = (r == 2);
-  }
-  if (tables && s.block_type == 2u) tables = !huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false);
-  if (tables) {
-    u32 nsorted = 0;
-    tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
-                                                          sh->cnt, d.hr_main, lane, false, &nsorted);
+  u32 fe = (f + 1u < nreal) ? rfl(ftab[f + 1u]) : u.in_len;       // where the table says the frame ends (a hint)
+  if (fe > u.in_len || fe <= fo) fe = u.in_len;
+  u8 *const fout = out_arena + u.out_off + (size_t) f * LZX_FRAME;
+  // the frame's first bytes up to the next 128-byte line: another wave may be writing that line (see lzx_parse_emit)
+  const u32 edge_n = (128u - (u32)((size_t) fout & 127u)) & 127u;
+  // ---- the frame, block by block.  Round 5: a frame need not be ONE block that begins where it begins (what this build's own
+  // encoder writes, and all rounds 2-4 handled here): Microsoft's encoder writes blocks of megabytes (the reference's
+  // large-files cabinets: one aligned block of 8 384 624 bytes, then the next), so a frame usually lies INSIDE a block -- it
+  // inherits the previous frame's code lengths and has no header at all -- and now and then holds the end of one block and the
+  // header and first tokens of the next.  The chain from frame to frame is "code lengths + bytes left of the open block"
+  // (rem_out); it is published as soon as the LAST header of the frame has been read, i.e. at once for a frame without one. ----
+  RecWriter W;
+  bool w_begun = false, published = false, seg_first = true, two_level = false;
+  u32 n_rec = 0, end_bit = 0, bytes_done = 0, e8flag = 0, run_rem = 0, emask = 0, pub_p0 = 0;
+  u32 cur_bit = rfl(d.w.origin) * 8u + rfl(d.cons_bits());     // the frame's first block header, or its first token
+  const u32 hdr_start = cur_bit;
+  bool whole_ok = true;
+  while (bytes_done < fsz) {
+    const u32 seg_p0 = bytes_done;
+    if (rem == 0u) {
+      if (!seg_first) lzx_seek_bit(d, cur_bit);
+      s.block_type = 0;
+      const bool hok = lzx_block_header(d, s, false) && !d.careful && !d.near_end;
+      if (!hok || (s.block_type != 1u && s.block_type != 2u) || s.block_length == 0u) { whole_ok = false; break; }
+      rem = s.block_length; btype = s.block_type;
+      if (rfl((u32) sh->main_len[0xE8]) != 0u) e8flag = 2u;       // lzxd.c:497: a block header with a code for 0xE8
+      cur_bit = rfl(d.w.origin) * 8u + rfl(d.cons_bits());       // the block's first token
+      if (w_begun) W.reload(lane);                                // (the header's pretree table lay over the chunk list)
+    }
+    else s.block_type = btype;
+    const u32 need = fsz - seg_p0;
+    if (!published && rem >= need) {
+      // the state behind this frame is known: the next frame's task may go on
+      PH(1);
+      for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) gst((u32 *) rec->main_len + i, ((const u32 *) sh->main_len)[i]);
+      for (u32 i = lane; i < (LZX_LEN_SYMS + 70) / 4u; i += WAVE) gst((u32 *) rec->len_len + i, ((const u32 *) sh->len_len)[i]);
+      if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
+      run_rem = seg_p0 + rem; pub_p0 = seg_p0;
+      if (lane == 0) {
+        rec->n_tokens = 0; rec->hdr_start_bit = hdr_start; rec->end_bit = cur_bit;
+        rec->block_type = btype; rec->block_length = rem; rec->rem_out = rem - need; rec->run_rem = run_rem;
+        rec->frame_start_bit = fo * 8u; rec->intel_filesize = intel; rec->bytes_done = 0; rec->prog = 0;
+        rec->n_edge = edge_n < fsz ? edge_n : fsz;
+      }
+      lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);      // the next frame's wave may go on
+      published = true;
+      PH(2);
+    }
+    // ---- tables (cf. lzx_parse_frame): length and aligned trees first, the main tree last -- its second level takes the room
+    // of the code lengths (which are in the record by now, or are read again by the next header of this frame) ----
+    bool tables = true;
+    two_level = false;
+    {
+      const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, lane, false);
+      tables = r != 1;
+      s.length_empty = (r == 2);
+    }
+    if (tables && btype == 2u) tables = !huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false);
+    if (tables) {
+      u32 nsorted = 0;
+      tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+                                                            sh->cnt, d.hr_main, lane, false, &nsorted);
 #ifndef LZX_NO_SUB_TABLE
-    if (tables) two_level = rfl(lzx_build_sub(sh, d.hr_main, nsorted, lane) ? 1u : 0u) != 0u;
+      // (the second level is built in the room of the code lengths: only when no later header of this frame needs them)
+      if (tables && published) two_level = rfl(lzx_build_sub(sh, d.hr_main, nsorted, lane) ? 1u : 0u) != 0u;
 #endif
+    }
+    if (!tables) { whole_ok = false; break; }
+    PH(3);
+    if (!w_begun) {
+      // (the frame's chunk list in LDS: the room of the pretree's table -- only a block header uses that: a later header of this
+      // frame finds the list saved in the record)
+      W.begin(pool, (u32 *) sh->pre_tab, rec->chunk);
+      w_begun = true;
+    }
+    const u32 plimit = seg_p0 + (rem < need ? rem : need);
+    if (btype == 2u) lzx_parse_emit<true>(d, s.length_empty, cur_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream, plimit, seg_first, emask);
+    else lzx_parse_emit<false>(d, s.length_empty, cur_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream, plimit, seg_first, emask);
+    seg_first = false;
+    if (bytes_done < plimit) break;                               // the record ends early: the serial path goes on behind it
+    rem -= plimit - seg_p0;
+    cur_bit = end_bit;
   }
-  if (!tables) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); return; }
-  PH(3);
-  u32 n_rec = 0, end_bit = 0, bytes_done = 0;
-  {
-    u32 fe = (f + 1u < nreal) ? rfl(ftab[f + 1u]) : u.in_len;     // where the table says the frame ends (a hint)
-    if (fe > u.in_len || fe * 8u <= start_bit) fe = u.in_len;
-    u8 *const fout = out_arena + u.out_off + (size_t) f * LZX_FRAME;
-    // the frame's first bytes up to the next 128-byte line: another wave may be writing that line (see lzx_parse_emit)
-    const u32 edge_n = (128u - (u32)((size_t) fout & 127u)) & 127u;
-    // (the frame's chunk list in LDS: the room of the pretree's table -- only a block header uses that, and this frame's is read)
-    RecWriter W;
-    W.begin(pool, (u32 *) sh->pre_tab, rec->chunk);
-    if (s.block_type == 2u) lzx_parse_emit<true>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream);
-    else lzx_parse_emit<false>(d, s.length_empty, start_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream);
+  if (!published) {
+    // no state to hand on (a header that is no verbatim / aligned block, tables that do not build, a record that ends in front of
+    // the frame's last header): nothing of this frame is used, the chain of code lengths ends here
+    lzx_status_publish(&rec->status, LZX_ST_FAILED, lane);
+    PHFLUSH();
+    return;
   }
+  // a record that ends early must end INSIDE the frame's last block, behind at least one of its tokens: the serial path goes on
+  // from its last bit with that block's tables.  Else (tables that do not build, nothing parsed): code lengths only
+  if (bytes_done < fsz && bytes_done <= pub_p0) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); PHFLUSH(); return; }
   if (lane == 0) {
     rec->n_tokens = n_rec; rec->end_bit = end_bit; rec->bytes_done = bytes_done;
-    rec->flags = rec->flags | (s.length_empty ? 1u : 0u);
+    rec->flags = e8flag | (s.length_empty ? 1u : 0u);
   }
   PH(4);
   lzx_status_publish(&rec->status, LZX_ST_EMITTED, lane);
@@ -2316,7 +2376,9 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
   bool bad = st != LZX_ST_EMITTED;
   if (!bad) {
     n_rec = rfl(rec->n_tokens); bytes = rfl(rec->bytes_done); end_bit = rfl(rec->end_bit);
-    bad = rfl(rec->frame_start_bit) != prev_end || rfl(rec->block_length) != fsz || bytes > fsz || n_rec > REC_CHUNK * REC_CHUNKS;
+    // (which blocks the frame lies in is the parse tasks' chain: code lengths and what is left of the open block travel from
+    // frame to frame with the records, and a record only counts when every frame below it was complete)
+    bad = rfl(rec->frame_start_bit) != prev_end || bytes > fsz || n_rec > REC_CHUNK * REC_CHUNKS;
   }
   if (!bad) {
     // ---- the literals of the frame's first cache line ----
@@ -2535,7 +2597,10 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
         // serial decoding starts with this frame: the state the pipe left at its first bit
         lzx_seek_bit(d, rs_next);
         d.P = rs_P; s.R0 = rs_R0; s.R1 = rs_R1; s.R2 = rs_R2;
-        if (rs_frame != 0u && !(s.reset_frames && (s.frame % s.reset_frames) == 0u)) stale = &recs[u.frame_base + rs_frame - 1u];
+        if (rs_frame != 0u && !(s.reset_frames && (s.frame % s.reset_frames) == 0u)) {
+          stale = &recs[u.frame_base + rs_frame - 1u];
+          stale_tables = s.block_remaining != 0u;                  // inside a block the pipe's frames left open: its tables too
+        }
         rs_on = false; positioned = true;
       }
 #endif
@@ -2572,8 +2637,8 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
       bool fail = false;
 #ifndef LZX_DELTA
       if (ff) {
-        // a frame the pipe finished: one block of the frame's size, decoded and in place
-        s.block_type = rfl(frec->block_type); s.block_length = frame_size; s.block_remaining = 0;
+        // a frame the pipe finished, decoded and in place: the block it ends in and what is left of that block
+        s.block_type = rfl(frec->block_type); s.block_length = rfl(frec->block_length); s.block_remaining = rfl(frec->rem_out);
         const u32 rfl_ = rfl(frec->flags);
         s.length_empty = (rfl_ & 1u) != 0u;
         if (rfl_ & 2u) s.intel_started = true;
@@ -2583,8 +2648,9 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
         todo = 0;
       }
       if (pf) {
+        // (the block the record ends in, counted as if it had begun with the frame: the loop below takes the frame's bytes off it)
         s.block_type = rfl(frec->block_type);
-        s.block_length = s.block_remaining = rfl(frec->block_length);
+        s.block_length = rfl(frec->block_length); s.block_remaining = rfl(frec->run_rem);
         const u32 rfl_ = rfl(frec->flags);
         s.length_empty = (rfl_ & 1u) != 0u;
         if (rfl_ & 2u) s.intel_started = true;
@@ -2741,7 +2807,7 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
 #ifndef LZX_DELTA
       if (ff) {                    // (a frame the pipe finished: its record says where the stream goes on)
         in_next = ff_end >> 3;
-        flags &= ~MSPACK_HIP_F_BLOCK_OPEN;
+        flags = s.block_remaining ? (flags | MSPACK_HIP_F_BLOCK_OPEN) : (flags & ~MSPACK_HIP_F_BLOCK_OPEN);
       }
       else
 #endif

@@ -21,6 +21,7 @@
 #pragma once
 #include "wave_common.hpp"
 #include "spec_queue.hpp"
+#include <type_traits>
 
 #define QTM_FRAME 32768u
 #ifdef LZX_MARKS        /* analysis builds: static instruction counts between marks (tools/count_isa.py) */
@@ -184,15 +185,19 @@ __device__ __attribute__((noinline)) QtmUpd qtm_update_model(u32 m, const u32 en
 // fail: no bounds arithmetic, no failure paths (the reference's bits_left is still tracked, see QtmDec::fill_t).
 // `shifts`: the nine models' shiftsleft counters (qtm.h:52), one per LANE of a vector register -- they are touched once
 // per ~50..400 symbols, and nine more scalar registers were what made the coder's hot state spill.
-template <bool FAST>
-__device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, u32 &shifts, const u32 model_ix)
+// Round 5: `tots` = the model's TOTAL (cumfreq[0]) kept on the scalar side, 16 bits of an SGPR per model (TSH = this model's
+// shift): it grows by 8 per symbol and is re-read from the register only after a rescale.  The total is the first thing a symbol
+// needs (X = (C - L + 1) * total - 1, qtmd.c:94) and used to arrive through a v_readlane hop (~36 cycles, micro-benchmarks of
+// round 2) behind the model-select branch, where nothing can be scheduled in front of it.
+template <bool FAST, u32 TSH>
+__device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, u32 &shifts, const u32 model_ix, u32 &tots)
 {
   const u32 lane = d.lane;
   QTM_MARK("qtm_sym_begin");
   QT0();
   u32 H = d.H, L = d.L, C = d.C;
   const u32 cf = m & 0xFFFFu;
-  const u32 tot = rdl(cf, 0);
+  const u32 tot = (tots >> TSH) & 0xFFFFu;
   const u32 range = ((H - L) & 0xFFFFu) + 1u;
   const u32 range2 = (u32)((int) H - (int) L + 1);
   // ---- per entry: floor(cumfreq * range / total), exact through one single-precision reciprocal (num < 2^32, quotient
@@ -226,11 +231,13 @@ __device__ __forceinline__ int qtm_get_symbol(QtmDec &d, u32 &m, u32 entries, u3
   L = (L + q_lo) & 0xFFFFu;
   // cumfreq[0..i-1] += 8; rescale when the total passes 3800
   if (lane < i) m += 8u;
+  tots += 8u << TSH;                                             // (entry 0 is below every i: the total always grows)
   QTM_MARK("qtm_sym_interval_done");
   QT(0);
   if (tot + 8u > 3800u) {
     const QtmUpd up = qtm_update_model(m, entries, (int) rdl(shifts, model_ix), lane);
     m = up.m; shifts = wrl(shifts, (u32) up.shiftsleft, model_ix);
+    tots = (tots & ~(0xFFFFu << TSH)) | (rdl(m & 0xFFFFu, 0u) << TSH);
   }
   QT(1);
   QTM_MARK("qtm_sym_renorm_begin");
@@ -338,6 +345,7 @@ struct QtmModels {
   u32 m0, m1, m2, m3, m4, m5, m6, m6l, m7;
   u32 shifts;                      /* lane k: shiftsleft of model k (0-3 literals, 4, 5, 6, 7 = 6len, 8 = selector) */
   u32 n4, n5, n6;
+  u32 t01, t23, t45, t66, t7;      /* the models' totals (cumfreq[0]) on the scalar side, two per register: qtm_get_symbol */
 };
 enum { QTM_T_LIT = 0, QTM_T_MATCH = 1, QTM_T_READ = -1, QTM_T_DECRUNCH = -2 };
 // one token (qtmd.c:292-350): the selector, then a literal from one of four models or a match's length / offset.
@@ -346,30 +354,30 @@ enum { QTM_T_LIT = 0, QTM_T_MATCH = 1, QTM_T_READ = -1, QTM_T_DECRUNCH = -2 };
 template <bool FAST>
 __device__ __forceinline__ int qtm_token(QtmDec &d, QtmModels &M, u32 &val, u32 &mlen)
 {
-  const int sel = qtm_get_symbol<FAST>(d, M.m7, 7, M.shifts, 8u);
+  const int sel = qtm_get_symbol<FAST, 0>(d, M.m7, 7, M.shifts, 8u, M.t7);
   int sym;
   u32 base, extra, v;
   switch (sel) {
-  case 0: sym = qtm_get_symbol<FAST>(d, M.m0, 64, M.shifts, 0u); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
-  case 1: sym = qtm_get_symbol<FAST>(d, M.m1, 64, M.shifts, 1u); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
-  case 2: sym = qtm_get_symbol<FAST>(d, M.m2, 64, M.shifts, 2u); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
-  case 3: sym = qtm_get_symbol<FAST>(d, M.m3, 64, M.shifts, 3u); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
+  case 0: sym = qtm_get_symbol<FAST, 0>(d, M.m0, 64, M.shifts, 0u, M.t01); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
+  case 1: sym = qtm_get_symbol<FAST, 16>(d, M.m1, 64, M.shifts, 1u, M.t01); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
+  case 2: sym = qtm_get_symbol<FAST, 0>(d, M.m2, 64, M.shifts, 2u, M.t23); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
+  case 3: sym = qtm_get_symbol<FAST, 16>(d, M.m3, 64, M.shifts, 3u, M.t23); if (sym < 0) return QTM_T_READ; val = (u32) sym; return QTM_T_LIT;
   case 4:
-    sym = qtm_get_symbol<FAST>(d, M.m4, M.n4, M.shifts, 4u); if (sym < 0) return QTM_T_READ;
+    sym = qtm_get_symbol<FAST, 0>(d, M.m4, M.n4, M.shifts, 4u, M.t45); if (sym < 0) return QTM_T_READ;
     qtm_pos_slot((u32) sym, base, extra);
     if (!d.template read_many_t<FAST>((int) extra, v)) return QTM_T_READ;
     val = base + v + 1u; mlen = 3u; return QTM_T_MATCH;
   case 5:
-    sym = qtm_get_symbol<FAST>(d, M.m5, M.n5, M.shifts, 5u); if (sym < 0) return QTM_T_READ;
+    sym = qtm_get_symbol<FAST, 16>(d, M.m5, M.n5, M.shifts, 5u, M.t45); if (sym < 0) return QTM_T_READ;
     qtm_pos_slot((u32) sym, base, extra);
     if (!d.template read_many_t<FAST>((int) extra, v)) return QTM_T_READ;
     val = base + v + 1u; mlen = 4u; return QTM_T_MATCH;
   case 6:
-    sym = qtm_get_symbol<FAST>(d, M.m6l, 27, M.shifts, 7u); if (sym < 0) return QTM_T_READ;
+    sym = qtm_get_symbol<FAST, 16>(d, M.m6l, 27, M.shifts, 7u, M.t66); if (sym < 0) return QTM_T_READ;
     qtm_len_slot((u32) sym, base, extra);
     if (!d.template read_many_t<FAST>((int) extra, v)) return QTM_T_READ;
     mlen = base + v + 5u;
-    sym = qtm_get_symbol<FAST>(d, M.m6, M.n6, M.shifts, 6u); if (sym < 0) return QTM_T_READ;
+    sym = qtm_get_symbol<FAST, 0>(d, M.m6, M.n6, M.shifts, 6u, M.t66); if (sym < 0) return QTM_T_READ;
     qtm_pos_slot((u32) sym, base, extra);
     if (!d.template read_many_t<FAST>((int) extra, v)) return QTM_T_READ;
     val = base + v + 1u; return QTM_T_MATCH;
@@ -378,8 +386,10 @@ __device__ __forceinline__ int qtm_token(QtmDec &d, QtmModels &M, u32 &val, u32 
   }
 }
 
-__device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
-                                mspack_hip_result *res, QtmShared *sh)
+// (forced inline: as a real function its arguments -- and with them the whole coder state -- arrive in VECTOR registers and
+// count as divergent; the chain then runs on the vector unit at twice the latency)
+__device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
+                                                mspack_hip_result *res, QtmShared *sh)
 {
   const u32 lane = threadIdx.x;
   const u32 wb = u.window_bits;
@@ -406,6 +416,8 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
   M.m3 = qtm_model_init(lane, 192, 64); M.m4 = qtm_model_init(lane, 0, M.n4); M.m5 = qtm_model_init(lane, 0, M.n5);
   M.m6 = qtm_model_init(lane, 0, M.n6); M.m6l = qtm_model_init(lane, 0, 27); M.m7 = qtm_model_init(lane, 0, 7);
   M.shifts = 4u;
+  // (qtm_model_init: cumfreq[0] = len)
+  M.t01 = 64u | (64u << 16); M.t23 = 64u | (64u << 16); M.t45 = M.n4 | (M.n5 << 16); M.t66 = M.n6 | (27u << 16); M.t7 = 7u;
 
   // the reference's loop variables (qtmd.c:257-479): window_posn, frame_todo, o_ptr/o_end as window
   // indices, out_bytes still wanted.  P is the linear position of window_posn.
@@ -439,72 +451,94 @@ __device__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8
     }                                                                                         \
   } while (0)
 
-  while ((long long)(o_end - o_ptr) < need) {
-    u32 v;
-    if (!header_read) {
-      d.H = 0xFFFFu; d.L = 0;
-      if (!d.read_bits(16, v)) { err = ERR_READ; break; }
-      d.C = v; header_read = true;
-    }
-    u32 frame_end = (u32)((long long) wpos + (need - (long long)(o_end - o_ptr)));
-    if (wpos + frame_todo < frame_end) frame_end = wpos + frame_todo;
-    if (frame_end > wsize) frame_end = wsize;
-    bool stop = false;
-
-    while (wpos < frame_end) {
-      good = P;
-      u32 moff = 0, mlen = 0;
-      // (far from the end of the input -- a token reads fewer than 96 bytes -- no read can fail: the lean decoder)
-      const bool fast = d.w.origin + d.w.wi * 4u + 96u <= d.w.in_len;
-      const int tk = fast ? qtm_token<true>(d, M, moff, mlen) : qtm_token<false>(d, M, moff, mlen);
-      if (tk < 0) { err = tk == QTM_T_READ ? ERR_READ : ERR_DECRUNCH; stop = true; break; }
-      if (tk == QTM_T_LIT) {
-        lit_buf = wrl(lit_buf, moff, lit_n); lit_pos = wrl(lit_pos, P, lit_n);
-        if (++lit_n == WAVE) QTM_FLUSH();
-        P++; wpos++; frame_todo--;
-        continue;
-      }
-
-      frame_todo -= mlen;
-      if (wpos + mlen > wsize) {                                      // qtmd.c:358-390
-        u32 i = wsize - o_ptr;
-        // (the copy itself is the same on the linear buffer; only the flush bookkeeping differs)
-        if ((long long) i > need) {
-          // first part was already copied by the reference before it bails out
-          QTM_COPY(P, moff, wsize - wpos);
-          err = ERR_DECRUNCH; stop = true; break;
-        }
-        QTM_COPY(P, moff, mlen);
-        written += i; need -= i; o_ptr = 0; o_end = 0;
-        P += mlen; wpos = wpos + mlen - wsize;
-        break;
-      }
-      if (moff > wpos && (moff - wpos) > wsize) { err = ERR_DECRUNCH; stop = true; break; }   // qtmd.c:399
-      QTM_COPY(P, moff, mlen);
-      P += mlen; wpos += mlen;
-      if (spq_due(Q, P)) { QTM_FLUSH(); spq_resolve(sh->spq, Q, out, P, false, lane, out_len); }
-    }
-    if (stop) break;
-    o_end = wpos;
-    // a match that overshot the frame fails every request that needed that match: `good` still
-    // holds the position where it started
-    if (frame_todo > QTM_FRAME) { err = ERR_DECRUNCH; break; }         // qtmd.c:424
-    good = P ? P - 1u : 0u;       // errors in the frame-end handling hit the request ending here
-    if (frame_todo == 0u) {
-      int n = d.rbl & 7;                                               // qtmd.c:432
-      if (n) { d.need(n); d.bb <<= n; d.bl -= n; d.rbl -= n; }
-      bool ok = true;
-      do { if (!d.read_bits(8, v)) { ok = false; break; } } while (v != 0xFFu);
-      if (!ok) { err = ERR_READ; break; }
-      header_read = false; frame_todo = QTM_FRAME;
-    }
-    good = P;
-    if (wpos == wsize) {
-      u32 i = o_end - o_ptr;
-      if ((long long) i >= need) break;
-      written += i; need -= i; o_ptr = 0; o_end = 0; wpos = 0;
-    }
+  // The decode loop (qtmd.c:283-470).  Far from the end of the input -- a token reads fewer than 96 bytes -- no read can fail:
+  // the lean decoder (FAST).  Round 5: the lean and the exact decoder are TWO copies of the whole loop, one run after the
+  // other, not two arms per token inside one loop: the hot loop holds nine GET_SYMBOL bodies instead of eighteen, and what
+  // only the exact reader needs stays out of its registers.  The lean copy leaves BETWEEN two tokens when the input's last
+  // 96 bytes begin (switch_; o_end = wpos as at the end of every pass: the head of the loop then recomputes the same frame_end
+  // from the state), so the exact copy just goes on.
+  // (Two loops in a row inside the frame loop -- the first attempt -- made the compiler treat the coder's wave-uniform
+  // state as divergent: the whole chain moved to the vector unit.  Checked in the ISA: build/isa/qtm_r5.txt.)
+#ifndef QTM_SPLIT_LOOPS
+#define QTM_SPLIT_LOOPS 1          /* 0: one loop, lean or exact decided per token (rounds 3-4) */
+#endif
+#define QTM_FAR_FROM_END() (d.w.origin + d.w.wi * 4u + 96u <= d.w.in_len)
+#define QTM_DECODE_LOOP(LEAVE_WHEN_NEAR_END_, TOKEN_, switch_)                                        \
+  while ((long long)(o_end - o_ptr) < need) {                                                         \
+    u32 v;                                                                                            \
+    if (!header_read) {                                                                               \
+      d.H = 0xFFFFu; d.L = 0;                                                                         \
+      if (!d.read_bits(16, v)) { err = ERR_READ; break; }                                             \
+      d.C = v; header_read = true;                                                                    \
+    }                                                                                                 \
+    u32 frame_end = (u32)((long long) wpos + (need - (long long)(o_end - o_ptr)));                    \
+    if (wpos + frame_todo < frame_end) frame_end = wpos + frame_todo;                                 \
+    if (frame_end > wsize) frame_end = wsize;                                                         \
+    bool stop = false;                                                                                \
+    while (wpos < frame_end) {                                                                        \
+      if (LEAVE_WHEN_NEAR_END_ && !QTM_FAR_FROM_END()) { o_end = wpos; switch_ = true; stop = true; break; } \
+      good = P;                                                                                       \
+      u32 moff = 0, mlen = 0;                                                                         \
+      const int tk = TOKEN_;                                                                          \
+      if (tk < 0) { err = tk == QTM_T_READ ? ERR_READ : ERR_DECRUNCH; stop = true; break; }           \
+      if (tk == QTM_T_LIT) {                                                                          \
+        lit_buf = wrl(lit_buf, moff, lit_n); lit_pos = wrl(lit_pos, P, lit_n);                        \
+        if (++lit_n == WAVE) QTM_FLUSH();                                                             \
+        P++; wpos++; frame_todo--;                                                                    \
+        continue;                                                                                     \
+      }                                                                                               \
+      frame_todo -= mlen;                                                                             \
+      if (wpos + mlen > wsize) {                                      /* qtmd.c:358-390 */            \
+        u32 i = wsize - o_ptr;                                                                        \
+        /* (the copy itself is the same on the linear buffer; only the flush bookkeeping differs) */  \
+        if ((long long) i > need) {                                                                   \
+          /* first part was already copied by the reference before it bails out */                    \
+          QTM_COPY(P, moff, wsize - wpos);                                                            \
+          err = ERR_DECRUNCH; stop = true; break;                                                     \
+        }                                                                                             \
+        QTM_COPY(P, moff, mlen);                                                                      \
+        written += i; need -= i; o_ptr = 0; o_end = 0;                                                \
+        P += mlen; wpos = wpos + mlen - wsize;                                                        \
+        break;                                                                                        \
+      }                                                                                               \
+      if (moff > wpos && (moff - wpos) > wsize) { err = ERR_DECRUNCH; stop = true; break; }   /* qtmd.c:399 */ \
+      QTM_COPY(P, moff, mlen);                                                                        \
+      P += mlen; wpos += mlen;                                                                        \
+      if (spq_due(Q, P)) { QTM_FLUSH(); spq_resolve(sh->spq, Q, out, P, false, lane, out_len); }      \
+    }                                                                                                 \
+    if (stop) break;                                                                                  \
+    o_end = wpos;                                                                                     \
+    /* a match that overshot the frame fails every request that needed that match: `good` still       \
+     * holds the position where it started */                                                         \
+    if (frame_todo > QTM_FRAME) { err = ERR_DECRUNCH; break; }         /* qtmd.c:424 */               \
+    good = P ? P - 1u : 0u;       /* errors in the frame-end handling hit the request ending here */  \
+    if (frame_todo == 0u) {                                                                           \
+      int n = d.rbl & 7;                                               /* qtmd.c:432 */               \
+      if (n) { d.need(n); d.bb <<= n; d.bl -= n; d.rbl -= n; }                                        \
+      bool ok = true;                                                                                 \
+      do { if (!d.read_bits(8, v)) { ok = false; break; } } while (v != 0xFFu);                       \
+      if (!ok) { err = ERR_READ; break; }                                                             \
+      header_read = false; frame_todo = QTM_FRAME;                                                    \
+    }                                                                                                 \
+    good = P;                                                                                         \
+    if (wpos == wsize) {                                                                              \
+      u32 i = o_end - o_ptr;                                                                          \
+      if ((long long) i >= need) break;                                                               \
+      written += i; need -= i; o_ptr = 0; o_end = 0; wpos = 0;                                        \
+    }                                                                                                 \
   }
+  {
+    bool to_exact = false;
+#if QTM_SPLIT_LOOPS
+    QTM_DECODE_LOOP(true, qtm_token<true>(d, M, moff, mlen), to_exact)
+    if (to_exact) { bool never = false; QTM_DECODE_LOOP(false, qtm_token<false>(d, M, moff, mlen), never) (void) never; }
+#else
+    QTM_DECODE_LOOP(false, (QTM_FAR_FROM_END() ? qtm_token<true>(d, M, moff, mlen) : qtm_token<false>(d, M, moff, mlen)), to_exact)
+    (void) to_exact;
+#endif
+  }
+#undef QTM_DECODE_LOOP
+#undef QTM_FAR_FROM_END
   QTM_FLUSH();
   // whatever is still queued lies below the highest position any token reached
   {

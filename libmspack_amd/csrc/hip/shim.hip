@@ -786,7 +786,6 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       if (u.out_len) { snprintf(errbuf, errcap, "unit %u: a checksum unit has no output", idx[i]); return -1; }
       if (u.in_off + u.in_len > in_bytes) { snprintf(errbuf, errcap, "unit outside arena"); return -1; }
       in_lo = std::min<uint64_t>(in_lo, u.in_off); in_hi = std::max<uint64_t>(in_hi, u.in_off + u.in_len);
-      in_sum += u.in_len;
       continue;
     }
     // kind 0 = "no codec": the unit is carried along, no kernel takes it, its result says MSPACK_ERR_ARGS
@@ -848,8 +847,17 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     // (a chunk: >= 8 MiB of input -- a copy of >= 150 us -- and >= 256 units)
     static const size_t chunk_bytes = (size_t) env_int("MSPACK_HIP_CHUNK_BYTES", 8 << 20, 1, 1 << 30);
     static const size_t chunk_units = (size_t) env_int("MSPACK_HIP_CHUNK_UNITS", 256, 1, 1 << 30);
+    bool has_qtm = false;
     size_t want = monotone ? std::min<size_t>((size_t) cx.max_chunks, std::max<size_t>(1, in_sum / chunk_bytes)) : 1;
-    want = std::min(want, std::max<size_t>(1, n_sel / chunk_units));
+    {
+      // (units that decode: checksum units ride along and are no reason to cut)
+      size_t n_dec = 0;
+      for (size_t i = 0; i < n_sel; i++) {
+        if (local[i].kind != MSPACK_HIP_KIND_XORSUM) n_dec++;
+        if (local[i].kind == MSPACK_HIP_KIND_QUANTUM) has_qtm = true;
+      }
+      want = std::min(want, std::max<size_t>(1, n_dec / chunk_units));
+    }
     std::vector<Chunk> chunks;
     {
       // shares of the input bytes.  MSPACK_HIP_CHUNK_SHAPE: 0 equal (to the device: the default); 1 = 1 : 1 : 2 : 4 ... (measured
@@ -934,7 +942,10 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     // compute streams in use: all of them when the output stays on the device (the chunks' launches side by side: the
     // last one ends earliest), two when it goes back to the host (the chunks then finish one after the other and the
     // copy-back, the longest leg, starts early) -- measured, profiles/round3_hostpath.txt
-    const size_t n_comp = host_out ? std::min<size_t>(2, (size_t) cx.n_compute) : (size_t) cx.n_compute;
+    // (A Quantum unit is one long serial chain: a launch of them takes as long as its slowest folder however few there are.
+    // Chunks that hold some must not queue behind each other on one compute stream: all streams then, also to the host --
+    // with 16 384 checksum units beside 512 folders config 4 was cut into four chunks on two streams: 794 ms instead of 416)
+    const size_t n_comp = (host_out && !has_qtm) ? std::min<size_t>(2, (size_t) cx.n_compute) : (size_t) cx.n_compute;
     hipStream_t st_in = cx.st[0], st_out = one ? cx.st[0] : cx.st[1];
     TRY(hipMemcpyAsync(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice, st_in));
     TRY(hipMemcpyAsync(d_order, order.data(), n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, st_in));

@@ -745,7 +745,7 @@ struct gathered {
 /* walk the CFDATA chain of one folder (reference cabd.c:1283-1345 + 1362-1459), following it through
  * the cabinets of a set.  Returns MSPACK_ERR_OPEN / SEEK / NOMEMORY when nothing could be started (the arena is as it
  * was); every later failure ends the chain and is recorded as the feeder's error (g->read_err, g->hard_eof). */
-static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_arena *A, struct ck_list *ck, unsigned int owner)
+static int gather_folder_once(struct cabd_p *self, struct gathered *g, struct in_arena *A, struct ck_list *ck, unsigned int owner)
 {
   struct mspack_system *sys = self->system;
   struct folder_p *fol = g->fol;
@@ -859,6 +859,22 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
     else { g->tab_off = A->len; memcpy(A->p + A->len, g->boff, (size_t) g->nblk * 4); A->len += (size_t) g->nblk * 4; }
   }
   return MSPACK_ERR_OK;
+}
+
+static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_arena *A, struct ck_list *ck, unsigned int owner)
+{
+  const size_t ck_mark = ck ? ck->n : 0, len0 = A->len;
+  int err = gather_folder_once(self, g, A, ck, owner);
+  if (!err && g->hard_eof && ck && ck->n > ck_mark) {
+    /* the chain broke behind blocks whose checksums nobody has verified yet (they were left to the device), and the input is cut
+     * at the failing read: those parts no longer lie in the arena as they were read.  Once more, verifying while the blocks are
+     * read -- what the reference does: a block whose checksum fails ends the chain first. */
+    ck->n = ck_mark; A->len = len0;
+    self->system->free(g->boff); g->boff = NULL;
+    g->fol->cksum_on_host = 1;
+    err = gather_folder_once(self, g, A, ck, owner);
+  }
+  return err;
 }
 
 /* decode every not-yet-decoded folder of `cab` (budget permitting, `want` always) in ONE batch */

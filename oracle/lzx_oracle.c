@@ -13,6 +13,8 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "oracle.h"
 __thread int oracle_hard_eof_;          /* oracle_set_hard_eof(): the feeder's read FAILS at in_len (cabd.c:1322-1324) instead of ending */
 void oracle_set_hard_eof(int on) { oracle_hard_eof_ = on; }
@@ -128,6 +130,7 @@ static int block_header(lzx_t *z) {
   if (rd_bits(b, 3, &t) || rd_bits(b, 16, &hi) || rd_bits(b, 8, &lo)) return 1;
   z->block_type = (int) t;
   z->block_remaining = z->block_length = (hi << 8) | lo;
+  if (getenv("ORACLE_LZX_TRACE")) fprintf(stderr, "lzx block: frame %u type %d length %u\n", (unsigned) z->frame, z->block_type, (unsigned) z->block_length);
   switch (z->block_type) {
   case BT_ALIGNED:
     for (i = 0; i < 8; i++) { if (rd_bits(b, 3, &v)) return 1; z->ali_len[i] = (uint8_t) v; }

@@ -222,3 +222,49 @@ def test_units_with_and_without_tables_in_one_batch(built, shape):
     with_tab = np.array([t is not None for t in tabs])
     assert ((res["flags"][with_tab] & ADOPTED) != 0).all(), "a unit with a frame table did not take the frame-parallel path"
     assert ((res["flags"][~with_tab] & ADOPTED) == 0).all()
+
+
+def test_blocks_that_span_frames(built):
+    """Round 5: a frame need not be one block.  Block sizes of several frames, of a fraction of a frame, ending anywhere inside a
+    frame (this build's encoder with block_size set), verbatim and aligned: with frame tables every such unit must come out of the
+    frame-parallel path (FRAMES_ADOPTED) and equal the oracle in error code, flags, in_next and every byte."""
+    data = M.gen_plaintext(31, M.TEXT_MIX, 14 * 32768 + 4321)
+    streams, params, tabs = [], [], []
+    for bs in (100000, 65536, 32768 * 5, 40000, 20000, 9999, 1 << 20):
+        for mode in (0, 1, 2):
+            for wb, reset in ((21, 0), (17, 4)):
+                comp, fo = M.lzx_encode(data, wb, reset, M.lzx_opts(mode=mode, block_size=bs))
+                fo = fo.astype(np.int64)
+                if reset == 0:
+                    streams.append(comp.tobytes()); params.append((data.size, wb, 0, 0)); tabs.append(fo[:-1])
+                else:
+                    ib = reset * 32768
+                    for k in range(0, data.size, ib):
+                        f0, f1 = k // 32768, min((k + ib + 32767) // 32768, len(fo) - 1)
+                        streams.append(comp[int(fo[f0]):].tobytes()); params.append((min(ib, data.size - k), wb, reset, k))
+                        tabs.append(fo[f0:f1] - fo[f0])
+    units, out, res = run(streams, params, tabs)
+    check(streams, params, units, out, res)
+    assert (res["flags"] & ADOPTED).all(), np.nonzero((res["flags"] & ADOPTED) == 0)[0][:10]
+
+
+def test_real_cabinet_blocks_of_megabytes(built):
+    """The reference's large-files.cab (Microsoft's encoder): LZX-15 and LZX-21 folders whose blocks are MEGABYTES long (the first
+    one 8 384 624 bytes: it ends inside frame 255) -- every frame but one in 256 lies inside a block and has no header.  The first
+    300 CFDATA blocks of both folders with the cabinet's block sizes as the frame table, against the oracle; the frame-parallel
+    path must have taken them (rounds 2-4 sent every real cabinet down the serial path)."""
+    import base64, json, os
+    import helpers
+    kat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_folders.json")
+    k = [v for v in json.load(open(kat)) if v["source"].endswith("large-files-cab.cab")][0]
+    e, inner, _r = oracle_lzx(base64.b64decode(k["stream_b64"]), k["out_len"], k["window_bits"], 0)
+    assert e == 0
+    streams, params, tabs = [], [], []
+    for f in helpers.cab_folders(helpers.cab_cut_folders(inner, 300))[1:3]:
+        assert (f["comp_type"] & 0x0F) == 3
+        blocks = [p for p, _u in f["blocks"]]
+        streams.append(b"".join(blocks)); params.append((sum(u for _p, u in f["blocks"]), (f["comp_type"] >> 8) & 0x1F, 0, 0))
+        tabs.append(np.cumsum([0] + [len(b) for b in blocks[:-1]]).astype(np.int64))
+    units, out, res = run(streams, params, tabs)
+    check(streams, params, units, out, res)
+    assert (res["flags"] & ADOPTED).all()
