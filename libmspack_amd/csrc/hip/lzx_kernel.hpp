@@ -2419,35 +2419,12 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
         if (!lzx_front_batch(ism, lane, opos, olen, which, c1, R0, R1, R2, frame_pos, wbase, wsize, vmoff)) { bad = true; break; }
         PH(9);
         // (3) queue the copies (cf. lzx_commit_batch)
+        // (runs -- matches in a row at one offset -- are written as periodic fills, the rest goes through the queue: spec_queue.hpp)
         const u32 newP = rdl(opos + olen, n - 1u);
-        if (spq_is_run(ism, n, opos, olen, vmoff, lane)) {
-          // the batch is one run (spec_queue.hpp): everything below it final, then stores only
-          const u32 rs = rdl(opos, 0u);
-          spq_resolve(*spq, Q, out, rs, true, lane);
-          spq_fill_run(out, rs, newP, rdl(vmoff, 0u), lane);
-          Q.Pf = newP;
-          PH(11);
-        }
-        else {
-          u64 mq = mm;
-          if (Q.mcount + (u32) __popcll(mq) > SPQ_CAP) spq_resolve(*spq, Q, out, rdl(opos, 0u), true, lane);
-          bool im = ism;
-          for (;;) {
-            const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
-            const u64 fit = newP <= limit ? mq : ballot(im && opos + olen <= limit);
-            if (fit) {
-              const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
-              spq_push(*spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, vmoff, olen);
-              mq &= ~fit;
-              im = lane_in(mq);
-            }
-            if (!mq) break;
-            spq_resolve(*spq, Q, out, rdl(opos, (u32) __ffsll((long long) mq) - 1u), true, lane);
-          }
-          PH(10);
-          if (spq_due(Q, newP)) spq_resolve(*spq, Q, out, newP, false, lane);
-          PH(11);
-        }
+        spq_push_runs(*spq, Q, out, ism, n, opos, olen, vmoff, lane);
+        PH(10);
+        if (spq_due(Q, newP)) spq_resolve(*spq, Q, out, newP, false, lane);
+        PH(11);
         th += n;
       }
       cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;

@@ -848,29 +848,8 @@ __device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *pool_base
                                  (dist > rpos && (!lin_hist || dist > rpos + ZIP_FRAME)));
       if (ballot(bad)) { ok = false; done = true; break; }
       const u32 newP = rdl(opos + olen, n - 1u);
-      u64 mm = ballot(valid);
-      bool ism = valid;
-      if (spq_is_run(valid, n, opos, olen, dist, lane)) {
-        // the batch is one run (spec_queue.hpp): everything below it final, then stores only
-        const u32 rs = rdl(opos, 0u);
-        spq_resolve(sh->spq, Q, out, rs, true, lane);
-        spq_fill_run(out, rs, newP, rdl(dist, 0u), lane);
-        Q.Pf = newP;
-        mm = 0ull;
-      }
-      else if (Q.mcount + n > SPQ_CAP) spq_resolve(sh->spq, Q, out, P, true, lane);
-      while (mm) {
-        const u32 limit = (Q.Pf & ~63u) + SPQ_RING;
-        const u64 fit = newP <= limit ? mm : ballot(ism && opos + olen <= limit);
-        if (fit) {
-          const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
-          spq_push(sh->spq, Q, lane_in(fit), rank, (u32) __popcll(fit), opos, dist, olen);
-          mm &= ~fit;
-          ism = lane_in(mm);
-        }
-        if (!mm) break;
-        spq_resolve(sh->spq, Q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
-      }
+      // (runs -- matches in a row at one distance -- are written as periodic fills, the rest goes through the queue: spec_queue.hpp)
+      spq_push_runs(sh->spq, Q, out, valid, n, opos, olen, dist, lane);
       P = newP;
       if (spq_due(Q, P)) spq_resolve(sh->spq, Q, out, P, false, lane);
     }

@@ -195,13 +195,25 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
 #ifndef SPQ_RUN_MIN
 #define SPQ_RUN_MIN 512u            /* a batch takes the run path when it spans at least this many bytes */
 #endif
-__device__ __forceinline__ bool spq_is_run(const bool ism, const u32 n, const u32 opos, const u32 olen, const u32 off, const u32 lane)
+// which matches of a batch (lanes 0..n-1, in position order) END a run that is worth the fill path: bit l set = the run that ends
+// with lane l spans at least SPQ_RUN_MIN bytes; seg_first = the lane the run of a lane's match begins with.  A run is a maximal
+// stretch of matches that follow each other without a gap and share one offset (one match alone -- at most 258 bytes -- never
+// qualifies).  A batch may hold several: the large-files MSZIP blocks open with one match at distance 320 or 256, then 126 at 64.
+__device__ __forceinline__ u64 spq_find_runs(const bool ism, const u32 n, const u32 opos, const u32 olen, const u32 off, const u32 lane,
+                                             u32 &seg_first)
 {
-  if (n < 2u) return false;
-  const u32 s = rdl(opos, 0u), e = rdl(opos + olen, n - 1u), off0 = rdl(off, 0u);
-  if (e - s < SPQ_RUN_MIN || off0 == 0u || off0 > s) return false;
-  const u32 nextp = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane + 1u) & 63u) << 2), (int) opos);
-  return !ballot(ism && (off != off0 || (lane + 1u < n && opos + olen != nextp)));
+  const u32 prev_end = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int)(opos + olen));
+  const u32 prev_off = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) off);
+  const bool cont = ism && lane != 0u && prev_end == opos && prev_off == off;      // continues the match of the lane below
+  const u64 contm = ballot(cont);
+  seg_first = lane;
+  if (!contm) return 0ull;                                                          // (ordinary data: no two matches in a row)
+  const u64 startm = ballot(ism && !cont);                                          // lanes that begin a run
+  const u64 below = startm & ((lane == 63u) ? ~0ull : ((2ull << lane) - 1ull));     // ... at or below this lane
+  seg_first = below ? 63u - (u32) __clzll((long long) below) : 0u;
+  const u32 first_pos = (u32) __builtin_amdgcn_ds_bpermute((int)(seg_first << 2), (int) opos);
+  const bool last = ism && (lane + 1u == n || !((contm >> ((lane + 1u) & 63u)) & 1ull) || lane == 63u);
+  return ballot(last && seg_first != lane && opos + olen - first_pos >= SPQ_RUN_MIN && off != 0u && off <= first_pos);
 }
 // write the run [s, e) with period `off` (everything below s is final in memory); stores at or above `clip` are dropped
 __device__ __forceinline__ void spq_fill_run(u8 *const out, const u32 s, const u32 e, const u32 off, const u32 lane,
@@ -216,7 +228,27 @@ __device__ __forceinline__ void spq_fill_run(u8 *const out, const u32 s, const u
     u32 k = lane % off;                                  // (one division per run)
     const u32 pat = (u32) gld(src + k);
     const u32 step = 64u % off;
-    for (u32 cb = s; cb < e; cb += 64u) {
+    u32 cb = s;
+    if (step == 0u) {
+      // the period divides the wave: every lane writes ONE value all the way down (zeros, a 64-byte line: large-files.test)
+      const u32 v = (u32) __builtin_amdgcn_ds_bpermute((int)(k << 2), (int) pat);
+      for (; cb + 64u <= e && cb + 64u <= clip; cb += 64u) gst(out + cb + lane, (u8) v);
+      if (cb < e && cb + lane < e && cb + lane < clip) gst(out + cb + lane, (u8) v);
+      return;
+    }
+    // four chunks per pass: their lane look-ups are in flight together (one LDS latency per 256 bytes, not per 64)
+    u32 step4 = step * 4u; while (step4 >= off) step4 -= off;
+    for (; cb + 256u <= e && cb + 256u <= clip; cb += 256u) {
+      u32 k1 = k + step; if (k1 >= off) k1 -= off;
+      u32 k2 = k1 + step; if (k2 >= off) k2 -= off;
+      u32 k3 = k2 + step; if (k3 >= off) k3 -= off;
+      const u32 v0 = (u32) __builtin_amdgcn_ds_bpermute((int)(k << 2), (int) pat), v1 = (u32) __builtin_amdgcn_ds_bpermute((int)(k1 << 2), (int) pat);
+      const u32 v2 = (u32) __builtin_amdgcn_ds_bpermute((int)(k2 << 2), (int) pat), v3 = (u32) __builtin_amdgcn_ds_bpermute((int)(k3 << 2), (int) pat);
+      u8 *const o = out + cb + lane;
+      gst(o, (u8) v0); gst(o + 64, (u8) v1); gst(o + 128, (u8) v2); gst(o + 192, (u8) v3);
+      k += step4; if (k >= off) k -= off;
+    }
+    for (; cb < e; cb += 64u) {
       const u32 b = cb + lane;
       const u32 v = (u32) __builtin_amdgcn_ds_bpermute((int)(k << 2), (int) pat);
       if (b < e && b < clip) gst(out + b, (u8) v);
@@ -252,4 +284,47 @@ __device__ __forceinline__ void spq_push(SpecQueueLds &l, SpecQueue &q, const bo
     atomicOr((unsigned long long *) &l.mbits[(pos & (SPQ_RING - 1u)) >> 6], 1ull << (pos & 63u));
   }
   q.mcount += n;
+}
+
+// queue the matches of the lanes in `mm` (position order; newP = the end of the last of them): a push must keep every start flag
+// inside the ring, so the matches that end inside it are taken, the queue is resolved up to the first one that does not, and on
+__device__ __forceinline__ void spq_push_batch(SpecQueueLds &l, SpecQueue &q, u8 *const out, u64 mm, const u32 opos, const u32 off,
+                                               const u32 olen, const u32 newP, const u32 lane)
+{
+  if (!mm) return;
+  if (q.mcount + (u32) __popcll(mm) > SPQ_CAP) spq_resolve(l, q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
+  bool im = lane_in(mm);
+  for (;;) {
+    const u32 limit = (q.Pf & ~63u) + SPQ_RING;
+    const u64 fit = newP <= limit ? mm : ballot(im && opos + olen <= limit);
+    if (fit) {
+      const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(fit >> 32), __builtin_amdgcn_mbcnt_lo((u32) fit, 0u));
+      spq_push(l, q, lane_in(fit), rank, (u32) __popcll(fit), opos, off, olen);
+      mm &= ~fit;
+      im = lane_in(mm);
+    }
+    if (!mm) break;
+    spq_resolve(l, q, out, rdl(opos, (u32) __ffsll((long long) mm) - 1u), true, lane);
+  }
+}
+
+// a batch of n matches (lanes 0..n-1): its runs through the fill path, everything else into the queue, in position order
+__device__ __forceinline__ void spq_push_runs(SpecQueueLds &l, SpecQueue &q, u8 *const out, const bool ism, const u32 n,
+                                              const u32 opos, const u32 olen, const u32 off, const u32 lane)
+{
+  u32 seg_first;
+  u64 runs = spq_find_runs(ism, n, opos, olen, off, lane, seg_first);
+  u64 rest = ballot(ism);
+  while (runs) {
+    const u32 b = (u32) __ffsll((long long) runs) - 1u, a = rdl(seg_first, b);
+    const u64 pre = rest & ((1ull << a) - 1ull);
+    if (pre) spq_push_batch(l, q, out, pre, opos, off, olen, rdl(opos, a), lane);
+    const u32 rs = rdl(opos, a), re = rdl(opos + olen, b);
+    spq_resolve(l, q, out, rs, true, lane);                 // everything below the run final
+    spq_fill_run(out, rs, re, rdl(off, a), lane);
+    q.Pf = re;
+    rest &= (b == 63u) ? 0ull : ~((2ull << b) - 1ull);
+    runs &= runs - 1ull;
+  }
+  if (rest) spq_push_batch(l, q, out, rest, opos, off, olen, rdl(opos + olen, n - 1u), lane);
 }

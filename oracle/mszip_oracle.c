@@ -11,6 +11,8 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "oracle.h"
 extern __thread int oracle_hard_eof_;   /* lzx_oracle.c: oracle_set_hard_eof() */
 #include "oracle_huff.h"
@@ -170,6 +172,7 @@ static int inflate_block_stream(zip_t *z) {
           if (sym >= 30) return INF_ERR;
           if (z_bits(b, dist_extra[sym], &e)) return ORC_READ;
           dist = dist_base[sym] + e;
+          if (getenv("ORACLE_ZIP_TRACE")) fprintf(stderr, "zip match: pos %u len %u dist %u\n", (unsigned) z->wpos, length, dist);
           mpos = ((dist > z->wpos) ? FRAME : 0) + z->wpos - dist;   /* mszipd.c:267-268 */
           while (length--) { uint8_t c = z->window[mpos++]; mpos &= FRAME - 1; PUT(z, c); }
         }
