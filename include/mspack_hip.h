@@ -244,6 +244,17 @@ void mspack_hip_host_path_stats(double *ms4, int reset);
 int  mspack_hip_pin(const void *p, size_t bytes);
 void mspack_hip_unpin(const void *p);
 
+/* ---- optional: arenas out of the library's own page-locked memory -------------------------------------------
+ * Page-locking a buffer costs about what the copy it speeds up costs, so a caller that builds a fresh arena for every batch
+ * (the C drivers do) gains little from mspack_hip_pin().  mspack_hip_stage_alloc() hands out page-locked memory (page aligned,
+ * every device of the process can copy to and from it) from blocks the library KEEPS when mspack_hip_stage_free() returns
+ * them: locked once per process, not once per call.  At most MSPACK_HIP_PINNED_MB MiB in all (environment; default 1024; 0 =
+ * never): a request beyond that -- or without a device -- returns NULL, and the caller allocates the ordinary way.
+ * mspack_hip_release() frees the idle blocks.  (The drivers use it for arenas of a MiB and more when the mspack_system they
+ * were given allocates with the library's own default allocator -- a caller who supplies an allocator gets every byte from it.) */
+void *mspack_hip_stage_alloc(size_t bytes);
+void  mspack_hip_stage_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,7 @@ EXPORTED_SYMBOLS = [
     "mspack_hip_decode_batch_multi", "mspack_hip_time_batch_device",
     "mspack_hip_decode_batch_to_device", "mspack_hip_release",
     "mspack_hip_set_default_devices", "mspack_hip_default_devices", "mspack_hip_set_cache_mb", "mspack_hip_cache_mb",
+    "mspack_hip_host_path_stats", "mspack_hip_pin", "mspack_hip_unpin", "mspack_hip_stage_alloc", "mspack_hip_stage_free",
 ]
 
 

@@ -111,16 +111,17 @@ static void ms_message(struct mspack_file *file, const char *format, ...)
   va_end(ap);
   log_line(line);
 }
-static void *ms_alloc(struct mspack_system *self, size_t bytes) { (void) self; return malloc(bytes); }
-static void ms_free(void *p) { free(p); }
-static void ms_copy(void *src, void *dest, size_t bytes) { memcpy(dest, src, bytes); }
+/* (alloc / free / copy: the library's own defaults, as in api.MemSystem -- an in-memory FILE layer, not an allocator.  With its
+ *  default allocator the library may take its big staging arenas from page-locked memory it keeps, mspack_hip.h) */
+extern struct mspack_system *mspack_default_system;
 
 static void mem_sys_init(struct mem_sys *ms, const unsigned char *image, size_t image_len, unsigned char *out, size_t out_cap)
 {
   memset(ms, 0, sizeof(*ms));
   ms->sys.open = ms_open; ms->sys.close = ms_close; ms->sys.read = ms_read; ms->sys.write = ms_write;
   ms->sys.seek = ms_seek; ms->sys.tell = ms_tell; ms->sys.message = ms_message;
-  ms->sys.alloc = ms_alloc; ms->sys.free = ms_free; ms->sys.copy = ms_copy; ms->sys.null_ptr = NULL;
+  ms->sys.alloc = mspack_default_system->alloc; ms->sys.free = mspack_default_system->free; ms->sys.copy = mspack_default_system->copy;
+  ms->sys.null_ptr = NULL;
   ms->image = image; ms->image_len = image_len; ms->out = out; ms->out_cap = out_cap;
   g_cur = ms;
 }

@@ -1007,7 +1007,16 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     bool refs_in_out = false;
     for (size_t i = 0; i < n_sel && !refs_in_out; i++) refs_in_out = local[i].kind == MSPACK_HIP_KIND_LZX_DELTA && local[i].ref_len != 0u;
     static const bool pin_out_env = env_int("MSPACK_HIP_PIN_OUT", 1, 0, 1) != 0;
-    const bool pin_out = pin_out_env && !refs_in_out;
+    // (a buffer that is page-locked already -- the drivers' arenas out of mspack_hip_stage_alloc, a caller's hipHostMalloc -- needs
+    // no lock, and ASKING for one is not free: the runtime walks the pages before it notices: ~3 ms per 64 MB chunk, on the
+    // copy-back's critical path)
+    bool out_locked = false;
+    if (host_out) {
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, host_out) == hipSuccess) out_locked = at.type == hipMemoryTypeHost;
+      else (void) hipGetLastError();
+    }
+    const bool pin_out = pin_out_env && !refs_in_out && !out_locked;
     // The INPUT is not locked here by default (MSPACK_HIP_PIN_IN=1 does it, one range per call): for a caller's warm buffer the
     // runtime's pageable path is as fast as the lock costs (to the host 7.4 -> 8.1 ms on the headline batch); for an arena that was
     // just written -- the C drivers' gather -- it runs at 5-6 GB/s, and those callers lock their arena themselves (mspack_hip_pin).
@@ -1218,6 +1227,54 @@ void mspack_hip_unpin(const void *p)
   if (base && hipHostUnregister((void *) base) != hipSuccess) (void) hipGetLastError();
 }
 
+// ---- the library's own page-locked staging memory ----------------------------------------------------------------------
+// Locking a caller's arena per call (mspack_hip_pin) costs about as much as the copy it speeds up (hipHostRegister + Unregister of
+// the 51 MB of config 2's payloads: ~8 of the 39 ms an extract-everything run took), and an output arena that has to be locked
+// chunk by chunk while the copies back wait for it costs more.  So the drivers' big arenas can come from here: blocks of
+// hipHostMalloc'ed memory that are KEPT when they are handed back and reused by the next batch -- the cost of locking is paid
+// once per process, not once per call.  Bounded: MSPACK_HIP_PINNED_MB (default 1024) MiB in all; a request that does not fit
+// returns NULL and the caller takes the sys->alloc + mspack_hip_pin way.  mspack_hip_release() gives the idle blocks back.
+struct StageBlock { void *p; size_t cap; bool busy; };
+static std::mutex g_stage_mu;
+static std::vector<StageBlock> g_stage;
+static size_t g_stage_total = 0;
+void *mspack_hip_stage_alloc(size_t bytes)
+{
+  static const size_t limit = (size_t) env_int("MSPACK_HIP_PINNED_MB", 1024, 0, 1 << 20) << 20;
+  if (!bytes || bytes > limit) return nullptr;
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  StageBlock *best = nullptr;
+  for (StageBlock &b : g_stage)
+    if (!b.busy && b.cap >= bytes && b.cap <= bytes + bytes / 2 + (1u << 20) && (!best || b.cap < best->cap)) best = &b;
+  if (best) { best->busy = true; return best->p; }
+  // room?  idle blocks that fit nothing are given back first
+  if (g_stage_total + bytes > limit) {
+    for (size_t i = 0; i < g_stage.size() && g_stage_total + bytes > limit; )
+      if (!g_stage[i].busy) { if (hipHostFree(g_stage[i].p) != hipSuccess) (void) hipGetLastError(); g_stage_total -= g_stage[i].cap; g_stage.erase(g_stage.begin() + (long) i); }
+      else i++;
+    if (g_stage_total + bytes > limit) return nullptr;
+  }
+  void *p = nullptr;
+  const size_t cap = (bytes + ((size_t) 2 << 20) - 1) & ~(((size_t) 2 << 20) - 1);
+  if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess || !p) { (void) hipGetLastError(); return nullptr; }
+  g_stage.push_back(StageBlock{ p, cap, true });
+  g_stage_total += cap;
+  return p;
+}
+void mspack_hip_stage_free(void *p)
+{
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  for (StageBlock &b : g_stage) if (b.p == p) { b.busy = false; return; }
+}
+static void stage_release_idle()
+{
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  for (size_t i = 0; i < g_stage.size(); )
+    if (!g_stage[i].busy) { if (hipHostFree(g_stage[i].p) != hipSuccess) (void) hipGetLastError(); g_stage_total -= g_stage[i].cap; g_stage.erase(g_stage.begin() + (long) i); }
+    else i++;
+}
+
 void mspack_hip_host_path_stats(double *ms4, int reset)
 {
   std::lock_guard<std::mutex> lock(g_stats_mu);
@@ -1229,6 +1286,7 @@ void mspack_hip_host_path_stats(double *ms4, int reset)
 void mspack_hip_release(void)
 {
   int keep = current_device();
+  stage_release_idle();
   for (int d = 0; d < MSPK_MAX_DEV; d++) {
     DevCtx &cx = g_ctx[d];
     std::lock_guard<std::mutex> lock(cx.mu);

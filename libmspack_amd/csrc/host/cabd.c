@@ -963,7 +963,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     memset(res, 0, nu * sizeof(*res));
     if (nhip) {
       /* the arena was written a moment ago: page-locked, its copy to the device is plain DMA (mspack_hip.h; advice only) */
-      const int pinned = A.len >= ((size_t) 4 << 20) && mspack_hip_pin(A.p, mspack_arena_room(A.len + 64)) == 0;
+      const int pinned = A.len >= ((size_t) 4 << 20) && !mspack_arena_is_locked(A.p) && mspack_hip_pin(A.p, mspack_arena_room(A.len + 64)) == 0;
       /* kinds other than 1..3 are answered with MSPACK_ERR_ARGS by the kernels; fix them up below */
       rc = (self->devices > 1)
         ? mspack_hip_decode_batch_multi(units, nu, A.p, A.len + 64, out_arena, out_bytes + 64, res, self->devices)

@@ -701,7 +701,7 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
   }
 
   /* every batch of this CHM reads the arena: page-locked once, its copies to the device are plain DMA (advice only) */
-  if (!c->arena_pinned && arena_alloc >= ((size_t) 4 << 20)) c->arena_pinned = mspack_hip_pin(c->arena, mspack_arena_room(arena_alloc)) == 0;
+  if (!c->arena_pinned && arena_alloc >= ((size_t) 4 << 20) && !mspack_arena_is_locked(c->arena)) c->arena_pinned = mspack_hip_pin(c->arena, mspack_arena_room(arena_alloc)) == 0;
 
   /* fast-result bookkeeping */
   if (c->n_fast) {

@@ -20,6 +20,8 @@ int mspack_sys_filelen(struct mspack_system *system, struct mspack_file *file, o
 void *mspack_arena_alloc(struct mspack_system *sys, size_t bytes);
 void mspack_arena_free(struct mspack_system *sys, void *arena);
 size_t mspack_arena_room(size_t bytes);
+/* does the arena already lie in page-locked memory (the library's staging blocks)?  Then there is nothing to mspack_hip_pin() */
+int mspack_arena_is_locked(const void *arena);
 
 static inline unsigned int rd_le16(const unsigned char *p) { return (unsigned int) p[0] | ((unsigned int) p[1] << 8); }
 static inline unsigned int rd_le32(const unsigned char *p) {

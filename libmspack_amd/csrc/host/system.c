@@ -14,15 +14,25 @@
  * (include/mspack_hip.h: mspack_hip_pin; DESIGN.md sec. 8h: what happened when one did).  The block sys->alloc returned is
  * remembered in the word below the arena; mspack_arena_free() hands that block back to sys->free. */
 #define ARENA_PAGE ((size_t) 4096)
+#define ARENA_TAG_SYS    0x41726e61u          /* the block came from sys->alloc */
+#define ARENA_TAG_STAGE  0x53746167u          /* ... from the library's page-locked staging memory (mspack_hip_stage_alloc) */
+struct arena_hdr { void *raw; unsigned int tag, pad; };     /* lies right below the arena */
+static void *std_alloc(struct mspack_system *self, size_t bytes);
 void *mspack_arena_alloc(struct mspack_system *sys, size_t bytes) {
   const size_t room = (bytes + ARENA_PAGE - 1) & ~(ARENA_PAGE - 1);
-  unsigned char *raw, *p;
-  if (room < bytes || room + ARENA_PAGE + sizeof(void *) < room) return NULL;
-  if (!(raw = (unsigned char *) sys->alloc(sys, room + ARENA_PAGE + sizeof(void *)))) return NULL;
-  p = (unsigned char *)(((uintptr_t) raw + sizeof(void *) + ARENA_PAGE - 1) & ~(uintptr_t)(ARENA_PAGE - 1));
-  memcpy(p - sizeof(void *), &raw, sizeof(void *));
+  unsigned char *raw = NULL, *p;
+  struct arena_hdr h;
+  if (room < bytes || room + 2 * ARENA_PAGE < room) return NULL;
+  h.tag = ARENA_TAG_SYS; h.pad = 0;
+  /* big arenas of a caller who did not bring an allocator: page-locked memory the library keeps between batches (mspack_hip.h) */
+  if (room >= ((size_t) 1 << 20) && sys->alloc == &std_alloc && (raw = (unsigned char *) mspack_hip_stage_alloc(room + ARENA_PAGE)))
+    h.tag = ARENA_TAG_STAGE;
+  if (!raw && !(raw = (unsigned char *) sys->alloc(sys, room + ARENA_PAGE + sizeof(struct arena_hdr)))) return NULL;
+  p = (unsigned char *)(((uintptr_t) raw + sizeof(struct arena_hdr) + ARENA_PAGE - 1) & ~(uintptr_t)(ARENA_PAGE - 1));
+  h.raw = raw;
+  memcpy(p - sizeof(h), &h, sizeof(h));
 #if defined(__linux__) && defined(MADV_HUGEPAGE)
-  {
+  if (h.tag == ARENA_TAG_SYS) {
     static int on = -1;                 /* MSPACK_ARENA_HUGEPAGES=0 turns the advice off */
     if (on < 0) { const char *e = getenv("MSPACK_ARENA_HUGEPAGES"); on = !(e && e[0] == '0'); }
     if (on && room >= ((size_t) 4 << 20)) {
@@ -35,10 +45,17 @@ void *mspack_arena_alloc(struct mspack_system *sys, size_t bytes) {
   return p;
 }
 void mspack_arena_free(struct mspack_system *sys, void *arena) {
-  void *raw;
+  struct arena_hdr h;
   if (!arena) return;
-  memcpy(&raw, (unsigned char *) arena - sizeof(void *), sizeof(void *));
-  sys->free(raw);
+  memcpy(&h, (unsigned char *) arena - sizeof(h), sizeof(h));
+  if (h.tag == ARENA_TAG_STAGE) mspack_hip_stage_free(h.raw);
+  else sys->free(h.raw);
+}
+int mspack_arena_is_locked(const void *arena) {
+  struct arena_hdr h;
+  if (!arena) return 0;
+  memcpy(&h, (const unsigned char *) arena - sizeof(h), sizeof(h));
+  return h.tag == ARENA_TAG_STAGE;
 }
 size_t mspack_arena_room(size_t bytes) { return (bytes + ARENA_PAGE - 1) & ~(ARENA_PAGE - 1); }
 

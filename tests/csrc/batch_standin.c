@@ -108,3 +108,5 @@ void mspack_hip_host_path_stats(double *ms4, int reset)
 }
 int mspack_hip_pin(const void *p, size_t bytes) { (void) p; (void) bytes; return 1; }      /* (nothing to lock without a device) */
 void mspack_hip_unpin(const void *p) { (void) p; }
+void *mspack_hip_stage_alloc(size_t bytes) { (void) bytes; return 0; }                       /* (no device: the ordinary allocator) */
+void mspack_hip_stage_free(void *p) { (void) p; }

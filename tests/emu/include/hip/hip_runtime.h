@@ -140,6 +140,7 @@ typedef struct emu_event_ *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
+#define hipHostMallocPortable 1
 #define hipEventDisableTiming 2
 struct hipDeviceProp_t { int multiProcessorCount; char name[64]; };
 const char *hipGetErrorString(hipError_t e);
@@ -164,6 +165,9 @@ void emu_test_delay(void);
 #define hipHostRegisterPortable 1
 static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeUnregistered; return hipSuccess; }
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s = 0);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s = 0);

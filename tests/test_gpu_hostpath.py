@@ -432,3 +432,34 @@ def test_xorsum_units_vs_oracle(built):
     for i, (o, ln) in enumerate(zip(offs, lens)):
         r = res[inv][len(units) + i]
         assert r["err"] == 0 and int(r["in_next"]) == oracle_cab_checksum(arena[o:o + ln].tobytes()), (i, o, ln)
+
+
+def test_staging_pool(built):
+    """mspack_hip_stage_alloc / _free: page-locked blocks the library keeps and hands out again (the drivers' arenas of a MiB and
+    more, when the caller's mspack_system allocates with the library's default allocator); a batch decodes out of and into them;
+    a request beyond MSPACK_HIP_PINNED_MB gets NULL (the caller then allocates the ordinary way)."""
+    import ctypes as C
+    L = M.lib()
+    L.mspack_hip_stage_alloc.restype = C.c_void_p
+    L.mspack_hip_stage_alloc.argtypes = [C.c_size_t]
+    L.mspack_hip_stage_free.argtypes = [C.c_void_p]
+    n, ub = 128, 65536
+    plain, comp, off, ln = M.corpus_lzx_units(0x5151, 0, n, ub, 21)
+    units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=2)
+    p_in = L.mspack_hip_stage_alloc(comp.size + 64)
+    p_out = L.mspack_hip_stage_alloc(out_bytes + 64)
+    assert p_in and p_out and p_in % 4096 == 0 and p_out % 4096 == 0
+    a = np.frombuffer((C.c_ubyte * (comp.size + 64)).from_address(p_in), dtype=np.uint8)
+    o = np.frombuffer((C.c_ubyte * (out_bytes + 64)).from_address(p_out), dtype=np.uint8)
+    a[:comp.size] = comp; a[comp.size:] = 0; o[:] = 0
+    res = np.zeros(n, dtype=M.RESULT_DTYPE)
+    u = np.ascontiguousarray(units)
+    rc = L.mspack_hip_decode_batch(u.ctypes.data, n, p_in, comp.size + 64, p_out, out_bytes + 64, res.ctypes.data)
+    assert rc == 0 and (res["err"] == 0).all() and np.array_equal(o[:n * ub], plain)
+    del a, o
+    L.mspack_hip_stage_free(p_in); L.mspack_hip_stage_free(p_out)
+    again = L.mspack_hip_stage_alloc(comp.size + 64)              # the same block comes back
+    assert again in (p_in, p_out)
+    L.mspack_hip_stage_free(again)
+    assert not L.mspack_hip_stage_alloc(1 << 44)                   # beyond any budget
+    M.lib().mspack_hip_release()

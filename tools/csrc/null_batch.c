@@ -36,3 +36,5 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n, const void *
 void mspack_hip_host_path_stats(double *ms4, int reset) { (void) reset; if (ms4) { ms4[0] = ms4[1] = ms4[3] = 0; ms4[2] = g_ms; } if (reset) g_ms = 0; }
 int mspack_hip_pin(const void *p, size_t bytes) { (void) p; (void) bytes; return 1; }      /* (nothing to lock without a device) */
 void mspack_hip_unpin(const void *p) { (void) p; }
+void *mspack_hip_stage_alloc(size_t bytes) { (void) bytes; return 0; }                       /* (no device: the ordinary allocator) */
+void mspack_hip_stage_free(void *p) { (void) p; }
