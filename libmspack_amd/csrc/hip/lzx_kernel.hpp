@@ -1717,10 +1717,11 @@ template <bool ALIGNED>
 __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empty, const u32 start_bit, const u32 frame_end_bit,
                                                u8 *const fout, const u32 frame_pos, const u32 frame_size, const u32 edge_n,
                                                LzxFrameRec *rec, RecWriter &W, u32 &n_rec, u32 &end_bit, u32 &bytes_done,
-                                               const bool two_level, const bool stream, const u32 plimit, const bool first_seg,
-                                               u32 &emask)
+                                               const bool two_level, const bool stream, const u32 plimit, const bool first_seg)
 {
-  // emask: lanes 0-3 hold the edge literals' position mask between the calls (its LDS words are the table builder's counters)
+  // (between two calls for one frame the edge literals' position mask -- its LDS words are the table builder's counters -- and
+  // the record writer's chunk list -- the pretree's table -- wait in the stage's last 64 words, which only a pass's look-ahead
+  // uses: nothing between the calls touches them)
   // n_rec / bytes_done: in and out -- a frame that holds the end of one block and the beginning of the next is parsed in two
   // calls (lzx_pipe_parse), each with its own tables, the second one going on where the first one stopped; plimit: the frame
   // position the call may not pass (the end of its block or of the frame: a match that crosses either is the serial path's to
@@ -1737,7 +1738,11 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
   const u32 main_fov = d.hr_main.fov, len_fov = d.hr_len.fov;
   u32 tt = rfl(n_rec), B = rfl(start_bit), P = rfl(bytes_done);   // records written, next bit, bytes of the frame done
   bool stop = false;
-  if (lane < 4u) sh->cnt[lane] = first_seg ? 0u : emask;       // the edge literals' positions (128 bits)
+  if (first_seg) { if (lane < 4u) sh->cnt[lane] = 0u; }        // the edge literals' positions (128 bits)
+  else {
+    if (lane < 4u) sh->cnt[lane] = sh->stage[LZX_STAGE_WORDS + REC_CHUNKS + lane];
+    W.restore(sh->stage + LZX_STAGE_WORDS, lane);
+  }
 #ifdef LZX_LIT_RING
   // literals below this position have left the ring (a multiple of 16).  (A second call starts with the first whole row at or
   // above P: the literals in front of it are stored on their own -- the row they lie in holds the first call's bytes)
@@ -2017,7 +2022,8 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     if (b0 + lane < P) gst(fout + b0 + lane, ((const u8 *) sh->litring)[(b0 + lane) & (LZX_LIT_RING - 1u)]);
   }
 #endif
-  if (lane < 4u) { emask = sh->cnt[lane]; rec->edge_mask[lane] = emask; }
+  if (lane < 4u) { const u32 em = sh->cnt[lane]; rec->edge_mask[lane] = em; sh->stage[LZX_STAGE_WORDS + REC_CHUNKS + lane] = em; }
+  W.save(sh->stage + LZX_STAGE_WORDS, lane);
   n_rec = tt; end_bit = B; bytes_done = P;
 }
 #endif  /* LZX_PARSE_ONLY */
@@ -2056,8 +2062,94 @@ __device__ __forceinline__ bool lzx_side_setup(LzxDec &d, LzxState &s, const msp
 // frame.  It works on guesses (one block per frame, at the table's position) and gives up silently; the serial path stays the judge.
 // Waiting is safe: the task it waits for has an earlier ticket (shim.hip), i.e. a live wave is working on it.
 // ---------------------------------------------------------------------------------------------------
-__device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *in_arena, u8 *out_arena, LzxFrameRec *urecs,
-                               const RecPool &pool, LzxShared *sh, const bool stream)
+// the rest of a frame whose first block ended inside it: header, tables, tokens -- block by block to the frame's end.  A real
+// call: frames like this are one in a few hundred, and inlined the general case's registers counted against every frame's
+// parse (scratch accesses of the task 26 -> 104).  The code lengths of the block that ended are still in LDS (no second-level
+// table was built over them), the record's first fields are written, `bytes_done` bytes / `n_rec` records are out.
+__device__ __attribute__((noinline)) void lzx_pipe_parse_tail(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
+                                                              LzxFrameRec *urecs, const RecPool pool, LzxShared *sh,
+                                                              u32 bytes_done, u32 n_rec, u32 cur_bit, const u32 n_chunks)
+{
+  const mspack_hip_unit u = *up;
+  const u32 lane = threadIdx.x;
+  LzxFrameRec *rec = &urecs[f];
+  LzxDec d;
+  LzxState s;
+  lzx_side_setup(d, s, u, in_arena, sh);
+  const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
+  const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
+  const u32 fo = rfl(ftab[f]);
+  u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
+  u32 fe = (f + 1u < nreal) ? rfl(ftab[f + 1u]) : u.in_len;
+  if (fe > u.in_len || fe <= fo) fe = u.in_len;
+  u8 *const fout = out_arena + u.out_off + (size_t) f * LZX_FRAME;
+  const u32 edge_n = (128u - (u32)((size_t) fout & 127u)) & 127u;
+  RecWriter W;
+  W.begin(pool, (u32 *) sh->pre_tab, rec->chunk);
+  W.n_chunks = n_chunks;
+  bool published = false, failed = false;
+  u32 rem = 0, btype = 0, end_bit = cur_bit, pub_p0 = 0, e8flag = 0;
+  while (bytes_done < fsz) {
+    const u32 seg_p0 = bytes_done;
+    if (rem == 0u) {
+      lzx_seek_bit(d, cur_bit);
+      d.err = 0; s.block_type = 0;
+      const bool hok = lzx_block_header(d, s, false) && !d.careful && !d.near_end;
+      if (!hok || (s.block_type != 1u && s.block_type != 2u) || s.block_length == 0u) { failed = true; break; }
+      rem = s.block_length; btype = s.block_type;
+      if (rfl((u32) sh->main_len[0xE8]) != 0u) e8flag = 2u;       // lzxd.c:497
+      cur_bit = rfl(d.w.origin) * 8u + rfl(d.cons_bits());
+    }
+    const u32 need = fsz - seg_p0;
+    if (!published && rem >= need) {
+      for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) gst((u32 *) rec->main_len + i, ((const u32 *) sh->main_len)[i]);
+      for (u32 i = lane; i < (LZX_LEN_SYMS + 70) / 4u; i += WAVE) gst((u32 *) rec->len_len + i, ((const u32 *) sh->len_len)[i]);
+      if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
+      pub_p0 = seg_p0;
+      if (lane == 0) {
+        rec->end_bit = cur_bit; rec->block_type = btype; rec->block_length = rem; rec->rem_out = rem - need;
+        rec->run_rem = seg_p0 + rem;      // (the block the record may end in, counted from the frame's first byte: lzx_decode_unit)
+      }
+      lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);
+      published = true;
+    }
+    bool tables = true, two_level = false;
+    {
+      const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, lane, false);
+      tables = r != 1;
+      s.length_empty = (r == 2);
+    }
+    if (tables && btype == 2u) tables = !huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false);
+    if (tables) {
+      u32 nsorted = 0;
+      tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+                                                            sh->cnt, d.hr_main, lane, false, &nsorted);
+#ifndef LZX_NO_SUB_TABLE
+      if (tables && published) two_level = rfl(lzx_build_sub(sh, d.hr_main, nsorted, lane) ? 1u : 0u) != 0u;
+#endif
+    }
+    if (!tables) { failed = !published; break; }
+    const u32 plimit = seg_p0 + (rem < need ? rem : need);
+    if (btype == 2u) lzx_parse_emit<true>(d, s.length_empty, cur_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, false, plimit, false);
+    else lzx_parse_emit<false>(d, s.length_empty, cur_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, false, plimit, false);
+    if (bytes_done < plimit) break;                               // the record ends early: the serial path goes on behind it
+    rem -= plimit - seg_p0;
+    cur_bit = end_bit;
+  }
+  // nothing to hand on (a header that is no verbatim / aligned block, tables that do not build, a record that ends in front of
+  // the frame's last header): nothing of this frame is used, the chain of code lengths ends here
+  if (failed || !published) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
+  // a record that ends early must end INSIDE the frame's last block, behind at least one of its tokens
+  if (bytes_done < fsz && bytes_done <= pub_p0) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); return; }
+  if (lane == 0) {
+    rec->n_tokens = n_rec; rec->end_bit = end_bit; rec->bytes_done = bytes_done;
+    rec->flags = rec->flags | e8flag | (s.length_empty ? 1u : 0u);
+  }
+  lzx_status_publish(&rec->status, LZX_ST_EMITTED, lane);
+}
+
+__device__ void lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
+                               LzxFrameRec *urecs, const RecPool &pool, LzxShared *sh, const bool stream)
 {
   const u32 lane = threadIdx.x;
   LzxFrameRec *rec = &urecs[f];
@@ -2120,97 +2212,84 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const u32 f, const u8 *
   u8 *const fout = out_arena + u.out_off + (size_t) f * LZX_FRAME;
   // the frame's first bytes up to the next 128-byte line: another wave may be writing that line (see lzx_parse_emit)
   const u32 edge_n = (128u - (u32)((size_t) fout & 127u)) & 127u;
-  // ---- the frame, block by block.  Round 5: a frame need not be ONE block that begins where it begins (what this build's own
-  // encoder writes, and all rounds 2-4 handled here): Microsoft's encoder writes blocks of megabytes (the reference's
-  // large-files cabinets: one aligned block of 8 384 624 bytes, then the next), so a frame usually lies INSIDE a block -- it
-  // inherits the previous frame's code lengths and has no header at all -- and now and then holds the end of one block and the
-  // header and first tokens of the next.  The chain from frame to frame is "code lengths + bytes left of the open block"
-  // (rem_out); it is published as soon as the LAST header of the frame has been read, i.e. at once for a frame without one. ----
-  RecWriter W;
-  bool w_begun = false, published = false, seg_first = true, two_level = false;
-  u32 n_rec = 0, end_bit = 0, bytes_done = 0, e8flag = 0, run_rem = 0, emask = 0, pub_p0 = 0;
+  // ---- the frame's first block (or what is left of the block it lies in).  Round 5: a frame need not be ONE block that begins
+  // where it begins (what this build's own encoder writes, and all rounds 2-4 handled here): Microsoft's encoder writes blocks of
+  // megabytes (the reference's large-files cabinets: one aligned block of 8 384 624 bytes, then the next), so a frame usually
+  // lies INSIDE a block -- it inherits the previous frame's code lengths and has no header at all -- and now and then holds the
+  // end of one block and the header and first tokens of the next (lzx_pipe_parse_tail).  The chain from frame to frame is "code
+  // lengths + bytes left of the open block" (rem_out); it is published as soon as the LAST header of the frame has been read,
+  // i.e. at once for a frame without one. ----
   u32 cur_bit = rfl(d.w.origin) * 8u + rfl(d.cons_bits());     // the frame's first block header, or its first token
-  const u32 hdr_start = cur_bit;
-  bool whole_ok = true;
-  while (bytes_done < fsz) {
-    const u32 seg_p0 = bytes_done;
-    if (rem == 0u) {
-      if (!seg_first) lzx_seek_bit(d, cur_bit);
-      s.block_type = 0;
-      const bool hok = lzx_block_header(d, s, false) && !d.careful && !d.near_end;
-      if (!hok || (s.block_type != 1u && s.block_type != 2u) || s.block_length == 0u) { whole_ok = false; break; }
-      rem = s.block_length; btype = s.block_type;
-      if (rfl((u32) sh->main_len[0xE8]) != 0u) e8flag = 2u;       // lzxd.c:497: a block header with a code for 0xE8
-      cur_bit = rfl(d.w.origin) * 8u + rfl(d.cons_bits());       // the block's first token
-      if (w_begun) W.reload(lane);                                // (the header's pretree table lay over the chunk list)
-    }
-    else s.block_type = btype;
-    const u32 need = fsz - seg_p0;
-    if (!published && rem >= need) {
-      // the state behind this frame is known: the next frame's task may go on
-      PH(1);
-      for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) gst((u32 *) rec->main_len + i, ((const u32 *) sh->main_len)[i]);
-      for (u32 i = lane; i < (LZX_LEN_SYMS + 70) / 4u; i += WAVE) gst((u32 *) rec->len_len + i, ((const u32 *) sh->len_len)[i]);
-      if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
-      run_rem = seg_p0 + rem; pub_p0 = seg_p0;
-      if (lane == 0) {
-        rec->n_tokens = 0; rec->hdr_start_bit = hdr_start; rec->end_bit = cur_bit;
-        rec->block_type = btype; rec->block_length = rem; rec->rem_out = rem - need; rec->run_rem = run_rem;
-        rec->frame_start_bit = fo * 8u; rec->intel_filesize = intel; rec->bytes_done = 0; rec->prog = 0;
-        rec->n_edge = edge_n < fsz ? edge_n : fsz;
-      }
-      lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);      // the next frame's wave may go on
-      published = true;
-      PH(2);
-    }
-    // ---- tables (cf. lzx_parse_frame): length and aligned trees first, the main tree last -- its second level takes the room
-    // of the code lengths (which are in the record by now, or are read again by the next header of this frame) ----
-    bool tables = true;
-    two_level = false;
-    {
-      const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, lane, false);
-      tables = r != 1;
-      s.length_empty = (r == 2);
-    }
-    if (tables && btype == 2u) tables = !huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false);
-    if (tables) {
-      u32 nsorted = 0;
-      tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
-                                                            sh->cnt, d.hr_main, lane, false, &nsorted);
+  if (lane == 0) {
+    // (what does not change any more goes into the record now: fewer values to carry through the parse)
+    rec->hdr_start_bit = cur_bit; rec->frame_start_bit = fo * 8u; rec->intel_filesize = intel;
+    rec->n_edge = edge_n < fsz ? edge_n : fsz; rec->n_tokens = 0; rec->bytes_done = 0; rec->prog = 0; rec->flags = 0;
+  }
+  if (rem == 0u) {
+    s.block_type = 0;
+    const bool hok = lzx_block_header(d, s, false) && !d.careful && !d.near_end;
+    if (!hok || (s.block_type != 1u && s.block_type != 2u) || s.block_length == 0u) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
+    rem = s.block_length; btype = s.block_type;
+    if (lane == 0 && sh->main_len[0xE8] != 0) rec->flags = 2u;   // lzxd.c:497: a block header with a code for 0xE8
+    cur_bit = rfl(d.w.origin) * 8u + rfl(d.cons_bits());         // the block's first token
+  }
+  else s.block_type = btype;
+  const bool published = rem >= fsz;
+  if (published) {
+    // the state behind this frame is known: the next frame's task may go on
+    PH(1);
+    for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) gst((u32 *) rec->main_len + i, ((const u32 *) sh->main_len)[i]);
+    for (u32 i = lane; i < (LZX_LEN_SYMS + 70) / 4u; i += WAVE) gst((u32 *) rec->len_len + i, ((const u32 *) sh->len_len)[i]);
+    if (lane < 8u) rec->ali_len[lane] = sh->ali_len[lane];
+    if (lane == 0) { rec->end_bit = cur_bit; rec->block_type = btype; rec->block_length = rem; rec->rem_out = rem - fsz; rec->run_rem = rem; }
+    lzx_status_publish(&rec->status, LZX_ST_HEADER, lane);      // the next frame's wave may go on
+    PH(2);
+  }
+  // ---- tables (cf. lzx_parse_frame): length and aligned trees first, the main tree last -- its second level takes the room of
+  // the code lengths (which are in the record by then; not while a later header of this frame still works on them) ----
+  bool tables = true, two_level = false;
+  {
+    const int r = huff_build<LZX_LEN_P>(sh->len_len, LZX_LEN_SYMS, 12, sh->len_tab, sh->len_sorted, sh->cnt, d.hr_len, lane, false);
+    tables = r != 1;
+    s.length_empty = (r == 2);
+  }
+  if (tables && btype == 2u) tables = !huff_build<LZX_ALI_P>(sh->ali_len, 8, 7, sh->ali_tab, sh->ali_sorted, sh->cnt, d.hr_ali, lane, false);
+  if (tables) {
+    u32 nsorted = 0;
+    tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
+                                                          sh->cnt, d.hr_main, lane, false, &nsorted);
 #ifndef LZX_NO_SUB_TABLE
-      // (the second level is built in the room of the code lengths: only when no later header of this frame needs them)
-      if (tables && published) two_level = rfl(lzx_build_sub(sh, d.hr_main, nsorted, lane) ? 1u : 0u) != 0u;
+    if (tables && published) two_level = rfl(lzx_build_sub(sh, d.hr_main, nsorted, lane) ? 1u : 0u) != 0u;
 #endif
-    }
-    if (!tables) { whole_ok = false; break; }
-    PH(3);
-    if (!w_begun) {
-      // (the frame's chunk list in LDS: the room of the pretree's table -- only a block header uses that: a later header of this
-      // frame finds the list saved in the record)
-      W.begin(pool, (u32 *) sh->pre_tab, rec->chunk);
-      w_begun = true;
-    }
-    const u32 plimit = seg_p0 + (rem < need ? rem : need);
-    if (btype == 2u) lzx_parse_emit<true>(d, s.length_empty, cur_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream, plimit, seg_first, emask);
-    else lzx_parse_emit<false>(d, s.length_empty, cur_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream, plimit, seg_first, emask);
-    seg_first = false;
-    if (bytes_done < plimit) break;                               // the record ends early: the serial path goes on behind it
-    rem -= plimit - seg_p0;
-    cur_bit = end_bit;
+  }
+  if (!tables) { lzx_status_publish(&rec->status, published ? LZX_ST_HDRONLY : LZX_ST_FAILED, lane); return; }
+  PH(3);
+  u32 n_rec = 0, end_bit = 0, bytes_done = 0;
+  u32 n_chunks = 0;
+  {
+    // (the frame's chunk list in LDS: the room of the pretree's table -- only a block header uses that; a later header of this
+    // frame finds the list put aside, lzx_parse_emit)
+    RecWriter W;
+    W.begin(pool, (u32 *) sh->pre_tab, rec->chunk);
+    const u32 plimit = rem < fsz ? rem : fsz;
+    if (btype == 2u) lzx_parse_emit<true>(d, s.length_empty, cur_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream, plimit, true);
+    else lzx_parse_emit<false>(d, s.length_empty, cur_bit, fe * 8u, fout, f * LZX_FRAME, fsz, edge_n, rec, W, n_rec, end_bit, bytes_done, two_level, stream, plimit, true);
+    n_chunks = W.n_chunks;
   }
   if (!published) {
-    // no state to hand on (a header that is no verbatim / aligned block, tables that do not build, a record that ends in front of
-    // the frame's last header): nothing of this frame is used, the chain of code lengths ends here
+    // the block ends inside the frame.  Parsed up to its end: the next header is read THERE (a real call: the hot path above
+    // does not carry the general case's registers).  Not that far: nothing to hand on -- the chain of code lengths ends here
+    if (bytes_done == rem) { PHFLUSH(); lzx_pipe_parse_tail(up, f, in_arena, out_arena, urecs, pool, sh, bytes_done, n_rec, end_bit, n_chunks); return; }
     lzx_status_publish(&rec->status, LZX_ST_FAILED, lane);
     PHFLUSH();
     return;
   }
-  // a record that ends early must end INSIDE the frame's last block, behind at least one of its tokens: the serial path goes on
-  // from its last bit with that block's tables.  Else (tables that do not build, nothing parsed): code lengths only
-  if (bytes_done < fsz && bytes_done <= pub_p0) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); PHFLUSH(); return; }
+  // a record that ends early must end behind at least one token of the block: the serial path goes on from its last bit with
+  // this block's tables.  Else: code lengths only
+  if (bytes_done < fsz && bytes_done == 0u) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); PHFLUSH(); return; }
   if (lane == 0) {
     rec->n_tokens = n_rec; rec->end_bit = end_bit; rec->bytes_done = bytes_done;
-    rec->flags = e8flag | (s.length_empty ? 1u : 0u);
+    rec->flags = rec->flags | (s.length_empty ? 1u : 0u);
   }
   PH(4);
   lzx_status_publish(&rec->status, LZX_ST_EMITTED, lane);

@@ -205,7 +205,7 @@ __device__ __attribute__((noinline)) void lzx_pipe_task_parse(const mspack_hip_u
 {
   const mspack_hip_unit u = *up;
   RecPool rp; rp.base = pool; rp.head = pool_head; rp.cap = pool_chunks;
-  lzxp::lzx_pipe_parse(u, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], rp, sh, false);
+  lzxp::lzx_pipe_parse(u, up, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], rp, sh, false);
 }
 __device__ __attribute__((noinline)) void lzx_pipe_task_resolve(const mspack_hip_unit *up, const u32 f, u8 *out_arena, lzxn::LzxFrameRec *recs,
                                                                 uint2 *toks, lzxn::LzxResolveLds *rl, const bool merged)

@@ -202,11 +202,17 @@ __device__ __forceinline__ void spq_resolve(SpecQueueLds &l, SpecQueue &q, u8 *c
 __device__ __forceinline__ u64 spq_find_runs(const bool ism, const u32 n, const u32 opos, const u32 olen, const u32 off, const u32 lane,
                                              u32 &seg_first)
 {
+  seg_first = lane;
+#ifdef SPQ_NO_RUNS                 /* analysis builds: everything through the queue */
+  return 0ull;
+#endif
+  // (a run of >= SPQ_RUN_MIN bytes is made of LONG matches -- encoders take the longest match there is --: without two of at
+  // least 64 bytes the batch is ordinary data and pays three instructions here, not twenty)
+  { const u64 longm = ballot(ism && olen >= 64u); if (!(longm & (longm - 1ull))) return 0ull; }
   const u32 prev_end = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int)(opos + olen));
   const u32 prev_off = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) off);
   const bool cont = ism && lane != 0u && prev_end == opos && prev_off == off;      // continues the match of the lane below
   const u64 contm = ballot(cont);
-  seg_first = lane;
   if (!contm) return 0ull;                                                          // (ordinary data: no two matches in a row)
   const u64 startm = ballot(ism && !cont);                                          // lanes that begin a run
   const u64 below = startm & ((lane == 63u) ? ~0ull : ((2ull << lane) - 1ull));     // ... at or below this lane
@@ -216,6 +222,7 @@ __device__ __forceinline__ u64 spq_find_runs(const bool ism, const u32 n, const 
   return ballot(last && seg_first != lane && opos + olen - first_pos >= SPQ_RUN_MIN && off != 0u && off <= first_pos);
 }
 // write the run [s, e) with period `off` (everything below s is final in memory); stores at or above `clip` are dropped
+// (inlined: as a real call it cost ~3 us per run -- callee-saved registers through scratch --, a third of a large-files block)
 __device__ __forceinline__ void spq_fill_run(u8 *const out, const u32 s, const u32 e, const u32 off, const u32 lane,
                                              const u32 clip = 0xFFFFFFFFu)
 {
@@ -309,6 +316,7 @@ __device__ __forceinline__ void spq_push_batch(SpecQueueLds &l, SpecQueue &q, u8
 }
 
 // a batch of n matches (lanes 0..n-1): its runs through the fill path, everything else into the queue, in position order
+// (inlined: as a real call the caller saved its registers around it -- the resolve task's scratch use tripled)
 __device__ __forceinline__ void spq_push_runs(SpecQueueLds &l, SpecQueue &q, u8 *const out, const bool ism, const u32 n,
                                               const u32 opos, const u32 olen, const u32 off, const u32 lane)
 {

@@ -265,11 +265,12 @@ struct RecWriter {
   u32 *ctab;                       /* LDS: REC_CHUNKS words, the frame's chunk list (record index of each chunk's first record) */
   u32 *gtab;                       /* the same in the frame's record (global memory), for the reader */
   u32 n_chunks;
-  u32 creg;                        /* lane k: ctab[k] -- the list once more, for a writer whose LDS table gets overwritten in between */
-  __device__ __forceinline__ void begin(const RecPool &p, u32 *lds_tab, u32 *rec_tab) { pool = p; ctab = lds_tab; gtab = rec_tab; n_chunks = 0; creg = 0; }
-  // the LDS table again after something else used its room (lzx_pipe_parse: a block header in the middle of a frame)
-  __device__ __forceinline__ void reload(const u32 lane) {
-    if (lane < n_chunks) ctab[lane] = creg;
+  __device__ __forceinline__ void begin(const RecPool &p, u32 *lds_tab, u32 *rec_tab) { pool = p; ctab = lds_tab; gtab = rec_tab; n_chunks = 0; }
+  // the LDS table put aside / taken back when something else needs its room in between (lzx_pipe_parse: a block header in the
+  // middle of a frame; `keep`: REC_CHUNKS words of LDS that survive it)
+  __device__ __forceinline__ void save(u32 *keep, const u32 lane) const { if (lane < REC_CHUNKS) keep[lane] = ctab[lane]; }
+  __device__ __forceinline__ void restore(const u32 *keep, const u32 lane) {
+    if (lane < REC_CHUNKS) ctab[lane] = keep[lane];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
   // room for the records with index < upto?  (wave-uniform; false: the pool is empty or the frame has more than 16384)
@@ -282,7 +283,6 @@ struct RecWriter {
       c = rfl(c);
       if (c >= pool.cap) return false;
       if (lane == 0) { ctab[n_chunks] = c * REC_CHUNK; gtab[n_chunks] = c * REC_CHUNK; }
-      creg = (lane == n_chunks) ? c * REC_CHUNK : creg;
       n_chunks++; grew = true;
     }
     if (grew) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
