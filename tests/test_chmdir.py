@@ -68,3 +68,28 @@ def test_listing_after_a_bad_encint():
         assert c.open_error == s["open_err"] == 0 and len(c.files) == s["n_files"]
         lst = [(nm, sec, off, ln) for nm, ln, off, sec in c.files]
         assert hashlib.md5(repr(lst).encode()).hexdigest() == s["list_md5"]
+
+
+@pytest.mark.gpu
+def test_fast_find_then_extract_gpu(built):
+    """F2 end to end on the hardware: `fast_open` (no file list), `fast_find` of every name through the PMGI / PMGL chunks, and
+    `extract` of what it found -- LZX intervals decoded by the HIP kernels -- against what the REAL chmd wrote for the same files
+    in the same order (tests/golden/chm_extract.json: clean, E8, damaged-content and short-table CHMs), plus names that are not
+    there (same code, no file)."""
+    import chm_extract_recipe as X
+    vecs = json.load(open(os.path.join(HERE, "golden", "chm_extract.json")))
+    tags = ("lzx21-r2", "lzx21-r64", "lzx21-r2-e8", "lzx16-r2-flip@f6", "lzx21-r2-fewentries", "lzx21-r2-cut", "config3-1024-intervals")
+    for v in [v for v in vecs if v["tag"] in tags]:
+        chm, _d, files = X.build(v["case"])
+        run = [r for r in v["runs"] if r["order"] == sorted(r["order"])][0]
+        with api.Chm(chm, fast=True, mem=True) as c:
+            assert c.open_error == v["open_err"] == 0 and c.files == []        # fast_open reads no file list
+            for idx, exp in zip(run["order"], run["results"]):
+                name, off, ln = files[idx]
+                err, f = c.find(name)
+                assert err == 0 and f is not None and (f.offset, f.length, f.section.contents.id) == (off, ln, 1), (v["tag"], name)
+                err, data = c.extract_found(f)
+                assert err == exp["err"] and len(data) == exp["n"] and hashlib.md5(data).hexdigest() == exp["md5"], (v["tag"], idx, err, exp)
+            for missing in (b"/nope.bin", b"/f9999.bin", b"/"):
+                err, f = c.find(missing)
+                assert err == 0 and f is None
