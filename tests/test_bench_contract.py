@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the line the final build printed on the GPU box (profiles/round4_final_bench.json,
+"""The bench line's contract, checked on the line the final build printed on the GPU box (profiles/round5_final_bench.json,
 copied there from the gpurun session): the keys the driver reads, the roofline and cpu_baseline objects, internal
 consistency of the numbers.  bench.py itself needs a GPU; what it prints must not drift from what is documented."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def line():
-    return json.loads(open(os.path.join(ROOT, "profiles", "round4_final_bench.json")).read().strip().splitlines()[-1])
+    return json.loads(open(os.path.join(ROOT, "profiles", "round5_final_bench.json")).read().strip().splitlines()[-1])
 
 
 def test_driver_keys_and_types():
@@ -70,10 +70,13 @@ def test_through_api_and_socket_estimate():
 
 def test_traffic_file_is_this_rounds():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert t["round"] == "round 4" and os.path.exists(os.path.join(ROOT, t["source"]))
+    assert t["round"] == "round 5" and os.path.exists(os.path.join(ROOT, t["source"]))
     src = json.load(open(os.path.join(ROOT, t["source"])))
     assert src["fetch_kib_per_launch"] == t["fetch_kib_per_launch"] and src["write_kib_per_launch"] == t["write_kib_per_launch"]
     d = line()
-    # (the line was printed a session before the final --pmc passes: same build, within a few per cent)
+    # (the line was printed minutes before the session's --pmc passes and replays the previous passes: within ten per cent)
     now = (2 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024
-    assert abs(d["roofline"]["traffic"] - now) / now < 0.05
+    assert abs(d["roofline"]["traffic"] - now) / now < 0.10
+    # SURVEY 8(d)'s metric as written, at the top level beside `value` (round 5)
+    assert d["value_host_inclusive"] == d["host_inclusive"]["MBps"] and d["value_host_to_host"] == d["host_inclusive"]["to_host_MBps"]
+    assert d["cpu_baseline"]["lscpu"].get("Core(s) per socket")
