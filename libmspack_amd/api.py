@@ -481,10 +481,10 @@ MsoabDecompressor._fields_ = [
 ]
 
 
-def oab_decompress(blob, base=None, decompbuf=0):
+def oab_decompress(blob, base=None, decompbuf=0, L=None):
     """mspack_create_oab_decompressor -> decompress / decompress_incremental over temporary files
-    -> (err, output bytes)"""
-    L = lib()
+    -> (err, output bytes).  L: as in _setup (the CPU stand-in build of the host logic: tests)"""
+    L = L or lib()
     L.mspack_create_oab_decompressor.restype = _P(MsoabDecompressor)
     L.mspack_create_oab_decompressor.argtypes = [C.c_void_p]
     L.mspack_destroy_oab_decompressor.argtypes = [_P(MsoabDecompressor)]
@@ -547,10 +547,11 @@ MskwajDecompressor._fields_ = [
 ]
 
 
-def szdd_kwaj_extract(kind, blob):
+def szdd_kwaj_extract(kind, blob, L=None):
     """kind 0 = SZDD, 1 = KWAJ: open() + extract() over temporary files
-    -> dict(open_err, err, data, comp_type (SZDD: format), length, filename (SZDD: the missing character))"""
-    L = lib()
+    -> dict(open_err, err, data, comp_type (SZDD: format), length, filename (SZDD: the missing character)).
+    L: as in _setup (the CPU stand-in build of the host logic: tests)"""
+    L = L or lib()
     T = MsszddDecompressor if kind == 0 else MskwajDecompressor
     create = L.mspack_create_szdd_decompressor if kind == 0 else L.mspack_create_kwaj_decompressor
     destroy = L.mspack_destroy_szdd_decompressor if kind == 0 else L.mspack_destroy_kwaj_decompressor

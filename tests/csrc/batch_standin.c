@@ -7,8 +7,9 @@
  * It provides the batch ABI of include/mspack_hip.h (host-buffer entry points only) on top of the CPU
  * oracle (oracle/liboracle.so): one oracle call per unit.  Supported: LZX units (CAB folders, CHM reset
  * intervals, E8 origin, the reset log of MSPACK_HIP_UF_LZX_LOG), MSZIP and Quantum folder units, frame tables
- * (ignored: the oracle is serial), the feeder's failed read (MSPACK_HIP_UF_HARD_EOF) and Quantum's good_len;
- * NOT MSZIP repair mode -- that makes the call fail, and the tests that need it run on the GPU.  The `-m gpu` parity tests never
+ * (ignored: the oracle is serial), the feeder's failed read (MSPACK_HIP_UF_HARD_EOF) and Quantum's good_len, LZX DELTA units (OAB
+ * blocks with their reference data), LZSS and KWAJ LZH units, checksum units;
+ * NOT MSZIP repair mode or KWAJ-framed MSZIP -- that makes the call fail, and the tests that need it run on the GPU.  The `-m gpu` parity tests never
  * see this file: they load the real library. */
 #include <stdio.h>
 #include <string.h>
@@ -83,6 +84,19 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *
         free(tmp);
         qtm_good = lo; have_qtm_good = 1;
       }
+      break;
+    case MSPACK_HIP_KIND_LZX_DELTA:                       /* OAB blocks: reference data right below the unit's output */
+      if (u->ref_len > u->out_off) { snprintf(g_err, sizeof(g_err), "unit's lower region outside arena"); return -1; }
+      oracle_lzxd_decode(src, u->in_len, dst, u->out_len, u->out_len, u->out_len, u->window_bits, u->reset_frames,
+                         u->e8_base, 1, dst - u->ref_len, u->ref_len, &o);
+      break;
+    case MSPACK_HIP_KIND_LZSS:                            /* out_len = room; the result says what the stream produced */
+      if (u->out_off < 4096) { snprintf(g_err, sizeof(g_err), "unit's lower region outside arena"); return -1; }
+      oracle_lzss_decode(src, u->in_len, u->window_bits, dst, u->out_len, &o);
+      break;
+    case MSPACK_HIP_KIND_KWAJ_LZH:
+      if (u->out_off < 4096) { snprintf(g_err, sizeof(g_err), "unit's lower region outside arena"); return -1; }
+      oracle_kwaj_lzh_decode(src, u->in_len, dst, u->out_len, &o);
       break;
     default:
       snprintf(g_err, sizeof(g_err), "stand-in: kind %d unsupported", u->kind); return -1;

@@ -11,7 +11,6 @@ import pytest
 from libmspack_amd import api
 import oab_recipe as R
 
-pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 G = {e["name"]: e for e in json.load(open(os.path.join(HERE, "golden", "oab.json")))}
 CASES = None
@@ -28,24 +27,37 @@ def _sig(err, out):
     return [err, len(out), hashlib.md5(out).hexdigest()]
 
 
-@pytest.mark.parametrize("name", sorted(G))
-def test_oab_file_and_damage(built, name):
+def check_case(name, L=None):
     _n, blob, base, want = _cases()[name]
     g = G[name]
     assert hashlib.md5(blob).hexdigest() == g["blob_md5"]            # the very file the reference saw
-    err, out = api.oab_decompress(blob, base)
+    err, out = api.oab_decompress(blob, base, L=L)
     assert err == 0 and out == want
     rng = np.random.default_rng(len(blob))
     for i, m in enumerate(R.damaged(blob, rng, len(g["damaged"]))):
-        err, out = api.oab_decompress(m, base)
+        err, out = api.oab_decompress(m, base, L=L)
         assert _sig(err, out) == g["damaged"][i], (name, i)
-    err, out = api.oab_decompress(blob[:len(blob) * 2 // 3], base, decompbuf=1000)
+    err, out = api.oab_decompress(blob[:len(blob) * 2 // 3], base, decompbuf=1000, L=L)
     assert _sig(err, out) == g["truncated_buf1000"]
     if base is not None:
-        err, out = api.oab_decompress(blob, base[:len(base) // 2])
+        err, out = api.oab_decompress(blob, base[:len(base) // 2], L=L)
         assert _sig(err, out) == g["short_base"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(G))
+def test_oab_file_and_damage(built, name):
+    check_case(name)
+
+
+@pytest.mark.parametrize("name", sorted(G))
+def test_oab_file_and_damage_host_logic_cpu(built, hostlogic, name):
+    """the same goldens through the same driver code (csrc/host/oabd.c) on the CPU stand-in for the batch ABI (LZX DELTA units
+    decoded by the oracle): block gathering, reference data, CRCs, the replay of a damaged file -- host logic only"""
+    check_case(name, L=hostlogic)
+
+
+@pytest.mark.gpu
 def test_oab_arguments(built):
     L = api.lib()
     L.mspack_create_oab_decompressor.restype = api._P(api.MsoabDecompressor)

@@ -5,7 +5,8 @@ tests/_build/libhostlogic_asan.so = libmspack_amd/csrc/host/*.c + the CPU stand-
 replays driver goldens that walk the drivers' hairy paths -- cabinets with damaged blocks and moved file offsets (several call
 orders, salvage on and off: sticky errors, checksum units and the re-gather behind a bad one), the split cabinet sets (blocks
 reassembled across cabinets, chains that run out of cabinets), CHMs with lying headers and damaged content, the CHM directory
-fixtures (the reference's own fuzz finds).  Any report fails the test.  CPU only."""
+fixtures (the reference's own fuzz finds), OAB files and patches and SZDD / KWAJ files with their damaged copies.  Any report fails the
+test.  CPU only."""
 import glob
 import os
 import subprocess
@@ -20,7 +21,7 @@ WORKER = r'''
 import ctypes, json, os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
 L = ctypes.CDLL(%(so)r)
-import test_cab_sticky as S, test_chm_extract as X, test_cabsets as CS, test_chmdir as D
+import test_cab_sticky as S, test_chm_extract as X, test_cabsets as CS, test_chmdir as D, test_oab as O, test_szdd_kwaj as Z
 from libmspack_amd import api
 n = 0
 for v in S.GOLD:
@@ -38,6 +39,10 @@ for fx in D.G["fixtures"]:
         if not c.open_error:
             D._finds(c, [q[0].encode("latin-1") for q in fx["finds"]])
     n += 1
+for name in sorted(O.G):                       # OAB files and patches, damaged and truncated (oabd.c)
+    O.check_case(name, L=L); n += 1
+for name in Z.CPU_FILES:                       # SZDD / KWAJ files, damaged (szdd_kwaj.c)
+    Z.check_file(name, L=L); n += 1
 print("SANITIZED_OK", n)
 '''
 
