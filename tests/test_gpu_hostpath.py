@@ -377,9 +377,11 @@ def test_copies_are_cut_at_pin_boundaries(built):
     (mspack_hip_pin) -- every copy the entry points make then starts inside a locked range and ends behind it, or the other
     way round.  The runtime refuses such a copy (hipErrorInvalidValue); the entry points cut theirs at the boundaries.
     Runs on the wavefront emulator only (tests/test_emu_kernels.py, CPU suite: the registry and the cutting are host code).  On the
-    hardware this test made the HIP runtime itself lock and unlock megabytes of pageable memory right beside ranges the test had
-    locked, over and over in one process -- it passed four whole-suite runs of round 5 and aborted inside the runtime in the fifth;
-    what the product does (arenas that are locked completely, or not at all) is held by test_many_decompressors_one_process."""
+    hardware it passed four whole-suite runs of round 5 and aborted once in the fifth (SIGABRT inside one of its decode calls; not
+    reproduced in 66 repetitions outside pytest, tools/repro_pin_boundary*.py; unexplained -- DESIGN.md section 8h).  What it does and
+    the product never does: the HIP runtime has to lock and unlock megabytes of PAGEABLE memory right beside ranges the test has
+    locked itself, over and over in one process.  What the product does (arenas locked completely, or not at all) is held by
+    test_many_decompressors_one_process."""
     if "emu" not in os.path.basename(M.HIP_SO):
         pytest.skip("host-side logic: runs against the emulator build in the CPU suite")
     n, ub = 24, 65536                      # (the emulator decodes ~1 MB/s: the cuts are what is tested, not the kernels)
