@@ -13,6 +13,7 @@
  *   E8 call translation (inverse applied here) lzxd.c:706-736
  * Matches never cross a frame or block end (lzxd.c:678-693 rejects that).
  */
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include "corpus.h"
@@ -29,14 +30,17 @@
 static const uint16_t slots_for_bits[11] = { 30, 32, 34, 36, 38, 42, 50, 66, 98, 162, 290 };
 static uint32_t slot_base[MAXSLOTS + 1];
 static uint8_t  slot_extra[MAXSLOTS + 1];
-static void init_slots(void) {
+static void init_slots_once(void) {
   uint32_t base = 0; int i;
-  if (slot_base[1]) return;
   for (i = 0; i <= MAXSLOTS; i++) {
     int e = (i < 4) ? 0 : (i < 36 ? (i / 2) - 1 : 17);
     slot_base[i] = base; slot_extra[i] = (uint8_t) e; base += 1u << e;
   }
 }
+/* (the batch generators encode on several threads: the first call of each used to fill the tables unsynchronised -- the same
+ * values from every thread, but a data race all the same: tests/hostcheck under ThreadSanitizer) */
+static pthread_once_t slots_once = PTHREAD_ONCE_INIT;
+static void init_slots(void) { pthread_once(&slots_once, init_slots_once); }
 static int slot_of(uint32_t formatted) {
   int lo = 0, hi = MAXSLOTS - 1;      /* (callers never pass offsets beyond their window) */
   while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (slot_base[mid] <= formatted) lo = mid; else hi = mid - 1; }

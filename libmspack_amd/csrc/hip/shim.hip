@@ -70,7 +70,7 @@ __host__ __device__ static inline LzxScratch lzx_scratch(void *base, size_t n_fr
   const size_t o_fu = (n0 * 4 + a) & ~a, o_hdr = o_fu + ((n * 4 + a) & ~a), o_rec = o_hdr + 1024,
                o_pool = (o_rec + n * sizeof(lzxn::LzxFrameRec) + a) & ~a;
   LzxScratch L;
-  char *b = (char *) base;
+  const uintptr_t b = (uintptr_t) base;                  // (a NULL base only asks for the size: no arithmetic on a null POINTER)
   L.meta = (int32_t *) b; L.frame_unit = (u32 *)(b + o_fu); L.hdr = (u32 *)(b + o_hdr); L.recs = (lzxn::LzxFrameRec *)(b + o_rec);
   L.pool = (uint2 *)(b + o_pool);
   L.bytes = o_pool + n * REC_SLOT_RECORDS * sizeof(uint2);
@@ -462,6 +462,10 @@ static hipError_t launch(void (*kernel)(P...), dim3 grid, dim3 block, hipStream_
 #endif
 }
 #define LK(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+#ifdef MSPACK_HOST_CHECK
+hipError_t hostcheck_launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
+                                 const void *d_in, void *d_out, mspack_hip_result *d_results, hipStream_t st);
+#endif
 
 static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
                               const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
@@ -470,6 +474,9 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
 {
   if (n_rec_slots == (size_t) -1) n_rec_slots = n_frames_total;
   if (n == 0) return hipSuccess;
+#ifdef MSPACK_HOST_CHECK      /* tests/hostcheck: the HOST half of this file under real sanitizers -- no kernel runs, a CPU stand-in takes the launch's place in the stream */
+  return hostcheck_launch_kind(kind, d_units, d_order, n, d_in, d_out, d_results, st);
+#endif
   const dim3 grid((unsigned) n), block(64);
   const u8 *const in = (const u8 *) d_in;
   u8 *const out = (u8 *) d_out;
@@ -872,7 +879,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       }
       size_t a = 0; uint64_t acc = 0, upto = 0;
       for (size_t i = 0; i < n_sel; i++) {
-        acc += local[i].in_len;
+        if (local[i].kind != MSPACK_HIP_KIND_XORSUM) acc += local[i].in_len;     // (in_sum leaves the checksum units out too)
         const uint64_t goal = (uint64_t)((double) in_sum * (double)(upto + w[chunks.size()]) / (double) wsum);
         if (i + 1 == n_sel || (acc >= goal && chunks.size() + 1 < want)) {
           Chunk c; c.a = a; c.b = i + 1; upto += w[chunks.size()]; chunks.push_back(c); a = i + 1;
@@ -966,14 +973,35 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     double pin_ms = 0.0, unpin_ms = 0.0;
     std::thread back;
     struct Pins {                                          // page-locked ranges of the caller's buffers (this call's own)
-      PinRange r[MSPK_MAX_CHUNKS + 1]; int n = 0;
-      bool lock(uintptr_t ra, uintptr_t rb) {
-        if (rb <= ra || n >= MSPK_MAX_CHUNKS + 1) return false;
+      std::vector<PinRange> r; int n = 0;
+      bool lock_one(uintptr_t ra, uintptr_t rb) {
+        if (rb <= ra) return false;
+        // (someone else's registration -- the caller's own hipHostRegister / hipHostMalloc -- is left alone: asking the runtime
+        // to register bytes it has registered already fails after it has walked the pages, and is not this library's to undo)
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, (const void *) ra) == hipSuccess) { if (at.type == hipMemoryTypeHost) return false; }
+        else (void) hipGetLastError();
         if (hipHostRegister((void *) ra, rb - ra, hipHostRegisterDefault) != hipSuccess) { (void) hipGetLastError(); return false; }
-        r[n].ra = ra; r[n].rb = rb; r[n].user = nullptr; n++;
+        r.push_back(PinRange{ ra, rb, nullptr }); n = (int) r.size();
         return true;
       }
-      void release() { for (int i = 0; i < n; i++) if (hipHostUnregister((void *) r[i].ra) != hipSuccess) (void) hipGetLastError(); n = 0; }
+      // [ra, rb) minus every range of mspack_hip_pin's registry: the library never asks the runtime to register a byte that
+      // lies inside a registration it knows about
+      bool lock(uintptr_t ra, uintptr_t rb) {
+        if (rb <= ra) return false;
+        std::vector<PinRange> known;
+        { std::lock_guard<std::mutex> lock(g_pin_mu); for (const PinRange &k : g_pins) if (k.rb > ra && k.ra < rb) known.push_back(k); }
+        std::sort(known.begin(), known.end(), [](const PinRange &x, const PinRange &y) { return x.ra < y.ra; });
+        bool any = false;
+        uintptr_t at = ra;
+        for (const PinRange &k : known) {
+          if (k.ra > at) any = lock_one(at, k.ra) || any;
+          if (k.rb > at) at = k.rb;
+        }
+        if (at < rb) any = lock_one(at, rb) || any;
+        return any;
+      }
+      void release() { for (const PinRange &x : r) if (hipHostUnregister((void *) x.ra) != hipSuccess) (void) hipGetLastError(); r.clear(); n = 0; }
       ~Pins() { if (n) { hipDeviceSynchronize(); release(); } }      // (an error path: nothing may still be writing them)
     } pins, pins_in;
     struct Staged { void *host; size_t off, n; };
@@ -983,7 +1011,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     // knows; pieces outside all of them that are small go through the pinned staging buffer (no pageable copy in the way)
     auto copy_out = [&](uintptr_t lo, uintptr_t hi, const u8 *d_src) -> hipError_t {
       std::vector<uintptr_t> cuts;
-      pin_cuts(lo, hi, pins.r, pins.n, cuts);
+      pin_cuts(lo, hi, pins.r.data(), pins.n, cuts);
       uintptr_t at = lo;
       for (size_t i = 0; i <= cuts.size(); i++) {
         const uintptr_t to = i < cuts.size() ? cuts[i] : hi;
@@ -1009,14 +1037,8 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     static const bool pin_out_env = env_int("MSPACK_HIP_PIN_OUT", 1, 0, 1) != 0;
     // (a buffer that is page-locked already -- the drivers' arenas out of mspack_hip_stage_alloc, a caller's hipHostMalloc -- needs
     // no lock, and ASKING for one is not free: the runtime walks the pages before it notices: ~3 ms per 64 MB chunk, on the
-    // copy-back's critical path)
-    bool out_locked = false;
-    if (host_out) {
-      hipPointerAttribute_t at;
-      if (hipPointerGetAttributes(&at, host_out) == hipSuccess) out_locked = at.type == hipMemoryTypeHost;
-      else (void) hipGetLastError();
-    }
-    const bool pin_out = pin_out_env && !refs_in_out && !out_locked;
+    // copy-back's critical path.  Pins::lock_one asks the runtime whose memory a range is before it asks for the lock, per range)
+    const bool pin_out = pin_out_env && !refs_in_out;
     // The INPUT is not locked here by default (MSPACK_HIP_PIN_IN=1 does it, one range per call): for a caller's warm buffer the
     // runtime's pageable path is as fast as the lock costs (to the host 7.4 -> 8.1 ms on the headline batch); for an arena that was
     // just written -- the C drivers' gather -- it runs at 5-6 GB/s, and those callers lock their arena themselves (mspack_hip_pin).
@@ -1056,7 +1078,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       const Chunk &c = chunks[ci];
       hipStream_t st = one ? cx.st[0] : cx.st[2 + ci % n_comp];
       TRY(copy_cut(d_in + (c.in_lo - in_lo), (const char *) in + c.in_lo, (size_t)(c.in_hi - c.in_lo), hipMemcpyHostToDevice, st_in,
-                   pins_in.r, pins_in.n));
+                   pins_in.r.data(), pins_in.n));
       if (host_out)
         for (size_t i = c.a; i < c.b; i++)               // LZX DELTA reference data sits below the unit's output
           if (local[i].ref_len && local[i].kind == MSPACK_HIP_KIND_LZX_DELTA)

@@ -11,6 +11,27 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _abort_backtrace()
+
+
+def _abort_backtrace():
+    """If anything in this process calls abort() -- the HIP runtime on a GPU memory fault, glibc on a corrupted heap, an assertion --
+    say WHO: tools/csrc/abort_bt.c prints the native backtrace of the aborting thread to the terminal pytest was started on (its
+    own dup of stderr, taken here, before any capture) and to tests/_build/abort_bt.log.  Round 5 lost a whole-suite run to a SIGABRT
+    whose message went into pytest's capture and died with the process."""
+    import ctypes
+    import subprocess
+    try:
+        bdir = os.path.join(ROOT, "tests", "_build")
+        os.makedirs(bdir, exist_ok=True)
+        so = os.path.join(bdir, "abort_bt.so")
+        src = os.path.join(ROOT, "tools", "csrc", "abort_bt.c")
+        if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+            subprocess.check_call(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", so, src])
+        os.environ.setdefault("ABORT_BT_LOG", os.path.join(bdir, "abort_bt.log"))
+        ctypes.CDLL(so)
+    except Exception:            # (diagnostics only: never a reason to fail a run)
+        pass
 
 
 # Collection order (VERDICT round 4, item 2b): the driver runs `pytest -m gpu -x`, so a failure in a container / driver test

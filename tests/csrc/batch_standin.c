@@ -18,18 +18,24 @@
 #include "../../oracle/oracle.h"
 
 static char g_err[160] = "";
+const char *mspack_standin_last_error(void) { return g_err; }
+#ifndef STANDIN_NO_ABI
 const char *mspack_hip_version(void) { return "host-logic stand-in (CPU oracle; tests only)"; }
 const char *mspack_hip_last_error(void) { return g_err; }
 int mspack_hip_device_count(void) { return 1; }
 int mspack_hip_set_device(int d) { (void) d; return 0; }
+#endif
 
-int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
-                            void *out, size_t out_bytes, mspack_hip_result *results)
+/* units[order[0 .. n)] (order NULL: units[0 .. n)), one oracle call each -- also what tests/hostcheck puts in the place of a
+ * kernel launch (STANDIN_NO_ABI: only this function, the batch ABI itself is then shim.hip's) */
+int mspack_standin_decode_units(const mspack_hip_unit *units, const uint32_t *order, size_t n_units, const void *in, size_t in_bytes,
+                                void *out, size_t out_bytes, mspack_hip_result *results)
 {
   size_t i;
   for (i = 0; i < n_units; i++) {
-    const mspack_hip_unit *u = &units[i];
-    mspack_hip_result *r = &results[i];
+    const size_t ui = order ? order[i] : i;
+    const mspack_hip_unit *u = &units[ui];
+    mspack_hip_result *r = &results[ui];
     oracle_result o;
     uint32_t qtm_good = 0; int have_qtm_good = 0;
     const uint8_t *src = (const uint8_t *) in + u->in_off;
@@ -108,6 +114,13 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *
   return 0;
 }
 
+#ifndef STANDIN_NO_ABI
+int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
+                            void *out, size_t out_bytes, mspack_hip_result *results)
+{
+  return mspack_standin_decode_units(units, NULL, n_units, in, in_bytes, out, out_bytes, results);
+}
+
 int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
                                   void *out, size_t out_bytes, mspack_hip_result *results, int n_devices)
 {
@@ -124,3 +137,4 @@ int mspack_hip_pin(const void *p, size_t bytes) { (void) p; (void) bytes; return
 void mspack_hip_unpin(const void *p) { (void) p; }
 void *mspack_hip_stage_alloc(size_t bytes) { (void) bytes; return 0; }                       /* (no device: the ordinary allocator) */
 void mspack_hip_stage_free(void *p) { (void) p; }
+#endif  /* !STANDIN_NO_ABI */

@@ -163,11 +163,17 @@ hipError_t hipHostFree(void *p);
 void emu_test_delay(void);
 #define hipHostRegisterDefault 0
 #define hipHostRegisterPortable 1
-static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
-static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
 struct hipPointerAttribute_t { hipMemoryType type; };
+#ifdef MSPACK_HOST_CHECK     /* tests/hostcheck: the host half of shim.hip under real sanitizers, against a MODEL of the runtime's rules */
+hipError_t hipHostRegister(void *p, size_t n, unsigned flags);
+hipError_t hipHostUnregister(void *p);
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p);
+#else
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { a->type = hipMemoryTypeUnregistered; return hipSuccess; }
+#endif
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s = 0);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s = 0);

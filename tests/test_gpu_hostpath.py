@@ -376,15 +376,12 @@ def test_copies_are_cut_at_pin_boundaries(built):
     """The deterministic form of the same fault: a caller page-locks PART of its input arena and of its output buffer
     (mspack_hip_pin) -- every copy the entry points make then starts inside a locked range and ends behind it, or the other
     way round.  The runtime refuses such a copy (hipErrorInvalidValue); the entry points cut theirs at the boundaries.
-    Runs on the wavefront emulator only (tests/test_emu_kernels.py, CPU suite: the registry and the cutting are host code).  On the
-    hardware it passed four whole-suite runs of round 5 and aborted once in the fifth (SIGABRT inside one of its decode calls; not
-    reproduced in 66 repetitions outside pytest, tools/repro_pin_boundary*.py; unexplained -- DESIGN.md section 8h).  What it does and
-    the product never does: the HIP runtime has to lock and unlock megabytes of PAGEABLE memory right beside ranges the test has
-    locked itself, over and over in one process.  What the product does (arenas locked completely, or not at all) is held by
-    test_many_decompressors_one_process."""
-    if "emu" not in os.path.basename(M.HIP_SO):
-        pytest.skip("host-side logic: runs against the emulator build in the CPU suite")
-    n, ub = 24, 65536                      # (the emulator decodes ~1 MB/s: the cuts are what is tested, not the kernels)
+    Runs on the hardware (256 units) and, smaller, on the wavefront emulator in the CPU suite (tests/test_emu_kernels.py); the same
+    scenario at the hardware's size runs under real ASan / TSan against a model of the runtime's page-lock rules in
+    tests/test_hostcheck.py.  History: in round 5 this test aborted the process ONCE in five whole-suite runs on the hardware and was
+    moved off it; round 6 put it back (what was found, what was not; tests/conftest.py now keeps the native
+    backtrace and the runtime's last words of anything that aborts)."""
+    n, ub = (24 if "emu" in os.path.basename(M.HIP_SO) else 256), 65536     # (the emulator decodes ~1 MB/s: the cuts are what is tested, not the kernels)
     plain, comp, off, ln = M.corpus_lzx_units(0x9191, 0, n, ub, 21)
     units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=2)
     L = M.lib()
