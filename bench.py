@@ -166,9 +166,10 @@ def ref_cpu_secondary(kind, comp, off, ln, out_lens, window_bits, reset_frames, 
         reps = max(1, min(64, int(budget_s / max(est_pass, 1e-3))))
         units = n if est_pass <= budget_s else max(cores, int(n * budget_s / est_pass))
         v, t = run(units, cores, reps)
-        return {"value": round(v, 1), "unit": "MB/s", "cores": cores, "kind": "reference",
+        used = min(cores, units)                                     # (a thread per unit at most: ONE folder is one core's work)
+        return {"value": round(v, 1), "unit": "MB/s", "cores": used, "kind": "reference",
                 "sample": "%d pass(es) over %d of the %d units on %d threads in %.2f s (libmspack's own codec, memory to memory)" %
-                          (reps, units, n, cores, t)}
+                          (reps, units, n, used, t)}
     except Exception as ex:          # pragma: no cover
         return {"value": None, "kind": "reference", "error": str(ex)}
 
@@ -293,9 +294,12 @@ def secondary_qtm(M, torch, dev, n=512, frames=32, window_bits=21, iters=2, cpu=
             "cpu_baseline": ref_cpu_secondary(2, comp, off, ln, np.full(n, ub), window_bits, 0) if cpu else None}
 
 
-def secondary_lzx(M, torch, dev, what, n, ub, seed, first_unit=0, iters=10, threads=1):
-    """another LZX launch shape (BASELINE configs 3 and 5): n CHM-style reset intervals of ub bytes, window 2^21, frame tables"""
-    plain, comp, off, ln, tab = M.corpus_lzx_units(seed, 0, n, ub, 21, n_threads=threads, first_unit=first_unit, frame_tables=True)
+def secondary_lzx(M, torch, dev, what, n, ub, seed, first_unit=0, iters=10, threads=1, block_size=0):
+    """another LZX launch shape (BASELINE configs 3 and 5): n CHM-style reset intervals of ub bytes, window 2^21, frame tables.
+    block_size: uncompressed bytes per LZX block (0: this build's encoder's default, one block per 32 KiB frame; real encoders
+    write blocks that span frames -- the parse tasks then carry the open block from frame to frame)"""
+    plain, comp, off, ln, tab = M.corpus_lzx_units(seed, 0, n, ub, 21, opts=M.lzx_opts(block_size=block_size) if block_size else None,
+                                                   n_threads=threads, first_unit=first_unit, frame_tables=True)
     units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=ub // 32768, frame_tabs=tab)
     b = DeviceBatch(M, torch, dev, units, comp, out_bytes, M.KIND_LZX)
     b.step(); torch.cuda.synchronize()
@@ -306,6 +310,43 @@ def secondary_lzx(M, torch, dev, what, n, ub, seed, first_unit=0, iters=10, thre
             "value": round(n * ub / ms / 1e3, 1), "unit": "MB/s", "kernel_ms": round(ms, 4), "bit_exact": ok,
             "units_on_frame_parallel_path": round(float(((res["flags"] & M.F_FRAMES_ADOPTED) != 0).mean()), 4),
             "roofline": roofline(float(ln.sum()) + n * ub, ms, LZX_KERNELS)}
+
+
+def secondary_one_folder(M, torch, dev, kind, frames=512, seed=77, iters=3, cpu=True):
+    """ONE folder of ordinary data: the text corpus as a single cabinet folder -- LZX-21 with blocks of
+    4 MiB (what Microsoft's encoder writes), or MSZIP with history -- `frames` CFDATA blocks, block table passed.  Nothing here is
+    independent but the parse: the folder's copies are a chain from frame to frame (mspack_lzx_fold / mspack_mszip_fold:
+    lzx_fold.hpp).  The reference codec on ONE host core beside it: what a user of one folder would otherwise have."""
+    import zlib
+    n = frames * 32768
+    plain = M.gen_plaintext(seed, 0, n)
+    if kind == M.KIND_LZX:
+        lz, fo = M.lzx_encode(plain, 21, 0, M.lzx_opts(block_size=4 << 20))
+        stream, tab, wb, what = lz.tobytes(), np.asarray(fo[:-1]), 21, "LZX-21, blocks of 4 MiB"
+    else:
+        blocks, prev = [], None
+        for k in range(0, n, 32768):
+            b = plain[k:k + 32768].tobytes()
+            c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, 0, prev) if prev else zlib.compressobj(6, zlib.DEFLATED, -15)
+            blocks.append(b"CK" + c.compress(b) + c.flush()); prev = b
+        stream, tab, wb, what = b"".join(blocks), np.cumsum([0] + [len(b) for b in blocks[:-1]]), 0, "MSZIP (zlib level 6, history)"
+    base = (len(stream) + 64 + 15) & ~15
+    arena = np.zeros(base + 4 * len(tab) + 64, dtype=np.uint8)
+    arena[:len(stream)] = np.frombuffer(stream, dtype=np.uint8)
+    arena[base:base + 4 * len(tab)] = np.asarray(tab, dtype=np.uint32).view(np.uint8)
+    units, out_bytes = M.make_units(kind, [0], [len(stream)], [n], window_bits=wb, reset_frames=0, frame_tabs=[base],
+                                    out_slack=32768 if kind == M.KIND_MSZIP else 0)
+    b = DeviceBatch(M, torch, dev, units, arena, out_bytes, kind)
+    b.step(); torch.cuda.synchronize()
+    ms = b.kernel_ms(iters)
+    res, out = b.results(), b.output()[:n]
+    ok = bool(res["err"][0] == 0 and res["out_len"][0] == n and np.array_equal(out, plain))
+    off, ln = np.zeros(1, dtype=np.uint64), np.asarray([len(stream)], dtype=np.uint32)
+    return {"config": "ONE cabinet folder of %d blocks (%d MiB of the text corpus), %s, ratio %.3f" % (frames, n >> 20, what, len(stream) / n),
+            "value": round(n / ms / 1e3, 1), "unit": "MB/s", "kernel_ms": round(ms, 3), "bit_exact": ok,
+            "units_on_frame_parallel_path": round(float(((res["flags"] & M.F_FRAMES_ADOPTED) != 0).mean()), 4),
+            "roofline": roofline(float(len(stream)) + n, ms, "the launches of one mspack_hip_decode_batch_device call (parse, fold, unit kernel)"),
+            "cpu_baseline": ref_cpu_secondary(0 if kind == M.KIND_LZX else 1, arena, off, ln, np.asarray([n]), wb, 0, budget_s=4.0) if cpu else None}
 
 
 class _HipBuf:
@@ -637,7 +678,12 @@ def main():
                               0xBA5E11, threads=threads),
                 secondary_lzx(M, torch, dev, "BASELINE config 5, rank 0's shard of 8: %d of 65536 LZX reset intervals of 64 KiB in one "
                               "launch (strong-scaling seeding)" % (hi5 - lo5), hi5 - lo5, ub, 0xC0F165, first_unit=lo5, threads=threads),
-                secondary_mszip(M, torch, dev, cpu=cpu), secondary_qtm(M, torch, dev, cpu=cpu)]
+                secondary_mszip(M, torch, dev, cpu=cpu), secondary_qtm(M, torch, dev, cpu=cpu),
+                # what real containers look like: LZX blocks that span frames; one long folder per codec
+                secondary_lzx(M, torch, dev, "config 3's launch shape with LZX blocks that SPAN frames (one block of 64 KiB per reset interval, "
+                              "as real encoders write them): 1024 LZX reset intervals of 64 KiB (window 2^21)", 1024, ub, 0xBA5E12,
+                              threads=threads, block_size=65536),
+                secondary_one_folder(M, torch, dev, M.KIND_LZX, cpu=cpu), secondary_one_folder(M, torch, dev, M.KIND_MSZIP, cpu=cpu)]
             ta = (host_clean or {}).pop("through_api", None) if isinstance(host_clean, dict) else None
             if "host_inclusive" in line:
                 line["host_inclusive"].pop("through_api", None)

@@ -195,8 +195,10 @@ class MemSystem:
 
         def m_message(_h, fmt):           # variadic in C; the extra arguments are simply not looked at
             self.messages.append(fmt)
+            self.message_handles.append(bool(_h))      # (the reference passes the cabinet's handle with some lines, NULL with others)
 
         self.messages = []
+        self.message_handles = []
         MSG = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)
         self._cbs = [OPEN(m_open), CLOSE(m_close), RW(m_read), RW(m_write), SEEK(m_seek), TELL(m_tell), MSG(m_message)]
         vp = [C.cast(cb, C.c_void_p).value for cb in self._cbs]

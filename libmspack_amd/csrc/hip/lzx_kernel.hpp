@@ -1400,7 +1400,10 @@ struct __align__(16) LzxFrameRec {
   /* the unit's chain of frames (lzx_pipe_resolve): 0 = open, 1 = this frame and every frame before it are complete in the
    * output (cR0-cR2: R0-R2 behind its last match), 2 = the chain ended at or before this frame */
   u32 chain, cR0, cR1, cR2;
-  u8 pad2[32];
+  /* lzx_fold.hpp: R0-R2 behind the frame's last match, published as soon as they are known -- long before its bytes are
+   * final (rst: 0 open, 1 valid, 2 the chain ends at or before this frame) */
+  u32 rst, rR0, rR1, rR2;
+  u8 pad2[16];
   u32 chunk[REC_CHUNKS];            /* where the frame's match records are: wave_common.hpp, RecPool */
 };
 static_assert(sizeof(LzxFrameRec) == 1408, "LzxFrameRec layout");
@@ -2346,8 +2349,9 @@ __device__ __forceinline__ void lzx_restore_tables(LzxDec &d, LzxState &s)
 // one batch of match records: every match's offset through the R0-R2 LRU (lzxd.c:565-586; cf. lzx_commit_batch) and the
 // reference's checks (lzxd.c:613-634) -- offsets no linear copy serves (0, beyond the window) end the fast path too.
 // Returns false when a check fails.
-__device__ __forceinline__ bool lzx_front_batch(const bool ism, const u32 lane, const u32 opos, const u32 olen, const u32 which, const u32 c1,
-                                                u32 &R0, u32 &R1, u32 &R2, const u32 frame_pos, const u32 wbase, const u32 wsize, u32 &vmoff_out)
+// the LRU half on its own: the offsets only MOVE (no arithmetic on them), so symbolic values pass through it unchanged
+// (lzx_fold.hpp runs it with "R0 / R1 / R2 as they are at the frame's first byte" as placeholders)
+__device__ __forceinline__ u32 lzx_lru_batch(const bool ism, const u32 lane, const u32 which, const u32 c1, u32 &R0, u32 &R1, u32 &R2)
 {
   const u32 sR0 = R0, sR1 = R1, sR2 = R2;
   u32 vmoff = c1;
@@ -2384,6 +2388,12 @@ __device__ __forceinline__ bool lzx_front_batch(const bool ism, const u32 lane, 
     R1 = (f1 & 0x80u) ? rdl(c1, f1 & 63u) : (f1 == 0u ? sR0 : (f1 == 1u ? sR1 : sR2));
     R2 = (f2 & 0x80u) ? rdl(c1, f2 & 63u) : (f2 == 0u ? sR0 : (f2 == 1u ? sR1 : sR2));
   }
+  return vmoff;
+}
+__device__ __forceinline__ bool lzx_front_batch(const bool ism, const u32 lane, const u32 opos, const u32 olen, const u32 which, const u32 c1,
+                                                u32 &R0, u32 &R1, u32 &R2, const u32 frame_pos, const u32 wbase, const u32 wsize, u32 &vmoff_out)
+{
+  const u32 vmoff = lzx_lru_batch(ism, lane, which, c1, R0, R1, R2);
   vmoff_out = vmoff;
   const u32 wp = opos - wbase;
   const bool b = ism && (wp + olen > wsize || LZX_BAD_SOURCE(vmoff, wp, frame_pos, 0u, wsize) ||
@@ -2530,6 +2540,7 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
   PHFLUSH();
 #undef MREC
 }
+#include "lzx_fold.hpp"
 #endif  /* !LZX_PARSE_ONLY */
 #endif  /* !LZX_DELTA */
 

@@ -42,7 +42,9 @@ struct ZipBlockRec {
   u32 eob_rbl;                     /* the reference's bits_left there */
   u32 total_out;                   /* bytes the block produces (<= 32768) */
   u32 chunk[REC_CHUNKS];           /* where the block's match records are (wave_common.hpp: RecPool) */
-  u32 pad[330];
+  u32 fold;                        /* mspack_mszip_fold (zip_fold_block): 0 = not (yet), 1 = this block's matches are copied and so are those
+                                      of every block of the folder below it, 2 = the chain of folded blocks ended at or below this one */
+  u32 pad[329];
 };
 static_assert(sizeof(ZipBlockRec) == 1408, "ZipBlockRec slot size");
 
@@ -859,6 +861,110 @@ __device__ __forceinline__ bool zip_run_tokens(ZipDec &d, const uint2 *pool_base
   return ok;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// zip_fold_block -- the copies of CFDATA block b of a folder as a FOLD task (fold_common.hpp; mspack_mszip_fold, shim.hip): what
+// zip_run_tokens does on the folder's own wave, block after block (0.25 ms per block: one folder of ordinary data at 130 MB/s),
+// done by one wave per block with only the gather of bytes that come from the block BELOW left on the folder's chain.
+// Same records, same checks as zip_run_tokens; a block is only folded when every block below it is a full one that was folded
+// too (its history is then the 32 KiB right below it).  The folder's wave (mszip_decode_unit) stays the judge: it takes a
+// folded block only if the record was parsed from exactly its bit position and every earlier block was taken the same way;
+// else it copies the block's matches itself, or decodes the block serially, as before.
+// ---------------------------------------------------------------------------------------------------
+#define ZIP_FOLD_DONE 1u
+#define ZIP_FOLD_ENDED 2u
+__device__ void zip_fold_block(const mspack_hip_unit &u, const u32 b, u8 *out_arena, ZipBlockRec *urecs, const uint2 *pool_base, FoldLds *L)
+{
+  // (FOLD_WAVES waves: wave 0 reads the records and talks to the other tasks, all waves do what is per byte -- fold_common.hpp)
+  const u32 lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  u8 *const out = out_arena + u.out_off;
+  ZipBlockRec *rec = &urecs[b];
+  const u32 B = b * ZIP_FRAME;
+  if (wid == 0u) {
+    const u32 st = rfl(gld(&rec->status));
+    const u32 n_tok = rfl(gld(&rec->n_tokens)), total = rfl(gld(&rec->total_out));
+    bool ok = st == 1u && n_tok <= ZIP_TOK_CAP && total <= ZIP_FRAME;
+    // (the block below: parsed, and a full one -- checked again through the chain word, which says the same of every block below IT)
+    if (ok && b != 0u) ok = rfl(gld(&urecs[b - 1u].status)) == 1u && rfl(gld(&urecs[b - 1u].total_out)) == ZIP_FRAME;
+    if (ok) {
+      fold_init(L, B, total, lane);
+      u32 P = 0;                                                    // everything below this position of the block is covered
+      uint2 cur0 = make_uint2(0u, 0u), cur1 = cur0, cur2 = cur0, cur3 = cur0;
+      if (n_tok) {
+        const uint2 *g0 = rec_group(pool_base, rec->chunk, 0u);
+        if (lane < n_tok) cur0 = gld(g0 + lane);
+        if (64u + lane < n_tok) cur1 = gld(g0 + 64u + lane);
+        if (128u + lane < n_tok) cur2 = gld(g0 + 128u + lane);
+        if (192u + lane < n_tok) cur3 = gld(g0 + 192u + lane);
+      }
+      u32 th = 0;
+      while (th < n_tok && ok) {
+        uint2 nx0 = make_uint2(0u, 0u), nx1 = nx0, nx2 = nx0, nx3 = nx0;
+        if (th + 256u < n_tok) {
+          const uint2 *g1 = rec_group(pool_base, rec->chunk, th + 256u);
+          const u32 tb = th + 256u + lane;
+          if (tb < n_tok) nx0 = gld(g1 + lane);
+          if (tb + 64u < n_tok) nx1 = gld(g1 + 64u + lane);
+          if (tb + 128u < n_tok) nx2 = gld(g1 + 128u + lane);
+          if (tb + 192u < n_tok) nx3 = gld(g1 + 192u + lane);
+        }
+#pragma unroll 1
+        for (u32 k = 0; k < 4u && th < n_tok && ok; k++) {
+          const u32 n = n_tok - th < 64u ? n_tok - th : 64u;
+          const uint2 cur = k == 0u ? cur0 : (k == 1u ? cur1 : (k == 2u ? cur2 : cur3));
+          const bool valid = lane < n;
+          const u32 rpos = cur.x, olen = valid ? (cur.y & 511u) : 0u, dist = cur.y >> 9;
+          // zip_run_tokens' checks: in order, inside the block; a source below the block only within the 32 KiB right below it
+          const u32 prev_end = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int)(rpos + olen));
+          const bool bad = valid && (olen < 3u || dist == 0u || rpos + olen > total || rpos < (lane == 0u ? P : prev_end) ||
+                                     (dist > rpos && (b == 0u || dist > rpos + ZIP_FRAME)));
+          if (ballot(bad)) { ok = false; break; }
+          fold_fill_batch(L, B, valid, n, rpos, olen, dist, lane);
+          P = rdl(rpos + olen, n - 1u);
+          th += n;
+        }
+        cur0 = nx0; cur1 = nx1; cur2 = nx2; cur3 = nx3;
+      }
+    }
+#if defined(MSPACK_WAVE_EMU)
+    if (lane == 0 && getenv("MSPACK_EMU_FOLD_TRACE")) fprintf(stderr, "zip_fold_block: block %u: %u records, %u bytes, ok %d\n", b, n_tok, total, (int) ok);
+#endif
+    if (lane == 0) { L->ctl[1] = ok ? 1u : 0u; L->ctl[2] = total; }
+  }
+  fold_barrier();
+  const bool ok = L->ctl[1] != 0u;
+  const u32 total = L->ctl[2];
+  u32 nl = 0;
+  if (ok) {
+    fold_jump_all(L, B, total, wid, lane);
+    fold_write_own(L, out, B, total, wid, lane);
+    // (a deflate distance reaches 32 KiB: whatever comes from below the block comes from the block right below it -- nothing to
+    // gather a link early; the list of those bytes is made now, off the chain)
+    nl = fold_write_early(L, out, B, total, wid, lane);
+  }
+  // the folder's chain: every block below folded?  (a task only waits for lower blocks of its folder: earlier tickets)
+  if (wid == 0u) {
+    u32 pch = ZIP_FOLD_DONE;
+    if (b != 0u) {
+      pch = zip_status_load(&urecs[b - 1u].fold);
+      for (u32 tries = 0; pch == 0u && tries < (1u << 24); tries++) { __builtin_amdgcn_s_sleep(4); pch = zip_status_load(&urecs[b - 1u].fold); }
+    }
+    if (lane == 0) L->ctl[3] = pch;
+  }
+  fold_barrier();
+  if (L->ctl[3] != ZIP_FOLD_DONE || !ok) {
+    if (wid == 0u) zip_status_publish(&rec->fold, ZIP_FOLD_ENDED, lane);
+    return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (nl) fold_write_late(L, out, B, total, nl, wid, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // (every wave's stores out of the door before wave 0 says so)
+#ifndef MSPACK_WAVE_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  fold_barrier();
+  if (wid == 0u) zip_status_publish(&rec->fold, ZIP_FOLD_DONE, lane);
+}
+
 // inflate (mszipd.c:154-316): 0 ok, <0 format error, >0 ERR_READ.  *bytes_output as the reference.
 __device__ __forceinline__ int zip_inflate(ZipDec &d, u32 &bytes_output)
 {
@@ -974,6 +1080,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
   u32 state0 = 0;                 // 'C','K' scanner state carried over a repair restart
   d.snap_iptr = 0; d.snap_rbl = 0;
   const bool use_recs = recs != nullptr && (u.flags & MSPACK_HIP_UF_FRAME_TABLE) != 0u && !repair && !kwaj;
+  bool fold_chain = true;         // every block so far was taken as mspack_mszip_fold left it (zip_fold_block)
   u32 blk = 0;                    // CFDATA blocks started so far (the frame slot of the next one)
   const u32 nblk = (u.out_len + ZIP_FRAME - 1u) / ZIP_FRAME;
   // repair mode with MSPACK_HIP_UF_MSZIP_LOG: which blocks were repaired and how many bytes each lost -- what the reference
@@ -1021,8 +1128,11 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
       const ZipBlockRec *rc_ = &recs[u.frame_base + blk];
       const u32 st_ = rfl(rc_->status);       // (the parse kernel ran before this one)
       // (and only where the parse wave put the literals: every earlier block of the folder a full one)
-      if (st_ == 1u && rfl(rc_->start_bit) == d.w.origin * 8u + d.cons_bits() && d.B == blk * ZIP_FRAME &&
-          zip_run_tokens(d, toks, rc_->chunk, rc_->n_tokens, rc_->total_out)) {
+      // (its matches may have been copied already, as a fold task: only usable when every block before it was taken that way)
+      const bool at = st_ == 1u && rfl(rc_->start_bit) == d.w.origin * 8u + d.cons_bits() && d.B == blk * ZIP_FRAME;
+      const bool folded = at && fold_chain && rfl(rc_->fold) == ZIP_FOLD_DONE;
+      if (!folded) fold_chain = false;
+      if (at && (folded || zip_run_tokens(d, toks, rc_->chunk, rc_->n_tokens, rc_->total_out))) {
         const u32 eb = rfl(rc_->end_bit), total = rfl(rc_->total_out);
         d.restart(eb >> 3);
         { const u32 sk = eb & 7u; if (sk) { d.need((int) sk); d.bb >>= sk; d.bl -= (int) sk; } }
@@ -1033,6 +1143,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
         rflags |= MSPACK_HIP_F_FRAMES_ADOPTED;
       }
     }
+    else fold_chain = false;
     blk++;
     if (!adopted) r = zip_inflate(d, bytes_output);
     if (r) {

@@ -11,6 +11,7 @@
 #include <array>
 #include "wave_common.hpp"
 #include "spec_queue.hpp"
+#include "fold_common.hpp"
 // lzx_kernel.hpp is compiled twice: plain LZX (CAB, CHM) and LZX DELTA (OAB) -- see its header
 namespace lzxn {
 #include "lzx_kernel.hpp"
@@ -96,7 +97,9 @@ __device__ __forceinline__ void frame_map_unit(const mspack_hip_unit &u, const u
   for (u32 f = threadIdx.x; f < nslots; f += 64u) {
     frame_unit[u.frame_base + f] = f < nreal ? ui : 0xFFFFFFFFu;
     recs[u.frame_base + f].status = 0u;
+    if (kind == MSPACK_HIP_KIND_MSZIP) ((ZipBlockRec *) &recs[u.frame_base + f])->fold = 0u;
   }
+  if (threadIdx.x == 0 && kind == MSPACK_HIP_KIND_MSZIP) atomicAdd(&hdr[5], 1u);      // (units with a table: mspack_mszip_fold's rule)
 }
 
 // the same for mspack_lzx_pipe, one unit per LANE (4096 one-wave blocks with two atomics each on the same words took
@@ -121,8 +124,12 @@ void mspack_lzx_pipe_map(const mspack_hip_unit *units, const u32 *order, u32 n_u
           frame_unit[u.frame_base + f] = f < nreal ? ui : 0xFFFFFFFFu;
           recs[u.frame_base + f].status = 0u;
           recs[u.frame_base + f].chain = 0u;
+          recs[u.frame_base + f].rst = 0u;
         }
         recs[u.frame_base].rs_valid = 0u;
+        // (what decides between lzx_pipe_resolve and mspack_lzx_fold: how many units carry a table; positions beyond 2^31 do not fit the fold's map)
+        atomicAdd(&ctl[5], 1u);
+        if (u.out_len > 0x7FFF0000u) atomicOr(&ctl[6], 1u);
       }
       fr = usable ? nreal : 0u;
     }
@@ -195,6 +202,47 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
 // one agent-scope acquire (lzx_kernel.hpp).  The first frame that is not a complete regular one ends its unit's chain and
 // says where serial decoding resumes; mspack_decode_lzx (launched behind the pipe) finishes every unit.
 // ---------------------------------------------------------------------------------------------------
+// ---- few units of many frames: the folder's chain as one gather pass per frame (lzx_fold.hpp) ----
+// Decided per launch from what the map kernel counted (ctl[0] = most frames of a unit with a table, ctl[5] = such units, ctl[6] =
+// some unit is too long for the map's positions): policy 0 never, 1 when it pays, 2 whenever it can (tests).  Where it pays: the
+// resolve tasks of lzx_pipe_resolve fill 16 waves per CU and cost ~0.25 ms per frame ON a unit's chain; the fold tasks fill ONE wave
+// per CU (128 KiB of LDS each) and leave ~15 us per frame on the chain -- so: long units, and too few of them to fill the chip.
+#ifndef LZX_FOLD_MIN_FRAMES
+#define LZX_FOLD_MIN_FRAMES 4u
+#endif
+#ifndef LZX_FOLD_MAX_UNITS
+#define LZX_FOLD_MAX_UNITS 128u
+#endif
+__device__ __forceinline__ bool lzx_fold_on(const u32 *ctl, const u32 policy)
+{
+  if (policy == 0u || rfl(ctl[6]) != 0u || rfl(ctl[0]) == 0u) return false;
+  return policy >= 2u || (rfl(ctl[0]) >= LZX_FOLD_MIN_FRAMES && rfl(ctl[5]) <= LZX_FOLD_MAX_UNITS);
+}
+// (a workgroup of FOLD_WAVES waves per task: fold_common.hpp; wave 0 pulls the tickets)
+#define FOLD_TICKET(counter)                                                      \
+  if (threadIdx.x == 0) sh.ctl[0] = atomicAdd(counter, 1u);                      \
+  fold_barrier();                                                                 \
+  const u32 t = rfl(sh.ctl[0]);                                                   \
+  fold_barrier();                                    /* (the word is free again) */
+__global__ __launch_bounds__(FOLD_THREADS)
+void mspack_lzx_fold(const mspack_hip_unit *units, u32 slot_lo, u32 n_slots, u8 *out_arena, const u32 *frame_unit, u32 *ctl,
+                     lzxn::LzxFrameRec *recs, const uint2 *toks, u32 fold_policy)
+{
+  __shared__ lzxn::LzxFoldLds sh;
+  if (!lzx_fold_on(ctl, fold_policy)) return;
+  for (;;) {
+    FOLD_TICKET(&ctl[7])
+    if (t >= n_slots) break;
+    const u32 slot = slot_lo + t;
+    const u32 ui = rfl(frame_unit[slot]);
+    if (ui == 0xFFFFFFFFu) continue;
+    const mspack_hip_unit u = units[ui];
+    if (u.kind != MSPACK_HIP_KIND_LZX || !(u.flags & MSPACK_HIP_UF_FRAME_TABLE)) continue;
+    lzxn::lzx_fold_frame(u, slot - u.frame_base, out_arena, &recs[u.frame_base], toks, &sh);
+    fold_barrier();                                   // the next task reuses the LDS
+  }
+}
+
 union LzxPipeLds { lzxp::LzxShared p; lzxn::LzxResolveLds r; };
 static_assert(sizeof(LzxPipeLds) <= 10240, "16 waves per CU");
 
@@ -223,7 +271,7 @@ __device__ unsigned long long g_pipe_trace[4 << 16];
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZX_PIPE_WAVES_PER_EU)))
 void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
                      const u8 *in_arena, u8 *out_arena, mspack_hip_result *results, int32_t *frame_meta,
-                     const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks, u32 pool_chunks)
+                     const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks, u32 pool_chunks, u32 fold_policy)
 {
   __shared__ LzxPipeLds sh;
   const u32 lane = threadIdx.x;
@@ -234,7 +282,10 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
   // frames and then sit on their slots until those units' first frames are through: 253 us waited per task, headline 3.25 ms).
   // Otherwise: one ticket per frame slot, parse + resolve by the same wave, a unit's frames in a row.
   const u32 Fmax = rfl(ctl[0]), Fmin = rfl(ctl[1]);
-  const u32 F = (Fmax != 0u && Fmax == Fmin) ? Fmax : 0u;
+  // few units of many frames: this launch only PARSES (a unit's frames in a row: the header chain); mspack_lzx_fold, launched behind
+  // it, does what lzx_pipe_resolve would have done (lzx_fold.hpp)
+  const bool fold = lzx_fold_on(ctl, fold_policy);
+  const u32 F = (Fmax != 0u && Fmax == Fmin && !fold) ? Fmax : 0u;
   const u32 T = F ? 2u * n_units * F : n_slots;
   for (;;) {
     u32 t = 0;
@@ -242,7 +293,7 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
     t = rfl(t);
     if (t >= T) break;
     u32 ui = 0xFFFFFFFFu, f = 0;
-    bool do_parse = true, do_resolve = true;
+    bool do_parse = true, do_resolve = !fold;
     if (F) {
       const u32 sct = t / n_units;
       ui = rfl(order ? order[t % n_units] : t % n_units);
@@ -324,6 +375,25 @@ void mspack_mszip_parse(const mspack_hip_unit *units, const u32 *order, u32 n_un
   const mspack_hip_unit u = units[ui];
   RecPool rp; rp.base = toks; rp.head = &hdr[4]; rp.cap = pool_chunks;
   zip_parse_block(u, slot - u.frame_base, in_arena, out_arena, (ZipBlockRec *) &recs[slot], rp, &sh);
+}
+
+// the copies of a launch's MSZIP blocks as fold tasks (zip_fold_block; the rule is mspack_lzx_fold's: few folders of many blocks)
+__global__ __launch_bounds__(FOLD_THREADS)
+void mspack_mszip_fold(const mspack_hip_unit *units, u32 slot_lo, u32 n_slots, u8 *out_arena, const u32 *frame_unit, u32 *hdr,
+                       lzxn::LzxFrameRec *recs, const uint2 *toks, u32 fold_policy)
+{
+  __shared__ FoldLds sh;
+  if (!lzx_fold_on(hdr, fold_policy)) return;
+  for (;;) {
+    FOLD_TICKET(&hdr[7])
+    if (t >= n_slots) break;
+    const u32 slot = slot_lo + t;
+    const u32 ui = rfl(frame_unit[slot]);
+    if (ui == 0xFFFFFFFFu) continue;
+    const mspack_hip_unit u = units[ui];
+    zip_fold_block(u, slot - u.frame_base, out_arena, (ZipBlockRec *) &recs[u.frame_base], toks, &sh);
+    fold_barrier();
+  }
 }
 
 __global__ __launch_bounds__(64)
@@ -423,6 +493,9 @@ static int fail(hipError_t e, const char *what) {
 // that carry a frame table get their frames parsed by one wave each first (slots [slot_lo, slot_lo + n_slots)
 // of the work scratch belong to this launch).
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
+// MSPACK_HIP_FOLD: 0 = a folder's copies always through lzx_pipe_resolve, 1 (default) = through mspack_lzx_fold when the launch is few
+// long units, 2 = whenever the units allow it (tests, A/B runs)
+static const u32 g_fold_policy = getenv("MSPACK_HIP_FOLD") ? (u32) atoi(getenv("MSPACK_HIP_FOLD")) : 1u;
 // persistent waves of mspack_lzx_pipe: as many as the device holds at once (nothing depends on that number being right)
 // (cached per device: mspack_hip_decode_batch_multi runs one host thread per device)
 static unsigned lzx_pipe_waves()
@@ -438,6 +511,20 @@ static unsigned lzx_pipe_waves()
     if (e != hipSuccess || per_cu < 1) per_cu = 16;
     { const char *ev = getenv("MSPACK_HIP_PIPE_WAVES_PER_CU"); if (ev && atoi(ev) > 0) per_cu = atoi(ev); }
     cache[dev] = (unsigned) pr.multiProcessorCount * (unsigned) per_cu;
+  }
+  return cache[dev];
+}
+// waves of mspack_lzx_fold: one per CU (its LDS block is most of a CU's)
+static unsigned lzx_fold_waves()
+{
+  int dev = 0; hipDeviceProp_t pr;
+  static std::mutex mu;
+  static unsigned cache[MSPK_MAX_DEV_CACHE] = { 0 };
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MSPK_MAX_DEV_CACHE) return 256u;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cache[dev]) {
+    if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256u;
+    cache[dev] = (unsigned) pr.multiProcessorCount;
   }
   return cache[dev];
 }
@@ -498,7 +585,12 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
       const size_t tickets = 2u * n_slots;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
       LK(launch(mspack_lzx_pipe, dim3(waves), block, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots, in, out, d_results,
-                L.meta, L.frame_unit, hdr, L.recs, pool, pool_chunks));
+                L.meta, L.frame_unit, hdr, L.recs, pool, pool_chunks, g_fold_policy));
+      // few long units: the frames' copies as fold tasks, one wave per CU (the kernel decides from what the map kernel counted and
+      // leaves at once otherwise; a launch of more units than the rule allows is not even asked)
+      if (g_fold_policy >= 2u || (g_fold_policy == 1u && n <= LZX_FOLD_MAX_UNITS && n_slots >= LZX_FOLD_MIN_FRAMES))
+        LK(launch(mspack_lzx_fold, dim3((unsigned) std::min<size_t>(n_slots, lzx_fold_waves())), dim3(FOLD_THREADS), st, d_units, (u32) slot_lo, (u32) n_slots,
+                  out, L.frame_unit, hdr, L.recs, pool, g_fold_policy));
       // what the pipe leaves: the last bytes of every unit's input (the EOF-exact reader's), the look-ahead frame, frames
       // that are not one regular block, errors, E8, the results -- the unit kernel, resuming where each unit's chain of frames ended
       LK(launch(mspack_decode_lzx, grid, block, st, d_units, d_order, (u32) n, in, out, d_results, L.meta, L.recs, pool, 1u));
@@ -525,6 +617,9 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
       LK(launch(mspack_lzx_frame_map, grid, block, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr, (u32) MSPACK_HIP_KIND_MSZIP));
       LK(launch(mspack_mszip_parse, dim3((unsigned) n_slots), block, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots, in, out,
                 L.frame_unit, hdr, L.recs, pool, pool_chunks));
+      if (g_fold_policy >= 2u || (g_fold_policy == 1u && n <= LZX_FOLD_MAX_UNITS && n_slots >= LZX_FOLD_MIN_FRAMES))
+        LK(launch(mspack_mszip_fold, dim3((unsigned) std::min<size_t>(n_slots, lzx_fold_waves())), dim3(FOLD_THREADS), st, d_units, (u32) slot_lo, (u32) n_slots,
+                  out, L.frame_unit, hdr, L.recs, pool, g_fold_policy));
     }
     LK(launch(mspack_decode_mszip, grid, block, st, d_units, d_order, (u32) n, in, out, d_results,
               frames ? L.recs : (lzxn::LzxFrameRec *) nullptr, pool));
@@ -556,6 +651,13 @@ int mspack_hip_debug_counters(unsigned long long *out8) {
 #ifdef QTM_TIMERS
 int mspack_hip_debug_qtm_timers(unsigned long long *out8) {
   return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_qtm_tm), 64) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef FOLD_TRACE
+int mspack_hip_debug_fold_phases(unsigned long long *out16) {
+  unsigned long long z[16] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fold_phase), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fold_phase), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
 #ifdef LZX_PIPE_TRACE

@@ -1139,7 +1139,12 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
       const int have_ck = self->msg_next_ck < fol->ck_n && fol->rep_ck[self->msg_next_ck] < end;
       const int have_rp = self->msg_next < fol->rep_n && fol->rep[2 * self->msg_next] < end;
       if (have_ck && (!have_rp || fol->rep_ck[self->msg_next_ck] <= fol->rep[2 * self->msg_next])) {
-        sys->message(NULL, "WARNING; bad block checksum found");
+        /* the reference says this with the handle of the cabinet it is reading (cabd.c:1415: sys->message(d->infh, ...)): a
+         * system that prints the file's name must find one.  This driver's gather closed the cabinet long ago, so it is opened
+         * for the occasion (the folder's first cabinet; if that fails the line goes out without a handle) */
+        struct mspack_file *mfh = sys->open(sys, fol->data.cab->base.filename, MSPACK_SYS_OPEN_READ);
+        sys->message(mfh, "WARNING; bad block checksum found");
+        if (mfh) sys->close(mfh);
         self->msg_next_ck++;
       }
       else if (have_rp) {

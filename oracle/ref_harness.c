@@ -98,10 +98,20 @@ static void msg_append(const char *line) {
   memcpy(g_msgs + g_msgs_len, line, n); g_msgs_len += n;
   g_msgs[g_msgs_len++] = '\n'; g_msgs[g_msgs_len] = 0;
 }
+/* ... and, per line, whether it came with a file handle ('H') or with NULL ('-'); the harness's own "#extract" marks are '#' */
+static char g_msg_handles[1 << 12];
+static size_t g_msg_handles_len;
+static void handle_append(char c) { if (g_msg_handles_len + 2 < sizeof(g_msg_handles)) { g_msg_handles[g_msg_handles_len++] = c; g_msg_handles[g_msg_handles_len] = 0; } }
+size_t refh_message_handles(char *buf, size_t cap) {
+  size_t n = g_msg_handles_len < cap ? g_msg_handles_len : (cap ? cap - 1 : 0);
+  if (cap) { memcpy(buf, g_msg_handles, n); buf[n] = 0; }
+  g_msg_handles_len = 0; g_msg_handles[0] = 0;
+  return n;
+}
 static void m_msg(struct mspack_file *file, const char *format, ...) {
   char line[512];
   va_list ap;
-  (void) file;
+  handle_append(file ? 'H' : '-');
   va_start(ap, format);
   vsnprintf(line, sizeof(line), format, ap);
   va_end(ap);
@@ -282,7 +292,7 @@ int refh_cab_extract(const uint8_t *cab, size_t cab_len, const int *order, int n
     int k = order[i];
     while (f && k-- > 0) f = f->next;
     if (!f) { errs[i] = MSPACK_ERR_ARGS; out_offs[i] = pos; out_lens[i] = 0; continue; }
-    { char mark[32]; snprintf(mark, sizeof(mark), "#extract %d", i); msg_append(mark); }
+    { char mark[32]; snprintf(mark, sizeof(mark), "#extract %d", i); msg_append(mark); handle_append('#'); }
     errs[i] = d->extract(d, f, (const char *) &dst);
     out_offs[i] = pos;
     out_lens[i] = dst.written;
@@ -423,7 +433,7 @@ int refh_chm_extract(const uint8_t *chm, size_t chm_len, const int *order, int n
     int k = order[i];
     while (f && k-- > 0) f = f->next;
     if (!f) { errs[i] = MSPACK_ERR_ARGS; out_offs[i] = pos; out_lens[i] = 0; continue; }
-    { char mark[32]; snprintf(mark, sizeof(mark), "#extract %d", i); msg_append(mark); }
+    { char mark[32]; snprintf(mark, sizeof(mark), "#extract %d", i); msg_append(mark); handle_append('#'); }
     errs[i] = d->extract(d, f, (const char *) &dst);
     out_offs[i] = pos;
     out_lens[i] = dst.written;

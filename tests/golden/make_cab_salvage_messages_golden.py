@@ -29,12 +29,14 @@ def main():
             helpers.ref_messages()
             rc, res = helpers.ref_cab_extract(cab, order, cap=len(order) * 160000 + 4096, salvage=1)
             assert rc == 0
-            per = []
-            for l in helpers.ref_messages():
-                if l.startswith("#extract"): per.append(0)
-                elif per and "bad block checksum" in l: per[-1] += 1
-            g["runs"].append(dict(order=order, errs=[e for e, _ in res], warnings=per))
-            print(v["seed"], order, [e for e, _ in res], per)
+            per, hnd = [], []
+            lines = helpers.ref_messages()
+            for l, h in zip(lines, helpers.ref_message_handles()):
+                if l.startswith("#extract"): per.append(0); hnd.append("")
+                elif per and "bad block checksum" in l: per[-1] += 1; hnd[-1] += h
+            # handles: per call, one character per warning -- 'H' = said with the cabinet's file handle (cabd.c:1415), '-' = with NULL
+            g["runs"].append(dict(order=order, errs=[e for e, _ in res], warnings=per, handles=hnd))
+            print(v["seed"], order, [e for e, _ in res], per, hnd)
         gold.append(g)
     json.dump(gold, open(os.path.join(HERE, "cab_salvage_messages.json"), "w"), indent=1)
 

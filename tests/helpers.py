@@ -225,6 +225,14 @@ def ref_messages():
     return buf.value.decode("latin1").splitlines()
 
 
+def ref_message_handles():
+    """per line of ref_messages() since the last call: 'H' = the reference passed a file handle to sys->message, '-' = NULL, '#' = one of
+    the harness's own '#extract i' marks.  Call it right after ref_messages()."""
+    buf = C.create_string_buffer(1 << 12)
+    ref().refh_message_handles(buf, len(buf))
+    return buf.value.decode("latin1")
+
+
 def ref_lzx(data, out_bytes, window_bits, reset_frames=0, length=None):
     if length is None:
         length = out_bytes

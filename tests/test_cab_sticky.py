@@ -77,11 +77,15 @@ def test_salvage_checksum_warnings_come_with_the_call_that_reads_the_block_cpu(b
     for run in g["runs"]:
         with api.Cab(cab, mem=True, L=hostlogic, salvage=1) as c:
             assert c.open_error == 0
-            got, errs = [], []
+            got, errs, hnd = [], [], []
             for i in run["order"]:
                 del c.mem.messages[:]
+                del c.mem.message_handles[:]
                 c.mem.outputs.clear()
                 err, _ = c.extract(i)
                 errs.append(err)
                 got.append(sum(1 for m in c.mem.messages if b"bad block checksum" in m))
+                hnd.append("".join("H" if h else "-" for m, h in zip(c.mem.messages, c.mem.message_handles) if b"bad block checksum" in m))
             assert errs == run["errs"] and got == run["warnings"], (g["seed"], run["order"], errs, got, run)
+            # ... and said the way the reference says it: with the cabinet's file handle (cabd.c:1415), not with NULL
+            assert hnd == run["handles"], (g["seed"], run["order"], hnd, run["handles"])

@@ -39,28 +39,29 @@ def main():
                 helpers.ref_messages()
                 rc, want = helpers.ref_cab_extract(cab, order, cap=len(order) * 160000 + 4096, salvage=salvage)
                 lines = helpers.ref_messages()
-                ref_open, ref_calls = [], []
-                for l in lines:
-                    if l.startswith("#extract"): ref_calls.append([])
-                    elif ref_calls: ref_calls[-1].append(l)
-                    else: ref_open.append(l)
+                ref_open, ref_calls, ref_h_open, ref_h_calls = [], [], [], []      # (lines, and per line: said with a file handle?)
+                for l, h in zip(lines, helpers.ref_message_handles()):
+                    if l.startswith("#extract"): ref_calls.append([]); ref_h_calls.append([])
+                    elif ref_calls: ref_calls[-1].append(l); ref_h_calls[-1].append(h == "H")
+                    else: ref_open.append(l); ref_h_open.append(h == "H")
                 with api.Cab(cab, mem=True, L=L, salvage=salvage) as c:
                     if c.open_error:
                         if rc == 0: bad += 1; print("case %d: open mine %d, the reference opens it" % (k, c.open_error))
                         break
                     if rc: break
-                    if not same(c.mem.messages, ref_open):
+                    if not same(c.mem.messages, ref_open) or c.mem.message_handles != ref_h_open:
                         bad += 1; print("case %d salvage %d open: reference %s mine %s" % (k, salvage, ref_open, c.mem.messages)); break
                     ok = True
                     for j, i in enumerate(order):
                         if i >= len(c.files): break
                         del c.mem.messages[:]
+                        del c.mem.message_handles[:]
                         c.mem.outputs.clear()
                         err, data = c.extract(i)
-                        if j < len(ref_calls) and not same(c.mem.messages, ref_calls[j]):
+                        if j < len(ref_calls) and (not same(c.mem.messages, ref_calls[j]) or c.mem.message_handles != ref_h_calls[j]):
                             bad += 1; ok = False
                             print("case %d salvage %d order %s call %d (file %d, err %d / %d): reference %s mine %s" %
-                                  (k, salvage, order, j, i, want[j][0], err, ref_calls[j], c.mem.messages)); break
+                                  (k, salvage, order, j, i, want[j][0], err, list(zip(ref_calls[j], ref_h_calls[j])), list(zip(c.mem.messages, c.mem.message_handles)))); break
                     if not ok: break
             else: continue
             break
