@@ -123,7 +123,10 @@ typedef struct mspack_hip_result {
   uint32_t in_next;      /* LZX: input byte offset (from in_off) right after the 16-bit realignment that
                             follows the last completely decoded non-empty frame (lzxd.c:695-697), i.e.
                             where a decoder that keeps going reads the next frame from.  The CHM driver
-                            checks the reset table against it; 0 if no frame was completed            */
+                            checks the reset table against it; 0 if no frame was completed.
+                            MSZIP (err 0): bytes the last decoded block inflated to BEYOND out_len -- mszipd sizes a block
+                            by its deflate stream, not by the CFDATA header (mszipd.c:377-460), and keeps those bytes for
+                            its next call; they lie in the unit's 32 KiB of slack behind out_len                     */
 } mspack_hip_result;
 
 /* ---- library / device ----------------------------------------------------------------------- */

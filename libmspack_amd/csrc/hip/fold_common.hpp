@@ -17,14 +17,15 @@
 
 // A fold task is run by FOLD_WAVES waves (one workgroup) that share the map: what costs time in the chain's passes is the round trip
 // of scattered byte gathers to memory another XCD has just written (~8 us per batch of 48 x 64, measured), and a wave cannot have
-// more than 63 memory instructions in flight -- four waves have four times that.  Wave 0 does what is serial (the records, the
+// more than 63 memory instructions in flight -- eight waves have eight times that (measured: 35.0 / 22.1 / 15.0 / 11.7 / 11.2 ms for a
+// 512-frame folder with 1 / 2 / 4 / 8 / 16 waves).  Wave 0 does what is serial (the records, the
 // hand-offs), all waves do what is per byte.  (The wavefront emulator models one wave per workgroup: there the task runs on one.)
 #if defined(MSPACK_WAVE_EMU)
 #define FOLD_WAVES 1u
 #define fold_barrier() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 #else
 #ifndef FOLD_WAVES
-#define FOLD_WAVES 4u
+#define FOLD_WAVES 8u
 #endif
 #define fold_barrier() __syncthreads()
 #endif
@@ -163,17 +164,19 @@ __device__ __forceinline__ void fold_write_own(const FoldLds *L, u8 *const out, 
   }
 }
 // The folder's chain.  A byte that comes from below the frame waits for the frames below to be final -- but only for the one its
-// source lies in: what comes from further down than the frame right below is gathered one link of the chain EARLIER (once the frame
-// before that one is final), beside the last pass of the frame below; what is left on the chain is the gather of the bytes that come
-// from the frame right below (measured on the hardware with ONE pass behind the frame below: ~76 us per link -- sixteen dependent
-// round trips to memory that another XCD has just written).
-// fold_write_early: everything below base - 32 KiB is final.  Gathers the bytes that come from there, and compacts the others
-// (sources in the 32 KiB right below the frame) into a list at the bottom of the map -- position in the frame << 16 | source
-// position in that 32 KiB -- in place: entry k is written when at least k bytes have been read.  Returns the list's length.
+// source lies in.  Measured on the hardware with ONE pass behind the frame below: ~76 us per link (sixteen dependent round trips to
+// memory that another XCD has just written); so the gathers are taken in three steps, each as early as its sources allow:
+//   fold_write_early   everything more than two frames below is final (the frame three below is): gathers what comes from there,
+//                      and compacts the rest -- sources in the 64 KiB right below the frame -- into a list at the bottom of the
+//                      wave's share of the map: position in the frame << 16 | source position in those 64 KiB; in place (entry k
+//                      is written when at least k bytes have been read).  Returns the list's length;
+//   fold_write_late(0) the frame two below is final: the list's entries that come from it;
+//   fold_write_late(1) the frame right below is final: the rest -- the only step left on the folder's chain.
 __device__ __forceinline__ u32 fold_write_early(FoldLds *L, u8 *const out, const u32 base, const u32 n, const u32 wid, const u32 lane)
 {
   // (every wave over its share of the frame; its list at the bottom of its share)
-  const u32 late_lo = base >= FOLD_FRAME ? base - FOLD_FRAME : 0u;
+  const u32 org = base - 2u * FOLD_FRAME;                          // (wraps for the first two frames: only differences are used)
+  const u32 late_lo = base >= 2u * FOLD_FRAME ? org : 0u;
   u32 c0, bytes;
   fold_share(n, wid, c0, bytes);
   u32 nl = c0;
@@ -190,7 +193,7 @@ __device__ __forceinline__ u32 fold_write_early(FoldLds *L, u8 *const out, const
       const u64 m = ballot(late);
       if (m) {
         const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32) m, 0u));
-        if (late) L->S[nl + rank] = (b << 16) | (s[g] - late_lo);
+        if (late) L->S[nl + rank] = (b << 16) | ((s[g] - org) & 0xFFFFu);
         nl += (u32) __popcll(m);
       }
     }
@@ -200,19 +203,24 @@ __device__ __forceinline__ u32 fold_write_early(FoldLds *L, u8 *const out, const
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   return nl - c0;
 }
-// fold_write_late: everything below `base` is final -- the list's bytes, FOLD_DEPTH x 64 gathers in flight
-__device__ __forceinline__ void fold_write_late(const FoldLds *L, u8 *const out, const u32 base, const u32 n, const u32 nl_, const u32 wid, const u32 lane)
+// the list's entries whose sources lie in the frame two below (which = 0) / right below (which = 1): FOLD_DEPTH x 64 gathers in flight
+__device__ __forceinline__ void fold_write_late(const FoldLds *L, u8 *const out, const u32 base, const u32 n, const u32 nl_, const u32 which,
+                                                const u32 wid, const u32 lane)
 {
-  const u8 *const src = out + (base - FOLD_FRAME);
+  const u32 org = base - 2u * FOLD_FRAME;
   u32 c0, c1;
   fold_share(n, wid, c0, c1);
   const u32 nl = c0 + nl_;
   for (u32 k0 = c0; k0 < nl; k0 += 64u * FOLD_DEPTH) {
     u32 e[FOLD_DEPTH], v[FOLD_DEPTH];
 #pragma unroll
-    for (int g = 0; g < FOLD_DEPTH; g++) { const u32 k = k0 + 64u * g + lane; e[g] = k < nl ? L->S[k] : 0xFFFFFFFFu; }
+    for (int g = 0; g < FOLD_DEPTH; g++) {
+      const u32 k = k0 + 64u * g + lane;
+      const u32 x = k < nl ? L->S[k] : 0xFFFFFFFFu;
+      e[g] = (x != 0xFFFFFFFFu && ((x >> 15) & 1u) == which) ? x : 0xFFFFFFFFu;
+    }
 #pragma unroll
-    for (int g = 0; g < FOLD_DEPTH; g++) v[g] = e[g] != 0xFFFFFFFFu ? (u32) gld(src + (e[g] & 0xFFFFu)) : 0u;
+    for (int g = 0; g < FOLD_DEPTH; g++) v[g] = e[g] != 0xFFFFFFFFu ? (u32) gld(out + (org + (e[g] & 0xFFFFu))) : 0u;
 #pragma unroll
     for (int g = 0; g < FOLD_DEPTH; g++) if (e[g] != 0xFFFFFFFFu) fold_st(out + base + (e[g] >> 16), (u8) v[g]);
   }

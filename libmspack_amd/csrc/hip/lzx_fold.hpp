@@ -168,36 +168,32 @@ __device__ void lzx_fold_frame(const mspack_hip_unit &u, const u32 f, u8 *out_ar
     fold_write_own(L, out, frame_pos, nb, wid, lane);
     FT(2);
   }
-  // ---- (3b) the folder's chain, in two links: what comes from below the frame right below is gathered as soon as the frame BEFORE
-  // that one is final; what comes from the frame right below, when that one is (fold_common.hpp) ----
-  if (wid == 0u) {
-    u32 pch2 = LZX_CH_DONE;
-    if (ok && f >= 2u) pch2 = lzx_chain_wait(&(pr - 1)->chain, false);
-    if (pch2 != LZX_CH_DONE) bad = true;                  // (the chain ended down there: it ends below this frame too)
-    if (lane == 0) L->ctl[6] = (ok && !bad) ? 1u : 0u;
-    FT(3);
-  }
-  fold_barrier();
-  ok = L->ctl[6] != 0u;
+  // ---- (3b) the folder's chain, in three steps, each as early as its sources allow (fold_common.hpp): what comes from more than two
+  // frames below once the frame THREE below is final, what comes from the frame two below once that one is, and -- the only step
+  // on the chain -- what comes from the frame right below ----
   u32 nl = 0;
-  if (ok) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    nl = fold_write_early(L, out, frame_pos, nb, wid, lane);
-    FT(4);
+  for (u32 step = 0; step < 3u; step++) {
+    const u32 dist = 3u - step;                           // wait for frame f - dist
+    if (wid == 0u) {
+      u32 pch = LZX_CH_DONE;
+      if ((ok || step == 2u) && f >= dist) pch = lzx_chain_wait(&(rec - dist)->chain, false);
+      if (lane == 0) L->ctl[3u + step] = pch;
+      FT(step == 2u ? 5 : 3);
+    }
+    fold_barrier();
+    const u32 pch = L->ctl[3u + step];
+    if (step == 2u && pch != LZX_CH_DONE) {
+      if (wid == 0u) { lzx_status_publish(&rec->chain, LZX_CH_ENDED, lane); FTFLUSH(); }
+      return;
+    }
+    if (pch != LZX_CH_DONE) { ok = false; bad = true; }   // (the chain ended down there: it ends below this frame too)
+    if (ok) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (step == 0u) nl = fold_write_early(L, out, frame_pos, nb, wid, lane);
+      else if (nl) fold_write_late(L, out, frame_pos, nb, nl, step - 1u, wid, lane);
+      FT(step == 2u ? 6 : 4);
+    }
   }
-  if (wid == 0u) {
-    u32 pch = LZX_CH_DONE;
-    if (f != 0u) pch = lzx_chain_wait(&pr->chain, false);
-    if (lane == 0) L->ctl[3] = pch;
-    FT(5);
-  }
-  fold_barrier();
-  if (L->ctl[3] != LZX_CH_DONE) {
-    if (wid == 0u) { lzx_status_publish(&rec->chain, LZX_CH_ENDED, lane); FTFLUSH(); }
-    return;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (ok && nl) fold_write_late(L, out, frame_pos, nb, nl, wid, lane);
   // (every wave's stores out of the door before wave 0 says so)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #ifndef MSPACK_WAVE_EMU

@@ -956,7 +956,7 @@ __device__ void zip_fold_block(const mspack_hip_unit &u, const u32 b, u8 *out_ar
     return;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (nl) fold_write_late(L, out, B, total, nl, wid, lane);
+  if (nl) fold_write_late(L, out, B, total, nl, 1u, wid, lane);        // (all of them come from the block right below)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // (every wave's stores out of the door before wave 0 says so)
 #ifndef MSPACK_WAVE_EMU
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1076,6 +1076,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
   const bool repair = (u.flags & MSPACK_HIP_UF_MSZIP_REPAIR) != 0u;
   const bool kwaj = (u.flags & MSPACK_HIP_UF_MSZIP_KWAJ) != 0u;
   u32 remaining = u.out_len, written = 0, rflags = 0;
+  u32 leftover = 0;               // what the last block inflated to beyond the request (mszipd keeps it for its next call)
   int err = ERR_OK;
   u32 state0 = 0;                 // 'C','K' scanner state carried over a repair restart
   d.snap_iptr = 0; d.snap_rbl = 0;
@@ -1191,6 +1192,7 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
     written += n;
     if (r > 0 && repair) { err = r; break; }                                     // mszipd.c:449
     remaining -= n;
+    leftover = bytes_output - n;
     // remember this block for later blocks' history reads; entries it shadows (not longer than
     // it) are dropped, so the stack stays strictly increasing in length towards older blocks
     if (bytes_output) {
@@ -1221,7 +1223,9 @@ __device__ __forceinline__ void mszip_decode_unit(const mspack_hip_unit &u, cons
   }
   if (logging && lane == 0) rlog[0] = n_repaired;
   if (lane == 0) {
-    res->err = err; res->flags = rflags; res->out_len = written; res->good_len = written; res->in_next = 0;
+    // in_next: a block is as long as its deflate stream, whatever the CFDATA header said (mszipd.c:386-392, 440-452): the bytes the
+    // last block produced beyond out_len lie in the unit's slack, and this says how many
+    res->err = err; res->flags = rflags; res->out_len = written; res->good_len = written; res->in_next = (err == ERR_OK && !kwaj) ? leftover : 0u;
     res->in_used = d.w.origin + ((d.cons_bits() + (d.careful ? (u32) d.rbl : 0u)) >> 3);
   }
 }

@@ -434,6 +434,16 @@ __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const 
   // store instruction (round 2 stored every literal on its own from lane 0: 12 M store instructions per launch of
   // config 4); they go out before anything reads the output (a resolve, a direct copy)
   u32 lit_buf = 0, lit_pos = 0, lit_n = 0;
+#ifdef QTM_NO_OUTPUT     /* analysis builds, never shipped: the arithmetic decoder ALONE -- no literal buffer, no
+                            match queue, no copies, nothing written.  What a launch of this build takes is the floor of any split of a
+                            folder into a decoding wave and a writing wave (tools/bench_qtm_config4.py; profiles/round6_qtm.txt) */
+#define QTM_FLUSH() do { lit_n = 0; } while (0)
+#define QTM_COPY(P_, off_, len_) do { } while (0)
+#define QTM_LIT(v_, P_) do { } while (0)
+#define QTM_RESOLVE_DUE(P_) do { } while (0)
+#else
+#define QTM_LIT(v_, P_) do { lit_buf = wrl(lit_buf, (v_), lit_n); lit_pos = wrl(lit_pos, (P_), lit_n); if (++lit_n == WAVE) QTM_FLUSH(); } while (0)
+#define QTM_RESOLVE_DUE(P_) do { if (spq_due(Q, (P_))) { QTM_FLUSH(); spq_resolve(sh->spq, Q, out, (P_), false, lane, out_len); } } while (0)
 #define QTM_FLUSH()                                                                           \
   do {                                                                                        \
     if (lit_n) { if (lane < lit_n && lit_pos < out_len) out[lit_pos] = (u8) lit_buf; lit_n = 0; } \
@@ -450,6 +460,7 @@ __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const 
       Q.Pf = (P_) + (len_);                                                                   \
     }                                                                                         \
   } while (0)
+#endif
 
   // The decode loop (qtmd.c:283-470).  Far from the end of the input -- a token reads fewer than 96 bytes -- no read can fail:
   // the lean decoder (FAST).  Round 5: the lean and the exact decoder are TWO copies of the whole loop, one run after the
@@ -482,8 +493,7 @@ __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const 
       const int tk = TOKEN_;                                                                          \
       if (tk < 0) { err = tk == QTM_T_READ ? ERR_READ : ERR_DECRUNCH; stop = true; break; }           \
       if (tk == QTM_T_LIT) {                                                                          \
-        lit_buf = wrl(lit_buf, moff, lit_n); lit_pos = wrl(lit_pos, P, lit_n);                        \
-        if (++lit_n == WAVE) QTM_FLUSH();                                                             \
+        QTM_LIT(moff, P);                                                                             \
         P++; wpos++; frame_todo--;                                                                    \
         continue;                                                                                     \
       }                                                                                               \
@@ -504,7 +514,7 @@ __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const 
       if (moff > wpos && (moff - wpos) > wsize) { err = ERR_DECRUNCH; stop = true; break; }   /* qtmd.c:399 */ \
       QTM_COPY(P, moff, mlen);                                                                        \
       P += mlen; wpos += mlen;                                                                        \
-      if (spq_due(Q, P)) { QTM_FLUSH(); spq_resolve(sh->spq, Q, out, P, false, lane, out_len); }      \
+      QTM_RESOLVE_DUE(P);                                                                             \
     }                                                                                                 \
     if (stop) break;                                                                                  \
     o_end = wpos;                                                                                     \
@@ -549,6 +559,8 @@ __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const 
   }
 #undef QTM_COPY
 #undef QTM_FLUSH
+#undef QTM_LIT
+#undef QTM_RESOLVE_DUE
 #ifdef QTM_TIMERS
   if (blockIdx.x == 0 && lane == 0) {
     for (int k_ = 0; k_ < 5; k_++) g_qtm_tm[k_] = d.tm[k_];

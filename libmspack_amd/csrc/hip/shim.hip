@@ -224,6 +224,23 @@ __device__ __forceinline__ bool lzx_fold_on(const u32 *ctl, const u32 policy)
   fold_barrier();                                                                 \
   const u32 t = rfl(sh.ctl[0]);                                                   \
   fold_barrier();                                    /* (the word is free again) */
+// A unit whose matches are long RUNS (the reference's large-files.test: ~127 matches of 257 bytes per frame, one line repeated) is
+// better off with lzx_pipe_resolve: its run fill writes such a frame without reading anything back (spec_queue.hpp), while a fold
+// task would gather every byte (measured: 1.55-1.78 GB/s against 1.2).  Decided per unit from its FIRST frame's record -- every task
+// of the unit, in both kernels, reads the same final words: at least 16 matches, and 96 bytes of output or more per match.
+__device__ __forceinline__ bool lzx_unit_runs(const lzxn::LzxFrameRec *r0)
+{
+  u32 st = lzxn::lzx_status_load(&r0->status);
+  // (the unit's first parse task has the unit's earliest ticket: a live wave holds it, or it is done)
+  for (u32 tries = 0; (st == LZX_ST_NONE || st == LZX_ST_CLAIMED || st == LZX_ST_HEADER) && tries < (1u << 24); tries++) {
+    __builtin_amdgcn_s_sleep(8);
+    st = lzxn::lzx_status_load(&r0->status);
+  }
+  if (st != LZX_ST_EMITTED) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const u32 n = rfl(gld(&r0->n_tokens)), b = rfl(gld(&r0->bytes_done));
+  return n >= 16u && b >= 96u * n;
+}
 __global__ __launch_bounds__(FOLD_THREADS)
 void mspack_lzx_fold(const mspack_hip_unit *units, u32 slot_lo, u32 n_slots, u8 *out_arena, const u32 *frame_unit, u32 *ctl,
                      lzxn::LzxFrameRec *recs, const uint2 *toks, u32 fold_policy)
@@ -238,6 +255,7 @@ void mspack_lzx_fold(const mspack_hip_unit *units, u32 slot_lo, u32 n_slots, u8 
     if (ui == 0xFFFFFFFFu) continue;
     const mspack_hip_unit u = units[ui];
     if (u.kind != MSPACK_HIP_KIND_LZX || !(u.flags & MSPACK_HIP_UF_FRAME_TABLE)) continue;
+    if (fold_policy == 1u && lzx_unit_runs(&recs[u.frame_base])) continue;      // (resolved by the pipe's own tasks; policy 2 folds these too: tests)
     lzxn::lzx_fold_frame(u, slot - u.frame_base, out_arena, &recs[u.frame_base], toks, &sh);
     fold_barrier();                                   // the next task reuses the LDS
   }
@@ -314,6 +332,7 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
     if (do_parse) {
       lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh.p);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the resolver reuses the LDS
+      if (fold) do_resolve = fold_policy == 1u && lzx_unit_runs(&recs[rfl(up->frame_base)]);    // (a unit of long runs keeps its resolve tasks)
     }
     if (do_resolve) lzx_pipe_task_resolve(up, f, out_arena, recs, toks, &sh.r, do_parse);
 #ifdef LZX_PIPE_TRACE
@@ -391,6 +410,12 @@ void mspack_mszip_fold(const mspack_hip_unit *units, u32 slot_lo, u32 n_slots, u
     const u32 ui = rfl(frame_unit[slot]);
     if (ui == 0xFFFFFFFFu) continue;
     const mspack_hip_unit u = units[ui];
+    {
+      // (a folder of long runs -- its first block says -- stays with zip_run_tokens' run fill: lzx_unit_runs above)
+      const ZipBlockRec *r0 = (const ZipBlockRec *) &recs[u.frame_base];
+      const u32 n0 = rfl(gld(&r0->n_tokens)), b0 = rfl(gld(&r0->total_out));
+      if (fold_policy == 1u && rfl(gld(&r0->status)) == 1u && n0 >= 16u && b0 >= 96u * n0) continue;
+    }
     zip_fold_block(u, slot - u.frame_base, out_arena, (ZipBlockRec *) &recs[u.frame_base], toks, &sh);
     fold_barrier();
   }

@@ -1000,6 +1000,13 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
         unsigned int g = res[k].good_len > gs[k].total ? gs[k].total : res[k].good_len;
         fp->good_len = g; fp->dec_err = res[k].err; fp->res_flags = res[k].flags;
         fp->written = res[k].out_len > gs[k].total ? gs[k].total : res[k].out_len;
+        if (method == MSCAB_COMP_MSZIP && res[k].err == MSPACK_ERR_OK && !(units[k].flags & MSPACK_HIP_UF_MSZIP_REPAIR) &&
+            res[k].in_next && res[k].in_next <= CAB_BLOCKMAX && res[k].out_len == gs[k].total) {
+          /* mszipd never reads a CFDATA header's uncompressed size: a block is as long as its deflate stream (mszipd.c:377-460), and
+           * what the folder's last block inflated to beyond the headers' sum is there for the files that ask for it (the unit's
+           * slack holds those bytes, in_next says how many: DESIGN.md section 8g) */
+          fp->total += res[k].in_next; fp->good_len = fp->total; fp->written = fp->total;
+        }
         if (units[k].flags & MSPACK_HIP_UF_MSZIP_LOG) {
           const unsigned char *lg = out_arena + units[k].out_off + (((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15);
           unsigned int cnt = rd_le32(lg), i;

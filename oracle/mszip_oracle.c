@@ -192,6 +192,7 @@ int oracle_mszip_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t o
   zip_t *z = (zip_t *) calloc(1, sizeof(*z));
   uint64_t written = 0, remaining = out_bytes;
   int err = ORC_OK, nb = 0;
+  uint32_t leftover = 0;
 
   memset(res, 0, sizeof(*res));
   init_tables();
@@ -200,6 +201,7 @@ int oracle_mszip_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t o
   while (remaining > 0) {
     unsigned v; int state = 0, r;
     uint32_t n;
+    leftover = 0;
     z_restore(&z->b);                                               /* mszipd.c:404 */
     ZDROP(&z->b, z->b.bl & 7);
     do {                                                            /* mszipd.c:406-414 */
@@ -229,10 +231,16 @@ int oracle_mszip_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t o
     written += n;
     if (r > 0 && repair_mode) { err = r; goto done; }
     remaining -= n;
+    leftover = z->bytes_output - n;
+    if (leftover && out && written + leftover <= out_cap) memcpy(out + written, z->window + n, leftover);   /* (room behind the request: the rest of the block) */
   }
 done:
   if (n_blocks) *n_blocks = nb;
   res->err = err; res->out_len = written; res->in_used = z->b.pos;
+  /* what the last block inflated to BEYOND the request: mszipd keeps those bytes (o_ptr .. o_end, mszipd.c:386-392, 440-452) and
+   * hands them to the next call -- a block is as long as its deflate stream, whatever the CFDATA header said (the batch ABI
+   * reports it in mspack_hip_result.in_next, unused for MSZIP otherwise; `out` holds the bytes when there is room) */
+  res->in_next = (err == 0) ? leftover : 0;
   free(z);
   return err;
 }

@@ -39,7 +39,7 @@ def _abort_backtrace():
 # against the oracle), then the host-buffer path and the fuzz sweeps, then the object API's drivers and containers, the
 # slow shapes last.  Within a module the order is the file's.
 _ORDER = ["test_gpu_kat", "test_gpu_lzx", "test_gpu_lzx_frames", "test_gpu_lzx_log", "test_gpu_lzxd", "test_gpu_mszip",
-          "test_gpu_mszip_blocks", "test_gpu_qtm", "test_szdd_kwaj", "test_oab", "test_gpu_hostpath", "test_gpu_fuzz",
+          "test_gpu_mszip_blocks", "test_gpu_fold", "test_gpu_qtm", "test_szdd_kwaj", "test_oab", "test_gpu_hostpath", "test_gpu_fuzz",
           "test_gpu_messages", "test_gpu_drivers", "test_chm_extract", "test_chmdir", "test_chm_messages", "test_cab_sticky",
           "test_cabsets", "test_config2_cab", "test_gpu_reference_suites", "test_api_bench", "test_gpu_bench_line",
           "test_gpu_large_files"]

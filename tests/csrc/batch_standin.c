@@ -42,7 +42,7 @@ int mspack_standin_decode_units(const mspack_hip_unit *units, const uint32_t *or
     uint8_t *dst = (uint8_t *) out + u->out_off;
     memset(&o, 0, sizeof(o));
     memset(r, 0, sizeof(*r));
-    if (u->in_off + u->in_len > in_bytes || u->out_off + u->out_len > out_bytes) {
+    if (u->in_off + u->in_len > in_bytes || u->out_off + u->out_len + (u->kind == MSPACK_HIP_KIND_MSZIP ? 32768u : 0u) > out_bytes) {
       snprintf(g_err, sizeof(g_err), "unit outside arena"); return -1;
     }
     /* the frame table is a hint for the GPU's frame-parallel parse; results do not depend on it */
@@ -70,7 +70,8 @@ int mspack_standin_decode_units(const mspack_hip_unit *units, const uint32_t *or
       }
       break;
     case MSPACK_HIP_KIND_MSZIP:
-      oracle_mszip_decode(src, u->in_len, dst, u->out_len, u->out_len, 0, NULL, 0, NULL, &o);
+      /* (an MSZIP unit owns 32 KiB of room behind out_len: what its last block inflated to beyond the request lands there) */
+      oracle_mszip_decode(src, u->in_len, dst, (size_t) u->out_len + 32768, u->out_len, 0, NULL, 0, NULL, &o);
       break;
     case MSPACK_HIP_KIND_QUANTUM:
       oracle_qtm_decode(src, u->in_len, dst, u->out_len, u->out_len, u->window_bits, &o);

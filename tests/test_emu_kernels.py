@@ -91,3 +91,59 @@ def test_some_gpu_parity_tests_on_the_emulator(built):
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"] + ids, cwd=ROOT, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1700)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
+
+
+FOLD_WORKER = r'''
+import sys, zlib
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import numpy as np
+import libmspack_amd as M
+import test_gpu_lzx_frames as T
+import test_gpu_fold as F
+from helpers import oracle_mszip
+assert "emu" in M.HIP_SO
+# LZX: a CAB-style and a CHM-style unit of four frames and a tail, a damaged one, one with a wrong table -- all through mspack_lzx_fold
+data = M.gen_plaintext(23, M.TEXT_MIX, 4 * 32768 + 777)
+streams, params, tabs = [], [], []
+for rf in (0, 2):
+    comp, fo = M.lzx_encode(data, 21, rf)
+    fo = fo.astype(np.int64)[:-1]
+    streams.append(comp.tobytes()); params.append((data.size, 21, rf, 0)); tabs.append(fo)
+bad = bytearray(streams[0]); bad[int(tabs[0][2]) + 300] ^= 0x08
+streams += [bytes(bad), streams[0]]; params += [params[0], params[0]]; tabs += [tabs[0], tabs[0] + 2]
+units, out, res = T.run(streams, params, tabs)
+T.check(streams, params, units, out, res, compare_bytes=False)
+for i in (0, 1, 3):
+    assert res["err"][i] == 0 and np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
+# MSZIP: a folder of four blocks with history, one of them damaged in a second copy -- through mspack_mszip_fold
+n = 3 * 32768 + 5000
+plain = M.gen_plaintext(29, M.TEXT_MIX, n)
+blocks, prev = [], None
+for k in range(0, n, 32768):
+    b = plain[k:k + 32768].tobytes()
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, 0, prev) if prev else zlib.compressobj(6, zlib.DEFLATED, -15)
+    blocks.append(bytearray(b"CK" + c.compress(b) + c.flush())); prev = b
+tab = np.cumsum([0] + [len(b) for b in blocks[:-1]])
+s = b"".join(bytes(b) for b in blocks)
+o, r = F.one_folder(M.KIND_MSZIP, s, tab, n, 0)
+assert r["err"] == 0 and np.array_equal(o, plain)
+blocks[2][len(blocks[2]) // 2] ^= 0x20
+s = b"".join(bytes(b) for b in blocks)
+o, r = F.one_folder(M.KIND_MSZIP, s, tab, n, 0)
+e, oo, orc, _ = oracle_mszip(s, n)
+assert r["err"] == e and r["out_len"] == orc.out_len and o[:orc.out_len].tobytes() == oo[:orc.out_len]
+print("EMU_FOLD_OK")
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="the emulator build needs ROCm's clang++")
+def test_fold_tasks_on_the_emulator(built, tmp_path):
+    """mspack_lzx_fold / mspack_mszip_fold (lzx_fold.hpp, fold_common.hpp) on the wavefront emulator: the records -> source map, R0-R2
+    with placeholders and their chain, pointer jumping, the chain's three gather steps, the hand-over to the serial path where a
+    frame is damaged -- with the tasks forced on (MSPACK_HIP_FOLD=2; the emulator runs a task on one wave)."""
+    assert os.path.exists(SO), "built by test_kernels_on_the_wavefront_emulator"
+    script = tmp_path / "w.py"
+    script.write_text(FOLD_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MSPACK_HIP_SO=SO, MSPACK_HIP_FOLD="2")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert p.returncode == 0 and b"EMU_FOLD_OK" in p.stdout, p.stdout.decode()[-3000:]

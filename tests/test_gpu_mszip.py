@@ -47,6 +47,7 @@ def check(streams, out_lens, units, out, res, plains=None):
         e, o, r, _bl = oracle_mszip(s, out_lens[i])
         assert res["err"][i] == e, (i, res[i], e)
         assert res["out_len"][i] == r.out_len, (i, res[i], r.out_len)
+        assert res["in_next"][i] == r.in_next, (i, res[i], r.in_next)        # (what the last block inflated to beyond the request)
         got = out[units["out_off"][i]:units["out_off"][i] + r.out_len].tobytes()
         if e == 0 or plains is None:
             assert got == o[:r.out_len], "unit %d differs" % i
@@ -121,3 +122,19 @@ def test_mszip_batch_4096_blocks(built):
     # checksum-of-everything property
     total = sum(int(out[units["out_off"][i]:units["out_off"][i] + 32768].astype(np.uint64).sum()) for i in range(n))
     assert total == int(plain.astype(np.uint64).sum())
+
+
+def test_mszip_request_that_ends_inside_a_block(built):
+    """mszipd sizes a block by its deflate stream and keeps what a call did not ask for (mszipd.c:386-392, 440-452): a unit asked for
+    fewer bytes than its last block holds says how many more there are (mspack_hip_result.in_next) and leaves them in its slack --
+    what the cabinet driver needs when a CFDATA header's uncompressed size is too small.  With block tables too."""
+    data = M.gen_plaintext(21, M.TEXT_MIX, 32768 * 2 + 20000).tobytes()
+    s = folder(data, history=True)
+    asks = [len(data), len(data) - 1, len(data) - 19999, 32768 * 2, 32768 + 5, 1]
+    units, out, res = run([s] * len(asks), asks)
+    check([s] * len(asks), asks, units, out, res, plains=[data] * len(asks))
+    for i, a in enumerate(asks):
+        more = int(res["in_next"][i])
+        assert more == ((len(data) - a) if a > 32768 * 2 else (32768 - a % 32768) % 32768 if a % 32768 else 0), (i, a, more)
+        o = int(units["out_off"][i])
+        assert out[o + a:o + a + more].tobytes() == data[a:a + more], (i, a, more)
