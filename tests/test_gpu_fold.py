@@ -62,7 +62,7 @@ def test_one_folder_of_ordinary_data(built, text):
     out, r = one_folder(M.KIND_MSZIP, s, np.cumsum([0] + [len(b) for b in blocks[:-1]]), n, 0)
     e, o, orc, _ = oracle_mszip(s, n)
     assert r["err"] == e == 0 and r["out_len"] == n and np.array_equal(out, plain)
-    assert r["flags"] & M.F_FRAMES_ADOPTED
+    assert text == M.TEXT_RANDOM or r["flags"] & M.F_FRAMES_ADOPTED       # (zlib STORES incompressible blocks: those are the serial path's)
 
 
 def test_one_folder_with_damage_in_the_middle(built):
