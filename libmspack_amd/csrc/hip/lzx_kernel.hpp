@@ -68,9 +68,6 @@
 #endif
 #define LZX_MMASK ((1u << LZX_MSH) - 1u)
 #define LZX_LEN_SYMS 250
-#ifndef LZX_SPEC_WIDE
-#define LZX_SPEC_WIDE 0          /* 1: every lane decodes two positions (128 per round) */
-#endif
 #ifdef LZX_EXP_STATS
 #define HT0() u64 ht_ = __builtin_amdgcn_s_memtime()
 #define HT(k) do { u64 n_ = __builtin_amdgcn_s_memtime(); d.st_h[k] += (u32)(n_ - ht_); ht_ = n_; } while (0)
@@ -82,11 +79,6 @@
 #define LZX_MARK(name) asm volatile("; MARK " name)
 #else
 #define LZX_MARK(name) do { } while (0)
-#endif
-#ifdef LZX_EXP_CNT
-#define CNT(k) (d.st_t[k]++)
-#else
-#define CNT(k) ((void) 0)
 #endif
 
 struct __align__(16) LzxShared {
@@ -488,9 +480,6 @@ __device__ __forceinline__ u32 lzx_scalar_token(const LzxDec &d, bool length_emp
 
 // one speculative token: everything lane-local, decoded from 64 bits of the stream
 struct SpecTok { u32 tot, sym, kind, olen, off; bool unk;
-#ifdef LZX_EXP_CNT
-  bool mlong;
-#endif
 };
 
 template <bool ALIGNED>
@@ -511,9 +500,6 @@ __device__ __forceinline__ SpecTok lzx_spec_token(const LzxShared *sh, const u32
     u32 idx = (fo >> 16) + ((peek16 >> (16u - lq)) - (fo & 0xFFFFu));
     if (idx >= LZX_MAIN_SYMS) idx = 0;
     u32 ls = sh->main_sorted[idx];
-#ifdef LZX_EXP_CNT
-    t.mlong = (e == 0u && lq != 0u);
-#endif
     if (e == 0u && lq != 0u) e = ls | (lq << LZX_MSH);
   }
   bool unk = (e == 0u);
@@ -786,7 +772,6 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
     if (late) { const u32 j = (u32) __ffsll((long long) late) - 1u; n = j; newP = rdl(opos, j); marker = 0; }
   }
   const bool valid = lane < n;
-#ifndef LZX_EXP_NOLIT
   if (valid && kind == 0u) {
     gst(out + opos, (u8) c1);
     if (olen > 1u) {                                        // a literal run: 2..4 bytes, first literal in the low byte
@@ -795,7 +780,6 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
       if (olen > 3u) gst(out + opos + 3u, (u8)(c1 >> 24));
     }
   }
-#endif
   const bool ism0 = valid && kind != 0u;
   u64 mm = ballot(ism0);
   if (mm) {
@@ -825,7 +809,6 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
       }
     }
     else {
-      CNT(2);
       u32 x = LRU_ID;
       if (ism0) x = kind == 1u ? (0x010080u | lane) : (kind == 3u ? 0x020001u : (kind == 4u ? 0x000102u : LRU_ID));
       const u32 Cm = lru_scan(x);
@@ -846,10 +829,6 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
       const u64 badm = ballot(bad);
       if (badm) { mm &= (1ull << ((u32) __ffsll((long long) badm) - 1u)) - 1ull; fail_after = true; }
     }
-#ifdef LZX_EXP_NOMATCH
-    mm = 0;
-#endif
-#ifndef LZX_EXP_NOCOPY
     // (3) queue the matches
     if (mm) {
       bool ism = lane_in(mm);
@@ -884,7 +863,6 @@ __device__ __forceinline__ u32 lzx_commit_batch(LzxDec &d, LzxCommit &C, const u
         }
       }
     }
-#endif
   }
   C.P = newP;
   return n;
@@ -935,7 +913,7 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
   // decode 17 more and the first symbol after it 7: with 56 the EOF-exact reader
   // (LzxDec::sym_ensure) still takes over at a symbol boundary at least 6 bytes before the
   // reference's read pointer can reach the end of the input.
-  const u32 bit_limit = spec_bit_limit(d, LZX_SPEC_WIDE ? 72u : 56u);
+  const u32 bit_limit = spec_bit_limit(d, 56u);
   if (rfl(d.cons_bits()) >= bit_limit) return LZX_RUN_SWITCH;
   // pending literals of the scalar path go out first: this path stores literals directly
   d.flush_lits();
@@ -968,14 +946,6 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       const u32 i0 = sh->inbuf[k], i1 = sh->inbuf[k + 1u], i2 = sh->inbuf[k + 2u];
       const u32 w0 = (u32)(((((u64) i0 << 32) | i1) << sft) >> 32);
       const u32 w1 = (u32)(((((u64) i1 << 32) | i2) << sft) >> 32);
-#if LZX_SPEC_WIDE
-      // second position set: bits (bitpos + 64 + lane), an independent instruction stream per lane
-      const u32 i3 = sh->inbuf[k + 3u], i4 = sh->inbuf[k + 4u];
-      const u32 x0 = (u32)(((((u64) i2 << 32) | i3) << sft) >> 32);
-      const u32 x1 = (u32)(((((u64) i3 << 32) | i4) << sft) >> 32);
-      const SpecTok u = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, x0, x1);
-      const u32 un = u.unk ? (320u + lane) : (64u + lane + u.tot);
-#endif
       const SpecTok t = lzx_spec_token<ALIGNED>(sh, d.hr_main.fov, mlim, length_empty, w0, w1);
       // next token start (in bits from bitpos); >= 256 marks "needs the scalar decoder" and ends the walk
       const u32 vn = t.unk ? (256u + lane) : (lane + t.tot);
@@ -984,25 +954,12 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
       u64 chain = 0, chain2 = 0;
       u32 q = 0;
       do { chain |= 1ull << q; q = rdl(vn, q); } while (q < 64u);
-#if LZX_SPEC_WIDE
-      while (q < 128u) { chain2 |= 1ull << (q - 64u); q = rdl(un, q - 64u); }
-#endif
       bool hit_unknown = false;
       if (q >= 256u) {
         q -= 256u; hit_unknown = true;
         if (q < 64u) chain &= ~(1ull << q); else chain2 &= ~(1ull << (q - 64u));
       }
       u32 nA = (u32) __popcll(chain), nB = (u32) __popcll(chain2);
-#if LZX_SPEC_WIDE
-      if (nA + nB > 64u) {
-        // more tokens than a commit takes (codes of 1 bit): give the last ones back
-        while (nA + nB > 64u) {
-          q = 127u - (u32) __clzll((long long) chain2);
-          chain2 &= ~(1ull << (q - 64u)); nB--;
-        }
-        hit_unknown = false;
-      }
-#endif
       TICK(1);
       // ---- queue the tokens on the chain ----
       {
@@ -1012,30 +969,13 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
           tq0[ti] = t.kind | (t.olen << 3) | (((bitpos + lane) & 0xFFFFu) << 12);
           tq1[ti] = t.kind == 0u ? t.sym : t.off;
         }
-#if LZX_SPEC_WIDE
-        const u32 rank2 = __builtin_amdgcn_mbcnt_hi((u32)(chain2 >> 32), __builtin_amdgcn_mbcnt_lo((u32) chain2, 0u));
-        if ((chain2 >> lane) & 1ull) {
-          const u32 ti = (tt + nA + rank2) & (LZX_TQ - 1u);
-          tq0[ti] = u.kind | (u.olen << 3) | (((bitpos + 64u + lane) & 0xFFFFu) << 12);
-          tq1[ti] = u.kind == 0u ? u.sym : u.off;
-        }
-#endif
         tt += nA + nB;
       }
-#ifdef LZX_EXP_CNT
-      d.st_t[5] += (u32) __popcll(ballot(((chain >> lane) & 1ull) && t.mlong));
-      if (ballot(t.mlong)) d.st_t[4]++;
-#endif
       bitpos += q;
       d.st_rounds++;
       if (hit_unknown) {
-        CNT(0);
         u32 tk_kind = 0, tk_val = 0, tk_off = 0;
-#if LZX_SPEC_WIDE
-        const u64 rq = q < 64u ? (((u64) rdl(w0, q) << 32) | rdl(w1, q)) : (((u64) rdl(x0, q - 64u) << 32) | rdl(x1, q - 64u));
-#else
         const u64 rq = ((u64) rdl(w0, q) << 32) | rdl(w1, q);
-#endif
         const u32 tk_tot = lzx_scalar_token<ALIGNED>(d, length_empty, rq, tk_kind, tk_val, tk_off);
         u32 r0, r1 = tk_kind == 0u ? tk_val : tk_off;
         if (tk_tot == 0u) { r0 = LZX_TK_FAIL; stop = true; }
@@ -1057,7 +997,6 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     }
 
     // =================================== COMMIT ===================================
-    CNT(1);
     u32 n = tt - th;
     if (n > 64u) n = 64u;
     if (n == 0u) { rc = LZX_RUN_SWITCH; break; }         // the input margin was reached and all is committed
@@ -1067,16 +1006,12 @@ __device__ __forceinline__ int lzx_run_spec(LzxDec &d, LzxState &s, const u32 ru
     u32 marker; bool fail_after;
     th += lzx_commit_batch(d, C, c0, c1, n, marker, fail_after);
     TICK(5);
-#ifndef LZX_EXP_NOCOPY
     if (spq_due(C.Q, C.P)) spq_resolve(sh->spq, C.Q, out, C.P, false, lane);
-#endif
     TICK(6);
     if (fail_after || marker == LZX_TK_FAIL) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; }
     else if (marker == LZX_TK_BAIL) bail = true;
   }
-#ifndef LZX_EXP_NOCOPY
   spq_resolve(sh->spq, C.Q, out, C.P, true, lane);
-#endif
   // parsed but not committed: the bit position goes back to the first such token
   if (tt != th) {
     const u32 lo = rfl(tq0[th & (LZX_TQ - 1u)]) >> 12;
@@ -1326,15 +1261,11 @@ __device__ __forceinline__ int lzx_run_spec2(LzxDec &d, LzxState &s, const u32 r
       qbase += (nx - qbase) & 0xFFFFu;
     }
     LZX_MARK("resolve_begin");
-#ifndef LZX_EXP_NOCOPY
     if (spq_due(C.Q, C.P)) spq_resolve(sh->spq, C.Q, out, C.P, false, lane);
-#endif
     LZX_MARK("resolve_end");
     if (fail_after || marker == LZX_TK_FAIL) { d.err = ERR_DECRUNCH; rc = LZX_RUN_FAIL; }
   }
-#ifndef LZX_EXP_NOCOPY
   spq_resolve(sh->spq, C.Q, out, C.P, true, lane);
-#endif
   // parsed but not committed: the bit position goes back to the first such token
   if (tt != th) bitpos = qbase;
   d.P = C.P;
@@ -1796,20 +1727,16 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     const u32 Lb = e0 - b0;
     u32 S = (Lb + 63u) >> 6; if (S < 64u) S = 64u;
     u32 S0 = S;
-#ifndef LZX_EQUAL_STRETCHES
     if (S > LZX_LANE_TAIL + 64u) { S0 = LZX_LANE_TAIL; S = (Lb - S0 + 62u) / 63u; }
-#endif
     const u32 nl = Lb <= S0 ? 1u : 1u + (Lb - S0 + S - 1u) / S;
     const u32 rstart = lane == 0u ? b0 : b0 + S0 + (lane - 1u) * S;
     u32 rend = rstart + (lane == 0u ? S0 : S); if (rend > e0) rend = e0;
     u32 entry = lane == 0u ? b0 : (rend > rstart + LZX_LANE_TAIL ? rend - LZX_LANE_TAIL : rstart);
     u32 n = 0, nb = 0, nmr = 0, exitp = entry, stop_at = 0;      // tokens / output bytes / matches of the stretch
     bool dead = false, changed = lane < nl;
-#ifndef LZX_EMIT_LANES
     // checkpoints of the lane's walk, one per LZX_SEG tokens: bit position | output bytes so far << 16, and matches so far
     // (a byte each).  All walking lanes take a token per step, so the capture is a wave-uniform branch every LZX_SEG steps.
     u32 ckA1 = 0, ckA2 = 0, ckA3 = 0, ckA4 = 0, ckA5 = 0, ckA6 = 0, ckA7 = 0, ckM0 = 0, ckM1 = 0;
-#endif
     for (u32 round = 0; ; ) {
       // ---- the lanes whose entry moved walk their stretch: token lengths, output lengths ----
       u32 p = entry, cnt = 0, cb = 0, cm = 0, sa = 0;
@@ -1817,7 +1744,6 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       for (u32 it = 0; ; it++) {
         const bool act = changed && p < rend;
         if (!ballot(act)) break;
-#ifndef LZX_EMIT_LANES
         if ((it & (LZX_SEG - 1u)) == 0u && it != 0u && it < 8u * LZX_SEG) {
           // (a lane that has stopped keeps cnt < it: its checkpoints beyond its last token are never used)
           const u32 a = p | (cb << 16), k = it / LZX_SEG;
@@ -1828,7 +1754,6 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
             else ckM1 = (ckM1 & ~(0xFFu << (8u * (k - 5u)))) | (cm << (8u * (k - 5u)));
           }
         }
-#endif
         LZX_MARK("emit_count_step_begin");
         STAGE_BITS(act ? p : 0u, w0, w1, ALIGNED)
         const EmitTok t = lzx_emit_token<ALIGNED, false>(sh, act, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
@@ -1857,45 +1782,6 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     PHE(7);
     // room for this pass's match records (taken from the launch's pool, a chunk at a time): without it the frame ends here
     if (!W.ensure(tt + (mm ? rdl(inclm, mm - 1u) : 0u), lane)) { stop = true; break; }
-#ifdef LZX_EMIT_LANES
-    // ---- last walk: literals into the output, one record per match ----
-    const u32 my_n = lane < mm ? n : 0u;
-    u32 p = entry, i = 0, pos = P + inclb - cvb, j = tt + inclm - cvm;
-    bool cross = false;
-    for (;;) {
-      const bool on = i < my_n && pos < plimit && !cross;
-      if (!ballot(on)) break;
-      STAGE_BITS(on ? p : 0u, w0, w1, true)
-      const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
-      const bool lit = on && !t.is_match;
-      const bool crs = on && t.is_match && pos + t.olen > plimit;   // lzxd.c:678-693: the serial path reports it
-      const bool mt = on && t.is_match && !crs;
-      if (lit) {
-        if (pos >= edge_n) gst_stream(fout + pos, (u8) t.sym);
-        else { gst(&rec->edge_lit[pos], (u8) t.sym); atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
-      }
-      // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
-      if (mt) gst_stream(W.at(j), make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
-                                                       (t.expl ? 0u : t.slot + 1u)));
-      cross = cross || crs;
-      const bool adv = lit || mt;
-      pos += lit ? 1u : (mt ? t.olen : 0u); j += mt ? 1u : 0u;
-      p += adv ? t.tot : 0u; i += adv ? 1u : 0u;
-    }
-    PHE(8);
-    // ---- where did this pass get to?  the first lane that did not emit its whole stretch ends the frame ----
-    const u64 tm = ballot(lane < mm && (i < my_n || cross));
-    if (tm) {
-      const u32 kq = (u32) __ffsll((long long) tm) - 1u;
-      P = rdl(pos, kq); tt = rdl(j, kq); B = sb_bit + rdl(p, kq); stop = true;
-    }
-    else {
-      if (mm) { P += rdl(inclb, mm - 1u); tt += rdl(inclm, mm - 1u); }
-      if (hit) { B = sb_bit + rdl(stop_at, dl); stop = true; }
-      else if (mm == 0u) stop = true;
-      else B = sb_bit + rdl(exitp, mm - 1u);
-    }
-#else
     // ---- last walk, BALANCED: the pass's tokens are cut into segments of LZX_SEG tokens (the lanes' checkpoints) and
     // segment r * 64 + l goes to lane l in round r.  Every lane then decodes the same number of tokens per round (the
     // stretches are equal in bits, not in tokens: the longest one used to set the pace), and the 64 segments of a round
@@ -2000,7 +1886,6 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       else if (mm == 0u) stop = true;
       else B = sb_bit + rdl(exitp, mm - 1u);
     }
-#endif
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");        // the stage is rewritten by the next pass
     // Another pass follows (and the launch has wave slots to spare, `stream`): what this one stored -- literals below P,
     // match records below tt -- is published now, so that the unit's commit task works on this frame while its later passes
@@ -2015,7 +1900,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#if defined(LZX_LIT_RING) && !defined(LZX_EMIT_LANES)
+#if defined(LZX_LIT_RING)
   if (P > lit_flushed && P - lit_flushed <= LZX_LIT_RING) {
     // the last rows (the frame's end, or where the parse stopped): byte by byte behind the last complete row
     const u32 full = P & ~15u;
@@ -2070,9 +1955,11 @@ __device__ __forceinline__ bool lzx_side_setup(LzxDec &d, LzxState &s, const msp
 // parse (scratch accesses of the task 26 -> 104).  The code lengths of the block that ended are still in LDS (no second-level
 // table was built over them), the record's first fields are written, `bytes_done` bytes / `n_rec` records are out.
 __device__ __attribute__((noinline)) void lzx_pipe_parse_tail(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
-                                                              LzxFrameRec *urecs, const RecPool pool, LzxShared *sh,
-                                                              u32 bytes_done, u32 n_rec, u32 cur_bit, const u32 n_chunks)
+                                                              LzxFrameRec *urecs, const RecPool pool, LzxShared *sh)
 {
+  // (where lzx_pipe_parse stopped: LZX_TAIL_ARGS)
+  u32 bytes_done = rfl(sh->stage[LZX_STAGE_WORDS + 32u]), n_rec = rfl(sh->stage[LZX_STAGE_WORDS + 33u]), cur_bit = rfl(sh->stage[LZX_STAGE_WORDS + 34u]);
+  const u32 n_chunks = rfl(sh->stage[LZX_STAGE_WORDS + 35u]);
   const mspack_hip_unit u = *up;
   const u32 lane = threadIdx.x;
   LzxFrameRec *rec = &urecs[f];
@@ -2127,9 +2014,7 @@ __device__ __attribute__((noinline)) void lzx_pipe_parse_tail(const mspack_hip_u
       u32 nsorted = 0;
       tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
                                                             sh->cnt, d.hr_main, lane, false, &nsorted);
-#ifndef LZX_NO_SUB_TABLE
       if (tables && published) two_level = rfl(lzx_build_sub(sh, d.hr_main, nsorted, lane) ? 1u : 0u) != 0u;
-#endif
     }
     if (!tables) { failed = !published; break; }
     const u32 plimit = seg_p0 + (rem < need ? rem : need);
@@ -2151,19 +2036,116 @@ __device__ __attribute__((noinline)) void lzx_pipe_parse_tail(const mspack_hip_u
   lzx_status_publish(&rec->status, LZX_ST_EMITTED, lane);
 }
 
-__device__ void lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
-                               LzxFrameRec *urecs, const RecPool &pool, LzxShared *sh, const bool stream)
+// ---------------------------------------------------------------------------------------------------
+// The header chain without the headers on it (round 6).  A block header's code lengths are DELTAS on the previous block's
+// (lzxd.c:138-183), so a folder written one block per frame -- this build's encoder, and others' -- chains its frames' parse
+// tasks: wait for the frame below, read the own header (~60 us), publish; 512 frames: 32 ms, however many waves there are
+// (measured: the whole fold path behind it takes 12).  But WHERE a header's bits end and WHAT it does to the lengths do not
+// depend on the lengths it is applied to: every entry comes out as (old[x] + a) mod 17, as (old[x - i] + a) mod 17 for the
+// i-th follower (i <= 4) of a run of equal lengths (pretree symbol 19: the run takes its value from ITS FIRST entry's old
+// length), or as a value that depends on nothing old (zero runs, and whatever is written over an earlier run's overshoot --
+// lzxd.c:159: runs are not clipped).  So a task whose predecessor is not ready reads its header at once, TWICE, against two
+// probe vectors -- all zeros, and 1 + (x mod 5): five neighbours all different, none zero -- and keeps, per entry, a and what
+// it is relative to (the difference of the two results names it: 0 = nothing, else the probe value of the entry it came
+// from); when the frame below publishes, its lengths go through that program (~2 us) instead of through a header decode.
+// Whether the frame STARTS with a header is the frame below's to say (rem_out): a frame inside a block throws the
+// speculation away, as does a header that does not read the same way twice.  lzx_read_lens itself is untouched -- this is
+// its own function applied to two inputs.  The program lives in the input stage's room (nothing is staged before the
+// frame's first parse pass): LZX_SPEC_LENS bytes a | rel << 5 (rel 7: absolute), the aligned tree's 8 lengths, then the
+// block's type, its length and the bit position behind the header.
+// ---------------------------------------------------------------------------------------------------
+#define LZX_SPEC_LENS (LZX_MAIN_SYMS + 16u + LZX_LEN_SYMS + 70u)     /* main_len and len_len lie back to back in LDS */
+static_assert(LZX_SPEC_LENS + 8u + 16u <= LZX_STAGE_WORDS * 4u, "the header program fits the input stage");
+static_assert(offsetof(LzxShared, len_len) == offsetof(LzxShared, main_len) + LZX_MAIN_SYMS + 16u, "main_len and len_len are contiguous");
+__device__ __attribute__((noinline)) bool lzx_pipe_spec_header(const mspack_hip_unit *up, const u32 fo, const u8 *in_arena, LzxShared *sh)
+{
+  const mspack_hip_unit u = *up;
+  const u32 lane = threadIdx.x;
+  LzxDec d;
+  LzxState s;
+  if (!lzx_side_setup(d, s, u, in_arena, sh)) return false;
+  u8 *const lens = sh->main_len;
+  u8 *const prog = (u8 *) sh->stage;
+  u32 bt = 0, bl = 0, cb = 0;
+  for (u32 run = 0; run < 2u; run++) {
+    for (u32 x = lane; x < LZX_SPEC_LENS; x += WAVE) lens[x] = run ? (u8)(1u + x % 5u) : (u8) 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    d.w.seek(fo, lane);
+    d.bb = 0; d.bl = 0; d.rbl = 0; d.near_end = false; d.careful = false; d.err = 0;
+    s.block_type = 0; s.raw_mode = false;
+    const bool hok = lzx_block_header(d, s, false) && !d.careful && !d.near_end;
+    if (!hok || (s.block_type != 1u && s.block_type != 2u) || s.block_length == 0u) return false;
+    const u32 c = rfl(d.w.origin) * 8u + rfl(d.cons_bits());
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (run == 0u) {
+      bt = s.block_type; bl = s.block_length; cb = c;
+      for (u32 x = lane; x < LZX_SPEC_LENS; x += WAVE) prog[x] = lens[x];
+      if (lane < 8u) prog[LZX_SPEC_LENS + lane] = sh->ali_len[lane];
+    }
+    else {
+      bool bad = s.block_type != bt || s.block_length != bl || c != cb;
+      for (u32 x = lane; x < LZX_SPEC_LENS; x += WAVE) {
+        const u32 a = prog[x], b = lens[x];
+        const u32 diff = (b + 17u - a) % 17u;                  // 0: nothing old went into it; else the probe value of the entry that did
+        const u32 rel = diff == 0u ? 7u : (x % 5u + 5u - (diff - 1u)) % 5u;
+        bad = bad || a > 16u || b > 16u || diff > 5u || (diff != 0u && rel > x);
+        prog[x] = (u8)(a | (rel << 5));
+      }
+      if (ballot(bad)) return false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  if (lane == 0) {
+    u32 *w = (u32 *)(prog + ((LZX_SPEC_LENS + 8u + 3u) & ~3u));
+    w[0] = bt; w[1] = bl; w[2] = cb;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  return true;
+}
+// the previous block's code lengths (in LDS) through the program
+__device__ __forceinline__ void lzx_pipe_apply_header(LzxShared *sh, const u32 lane)
+{
+  u8 *const lens = sh->main_len;
+  const u8 *const prog = (const u8 *) sh->stage;
+  u32 nv[(LZX_SPEC_LENS + 63u) / 64u];
+#pragma unroll
+  for (u32 k = 0; k < (LZX_SPEC_LENS + 63u) / 64u; k++) {
+    const u32 x = k * 64u + lane;
+    u32 v = 0;
+    if (x < LZX_SPEC_LENS) {
+      const u32 p = prog[x], a = p & 31u, rel = p >> 5;
+      v = rel == 7u ? a : ((u32) lens[x - rel] + a) % 17u;
+    }
+    nv[k] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+  for (u32 k = 0; k < (LZX_SPEC_LENS + 63u) / 64u; k++) {
+    const u32 x = k * 64u + lane;
+    if (x < LZX_SPEC_LENS) lens[x] = (u8) nv[k];
+  }
+  if (lane < 8u) sh->ali_len[lane] = prog[LZX_SPEC_LENS + lane];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+// Returns 1 when the frame's first block ended inside it and lzx_pipe_parse_tail has to go on (its arguments wait in the stage's
+// spare words); 0 otherwise.  `spec`: the caller has read the frame's header ahead of the chain (lzx_pipe_spec_header: the
+// program is in the stage).  Both are calls of the ticket loop (shim.hip), not of this function: nested, their frames -- and the
+// registers this function had to save around them -- added up in every wave's scratch allocation (324 B per lane in round 5).
+#define LZX_TAIL_ARGS (LZX_STAGE_WORDS + 32u)                  /* stage words: bytes done, records, bit position, record chunks */
+__device__ u32 lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
+                              LzxFrameRec *urecs, const RecPool &pool, LzxShared *sh, const bool stream, const bool spec)
 {
   const u32 lane = threadIdx.x;
   LzxFrameRec *rec = &urecs[f];
   {
     u32 st = 0;
     if (lane == 0) st = atomicCAS(&rec->status, LZX_ST_NONE, LZX_ST_CLAIMED);
-    if (rfl(st) != LZX_ST_NONE) return;                        // the unit's wave was faster: it decodes this frame itself
+    if (rfl(st) != LZX_ST_NONE) return 0u;                        // the unit's wave was faster: it decodes this frame itself
   }
   LzxDec d;
   LzxState s;
-  if (!lzx_side_setup(d, s, u, in_arena, sh) || u.in_len >= (1u << 28)) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
+  if (!lzx_side_setup(d, s, u, in_arena, sh) || u.in_len >= (1u << 28)) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return 0u; }
   const u32 *ftab = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
   const u32 rf = u.reset_frames;
   const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
@@ -2184,7 +2166,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *
       if (tries >= (1u << 24)) { ps = LZX_ST_FAILED; break; }
       __builtin_amdgcn_s_sleep(8);
     }
-    if (ps == LZX_ST_FAILED || ps == LZX_ST_TAKEN) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
+    if (ps == LZX_ST_FAILED || ps == LZX_ST_TAKEN) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return 0u; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // (1056 bytes, a dword per lane and step)
     for (u32 i = lane; i < (LZX_MAIN_SYMS + 16) / 4u; i += WAVE) ((u32 *) sh->main_len)[i] = gld((const u32 *) pr->main_len + i);
@@ -2208,7 +2190,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *
       intel = (hi << 16) | lo;
     }
   }
-  if (!ok || (rem != 0u && btype != 1u && btype != 2u)) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
+  if (!ok || (rem != 0u && btype != 1u && btype != 2u)) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return 0u; }
   u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
   u32 fe = (f + 1u < nreal) ? rfl(ftab[f + 1u]) : u.in_len;       // where the table says the frame ends (a hint)
   if (fe > u.in_len || fe <= fo) fe = u.in_len;
@@ -2228,10 +2210,21 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *
     rec->hdr_start_bit = cur_bit; rec->frame_start_bit = fo * 8u; rec->intel_filesize = intel;
     rec->n_edge = edge_n < fsz ? edge_n : fsz; rec->n_tokens = 0; rec->bytes_done = 0; rec->prog = 0; rec->flags = 0;
   }
-  if (rem == 0u) {
+  if (rem == 0u && spec) {
+    // the header was read ahead of the chain: the previous block's lengths go through its program
+    lzx_pipe_apply_header(sh, lane);
+    const u32 *w = (const u32 *)((const u8 *) sh->stage + ((LZX_SPEC_LENS + 8u + 3u) & ~3u));
+    btype = rfl(w[0]); rem = rfl(w[1]); cur_bit = rfl(w[2]);
+    s.block_type = btype; s.block_length = rem;
+#if defined(MSPACK_WAVE_EMU)                                   /* emulator analysis runs: which frames took their header this way */
+    if (lane == 0 && getenv("MSPACK_EMU_SPEC_TRACE")) fprintf(stderr, "lzx_pipe_parse: frame %u: header read ahead of the chain (block type %u, %u bytes)\n", f, btype, rem);
+#endif
+    if (lane == 0 && sh->main_len[0xE8] != 0) rec->flags = 2u;   // lzxd.c:497
+  }
+  else if (rem == 0u) {
     s.block_type = 0;
     const bool hok = lzx_block_header(d, s, false) && !d.careful && !d.near_end;
-    if (!hok || (s.block_type != 1u && s.block_type != 2u) || s.block_length == 0u) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return; }
+    if (!hok || (s.block_type != 1u && s.block_type != 2u) || s.block_length == 0u) { lzx_status_publish(&rec->status, LZX_ST_FAILED, lane); return 0u; }
     rem = s.block_length; btype = s.block_type;
     if (lane == 0 && sh->main_len[0xE8] != 0) rec->flags = 2u;   // lzxd.c:497: a block header with a code for 0xE8
     cur_bit = rfl(d.w.origin) * 8u + rfl(d.cons_bits());         // the block's first token
@@ -2261,11 +2254,9 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *
     u32 nsorted = 0;
     tables = !huff_build<LZX_MAIN_P, LZX_MSH, LZX_MTAB_T>(sh->main_len, 256 + (int) s.num_offsets + 64, 12, sh->main_tab, sh->main_sorted,
                                                           sh->cnt, d.hr_main, lane, false, &nsorted);
-#ifndef LZX_NO_SUB_TABLE
     if (tables && published) two_level = rfl(lzx_build_sub(sh, d.hr_main, nsorted, lane) ? 1u : 0u) != 0u;
-#endif
   }
-  if (!tables) { lzx_status_publish(&rec->status, published ? LZX_ST_HDRONLY : LZX_ST_FAILED, lane); return; }
+  if (!tables) { lzx_status_publish(&rec->status, published ? LZX_ST_HDRONLY : LZX_ST_FAILED, lane); return 0u; }
   PH(3);
   u32 n_rec = 0, end_bit = 0, bytes_done = 0;
   u32 n_chunks = 0;
@@ -2282,14 +2273,19 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *
   if (!published) {
     // the block ends inside the frame.  Parsed up to its end: the next header is read THERE (a real call: the hot path above
     // does not carry the general case's registers).  Not that far: nothing to hand on -- the chain of code lengths ends here
-    if (bytes_done == rem) { PHFLUSH(); lzx_pipe_parse_tail(up, f, in_arena, out_arena, urecs, pool, sh, bytes_done, n_rec, end_bit, n_chunks); return; }
+    if (bytes_done == rem) {
+      if (lane == 0) { sh->stage[LZX_TAIL_ARGS] = bytes_done; sh->stage[LZX_TAIL_ARGS + 1u] = n_rec; sh->stage[LZX_TAIL_ARGS + 2u] = end_bit; sh->stage[LZX_TAIL_ARGS + 3u] = n_chunks; }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      PHFLUSH();
+      return 1u;
+    }
     lzx_status_publish(&rec->status, LZX_ST_FAILED, lane);
     PHFLUSH();
-    return;
+    return 0u;
   }
   // a record that ends early must end behind at least one token of the block: the serial path goes on from its last bit with
   // this block's tables.  Else: code lengths only
-  if (bytes_done < fsz && bytes_done == 0u) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); PHFLUSH(); return; }
+  if (bytes_done < fsz && bytes_done == 0u) { lzx_status_publish(&rec->status, LZX_ST_HDRONLY, lane); PHFLUSH(); return 0u; }
   if (lane == 0) {
     rec->n_tokens = n_rec; rec->end_bit = end_bit; rec->bytes_done = bytes_done;
     rec->flags = rec->flags | (s.length_empty ? 1u : 0u);
@@ -2301,6 +2297,7 @@ __device__ void lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *
   pha_[6] = d.st_t[6]; pha_[7] = d.st_t[7]; pha_[8] = d.st_t[8];
 #endif
   PHFLUSH();
+  return 0u;
 }
 #endif  /* LZX_PARSE_ONLY */
 
@@ -2837,13 +2834,9 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
             if (d.P + len > run_end) { d.err = ERR_DECRUNCH; fail = true; break; }
             if (wp + len > s.wsize) { d.err = ERR_DECRUNCH; fail = true; break; }       // lzxd.c:613
             if (LZX_BAD_SOURCE(off, wp, s.offset, s.ref_size, s.wsize)) { d.err = ERR_DECRUNCH; fail = true; break; }
-#ifndef LZX_EXP_NOCOPY
             d.flush_lits();
             if (off != 0u && off <= s.wsize) lzx_copy_match(d.out, d.P, off, len, lane);
             else { if (lane == 0) lzx_copy_match_odd(d.out, d.P, wp, s.wsize, off, len); }
-#else
-            d.lit_n = 0;
-#endif
             d.P += len;
             TS9();
           }
@@ -2925,10 +2918,6 @@ __device__ __forceinline__ void lzx_decode_unit(const mspack_hip_unit &u, const 
 #endif
     res->err = err; res->flags = flags; res->out_len = s.offset; res->good_len = s.offset; res->in_next = in_next;
     res->in_used = s.raw_mode ? s.raw_pos : d.iptr();
-#ifdef LZX_EXP_CNT
-    res->flags = d.st_t[0]; res->out_len = d.st_t[1]; res->good_len = d.st_t[2]; res->err = (int) d.st_t[4];
-    ((u32 *) res)[5] = d.st_rounds; ((u32 *) res)[3] = d.st_t[5];
-#endif
 #ifdef LZX_EXP_STATS
     {   // scratch builds only: section timers overwrite the head of the unit's output
       u32 *so = (u32 *) d.out;

@@ -265,13 +265,35 @@ union LzxPipeLds { lzxp::LzxShared p; lzxn::LzxResolveLds r; };
 static_assert(sizeof(LzxPipeLds) <= 10240, "16 waves per CU");
 
 // the two halves of a task are real calls: each gets its own register allocation (inlined into the ticket loop they spill)
-__device__ __attribute__((noinline)) void lzx_pipe_task_parse(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
-                                                              lzxn::LzxFrameRec *recs, uint2 *pool, u32 *pool_head, const u32 pool_chunks,
-                                                              lzxp::LzxShared *sh)
+__device__ __attribute__((noinline)) u32 lzx_pipe_task_parse(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
+                                                             lzxn::LzxFrameRec *recs, uint2 *pool, u32 *pool_head, const u32 pool_chunks,
+                                                             lzxp::LzxShared *sh, const u32 spec)
 {
   const mspack_hip_unit u = *up;
   RecPool rp; rp.base = pool; rp.head = pool_head; rp.cap = pool_chunks;
-  lzxp::lzx_pipe_parse(u, up, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], rp, sh, false);
+  return lzxp::lzx_pipe_parse(u, up, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], rp, sh, false, spec != 0u);
+}
+// (the rest of a frame whose first block ended inside it: one frame in a few hundred)
+__device__ __attribute__((noinline)) void lzx_pipe_task_tail(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
+                                                             lzxn::LzxFrameRec *recs, uint2 *pool, u32 *pool_head, const u32 pool_chunks,
+                                                             lzxp::LzxShared *sh)
+{
+  RecPool rp; rp.base = pool; rp.head = pool_head; rp.cap = pool_chunks;
+  lzxp::lzx_pipe_parse_tail(up, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[rfl(up->frame_base)], rp, sh);
+}
+// (a frame's block header read ahead of the header chain, while the frame below is not that far: lzx_kernel.hpp)
+__device__ __attribute__((noinline)) u32 lzx_pipe_task_spec(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, const lzxn::LzxFrameRec *recs,
+                                                            lzxp::LzxShared *sh)
+{
+  const u32 rf = rfl((u32) up->reset_frames);
+  if (rf ? (f % rf) == 0u : f == 0u) return 0u;                 // (a frame that starts a reset interval has no chain below it)
+  const lzxn::LzxFrameRec *pr = &recs[rfl(up->frame_base) + f - 1u];
+  const u32 ps = lzxn::lzx_status_load(&pr->status);
+  if (ps != LZX_ST_NONE && ps != LZX_ST_CLAIMED) return 0u;     // the frame below is there: nothing to wait for, nothing to guess
+  const u32 in_len = rfl(up->in_len);
+  const u32 fo = rfl(((const u32 *)(in_arena + (size_t) rfl(up->in_chunk) * 4u))[f]);
+  if (fo >= in_len || in_len - fo <= 64u) return 0u;
+  return rfl(lzxp::lzx_pipe_spec_header(up, fo, in_arena, sh) ? 1u : 0u);
 }
 __device__ __attribute__((noinline)) void lzx_pipe_task_resolve(const mspack_hip_unit *up, const u32 f, u8 *out_arena, lzxn::LzxFrameRec *recs,
                                                                 uint2 *toks, lzxn::LzxResolveLds *rl, const bool merged)
@@ -330,7 +352,13 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
     if (lane == 0) lzxn::g_pipe_wait[blockIdx.x & 0xFFFFu] = 0;
 #endif
     if (do_parse) {
-      lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh.p);
+#ifndef LZX_NO_SPEC_HEADER
+      const u32 spec = lzx_pipe_task_spec(up, f, in_arena, recs, &sh.p);
+#else
+      const u32 spec = 0u;
+#endif
+      if (lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh.p, spec))
+        lzx_pipe_task_tail(up, f, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh.p);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the resolver reuses the LDS
       if (fold) do_resolve = fold_policy == 1u && lzx_unit_runs(&recs[rfl(up->frame_base)]);    // (a unit of long runs keeps its resolve tasks)
     }
