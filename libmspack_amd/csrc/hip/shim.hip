@@ -1441,8 +1441,21 @@ void *mspack_hip_stage_alloc(size_t bytes)
 void mspack_hip_stage_free(void *p)
 {
   if (!p) return;
+  // what stays page-locked while nobody uses it is bounded too (a process that once opened a large cabinet kept
+  // hundreds of MiB locked for good): MSPACK_HIP_PINNED_IDLE_MB, default 512 -- the arenas of a cabinet of 128 MiB come back at
+  // once for the next one; beyond that the largest idle blocks go back to the system
+  static const size_t idle_limit = (size_t) env_int("MSPACK_HIP_PINNED_IDLE_MB", 512, 0, 1 << 20) << 20;
   std::lock_guard<std::mutex> lock(g_stage_mu);
-  for (StageBlock &b : g_stage) if (b.p == p) { b.busy = false; return; }
+  for (StageBlock &b : g_stage) if (b.p == p) { b.busy = false; break; }
+  for (;;) {
+    size_t idle = 0, big = (size_t) -1;
+    for (size_t i = 0; i < g_stage.size(); i++)
+      if (!g_stage[i].busy) { idle += g_stage[i].cap; if (big == (size_t) -1 || g_stage[i].cap > g_stage[big].cap) big = i; }
+    if (idle <= idle_limit || big == (size_t) -1) break;
+    if (hipHostFree(g_stage[big].p) != hipSuccess) (void) hipGetLastError();
+    g_stage_total -= g_stage[big].cap;
+    g_stage.erase(g_stage.begin() + (long) big);
+  }
 }
 static void stage_release_idle()
 {

@@ -614,9 +614,12 @@ static int reader_block(struct cabd_p *self, struct blk_reader *r, unsigned int 
         L->p[L->n].off = r->defer_base + r->i_end; L->p[L->n].len = len;
         L->p[L->n].want = cksum ^ rd_le32(hdr + 4);       /* (cab_checksum over one whole dword is an XOR) */
         L->p[L->n].owner = r->defer_owner; L->n++;
+        cksum = 0;                                        /* (verified on the device, with the batch) */
       }
+      /* else: the list could not grow -- THIS part is verified right here (it used to go unverified, and the
+       * parts recorded so far were thrown away with it) */
     }
-    else if (cksum) {                                     /* every part carries its own checksum */
+    if (cksum) {                                          /* every part carries its own checksum */
       unsigned int sum = cab_checksum(r->input + r->i_end, len, 0);
       if (cab_checksum(hdr + 4, 4, sum) != cksum) {
         if (!ignore_cksum) return MSPACK_ERR_CHECKSUM;
@@ -920,7 +923,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     n++;
   }
   if (!err && !arena_room(sys, &A, 64)) err = MSPACK_ERR_NOMEMORY;
-  if (ck.failed) ck.n = 0;             /* (the list could not grow: those folders verified on the host from then on -- none deferred twice) */
+  /* (a list that could not grow: the parts it holds are still verified with the batch, the others were verified while they were read) */
   nu = n + ck.n;
   if (!err) {
     units = (mspack_hip_unit *) sys->alloc(sys, (nu ? nu : 1) * sizeof(*units));
@@ -961,7 +964,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     size_t nhip = 0;
     for (k = 0; k < n; k++) if (units[k].kind != 0) nhip++;
     memset(res, 0, nu * sizeof(*res));
-    if (nhip) {
+    if (nhip || ck.n) {                  /* (checksum units alone are a batch too: stored folders' parts -- ADVICE round 5) */
       /* the arena was written a moment ago: page-locked, its copy to the device is plain DMA (mspack_hip.h; advice only) */
       const int pinned = A.len >= ((size_t) 4 << 20) && !mspack_arena_is_locked(A.p) && mspack_hip_pin(A.p, mspack_arena_room(A.len + 64)) == 0;
       /* kinds other than 1..3 are answered with MSPACK_ERR_ARGS by the kernels; fix them up below */

@@ -15,10 +15,18 @@ for m in re.finditer(r"\.group_segment_fixed_size:\s*(\d+).*?\.name:\s*(\S+).*?\
     nm = re.sub(r"^_Z\d+", "", name); nm = re.match(r"[a-z_0-9]+", nm).group(0)
     print("%-26s %6s %6s %8s %9s %11s %11s" % (nm, vg, sg, lds, scr, sgs, vgs))
 print("\n# device functions that are real calls (a kernel's scratch = its own frame + the deepest chain of these):")
-for m in re.finditer(r"^(\S+):\s*; @\S+\n(?:(?!^\S+:\s*; @).)*?; Function info:\n; codeLenInByte = (\d+)\n(?:;.*\n)*?; NumVgprs: (\d+)\n(?:;.*\n)*?; ScratchSize: (\d+)", s, re.M | re.S):
-    name, code, vg, scr = m.groups()
-    nm = re.sub(r"^_ZN?\d*", "", name)
-    mm = re.search(r"(lzx_pipe_[a-z_]+|qtm_update_model|lzx_copy_match_odd|[a-z_]+fold[a-z_]*)", name)
-    print("  %-28s code %6s B, %3s VGPRs, frame %4s B" % (mm.group(1) if mm else nm[:28], code, vg, scr))
+cur = None
+for line in s.split("\n"):
+    m = re.match(r"\s*\.type\s+(\S+),@function", line)
+    if m: cur = m.group(1); code = vg = None; continue
+    m = re.match(r"; codeLenInByte = (\d+)", line)
+    if m: code = m.group(1)
+    m = re.match(r"; NumVgprs: (\d+)", line)
+    if m: vg = m.group(1)
+    m = re.match(r"; ScratchSize: (\d+)", line)
+    if m and cur and not re.match(r"_Z\d+mspack_", cur):
+        mm = re.search(r"(lzx_pipe_[a-z_]+|qtm_update_model|lzx_copy_match_odd|zip_[a-z_]+|lzx_[a-z_]+)", cur)
+        print("  %-28s code %6s B, %3s VGPRs, frame %4s B" % (mm.group(1) if mm else cur[:28], code, vg, m.group(1)))
+        cur = None
 P
 rm -rf $T
