@@ -213,10 +213,20 @@ void mspack_decode_lzx(const mspack_hip_unit *units, const u32 *order, u32 n_uni
 #ifndef LZX_FOLD_MAX_UNITS
 #define LZX_FOLD_MAX_UNITS 128u
 #endif
-__device__ __forceinline__ bool lzx_fold_on(const u32 *ctl, const u32 policy)
+// (measured, tools/fold_policy_sweep.py, profiles/round6_fold_policy.txt: n folders of f frames, LZX, resolve tasks / fold tasks, ms:
+//  4 x 256: 68.5 / 13.4; 16 x 64: 20.9 / 8.3; 32 x 32: 12.2 / 6.5; 64 x 16: 8.1 / 6.0; 128 x 8: 6.2 / 5.8; 128 x 4: 2.7 / 3.1;
+//  256 x 8: 8.3 / 9.0 -- so: at most 128 units, and eight frames in the longest, or at least four when every frame gets a task of its
+//  own at once; MSZIP folders gain at 128 x 4 too (2.6 / 2.2): four blocks)
+#ifndef LZX_FOLD_LONG_FRAMES
+#define LZX_FOLD_LONG_FRAMES 8u
+#endif
+__device__ __forceinline__ bool lzx_fold_on(const u32 *ctl, const u32 policy, const u32 n_slots, const bool mszip)
 {
   if (policy == 0u || rfl(ctl[6]) != 0u || rfl(ctl[0]) == 0u) return false;
-  return policy >= 2u || (rfl(ctl[0]) >= LZX_FOLD_MIN_FRAMES && rfl(ctl[5]) <= LZX_FOLD_MAX_UNITS);
+  if (policy >= 2u) return true;
+  const u32 fmax = rfl(ctl[0]);
+  if (rfl(ctl[5]) > LZX_FOLD_MAX_UNITS || fmax < LZX_FOLD_MIN_FRAMES) return false;
+  return mszip || fmax >= LZX_FOLD_LONG_FRAMES || n_slots <= 256u;
 }
 // (a workgroup of FOLD_WAVES waves per task: fold_common.hpp; wave 0 pulls the tickets)
 #define FOLD_TICKET(counter)                                                      \
@@ -246,7 +256,7 @@ void mspack_lzx_fold(const mspack_hip_unit *units, u32 slot_lo, u32 n_slots, u8 
                      lzxn::LzxFrameRec *recs, const uint2 *toks, u32 fold_policy)
 {
   __shared__ lzxn::LzxFoldLds sh;
-  if (!lzx_fold_on(ctl, fold_policy)) return;
+  if (!lzx_fold_on(ctl, fold_policy, n_slots, false)) return;
   for (;;) {
     FOLD_TICKET(&ctl[7])
     if (t >= n_slots) break;
@@ -324,7 +334,7 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
   const u32 Fmax = rfl(ctl[0]), Fmin = rfl(ctl[1]);
   // few units of many frames: this launch only PARSES (a unit's frames in a row: the header chain); mspack_lzx_fold, launched behind
   // it, does what lzx_pipe_resolve would have done (lzx_fold.hpp)
-  const bool fold = lzx_fold_on(ctl, fold_policy);
+  const bool fold = lzx_fold_on(ctl, fold_policy, n_slots, false);
   const u32 F = (Fmax != 0u && Fmax == Fmin && !fold) ? Fmax : 0u;
   const u32 T = F ? 2u * n_units * F : n_slots;
   for (;;) {
@@ -430,7 +440,7 @@ void mspack_mszip_fold(const mspack_hip_unit *units, u32 slot_lo, u32 n_slots, u
                        lzxn::LzxFrameRec *recs, const uint2 *toks, u32 fold_policy)
 {
   __shared__ FoldLds sh;
-  if (!lzx_fold_on(hdr, fold_policy)) return;
+  if (!lzx_fold_on(hdr, fold_policy, n_slots, true)) return;
   for (;;) {
     FOLD_TICKET(&hdr[7])
     if (t >= n_slots) break;

@@ -52,6 +52,12 @@ def pytest_collection_modifyitems(session, config, items):
         mod = os.path.splitext(os.path.basename(str(it.fspath)))[0]
         return rank.get(mod, len(_ORDER) // 2)
     items.sort(key=key)           # (stable: a module's tests keep their order)
+    # The one test that has ever taken the whole process down (round 5: SIGABRT inside the HIP runtime, once in five whole-suite
+    # runs, never again in round 6's eight) runs LAST: if it ever does that again, every other result is
+    # already on the terminal -- and the native backtrace follows (_abort_backtrace above).
+    last = [it for it in items if it.name.startswith("test_copies_are_cut_at_pin_boundaries")]
+    if last:
+        items[:] = [it for it in items if it not in last] + last
 
 
 @pytest.fixture(scope="session")

@@ -39,6 +39,21 @@ for i in (0, 1):
     assert res["err"][i] == 0 or res["out_len"][i] == data.size
     assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
 assert res["flags"][0] & T.ADOPTED and res["flags"][4] & T.ADOPTED
+# ---- (ADVICE round 5) a frame that holds a block's END and the next block's header (lzx_pipe_parse_tail: blocks of 40 000 bytes),
+# and run fills whose period is <= 64 and does not divide 64 (spq_fill_run: 24- and 7-byte periods, runs of >= 512 bytes) ----
+d2 = M.gen_plaintext(31, M.TEXT_MIX, 3 * 32768 + 99)
+c2, f2 = M.lzx_encode(d2, 21, 0, M.lzx_opts(block_size=40000))
+rep = (np.frombuffer(bytes(range(24)) * 700, dtype=np.uint8).tolist() + M.gen_plaintext(32, M.TEXT_MIX, 3000).tolist() +
+       list(b"abcdefg" * 1500) + M.gen_plaintext(33, M.TEXT_MIX, 2 * 32768).tolist())
+d3 = np.asarray(rep[:2 * 32768 + 500], dtype=np.uint8)
+c3, f3 = M.lzx_encode(d3, 21, 0)
+streams = [c2.tobytes(), c3.tobytes()]
+params = [(d2.size, 21, 0, 0), (d3.size, 21, 0, 0)]
+units, out, res = T.run(streams, params, [f2.astype(np.int64)[:-1], f3.astype(np.int64)[:-1]])
+T.check(streams, params, units, out, res, compare_bytes=False)
+for i, dd in enumerate((d2, d3)):
+    assert res["err"][i] == 0 and np.array_equal(out[units["out_off"][i]:units["out_off"][i] + dd.size], dd), i
+    assert res["flags"][i] & T.ADOPTED, i
 # ---- MSZIP: one folder of two blocks with history; Quantum: one folder ----
 d = M.gen_plaintext(9, 0, 50000).tobytes()
 co = zlib.compressobj(6, zlib.DEFLATED, -15); b0 = b"CK" + co.compress(d[:32768]) + co.flush()
