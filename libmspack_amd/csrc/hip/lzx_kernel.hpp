@@ -2537,6 +2537,130 @@ __device__ void lzx_pipe_resolve(const mspack_hip_unit &u, const u32 f, u8 *out_
   PHFLUSH();
 #undef MREC
 }
+// ---------------------------------------------------------------------------------------------------
+// lzx_pipe_resolve_stream -- the resolve task of a launch that has wave slots to spare (round 6; round 3's commit task had this,
+// round 4's restructure dropped it, and BASELINE config 3's launch shape -- 1024 intervals: 4096 tickets for 4096 waves -- got slower
+// every round since: 1.44 -> 1.58 -> 1.60 ms).  In such a launch every ticket is pulled at once, and a unit's chain is
+// P(f0) -> R(f0) -> R(f1): the resolve task of a frame sat idle until the frame's parse task had stored its last record.  Here it
+// takes the records up WHILE the frame is parsed: lzx_parse_emit publishes, behind every pass but the last, how many match records
+// and output bytes are in memory (`prog`, with the same release recipe as a status word), and this task works through what has
+// arrived -- whole groups of 256 records -- one acquire per event.  The frame's chain is then the longer of its parse and its
+// resolve, not their sum.  Only where waves are spare (shim.hip: control word 3): a resolve wave that has started on a frame
+// holds its slot until the frame's parse task is through.  Same records, same checks, same hand-over as lzx_pipe_resolve.
+// ---------------------------------------------------------------------------------------------------
+__device__ void lzx_pipe_resolve_stream(const mspack_hip_unit &u, const u32 f, u8 *out_arena, LzxFrameRec *urecs, const uint2 *pool_base, LzxResolveLds *rl)
+{
+  SpecQueueLds *const spq = &rl->q;
+  const u32 lane = threadIdx.x;
+  u8 *const out = out_arena + u.out_off;
+  const u32 rf = u.reset_frames;
+  const u32 nreal = (u.out_len + LZX_FRAME - 1u) / LZX_FRAME;
+  const u32 wsize = 1u << u.window_bits;
+  LzxFrameRec *rec = &urecs[f];
+  LzxFrameRec *pr = rec - 1;
+  const bool first = rf ? (f % rf) == 0u : f == 0u;
+  u32 R0 = 1, R1 = 1, R2 = 1, prev_end = 0;
+  if (f != 0u) {
+    const u32 pch = lzx_chain_wait(&pr->chain, false);
+    if (pch != LZX_CH_DONE) { lzx_status_publish(&rec->chain, LZX_CH_ENDED, lane); return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    prev_end = (rfl(pr->end_bit) + 15u) & ~15u;
+    if (!first) { R0 = rfl(pr->cR0); R1 = rfl(pr->cR1); R2 = rfl(pr->cR2); }
+  }
+  // the frame's parse task: an earlier ticket.  Its header (status HEADER: the record's first fields stand) or its end
+  u32 st = lzx_status_load(&rec->status);
+  for (u32 tries = 0; (st == LZX_ST_NONE || st == LZX_ST_CLAIMED) && tries < (1u << 24); tries++) {
+    __builtin_amdgcn_s_sleep(8);
+    st = lzx_status_load(&rec->status);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  u32 fsz = u.out_len - f * LZX_FRAME; if (fsz > LZX_FRAME) fsz = LZX_FRAME;
+  const u32 frame_pos = f * LZX_FRAME;
+  const u32 wbase = frame_pos & ~(wsize - 1u);
+  const u32 eR0 = R0, eR1 = R1, eR2 = R2;
+  u32 n_rec = 0, bytes = 0, end_bit = 0;
+  bool bad = !(st == LZX_ST_EMITTED || st == LZX_ST_HEADER);
+  if (!bad) bad = rfl(gld(&rec->frame_start_bit)) != prev_end;
+  bool fin = false;                                          // the parse task has said its last word
+  u32 avail = 0, th = 0;
+  bool edge_done = false;
+  SpecQueue Q;
+  spq_init(*spq, Q, frame_pos, lane);
+  while (!bad) {
+    if (!fin) {
+      st = lzx_status_load(&rec->status);
+      if (st != LZX_ST_HEADER) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        fin = true;
+        if (st != LZX_ST_EMITTED) { bad = true; break; }
+        n_rec = rfl(gld(&rec->n_tokens)); bytes = rfl(gld(&rec->bytes_done)); end_bit = rfl(gld(&rec->end_bit));
+        if (bytes > fsz || n_rec > REC_CHUNK * REC_CHUNKS || n_rec < avail) { bad = true; break; }
+        avail = n_rec;
+      }
+      else {
+        const u32 pg = lzx_status_load(&rec->prog) & 0x7FFFu;
+        if (pg > avail) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); avail = pg;
+#if defined(MSPACK_WAVE_EMU)
+          if (lane == 0 && getenv("MSPACK_EMU_STREAM_TRACE")) fprintf(stderr, "lzx_pipe_resolve_stream: frame %u: %u records in while the frame is parsed\n", f, avail);
+#endif
+        }
+        else if (th + 256u > avail) { __builtin_amdgcn_s_sleep(8); continue; }
+      }
+    }
+    if (!edge_done && (fin || avail != 0u)) {
+      // the literals of the frame's first cache line (their mask is complete once a pass has been published: lzx_parse_emit)
+      const u32 ne = rfl(gld(&rec->n_edge));
+      for (u32 i = lane; i < ne; i += WAVE)
+        if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
+      edge_done = true;
+    }
+    // whole groups of 256 records (all that is left once the parse is through)
+    while (th < avail && (fin || th + 256u <= avail) && !bad) {
+      const uint2 *g0 = rec_group(pool_base, rec->chunk, th);
+      uint2 c4[4];
+#pragma unroll
+      for (u32 k = 0; k < 4u; k++) { c4[k] = make_uint2(0u, 0u); if (th + 64u * k + lane < avail) c4[k] = gld(g0 + 64u * k + lane); }
+#pragma unroll 1
+      for (u32 k = 0; k < 4u && th < avail && !bad; k++) {
+        u32 n = avail - th; if (n > 64u) n = 64u;
+        const uint2 cur = k == 0u ? c4[0] : (k == 1u ? c4[1] : (k == 2u ? c4[2] : c4[3]));
+        const bool ism = lane < n;
+        const u32 opos = cur.x, olen = (cur.y >> 2) & 511u, which = cur.y & 3u, c1 = cur.y >> 11;
+        u32 vmoff = c1;
+        if (!lzx_front_batch(ism, lane, opos, olen, which, c1, R0, R1, R2, frame_pos, wbase, wsize, vmoff)) { bad = true; break; }
+        const u32 newP = rdl(opos + olen, n - 1u);
+        spq_push_runs(*spq, Q, out, ism, n, opos, olen, vmoff, lane);
+        if (spq_due(Q, newP)) spq_resolve(*spq, Q, out, newP, false, lane);
+        th += n;
+      }
+    }
+    if (fin && th >= avail) break;
+  }
+  if (!bad) {
+    if (!edge_done) {
+      const u32 ne = rfl(gld(&rec->n_edge));
+      for (u32 i = lane; i < ne; i += WAVE)
+        if ((gld(&rec->edge_mask[i >> 5]) >> (i & 31u)) & 1u) gst(out + frame_pos + i, gld(&rec->edge_lit[i]));
+    }
+    spq_resolve(*spq, Q, out, frame_pos + bytes, true, lane);
+  }
+  const bool whole = !bad && bytes == fsz;
+  if (lane == 0) {
+    if (whole) { rec->cR0 = R0; rec->cR1 = R1; rec->cR2 = R2; }
+    if (!whole || f + 1u == nreal) {
+      LzxFrameRec *r0 = &urecs[0];
+      const bool partial = !bad && !whole;
+      r0->rs_frame = whole ? f + 1u : f; r0->rs_partial = partial ? 1u : 0u;
+      r0->rs_P = whole ? (f + 1u) * LZX_FRAME : (partial ? frame_pos + bytes : frame_pos);
+      r0->rs_next_bit = whole ? ((end_bit + 15u) & ~15u) : (partial ? end_bit : prev_end);
+      r0->rs_R0 = bad ? eR0 : R0; r0->rs_R1 = bad ? eR1 : R1; r0->rs_R2 = bad ? eR2 : R2;
+      r0->rs_valid = 1u;
+    }
+  }
+  lzx_status_publish(&rec->chain, whole ? LZX_CH_DONE : LZX_CH_ENDED, lane);
+}
+
 #include "lzx_fold.hpp"
 #endif  /* !LZX_PARSE_ONLY */
 #endif  /* !LZX_DELTA */

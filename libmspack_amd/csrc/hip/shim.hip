@@ -277,11 +277,11 @@ static_assert(sizeof(LzxPipeLds) <= 10240, "16 waves per CU");
 // the two halves of a task are real calls: each gets its own register allocation (inlined into the ticket loop they spill)
 __device__ __attribute__((noinline)) u32 lzx_pipe_task_parse(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
                                                              lzxn::LzxFrameRec *recs, uint2 *pool, u32 *pool_head, const u32 pool_chunks,
-                                                             lzxp::LzxShared *sh, const u32 spec)
+                                                             lzxp::LzxShared *sh, const u32 spec, const u32 stream)
 {
   const mspack_hip_unit u = *up;
   RecPool rp; rp.base = pool; rp.head = pool_head; rp.cap = pool_chunks;
-  return lzxp::lzx_pipe_parse(u, up, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], rp, sh, false, spec != 0u);
+  return lzxp::lzx_pipe_parse(u, up, f, in_arena, out_arena, (lzxp::LzxFrameRec *) &recs[u.frame_base], rp, sh, stream != 0u, spec != 0u);
 }
 // (the rest of a frame whose first block ended inside it: one frame in a few hundred)
 __device__ __attribute__((noinline)) void lzx_pipe_task_tail(const mspack_hip_unit *up, const u32 f, const u8 *in_arena, u8 *out_arena,
@@ -311,6 +311,13 @@ __device__ __attribute__((noinline)) void lzx_pipe_task_resolve(const mspack_hip
   const mspack_hip_unit u = *up;
   lzxn::lzx_pipe_resolve(u, f, out_arena, &recs[u.frame_base], toks, rl, merged);
 }
+// (the same where the launch has wave slots to spare: the frame's records taken up while it is parsed -- lzx_kernel.hpp)
+__device__ __attribute__((noinline)) void lzx_pipe_task_resolve_stream(const mspack_hip_unit *up, const u32 f, u8 *out_arena, lzxn::LzxFrameRec *recs,
+                                                                       uint2 *toks, lzxn::LzxResolveLds *rl)
+{
+  const mspack_hip_unit u = *up;
+  lzxn::lzx_pipe_resolve_stream(u, f, out_arena, &recs[u.frame_base], toks, rl);
+}
 
 #ifdef LZX_PIPE_TRACE      /* analysis builds: one line per ticket = start, end (s_memrealtime, 100 MHz), task, time waited */
 __device__ unsigned long long g_pipe_trace[4 << 16];
@@ -335,8 +342,12 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
   // few units of many frames: this launch only PARSES (a unit's frames in a row: the header chain); mspack_lzx_fold, launched behind
   // it, does what lzx_pipe_resolve would have done (lzx_fold.hpp)
   const bool fold = lzx_fold_on(ctl, fold_policy, n_slots, false);
+  // control word 3 (the host's): this launch has a wave for every ticket and nothing runs beside it -- resolve tasks take their
+  // frames up while they are parsed (lzx_pipe_resolve_stream)
+  const u32 stream_ok = rfl(ctl[3]);
   const u32 F = (Fmax != 0u && Fmax == Fmin && !fold) ? Fmax : 0u;
   const u32 T = F ? 2u * n_units * F : n_slots;
+  const u32 stream = (stream_ok != 0u && F != 0u && T <= gridDim.x) ? 1u : 0u;      // (every ticket finds a wave at once)
   for (;;) {
     u32 t = 0;
     if (lane == 0) t = atomicAdd(&ctl[2], 1u);
@@ -367,12 +378,15 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
 #else
       const u32 spec = 0u;
 #endif
-      if (lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh.p, spec))
+      if (lzx_pipe_task_parse(up, f, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh.p, spec, stream))
         lzx_pipe_task_tail(up, f, in_arena, out_arena, recs, toks, &ctl[4], pool_chunks, &sh.p);
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the resolver reuses the LDS
       if (fold) do_resolve = fold_policy == 1u && lzx_unit_runs(&recs[rfl(up->frame_base)]);    // (a unit of long runs keeps its resolve tasks)
     }
-    if (do_resolve) lzx_pipe_task_resolve(up, f, out_arena, recs, toks, &sh.r, do_parse);
+    if (do_resolve) {
+      if (stream && !do_parse) lzx_pipe_task_resolve_stream(up, f, out_arena, recs, toks, &sh.r);
+      else lzx_pipe_task_resolve(up, f, out_arena, recs, toks, &sh.r, do_parse);
+    }
 #ifdef LZX_PIPE_TRACE
     if (lane == 0 && t < (1u << 16)) {
       g_pipe_trace[4u * t] = tr0; g_pipe_trace[4u * t + 1u] = __builtin_amdgcn_s_memrealtime();
@@ -558,6 +572,8 @@ static int fail(hipError_t e, const char *what) {
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
 // MSPACK_HIP_FOLD: 0 = a folder's copies always through lzx_pipe_resolve, 1 (default) = through mspack_lzx_fold when the launch is few
 // long units, 2 = whenever the units allow it (tests, A/B runs)
+// MSPACK_HIP_STREAM_RESOLVE=0: resolve tasks never take frames up while they are parsed (A/B runs)
+static const bool g_stream_resolve = !getenv("MSPACK_HIP_STREAM_RESOLVE") || atoi(getenv("MSPACK_HIP_STREAM_RESOLVE")) != 0;
 static const u32 g_fold_policy = getenv("MSPACK_HIP_FOLD") ? (u32) atoi(getenv("MSPACK_HIP_FOLD")) : 1u;
 // persistent waves of mspack_lzx_pipe: as many as the device holds at once (nothing depends on that number being right)
 // (cached per device: mspack_hip_decode_batch_multi runs one host thread per device)
@@ -620,7 +636,7 @@ hipError_t hostcheck_launch_kind(unsigned kind, const mspack_hip_unit *d_units, 
 static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, const uint32_t *d_order, size_t n,
                               const void *d_in, void *d_out, mspack_hip_result *d_results, void *d_fm, size_t n_frames_total,
                               size_t slot_lo, size_t n_slots, hipStream_t st, bool frame_tables = true, unsigned launch_ix = 0,
-                              size_t n_rec_slots = (size_t) -1)
+                              size_t n_rec_slots = (size_t) -1, bool alone = true)
 {
   if (n_rec_slots == (size_t) -1) n_rec_slots = n_frames_total;
   if (n == 0) return hipSuccess;
@@ -631,6 +647,7 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
   const u8 *const in = (const u8 *) d_in;
   u8 *const out = (u8 *) d_out;
   static const u32 hdr_init[8] = { 0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u };
+  static const u32 hdr_init_stream[8] = { 0u, 0xFFFFFFFFu, 0u, 1u, 0u, 0u, 0u, 0u };
   switch (kind) {
   case MSPACK_HIP_KIND_LZX: {
     LzxScratch L = lzx_scratch(d_fm, n_frames_total, n_rec_slots);
@@ -643,7 +660,10 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
     if (frames) {
       // one dependency-driven launch: parse and resolve tasks from a ticket counter (mspack_lzx_pipe)
       LK(hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st));
-      LK(hipMemcpyAsync(hdr, hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st));
+      // (resolve tasks that take their frames up while they are parsed: only where every ticket finds a wave at once -- a resolve
+      // wave that has started holds its slot until its frame's parse task is through -- and no other launch runs beside this one)
+      const bool stream = alone && g_stream_resolve;      // (and the kernel knows how many tickets the launch has)
+      LK(hipMemcpyAsync(hdr, stream ? hdr_init_stream : hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st));
       LK(launch(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr));
       const size_t tickets = 2u * n_slots;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
@@ -1253,7 +1273,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       if (!one) { TRY(hipEventRecord(cx.ev_in[ci], st_in)); TRY(hipStreamWaitEvent(st, cx.ev_in[ci], 0)); }
       for (unsigned k = 1; k <= MSPACK_HIP_KIND_XORSUM; k++)
         TRY(launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
-                        c.has_ftab, (unsigned) ci, n_rec_slots));
+                        c.has_ftab, (unsigned) ci, n_rec_slots, one));
       TRY(hipMemcpyAsync(h_res + c.a, d_res + c.a, (c.b - c.a) * sizeof(mspack_hip_result), hipMemcpyDeviceToHost, st));
       if (!one) { TRY(hipEventRecord(cx.ev_done[ci], st)); issued.store(ci + 1, std::memory_order_release); }
     }

@@ -162,3 +162,43 @@ def test_fold_tasks_on_the_emulator(built, tmp_path):
     env = dict(os.environ, MSPACK_HIP_SO=SO, MSPACK_HIP_FOLD="2")
     p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert p.returncode == 0 and b"EMU_FOLD_OK" in p.stdout, p.stdout.decode()[-3000:]
+
+
+STREAM_WORKER = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import numpy as np
+import libmspack_amd as M
+import test_gpu_lzx_frames as T
+assert "emu" in M.HIP_SO
+# three units of three frames each (a uniform launch: 18 tickets for 32 waves), one of them with blocks that span frames, one damaged
+data = [M.gen_plaintext(40 + i, M.TEXT_MIX, 3 * 32768) for i in range(3)]
+streams, params, tabs = [], [], []
+for i, d in enumerate(data):
+    comp, fo = M.lzx_encode(d, 21, 0, M.lzx_opts(block_size=50000) if i == 2 else None)
+    streams.append(comp.tobytes()); params.append((d.size, 21, 0, 0)); tabs.append(fo.astype(np.int64)[:-1])
+units, out, res = T.run(streams, params, tabs)
+T.check(streams, params, units, out, res, compare_bytes=False)
+for i, d in enumerate(data):
+    assert res["err"][i] == 0 and np.array_equal(out[units["out_off"][i]:units["out_off"][i] + d.size], d), i
+    assert res["flags"][i] & T.ADOPTED, i
+bad = bytearray(streams[1]); bad[int(tabs[1][1]) + 4000] ^= 0x40
+streams[1] = bytes(bad)
+units, out, res = T.run(streams, params, tabs)
+T.check(streams, params, units, out, res, compare_bytes=False)
+print("EMU_STREAM_OK")
+'''
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="the emulator build needs ROCm's clang++")
+def test_resolve_tasks_that_take_frames_up_while_they_are_parsed(built, tmp_path):
+    """lzx_pipe_resolve_stream (round 6) on the wavefront emulator: a launch with a wave for every ticket (MSPACK_EMU_CUS=8: 32 waves),
+    parse waves that pause behind every published pass -- the resolve tasks must be seen working on partial frames (the trace line), and
+    results, flags and bytes must be the oracle's, with a damaged frame in the batch too."""
+    assert os.path.exists(SO), "built by test_kernels_on_the_wavefront_emulator"
+    script = tmp_path / "w.py"
+    script.write_text(STREAM_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MSPACK_HIP_SO=SO, MSPACK_EMU_CUS="8", MSPACK_EMU_PUBLISH_DELAY_US="3000", MSPACK_EMU_STREAM_TRACE="1")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    assert p.returncode == 0 and b"EMU_STREAM_OK" in p.stdout, p.stdout.decode()[-3000:]
+    assert b"records in while the frame is parsed" in p.stdout, p.stdout.decode()[-2000:]
