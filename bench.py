@@ -262,7 +262,7 @@ def secondary_mszip(M, torch, dev, n=4096, ub=32768, iters=10, cpu=True):
             "cpu_baseline": ref_cpu_secondary(1, comp, off, ln, np.full(n, ub), 0, 0) if cpu else None}
 
 
-def secondary_qtm(M, torch, dev, n=512, frames=32, window_bits=21, iters=2, cpu=True):
+def secondary_qtm(M, torch, dev, n=512, frames=32, window_bits=21, iters=2, cpu=True, marks=0):
     """BASELINE config 4 as SURVEY 8(d) specifies it: comp_type 0x1572 -- Quantum, window 2^21 -- n folders of
     `frames` 32 KiB blocks each (the folder stream as cabd feeds it: every block followed by the 0xFF trailer)"""
     from concurrent.futures import ThreadPoolExecutor
@@ -278,9 +278,14 @@ def secondary_qtm(M, torch, dev, n=512, frames=32, window_bits=21, iters=2, cpu=
     for blob in blobs:
         pad = (-len(blob)) % 16
         offs.append(pos); lens.append(len(blob)); parts.append(blob + b"\0" * pad); pos += len(blob) + pad
+    if marks:       # (tools/bench_qtm_config4.py: every folder with a table of marks, as the cabinet driver's folders carry -- MSPACK_HIP_UF_QTM_MARKS)
+        tab = np.sort(np.random.default_rng(1).integers(1, ub, marks)).astype(np.uint32).tobytes()
+        tab_off = pos; parts.append(tab)
     comp = np.frombuffer(b"".join(parts) + b"\0" * 64, dtype=np.uint8).copy()
     off = np.array(offs, dtype=np.uint64); ln = np.array(lens, dtype=np.uint32)
-    units, out_bytes = M.make_units(M.KIND_QUANTUM, off, ln, np.full(n, ub), window_bits=window_bits)
+    units, out_bytes = M.make_units(M.KIND_QUANTUM, off, ln, np.full(n, ub), window_bits=window_bits, out_slack=(16 + 4 * marks) if marks else 0)
+    if marks:
+        units["flags"] |= M.UF_QTM_MARKS; units["in_chunk"] = tab_off // 4; units["ref_len"] = marks
     b = DeviceBatch(M, torch, dev, units, comp, out_bytes, M.KIND_QUANTUM)
     b.step(); torch.cuda.synchronize()
     ms = b.kernel_ms(iters)

@@ -85,6 +85,20 @@ extern "C" {
                                            decompression" (lzxd.c:423-431).  ref_len = capacity N of a log the unit owns in the
                                            output arena at out_off + ((out_len + 32768 + 15) & ~15): uint32 count (all of them,
                                            also beyond N), then N frame indices (counted from the unit's first frame) */
+#define MSPACK_HIP_UF_QTM_MARKS    64u  /* MSPACK_HIP_KIND_QUANTUM: what qtmd holds back at request boundaries.  A qtmd_decompress() call decodes
+                                           whole tokens: the match that covers the last byte asked for usually runs past it, and the
+                                           bytes beyond stay in the window until the NEXT call, which hands them to ITS output before
+                                           it decodes anything (qtmd.c:268-276) -- a next call that then FAILS has still written them.
+                                           The token sequence does not depend on where requests end, so one decode of the whole stream
+                                           can say it for every boundary a caller may use: in_chunk * 4 = byte offset, in the input
+                                           arena, of a uint32 table of ref_len ascending positions p (0 < p < out_len; a cabinet: the
+                                           offsets at which the folder's files begin); the unit owns a log of ref_len uint32 in the
+                                           output arena at out_off + ((out_len + 15) & ~15): entry i = how many bytes beyond p_i were
+                                           decoded when a request ending at p_i returns (0: a token ends exactly there -- or the
+                                           stream failed before p_i was reached); 0xFFFFFFFF: a request ending at p_i FAILS in the
+                                           reference (MSPACK_ERR_DECRUNCH) although the stream decodes beyond it -- p_i lies inside a
+                                           match that crosses the window's end, in front of that end (qtmd.c:358-374).  out_off must
+                                           be a multiple of 4 */
 #define MSPACK_HIP_UF_HARD_EOF      2u  /* the feeder's read FAILED at in_len (sys->read < 0, e.g. a bad
                                            CFDATA block, cabd.c:1322-1324): ERR_READ at once, without the
                                            two fabricated zero bytes of a clean EOF (readbits.h:194-208) */
@@ -103,12 +117,14 @@ typedef struct mspack_hip_unit {
   uint32_t flags;        /* MSPACK_HIP_UF_*                                                        */
   uint32_t ref_len;      /* LZX DELTA: bytes of reference data (lzxd_set_reference_data, lzxd.c:348-382)
                             that the caller placed in the output arena at [out_off - ref_len, out_off);
-                            LZX with MSPACK_HIP_UF_LZX_LOG: capacity of the unit's log */
+                            LZX with MSPACK_HIP_UF_LZX_LOG: capacity of the unit's log;
+                            Quantum with MSPACK_HIP_UF_QTM_MARKS: entries of the unit's table of marks */
   uint32_t in_chunk;     /* MSZIP repair mode: input_buffer_size of mszipd_init (mszipd.c:338-375), i.e.
                             the chunking of the folder stream by the reference's feeder; where the
                             next block is looked for after a failed one depends on it (mszipd.c:404,
                             readbits.h:184-214).  0 = 4096 (the cabd default).
-                            LZX with MSPACK_HIP_UF_FRAME_TABLE: arena offset / 4 of the frame table.  Else ignored */
+                            LZX with MSPACK_HIP_UF_FRAME_TABLE: arena offset / 4 of the frame table.
+                            Quantum with MSPACK_HIP_UF_QTM_MARKS: arena offset / 4 of the table of marks.  Else ignored */
 } mspack_hip_unit;
 
 typedef struct mspack_hip_result {

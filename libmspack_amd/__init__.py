@@ -87,6 +87,8 @@ def frames_of(units):
 
 
 UF_FRAME_TABLE = 8
+UF_QTM_MARKS = 64           # Quantum: what requests ending at marked positions hold back (include/mspack_hip.h)
+QTM_MARK_FAILS = 0xFFFFFFFF
 
 
 def make_units(kind, in_offs, in_lens, out_lens, window_bits=0, reset_frames=0, e8_base=0, flags=0,

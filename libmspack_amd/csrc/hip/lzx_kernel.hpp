@@ -1347,16 +1347,18 @@ static_assert(sizeof(LzxFrameRec) == 1408, "LzxFrameRec layout");
 __device__ unsigned long long g_pipe_wait[1 << 16];
 __device__ unsigned long long g_pipe_phase[16];     /* summed over all waves: s_memrealtime ticks per phase (PH below) */
 /* (accumulated in registers, added to the global sums once per task: an atomic per stamp would serialise the waves) */
-#define PHDECL() u32 pha_[12] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u }
+#define PHDECL() u32 pha_[16] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u }
 #define PH0() unsigned long long ph_ = __builtin_amdgcn_s_memrealtime()
 #define PH(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); pha_[k] += (u32)(n_ - ph_); ph_ = n_; } while (0)
 #define PHE0() unsigned long long phe_ = __builtin_amdgcn_s_memrealtime()
 #define PHE(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); d.st_t[k] += (u32)(n_ - phe_); phe_ = n_; } while (0)
-#define PHFLUSH() do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 12; k_++) if (pha_[k_]) atomicAdd(&g_pipe_phase[k_], (unsigned long long) pha_[k_]); } while (0)
+#define PHFLUSH() do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 16; k_++) if (pha_[k_]) atomicAdd(&g_pipe_phase[k_], (unsigned long long) pha_[k_]); } while (0)
+#define PHCNT(k, n) do { d.st_t[k] += (n); } while (0)       /* (12..15: counts, not times -- steps of the count walks, rounds, steps of the last walk, passes) */
 #else
 #define PHDECL() do { } while (0)
 #define PHE0() do { } while (0)
 #define PHE(k) do { } while (0)
+#define PHCNT(k, n) do { } while (0)
 #define PH0() do { } while (0)
 #define PH(k) do { } while (0)
 #define PHFLUSH() do { } while (0)
@@ -1685,6 +1687,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
 
   while (!stop && B < Eall && P < plimit) {
     PHE0();
+    PHCNT(3, 1u);
     // ---- stage the input from the dword that holds bit B ----
     const u32 sb_byte = (B >> 5) << 2, sb_bit = sb_byte * 8u;
     u32 E = sb_bit + LZX_STAGE_WORDS * 32u; if (E > Eall) E = Eall;
@@ -1754,6 +1757,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
             else ckM1 = (ckM1 & ~(0xFFu << (8u * (k - 5u)))) | (cm << (8u * (k - 5u)));
           }
         }
+        PHCNT(0, 1u);
         LZX_MARK("emit_count_step_begin");
         STAGE_BITS(act ? p : 0u, w0, w1, ALIGNED)
         const EmitTok t = lzx_emit_token<ALIGNED, false>(sh, act, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
@@ -1765,6 +1769,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       }
       if (changed) { n = cnt; nb = cb; nmr = cm; exitp = p; dead = dd; stop_at = sa; }
       round++;
+      PHCNT(1, 1u);
       const u32 pe = (u32) __builtin_amdgcn_ds_bpermute((int)(((lane - 1u) & 63u) << 2), (int) exitp);
       const u32 ne = lane == 0u ? b0 : pe;
       changed = lane < nl && ne != entry;
@@ -1820,6 +1825,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       for (;;) {
         const bool on = i < ntok && pos < plimit && !cross;
         if (!ballot(on)) break;
+        PHCNT(2, 1u);
         LZX_MARK("emit_last_step_begin");
         STAGE_BITS(on ? p : 0u, w0, w1, true)
         const EmitTok t = lzx_emit_token<ALIGNED, true>(sh, on, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
@@ -2295,6 +2301,7 @@ __device__ u32 lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *u
   PH(5);
 #ifdef LZX_PIPE_TRACE
   pha_[6] = d.st_t[6]; pha_[7] = d.st_t[7]; pha_[8] = d.st_t[8];
+  pha_[12] = d.st_t[0]; pha_[13] = d.st_t[1]; pha_[14] = d.st_t[2]; pha_[15] = d.st_t[3];
 #endif
   PHFLUSH();
   return 0u;

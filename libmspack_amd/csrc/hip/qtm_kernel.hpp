@@ -30,7 +30,32 @@
 #define QTM_MARK(name) do { } while (0)
 #endif
 
-struct QtmShared { SpecQueueLds spq; };
+struct QtmShared {
+  SpecQueueLds spq;
+  /* MSPACK_HIP_UF_QTM_MARKS: where the unit is in its table of marks -- in LDS, not in registers: the decode loop carries ONE extra
+   * scalar (the next mark) and the rest is looked at when a mark is passed (qtm_marks_passed) */
+  u32 mark_i, n_marks;
+  const u32 *marks; u32 *mark_log;
+};
+// the marks a token has passed (P: the position behind it): their entries of the log; -> the next mark.  fail_below: marks below
+// this position get 0xFFFFFFFF instead (they lie inside the part of a window-crossing match in front of the window's end)
+__device__ __attribute__((noinline)) u32 qtm_marks_passed(QtmShared *sh, const u32 P, const u32 fail_below, const u32 lane)
+{
+  u32 i = rfl(sh->mark_i);
+  const u32 n = rfl(sh->n_marks);
+  const u32 *const marks = sh->marks;
+  u32 *const log = sh->mark_log;
+  u32 next = 0xFFFFFFFFu;
+  for (;;) {
+    next = i < n ? rfl(gld(marks + i)) : 0xFFFFFFFFu;
+    if (fail_below ? next >= fail_below : P < next) break;
+    if (lane == 0) log[i] = fail_below ? 0xFFFFFFFFu : P - next;
+    i++;
+  }
+  if (lane == 0) sh->mark_i = i;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  return next;
+}
 #ifdef QTM_TIMERS       /* analysis builds: cycles per part of the token loop, block 0's wave (mspack_hip_debug_qtm_timers) */
 __device__ unsigned long long g_qtm_tm[8];
 #define QT0() unsigned long long qt_ = __builtin_amdgcn_s_memtime()
@@ -388,6 +413,10 @@ __device__ __forceinline__ int qtm_token(QtmDec &d, QtmModels &M, u32 &val, u32 
 
 // (forced inline: as a real function its arguments -- and with them the whole coder state -- arrive in VECTOR registers and
 // count as divergent; the chain then runs on the vector unit at twice the latency)
+// MARKS: the instantiation for units that carry marks (MSPACK_HIP_UF_QTM_MARKS) -- a kernel of its own (mspack_decode_qtm_marks):
+// inside the one loop the compare per token cost the folders WITHOUT marks 5.7 % (config 4: 342 -> 362 ms; the coder's chain is one
+// wave's in-order instruction stream, every instruction in the loop is on it)
+template <bool MARKS>
 __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const u8 *in_arena, u8 *out_arena,
                                                 mspack_hip_result *res, QtmShared *sh)
 {
@@ -434,6 +463,21 @@ __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const 
   // store instruction (round 2 stored every literal on its own from lane 0: 12 M store instructions per launch of
   // config 4); they go out before anything reads the output (a resolve, a direct copy)
   u32 lit_buf = 0, lit_pos = 0, lit_n = 0;
+  // MSPACK_HIP_UF_QTM_MARKS (mspack_hip.h): how far the token that covers the byte in front of a marked position runs past it --
+  // what qtmd keeps in its window when a request ends there and hands to the NEXT request's output before it decodes anything
+  // (qtmd.c:268-276).  One scalar compare per token; the positions come out of their table one at a time as they are passed.
+  const u32 n_marks = (MARKS && (u.flags & MSPACK_HIP_UF_QTM_MARKS)) ? u.ref_len : 0u;
+  u32 next_mark = 0xFFFFFFFFu;
+  if (MARKS) {
+    const u32 *const marks = (const u32 *)(in_arena + (size_t) u.in_chunk * 4u);
+    u32 *const mark_log = (u32 *)(out + (((size_t) out_len + 15u) & ~(size_t) 15u));
+    for (u32 i = lane; i < n_marks; i += WAVE) mark_log[i] = 0u;
+    if (lane == 0) { sh->mark_i = 0u; sh->n_marks = n_marks; sh->marks = marks; sh->mark_log = mark_log; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (n_marks) next_mark = rfl(gld(marks));
+  }
+#define QTM_MARKS() do { if (MARKS && P >= next_mark) next_mark = qtm_marks_passed(sh, P, 0u, lane); } while (0)
+#define QTM_MARKS_FAIL(below_) do { if (MARKS && next_mark < (below_)) next_mark = qtm_marks_passed(sh, P, (below_), lane); } while (0)
 #ifdef QTM_NO_OUTPUT     /* analysis builds, never shipped: the arithmetic decoder ALONE -- no literal buffer, no
                             match queue, no copies, nothing written.  What a launch of this build takes is the floor of any split of a
                             folder into a decoding wave and a writing wave (tools/bench_qtm_config4.py; profiles/round6_qtm.txt) */
@@ -488,6 +532,7 @@ __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const 
     bool stop = false;                                                                                \
     while (wpos < frame_end) {                                                                        \
       if (LEAVE_WHEN_NEAR_END_ && !QTM_FAR_FROM_END()) { o_end = wpos; switch_ = true; stop = true; break; } \
+      QTM_MARKS();                                                                                    \
       good = P;                                                                                       \
       u32 moff = 0, mlen = 0;                                                                         \
       const int tk = TOKEN_;                                                                          \
@@ -500,6 +545,8 @@ __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const 
       frame_todo -= mlen;                                                                             \
       if (wpos + mlen > wsize) {                                      /* qtmd.c:358-390 */            \
         u32 i = wsize - o_ptr;                                                                        \
+        /* (marks inside the part of the match in front of the window's end: a request ending there fails, qtmd.c:366-374) */ \
+        QTM_MARKS_FAIL(P + (wsize - wpos));                                                           \
         /* (the copy itself is the same on the linear buffer; only the flush bookkeeping differs) */  \
         if ((long long) i > need) {                                                                   \
           /* first part was already copied by the reference before it bails out */                    \
@@ -549,6 +596,10 @@ __device__ __forceinline__ void qtm_decode_unit(const mspack_hip_unit &u, const 
   }
 #undef QTM_DECODE_LOOP
 #undef QTM_FAR_FROM_END
+  if (err == ERR_OK) QTM_MARKS();      // (the marks the last tokens passed -- unless what follows those tokens failed: a request that
+                                       // ends inside them then fails too: the frame's end, its trailer, qtmd.c:424-441)
+#undef QTM_MARKS
+#undef QTM_MARKS_FAIL
   QTM_FLUSH();
   // whatever is still queued lies below the highest position any token reached
   {

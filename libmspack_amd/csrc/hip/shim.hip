@@ -494,7 +494,21 @@ void mspack_decode_qtm(const mspack_hip_unit *units, const u32 *order, u32 n_uni
   u32 ui;
   if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_QUANTUM, ui)) return;
   const mspack_hip_unit u = units[ui];
-  qtm_decode_unit(u, in_arena, out_arena, &results[ui], &sh);
+  if ((u.flags & MSPACK_HIP_UF_QTM_MARKS) && u.ref_len) return;          // (mspack_decode_qtm_marks' unit)
+  qtm_decode_unit<false>(u, in_arena, out_arena, &results[ui], &sh);
+}
+// the same for the units that carry marks (MSPACK_HIP_UF_QTM_MARKS: what requests ending at the marked positions hold back) -- the
+// cabinet driver's Quantum folders; launched behind mspack_decode_qtm over the same list, each kernel leaves the other's units alone
+__global__ __launch_bounds__(64)
+void mspack_decode_qtm_marks(const mspack_hip_unit *units, const u32 *order, u32 n_units,
+                             const u8 *in_arena, u8 *out_arena, mspack_hip_result *results)
+{
+  __shared__ QtmShared sh;
+  u32 ui;
+  if (!pick_unit(units, order, n_units, MSPACK_HIP_KIND_QUANTUM, ui)) return;
+  const mspack_hip_unit u = units[ui];
+  if (!((u.flags & MSPACK_HIP_UF_QTM_MARKS) && u.ref_len)) return;
+  qtm_decode_unit<true>(u, in_arena, out_arena, &results[ui], &sh);
 }
 
 __global__ __launch_bounds__(64)
@@ -708,7 +722,8 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
               frames ? L.recs : (lzxn::LzxFrameRec *) nullptr, pool));
     break; }
   case MSPACK_HIP_KIND_QUANTUM:
-    LK(launch(mspack_decode_qtm, grid, block, st, d_units, d_order, (u32) n, in, out, d_results)); break;
+    LK(launch(mspack_decode_qtm, grid, block, st, d_units, d_order, (u32) n, in, out, d_results));
+    LK(launch(mspack_decode_qtm_marks, grid, block, st, d_units, d_order, (u32) n, in, out, d_results)); break;
   case MSPACK_HIP_KIND_LZSS:
     LK(launch(mspack_decode_lzss, grid, block, st, d_units, d_order, (u32) n, in, out, d_results)); break;
   case MSPACK_HIP_KIND_KWAJ_LZH:
@@ -876,6 +891,8 @@ static inline uint64_t unit_below(const mspack_hip_unit &u) {
 static inline uint64_t unit_above(const mspack_hip_unit &u) {
   if (u.kind == MSPACK_HIP_KIND_LZX && (u.flags & MSPACK_HIP_UF_LZX_LOG))                   // the reset log, where MSZIP's would be
     return ((((uint64_t) u.out_len + 32768u + 15u) & ~15ull) - u.out_len) + 4u + 4u * (uint64_t) u.ref_len;
+  if (u.kind == MSPACK_HIP_KIND_QUANTUM && (u.flags & MSPACK_HIP_UF_QTM_MARKS) && u.ref_len)   // the log of its marks
+    return ((((uint64_t) u.out_len + 15u) & ~15ull) - u.out_len) + 4u * (uint64_t) u.ref_len;
   if (u.kind != MSPACK_HIP_KIND_MSZIP) return 0u;
   uint64_t a = 32768u;
   if ((u.flags & MSPACK_HIP_UF_MSZIP_REPAIR) && (u.flags & MSPACK_HIP_UF_MSZIP_LOG))      // the repair log behind the slack
@@ -888,6 +905,14 @@ static inline bool unit_has_ftab(const mspack_hip_unit &u) {
   return u.kind == MSPACK_HIP_KIND_MSZIP && !(u.flags & (MSPACK_HIP_UF_MSZIP_REPAIR | MSPACK_HIP_UF_MSZIP_KWAJ));
 }
 static inline uint64_t unit_ftab_bytes(const mspack_hip_unit &u) { return (((uint64_t) u.out_len + 32767u) / 32768u) * 4u; }
+// a table the unit reads out of the input arena besides its stream (in_chunk * 4: a frame / block table, a Quantum unit's marks)
+static inline bool unit_side_table(const mspack_hip_unit &u, uint64_t &lo, uint64_t &hi) {
+  if (unit_has_ftab(u)) { lo = (uint64_t) u.in_chunk * 4u; hi = lo + unit_ftab_bytes(u); return true; }
+  if (u.kind == MSPACK_HIP_KIND_QUANTUM && (u.flags & MSPACK_HIP_UF_QTM_MARKS) && u.ref_len) {
+    lo = (uint64_t) u.in_chunk * 4u; hi = lo + 4u * (uint64_t) u.ref_len; return true;
+  }
+  return false;
+}
 static inline size_t unit_frames(const mspack_hip_unit &u) {
   if (u.kind == MSPACK_HIP_KIND_LZX || u.kind == MSPACK_HIP_KIND_LZX_DELTA) return (size_t) u.out_len / 32768u + 1u;
   if (u.kind == MSPACK_HIP_KIND_MSZIP && unit_has_ftab(u)) return ((size_t) u.out_len + 32767u) / 32768u;   // one per CFDATA block
@@ -972,7 +997,8 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
   for (size_t i = 0; i < n_sel; i++) {
     mspack_hip_unit &u = local[i];
     u = units[idx[i]];
-    if (u.kind != MSPACK_HIP_KIND_LZX_DELTA && !(u.kind == MSPACK_HIP_KIND_LZX && (u.flags & MSPACK_HIP_UF_LZX_LOG))) u.ref_len = 0;
+    if (u.kind != MSPACK_HIP_KIND_LZX_DELTA && !(u.kind == MSPACK_HIP_KIND_LZX && (u.flags & MSPACK_HIP_UF_LZX_LOG)) &&
+        !(u.kind == MSPACK_HIP_KIND_QUANTUM && (u.flags & MSPACK_HIP_UF_QTM_MARKS))) u.ref_len = 0;
     if (u.kind > MSPACK_HIP_KIND_XORSUM) { snprintf(errbuf, errcap, "unit %u: unknown kind %u", idx[i], u.kind); return -1; }
     if (u.kind == MSPACK_HIP_KIND_XORSUM) {                // reads its input, owns no output
       if (u.out_len) { snprintf(errbuf, errcap, "unit %u: a checksum unit has no output", idx[i]); return -1; }
@@ -988,10 +1014,12 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     if (i && lo < prev_hi) monotone = false;
     prev_hi = hi;
     in_lo = std::min<uint64_t>(in_lo, u.in_off); in_hi = std::max<uint64_t>(in_hi, u.in_off + u.in_len);
-    if (unit_has_ftab(u)) {
-      const uint64_t tl = (uint64_t) u.in_chunk * 4u, th = tl + unit_ftab_bytes(u);
-      if (th > in_bytes) { snprintf(errbuf, errcap, "unit's frame table outside arena"); return -1; }
-      in_lo = std::min(in_lo, tl); in_hi = std::max(in_hi, th);
+    {
+      uint64_t tl, th;
+      if (unit_side_table(u, tl, th)) {
+        if (th > in_bytes) { snprintf(errbuf, errcap, "unit's table outside arena"); return -1; }
+        in_lo = std::min(in_lo, tl); in_hi = std::max(in_hi, th);
+      }
     }
     out_lo = std::min(out_lo, lo); out_hi = std::max(out_hi, hi);
     in_sum += u.in_len;
@@ -1081,10 +1109,9 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       for (size_t i = c.a; i < c.b; i++) {
         const mspack_hip_unit &u = local[i];
         c.in_lo = std::min<uint64_t>(c.in_lo, u.in_off); c.in_hi = std::max<uint64_t>(c.in_hi, u.in_off + u.in_len);
+        { uint64_t tl, th; if (unit_side_table(u, tl, th)) { c.in_lo = std::min(c.in_lo, tl); c.in_hi = std::max(c.in_hi, th); } }
         if (unit_has_ftab(u)) {
           c.has_ftab = true;
-          c.in_lo = std::min<uint64_t>(c.in_lo, (uint64_t) u.in_chunk * 4u);
-          c.in_hi = std::max<uint64_t>(c.in_hi, (uint64_t) u.in_chunk * 4u + unit_ftab_bytes(u));
           c.fm_lo = std::min<size_t>(c.fm_lo, u.frame_base);          // (the chunk's table units' slots are contiguous)
           c.fm_n += unit_frames(u);
         }
@@ -1105,7 +1132,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       }
     }
     for (size_t i = 0; i < n_sel; i++) {
-      if (unit_has_ftab(local[i])) local[i].in_chunk -= (uint32_t)(in_lo >> 2);      // in_lo is a multiple of 16
+      { uint64_t tl, th; if (unit_side_table(local[i], tl, th)) local[i].in_chunk -= (uint32_t)(in_lo >> 2); }      // in_lo is a multiple of 16
       local[i].in_off -= in_lo;
       if (local[i].kind != MSPACK_HIP_KIND_XORSUM) local[i].out_off -= out_lo;
     }
@@ -1285,7 +1312,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
         TRY(copy_out((uintptr_t) host_out + c.out_lo, (uintptr_t) host_out + c.out_hi, d_out + (c.out_lo - out_lo)));
       else
         for (size_t i = c.a; i < c.b; i++) {
-          const size_t nb = (size_t) local[i].out_len + ((local[i].flags & (MSPACK_HIP_UF_MSZIP_LOG | MSPACK_HIP_UF_LZX_LOG)) ? (size_t) unit_above(local[i]) : 0u);   // (a unit's log lies behind its slack)
+          const size_t nb = (size_t) local[i].out_len + ((local[i].flags & (MSPACK_HIP_UF_MSZIP_LOG | MSPACK_HIP_UF_LZX_LOG | MSPACK_HIP_UF_QTM_MARKS)) ? (size_t) unit_above(local[i]) : 0u);   // (a unit's log lies behind its slack)
           const uintptr_t lo = (uintptr_t) host_out + out_lo + local[i].out_off;
           TRY(copy_out(lo, lo + nb, d_out + local[i].out_off));
         }

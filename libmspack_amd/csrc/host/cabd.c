@@ -65,6 +65,12 @@ struct folder_p {
    * the block whose decoding pulls the input chunk (MSCABD_PARAM_DECOMPBUF bytes) that block i starts in */
   unsigned int ck_n;
   unsigned int *rep_ck;
+  /* Quantum: the request boundaries the folder's files imply (their first bytes and the bytes behind their last), ascending, and
+   * what qtmd holds back at each -- the rest of the match that covers the request's last byte, which the NEXT call writes before it
+   * decodes anything (qtmd.c:268-276) -- as the batch reported it (MSPACK_HIP_UF_QTM_MARKS; mark_log lies inside `store`) */
+  unsigned int n_marks;
+  unsigned int *marks;
+  const unsigned char *mark_log;
 };
 struct cab_p {
   struct mscabd_cabinet base;
@@ -163,6 +169,7 @@ static void free_folder_cache(struct mspack_system *sys, struct folder_p *f) {
   f->store = NULL; f->dec = NULL; f->decoded = 0;
   sys->free(f->rep); f->rep = NULL; f->rep_n = 0;
   sys->free(f->rep_ck); f->rep_ck = NULL; f->ck_n = 0;
+  sys->free(f->marks); f->marks = NULL; f->n_marks = 0; f->mark_log = NULL;
 }
 
 /* ---- headers (reference cabd.c:317-628) ------------------------------------------------------------- */
@@ -743,7 +750,37 @@ struct gathered {
   uint32_t *boff; unsigned int nblk;            /* where every block's payload starts in the stream; frames_ok: every
                                                    block but the last holds exactly one 32 KiB frame  */
   int frames_ok;
+  size_t marks_off; unsigned int n_marks;       /* Quantum: the folder's request boundaries as a table in the arena (gather_marks) */
+  unsigned int *marks;
 };
+
+/* The request boundaries a Quantum folder's files imply -- cabd_extract asks its codec for the bytes in front of a file, then for
+ * the file (cabd.c:1195-1218): requests end where files begin and where they end.  Ascending, without duplicates, inside
+ * (0, total): appended to the arena as a uint32 table for MSPACK_HIP_UF_QTM_MARKS (mspack_hip.h).  Without memory for it the
+ * folder decodes without marks (what a failing call leaves of its predecessor's last match is then not known: nothing). */
+static int cmp_u32(const void *a, const void *b) { const unsigned int x = *(const unsigned int *) a, y = *(const unsigned int *) b; return x < y ? -1 : x > y; }
+static void gather_marks(struct mspack_system *sys, struct cab_p *cab, struct gathered *g, struct in_arena *A)
+{
+  struct mscabd_file *f;
+  size_t nf = 0, m = 0, i;
+  unsigned int *v;
+  g->n_marks = 0; g->marks = NULL; g->marks_off = 0;
+  for (f = cab->base.files; f; f = f->next) if ((struct folder_p *) f->folder == g->fol) nf++;
+  if (!nf || !(v = (unsigned int *) sys->alloc(sys, 2 * nf * sizeof(unsigned int)))) return;
+  for (f = cab->base.files; f; f = f->next) {
+    if ((struct folder_p *) f->folder != g->fol) continue;
+    if (f->offset > 0 && f->offset < g->total) v[m++] = f->offset;
+    if (f->length < g->total && f->offset < g->total - f->length && f->offset + f->length > 0) v[m++] = f->offset + f->length;
+  }
+  qsort(v, m, sizeof(unsigned int), cmp_u32);
+  for (i = 0, nf = 0; i < m; i++) if (!nf || v[i] != v[nf - 1]) v[nf++] = v[i];
+  m = nf;
+  if (!m || !arena_room(sys, A, 4 * m + 8)) { sys->free(v); return; }
+  A->len = (A->len + 3) & ~(size_t) 3;
+  memcpy(A->p + A->len, v, 4 * m);
+  g->marks_off = A->len; g->n_marks = (unsigned int) m; g->marks = v;
+  A->len += 4 * m;
+}
 
 /* walk the CFDATA chain of one folder (reference cabd.c:1283-1345 + 1362-1459), following it through
  * the cabinets of a set.  Returns MSPACK_ERR_OPEN / SEEK / NOMEMORY when nothing could be started (the arena is as it
@@ -919,6 +956,8 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     }
     if (err == MSPACK_ERR_OPEN && fp != want) { err = MSPACK_ERR_OK; continue; }   /* that folder stays undecoded */
     if (err) break;
+    gs[n].n_marks = 0; gs[n].marks = NULL; gs[n].marks_off = 0;
+    if ((fo->comp_type & 0x0F) == MSCAB_COMP_QUANTUM) gather_marks(sys, cab, &gs[n], &A);
     used += est;
     n++;
   }
@@ -930,7 +969,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     res = (mspack_hip_result *) sys->alloc(sys, (nu ? nu : 1) * sizeof(*res));
     if (!units || !res) err = MSPACK_ERR_NOMEMORY;
   }
-  if (err) { for (k = 0; k < n; k++) sys->free(gs[k].boff); sys->free(gs); sys->free(units); sys->free(res); sys->free(ck.p); mspack_arena_free(sys, A.p); return err; }
+  if (err) { for (k = 0; k < n; k++) { sys->free(gs[k].boff); sys->free(gs[k].marks); } sys->free(gs); sys->free(units); sys->free(res); sys->free(ck.p); mspack_arena_free(sys, A.p); return err; }
   memset(A.p + A.len, 0, 64);
 
   /* the units: where gather_folder put their input, one stretch of the output arena each */
@@ -957,6 +996,11 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
                      ((self->fix_mszip && method == MSCAB_COMP_MSZIP) ? (MSPACK_HIP_UF_MSZIP_REPAIR | MSPACK_HIP_UF_MSZIP_LOG) : 0) |
                      (gs[k].frames_ok ? MSPACK_HIP_UF_FRAME_TABLE : 0);
     if (!gs[k].frames_ok) units[k].in_chunk = (uint32_t)((self->buf_size + 1) & ~1);    /* mszipd.c:348 */
+    if (method == MSCAB_COMP_QUANTUM && gs[k].n_marks) {        /* the folder's request boundaries; their log behind the output */
+      units[k].flags |= MSPACK_HIP_UF_QTM_MARKS;
+      units[k].in_chunk = (uint32_t)(gs[k].marks_off / 4); units[k].ref_len = gs[k].n_marks;
+      if (4 * (size_t) gs[k].n_marks + 16 > 32768) out_bytes += (4 * (size_t) gs[k].n_marks + 15) & ~(size_t) 15;
+    }
   }
   out_arena = (unsigned char *) mspack_arena_alloc(sys, out_bytes + 64);
   if (!out_arena) err = MSPACK_ERR_NOMEMORY;
@@ -1010,6 +1054,11 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
            * slack holds those bytes, in_next says how many: DESIGN.md section 8g) */
           fp->total += res[k].in_next; fp->good_len = fp->total; fp->written = fp->total;
         }
+        sys->free(fp->marks); fp->marks = NULL; fp->n_marks = 0; fp->mark_log = NULL;
+        if (units[k].flags & MSPACK_HIP_UF_QTM_MARKS) {
+          fp->marks = gs[k].marks; fp->n_marks = gs[k].n_marks; gs[k].marks = NULL;
+          fp->mark_log = out_arena + units[k].out_off + (((size_t) gs[k].total + 15) & ~(size_t) 15);
+        }
         if (units[k].flags & MSPACK_HIP_UF_MSZIP_LOG) {
           const unsigned char *lg = out_arena + units[k].out_off + (((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15);
           unsigned int cnt = rd_le32(lg), i;
@@ -1028,11 +1077,22 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     if (store && store->refs) out_arena = NULL;            /* the folders own it now */
     else if (store) sys->free(store);
   }
-  for (k = 0; k < n; k++) sys->free(gs[k].boff);
+  for (k = 0; k < n; k++) { sys->free(gs[k].boff); sys->free(gs[k].marks); }
   sys->free(gs); sys->free(units); sys->free(res); sys->free(ck.p); mspack_arena_free(sys, A.p); mspack_arena_free(sys, out_arena);
   /* (the folders flagged above defer nothing the second time: one more round at most) */
   if (!err && again) return decode_cabinet(self, cab, want);
   return err;
+}
+
+/* Quantum: what the codec holds back when a request ends at `pos` -- the batch's answer for the folder's marks (0: nothing, or not
+ * known); QTM_MARK_FAILS: a request that ends there fails although the stream decodes beyond it (mspack_hip.h) */
+#define QTM_MARK_FAILS 0xFFFFFFFFu
+static unsigned int qtm_mark(const struct folder_p *fp, unsigned int pos)
+{
+  unsigned int lo = 0, hi = fp->n_marks;
+  if (!fp->marks || !fp->mark_log) return 0;
+  while (lo < hi) { const unsigned int mid = lo + (hi - lo) / 2; if (fp->marks[mid] < pos) lo = mid + 1; else hi = mid; }
+  return (lo < fp->n_marks && fp->marks[lo] == pos) ? rd_le32(fp->mark_log + 4 * (size_t) lo) : 0;
 }
 
 /* can the reference produce bytes [0, end) of this folder, and with which error if not? */
@@ -1055,7 +1115,12 @@ static int folder_status(struct folder_p *fp, unsigned int end, int read_error, 
     else if (fp->good_len >= fp->total) ok = (need_f < nframes);          /* only the look-ahead failed */
     else ok = (need_f < fp->n_frames_good);
   }
-  else ok = (end <= fp->good_len);
+  else {
+    ok = (end <= fp->good_len);
+    /* (a request that ends inside a match which crosses the window's end, in front of that end: qtmd cannot serve it, qtmd.c:366-374
+     * -- windows below the frame size, or damage) */
+    if (ok && method == MSCAB_COMP_QUANTUM && qtm_mark(fp, end) == QTM_MARK_FAILS) return MSPACK_ERR_DECRUNCH;
+  }
   if (ok) { *failed = 0; return MSPACK_ERR_OK; }
   if (fp->dec_err == MSPACK_ERR_OK) return read_error;
   return (fp->dec_err == MSPACK_ERR_READ) ? read_error : fp->dec_err;
@@ -1074,6 +1139,7 @@ static unsigned int flushed_at_failure(struct folder_p *fp, unsigned int end)
     /* (a stream that fails does so at the same symbol whatever the request: what the codec wrote for the whole folder -- its
      * window can wrap right in front of a failing frame trailer, one byte beyond good_len) */
     f = fp->dec_err != MSPACK_ERR_OK ? fp->written : reached / w * w;
+    if (end <= fp->good_len && qtm_mark(fp, end) == QTM_MARK_FAILS) f = end / w * w;   /* (that request's own failure: the windows below it) */
   }
   else if (method == MSCAB_COMP_LZX && fp->dec_err != MSPACK_ERR_OK && fp->good_len < fp->total) f = fp->n_frames_good * CAB_BLOCKMAX;
   else f = (reached == fp->total) ? fp->total : reached / CAB_BLOCKMAX * CAB_BLOCKMAX;
@@ -1171,7 +1237,7 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
     /* skip phase: getting to file->offset must itself be error free (cabd.c:1195-1199) */
     int failed = 0;
     int err = file->offset ? folder_status(fol, file->offset, self->read_error, &failed) : MSPACK_ERR_OK;
-    unsigned int end = file->offset;
+    unsigned int end = file->offset, wrote_to = 0;
     if (!err) {
       /* (a skip that failed with a code that reads OK -- salvage mode, out of blocks -- is followed by the emit call, which meets
        * the codec's sticky error: the same code again, nothing written) */
@@ -1187,9 +1253,15 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
           const unsigned int w = 1u << ((fol->base.comp_type >> 8) & 0x1F);
           /* (a folder that decodes cleanly but is asked for more than it holds fails at the end of its input: the last window's
            * bytes were never flushed) */
-          const unsigned int wr = fol->dec_err == MSPACK_ERR_OK ? fol->total / w * w : fol->written;
+          unsigned int wr = fol->dec_err == MSPACK_ERR_OK ? fol->total / w * w : fol->written;
+          /* before it decodes anything the call hands over what its predecessor -- the skip to this file -- held back: the rest
+           * of the match that covers the byte in front of the file (qtmd.c:268-276) */
+          unsigned int carry = qtm_mark(fol, file->offset);
+          if (end <= fol->good_len && qtm_mark(fol, end) == QTM_MARK_FAILS) wr = end / w * w;
           have = wr > file->offset ? wr - file->offset : 0;
+          if (carry != QTM_MARK_FAILS && have < carry) have = carry;
           if (have > filelen) have = filelen;
+          wrote_to = file->offset + have;
         }
         if (write_slice(sys, fh, fol->dec + file->offset, have) != MSPACK_ERR_OK) err = MSPACK_ERR_WRITE;
       }
@@ -1199,6 +1271,7 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
       const unsigned int fl = flushed_at_failure(fol, end);
       self->live_failed = 1; self->live_err = err;
       if (fl > self->live_offset) self->live_offset = fl;
+      if (wrote_to > self->live_offset) self->live_offset = wrote_to;
     }
     else self->live_offset = file->offset + filelen;
   }

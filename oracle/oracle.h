@@ -44,7 +44,9 @@ typedef struct oracle_result {
   uint64_t in_used;   /* the reference's i_ptr position (bytes pulled into the bit buffer)      */
   uint64_t in_next;   /* LZX: input byte position right after the 16-bit realignment that follows the
                          last completely decoded non-empty frame (lzxd.c:695-697) = where the next frame's
-                         bits start; 0 if no frame was completed                                        */
+                         bits start; 0 if no frame was completed.
+                         Quantum (err 0): bytes decoded beyond the request -- what qtmd keeps in its window (o_end - o_ptr)
+                         and hands to the NEXT call's output before it decodes anything (qtmd.c:268-276)          */
 } oracle_result;
 
 /* LZX: equivalent to lzxd_init(window_bits, reset_frames, bufsize, length, is_delta=0) followed
@@ -60,6 +62,8 @@ int oracle_lzx_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
  * instead of reporting the end of the input: MSPACK_ERR_READ at once, without the two zero bytes read_input fabricates at a clean end
  * (readbits.h:192-208).  What MSPACK_HIP_UF_HARD_EOF tells the kernels.  0 switches it off again. */
 void oracle_set_hard_eof(int on);
+/* for the next oracle_qtm_decode() of the calling thread: see qtm_oracle.c */
+void oracle_qtm_set_marks(const uint32_t *marks, uint32_t n, uint32_t *log);
 /* the reset points (frame indices) at which the last oracle_lzx_decode / oracle_lzxd_decode of THIS thread found a block still
  * open -- lzxd.c:423-431, where the reference warns through sys->message.  Returns how many there were (also beyond cap). */
 uint32_t oracle_lzx_open_resets(uint32_t *frames, uint32_t cap);

@@ -136,15 +136,31 @@ static int get_symbol(qtm_t *q, model_t *m, int *out) {
   return 0;
 }
 
+/* oracle_qtm_set_marks(): for the NEXT oracle_qtm_decode() of this thread -- positions (ascending) at which later requests of the
+ * same stream may end; log[i] = how far the token that covers the byte in front of marks[i] runs past it, i.e. what a request
+ * ending there leaves in the window for the next call (qtmd.c:268-276; the token sequence does not depend on where requests end).
+ * 0 where a token ends exactly there, and for marks the decoding never reached; 0xFFFFFFFF where a request ending there FAILS in
+ * the reference: the mark lies inside a match that crosses the window's end, in front of that end (qtmd.c:358-374: "can't flush
+ * up to the end of the window, but can't break out either" -> MSPACK_ERR_DECRUNCH).  The ground truth of MSPACK_HIP_UF_QTM_MARKS. */
+static __thread const uint32_t *qtm_marks_;
+static __thread uint32_t qtm_n_marks_;
+static __thread uint32_t *qtm_mark_log_;
+void oracle_qtm_set_marks(const uint32_t *marks, uint32_t n, uint32_t *log) { qtm_marks_ = marks; qtm_n_marks_ = n; qtm_mark_log_ = log; }
+
 int oracle_qtm_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap,
                       uint64_t out_bytes, int window_bits, oracle_result *res)
 {
+  const uint32_t *marks = qtm_marks_; uint32_t n_marks = qtm_n_marks_, *mark_log = qtm_mark_log_, mk = 0;
+  uint64_t lin = 0;                                /* bytes decoded so far (the linear position of wpos) */
   qtm_t *q;
   uint64_t written = 0;
   int64_t need = (int64_t) out_bytes;
   uint32_t o_ptr = 0, o_end = 0;
   int err = ORC_OK, wb2;
 
+  qtm_marks_ = NULL; qtm_n_marks_ = 0; qtm_mark_log_ = NULL;
+  { uint32_t i; for (i = 0; i < n_marks; i++) mark_log[i] = 0; }
+#define MARKS() do { while (mk < n_marks && lin >= marks[mk]) { mark_log[mk] = (uint32_t)(lin - marks[mk]); mk++; } } while (0)
   memset(res, 0, sizeof(*res));
   if (window_bits < 10 || window_bits > 21) { res->err = ORC_ARGS; return ORC_ARGS; }
   init_tables();
@@ -182,11 +198,15 @@ int oracle_qtm_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
     while (q->wpos < frame_end) {
       int sel, sym;
       uint32_t moff; int mlen;
+      /* (the marks the tokens so far have passed: said once the checks behind a token -- the frame's end, its trailer -- are
+       * through too; a request that ends inside a token which fails those fails with it) */
+      MARKS();
       if (get_symbol(q, &q->m7, &sel)) goto rderr;
       if (sel < 4) {
         model_t *m = sel == 0 ? &q->m0 : sel == 1 ? &q->m1 : sel == 2 ? &q->m2 : &q->m3;
         if (get_symbol(q, m, &sym)) goto rderr;
         q->win[q->wpos++] = (uint8_t) sym; q->frame_todo--;
+        lin++;
         continue;
       }
       if (sel == 4) {
@@ -210,12 +230,16 @@ int oracle_qtm_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
         uint32_t i = q->wsize - q->wpos, d = q->wpos;
         int32_t j = (int32_t) q->wpos - (int32_t) moff;
         while (i--) q->win[d++] = q->win[(uint32_t)(j++) & (q->wsize - 1)];
+        /* (marks inside the part of the match in front of the window's end: a request that ends there cannot be served -- the
+         * reference gives up below whenever it is asked for less than the window still holds, qtmd.c:366-374) */
+        while (mk < n_marks && marks[mk] < lin + (q->wsize - q->wpos)) mark_log[mk++] = 0xFFFFFFFFu;
         i = q->wsize - o_ptr;
         if ((int64_t) i > need) { err = ORC_DECRUNCH; goto done; }
         EMIT(o_ptr, i); need -= i; o_ptr = o_end = 0;
         d = 0; i = (uint32_t) mlen - (q->wsize - q->wpos);
         while (i--) q->win[d++] = q->win[(uint32_t)(j++) & (q->wsize - 1)];
         q->wpos = q->wpos + (uint32_t) mlen - q->wsize;
+        lin += (uint32_t) mlen;
         break;
       }
       else {
@@ -229,6 +253,7 @@ int oracle_qtm_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
         }
         else { s = d - moff; while (i-- > 0) q->win[d++] = q->win[s++]; }
         q->wpos += (uint32_t) mlen;
+        lin += (uint32_t) mlen;
       }
     }
     o_end = q->wpos;
@@ -244,7 +269,11 @@ int oracle_qtm_decode(const uint8_t *in, size_t in_len, uint8_t *out, size_t out
       EMIT(o_ptr, i); need -= i; o_ptr = o_end = 0; q->wpos = 0;
     }
   }
-  if (need) { EMIT(o_ptr, (uint32_t) need); }
+  if (need) { EMIT(o_ptr, (uint32_t) need); o_ptr += (uint32_t) need; }
+  /* what the call decoded beyond the request -- the rest of the match that covers its last byte -- stays in the window and is
+   * the first thing the NEXT call hands to its output (qtmd.c:268-276: o_end - o_ptr) */
+  res->in_next = o_end - o_ptr;
+  MARKS();
   goto done;
 rderr:
   err = ORC_READ;

@@ -237,6 +237,22 @@ int refh_qtm(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap, lon
   return err;
 }
 
+/* what the real qtmd holds back when a request of `out_bytes` returns: o_end - o_ptr (qtmd.c:268-276 hands it to the next call's
+ * output first) -- read from the stream's own state after ONE qtmd_decompress(out_bytes) */
+int refh_qtm_carry(const uint8_t *in, size_t in_len, long long out_bytes, int window_bits, long long *carry)
+{
+  struct memname src = { MEMNAME_MAGIC, (uint8_t *) in, in_len, 0 };
+  struct memname dst = { MEMNAME_MAGIC, NULL, 0, 0 };
+  struct mspack_file *fi = m_open(&mem_system, (const char *) &src, MSPACK_SYS_OPEN_READ);
+  struct mspack_file *fo = m_open(&mem_system, (const char *) &dst, MSPACK_SYS_OPEN_WRITE);
+  struct qtmd_stream *qtm = qtmd_init(&mem_system, fi, fo, window_bits, 4096);
+  int err = MSPACK_ERR_ARGS;
+  *carry = -1;
+  if (qtm) { err = qtmd_decompress(qtm, (off_t) out_bytes); *carry = (long long)(qtm->o_end - qtm->o_ptr); qtmd_free(qtm); }
+  m_close(fi); m_close(fo);
+  return err;
+}
+
 /* ---- container-level: CAB / CHM held in memory --------------------------------------------- */
 /* Enumerate files: fills arrays (up to cap) and returns the number of files, or -err. */
 int refh_cab_list(const uint8_t *cab, size_t cab_len, int cap,

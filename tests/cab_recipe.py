@@ -48,3 +48,17 @@ def file_entry_offsets(cab):
             pos += 1
         pos += 1
     return out
+
+
+def qtm_cab(seed, wb, cuts, n, kind=0):
+    """ONE Quantum folder (window 2^wb) of n bytes, its files cut at `cuts` (ascending positions inside (0, n)): the cabinets of
+    tests/golden/cab_qtm_carry.json -- requests then end at chosen places of the token stream (qtmd.c:268-276, 358-374)"""
+    data = M.gen_plaintext(seed, kind, n)
+    qs, fs = M.qtm_encode(data, wb)
+    pos, qb = 0, []
+    for s in fs:
+        qb.append(bytes(qs[pos:pos + int(s)])); pos += int(s) + 1
+    mu = [min(32768, n - k) for k in range(0, n, 32768)]
+    edges = [0] + list(cuts) + [n]
+    files = [(b"f%02d.bin" % i, edges[i + 1] - edges[i], edges[i], 0) for i in range(len(edges) - 1)]
+    return bytearray(M.cab_write([(2 | (wb << 8), qb, mu)], files)), data

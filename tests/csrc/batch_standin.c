@@ -7,7 +7,8 @@
  * It provides the batch ABI of include/mspack_hip.h (host-buffer entry points only) on top of the CPU
  * oracle (oracle/liboracle.so): one oracle call per unit.  Supported: LZX units (CAB folders, CHM reset
  * intervals, E8 origin, the reset log of MSPACK_HIP_UF_LZX_LOG), MSZIP and Quantum folder units, frame tables
- * (ignored: the oracle is serial), the feeder's failed read (MSPACK_HIP_UF_HARD_EOF) and Quantum's good_len, LZX DELTA units (OAB
+ * (ignored: the oracle is serial), the feeder's failed read (MSPACK_HIP_UF_HARD_EOF), Quantum's good_len and marks
+ * (MSPACK_HIP_UF_QTM_MARKS), LZX DELTA units (OAB
  * blocks with their reference data), LZSS and KWAJ LZH units, checksum units;
  * NOT MSZIP repair mode or KWAJ-framed MSZIP -- that makes the call fail, and the tests that need it run on the GPU.  The `-m gpu` parity tests never
  * see this file: they load the real library. */
@@ -46,7 +47,8 @@ int mspack_standin_decode_units(const mspack_hip_unit *units, const uint32_t *or
       snprintf(g_err, sizeof(g_err), "unit outside arena"); return -1;
     }
     /* the frame table is a hint for the GPU's frame-parallel parse; results do not depend on it */
-    if (u->flags & ~(MSPACK_HIP_UF_FRAME_TABLE | MSPACK_HIP_UF_HARD_EOF | (u->kind == MSPACK_HIP_KIND_LZX ? MSPACK_HIP_UF_LZX_LOG : 0u))) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
+    if (u->flags & ~(MSPACK_HIP_UF_FRAME_TABLE | MSPACK_HIP_UF_HARD_EOF | (u->kind == MSPACK_HIP_KIND_LZX ? MSPACK_HIP_UF_LZX_LOG : 0u) |
+                     (u->kind == MSPACK_HIP_KIND_QUANTUM ? MSPACK_HIP_UF_QTM_MARKS : 0u))) { snprintf(g_err, sizeof(g_err), "stand-in: unit flags 0x%x unsupported", u->flags); return -1; }
     if (u->kind == 0) { r->err = 1; continue; }
     if (u->kind == MSPACK_HIP_KIND_XORSUM) {                     /* a CFDATA block's checksum (cabd.c:1462-1479) */
       if (u->out_len) { snprintf(g_err, sizeof(g_err), "a checksum unit has no output"); return -1; }
@@ -74,6 +76,13 @@ int mspack_standin_decode_units(const mspack_hip_unit *units, const uint32_t *or
       oracle_mszip_decode(src, u->in_len, dst, (size_t) u->out_len + 32768, u->out_len, 0, NULL, 0, NULL, &o);
       break;
     case MSPACK_HIP_KIND_QUANTUM:
+      if ((u->flags & MSPACK_HIP_UF_QTM_MARKS) && u->ref_len) {  /* the unit's marks and their log (mspack_hip.h) */
+        const size_t lo = ((size_t) u->out_len + 15) & ~(size_t) 15;
+        if ((size_t) u->in_chunk * 4 + 4 * (size_t) u->ref_len > in_bytes || u->out_off + lo + 4 * (size_t) u->ref_len > out_bytes || (u->out_off & 3)) {
+          snprintf(g_err, sizeof(g_err), "unit's marks or their log outside arena"); return -1;
+        }
+        oracle_qtm_set_marks((const uint32_t *)((const uint8_t *) in + (size_t) u->in_chunk * 4), u->ref_len, (uint32_t *)(dst + lo));
+      }
       oracle_qtm_decode(src, u->in_len, dst, u->out_len, u->out_len, u->window_bits, &o);
       if (o.err != 0 && u->out_len) {
         /* good_len (mspack_hip.h): how far a SHORTER request would still have succeeded -- qtmd writes only when its window wraps

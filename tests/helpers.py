@@ -169,6 +169,19 @@ def oracle_qtm(data, out_bytes, window_bits):
     return res.err, buf.raw[:min(res.out_len, out_bytes)], res
 
 
+def oracle_qtm_marks(data, out_bytes, window_bits, marks):
+    """one oracle decode of the whole request with marks (oracle_qtm_set_marks): -> (err, [what a request ending at each mark holds back])"""
+    import numpy as np
+    m = np.ascontiguousarray(np.asarray(marks, dtype=np.uint32))
+    log = np.zeros(max(len(m), 1), dtype=np.uint32)
+    L = oracle()
+    L.oracle_qtm_set_marks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.oracle_qtm_set_marks.restype = None
+    L.oracle_qtm_set_marks(m.ctypes.data, len(m), log.ctypes.data)
+    err, _o, res = oracle_qtm(data, out_bytes, window_bits)
+    return err, log[:len(m)].tolist()
+
+
 # ---- the compiled reference (only where oracle/_ref exists) ------------------------------------
 _ref = None
 
@@ -188,6 +201,7 @@ def ref():
                                   C.c_longlong, C.c_char_p, C.c_size_t, sz]
         lib.refh_mszip.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_longlong, C.c_int, sz]
         lib.refh_qtm.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_longlong, C.c_int, sz]
+        lib.refh_qtm_carry.argtypes = [C.c_char_p, C.c_size_t, C.c_longlong, C.c_int, C.POINTER(C.c_longlong)]
         lib.refh_cab_list.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint),
                                       C.POINTER(C.c_uint), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.c_char_p, C.c_int]
@@ -265,6 +279,13 @@ def ref_qtm(data, out_bytes, window_bits):
     w = C.c_size_t(0)
     err = ref().refh_qtm(bytes(data), len(data), buf, int(out_bytes), int(out_bytes), window_bits, C.byref(w))
     return err, buf.raw[:min(w.value, out_bytes)], w.value
+
+
+def ref_qtm_carry(data, out_bytes, window_bits):
+    """the real qtmd after ONE qtmd_decompress(out_bytes): (err, o_end - o_ptr) -- what it holds back for the next call (qtmd.c:268-276)"""
+    c = C.c_longlong(-1)
+    err = ref().refh_qtm_carry(bytes(data), len(data), int(out_bytes), window_bits, C.byref(c))
+    return err, c.value
 
 
 def ref_cab_list(cab):

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import libmspack_amd as M
-from helpers import oracle_lzx, oracle_mszip, oracle_qtm
+from helpers import oracle_lzx, oracle_mszip, oracle_qtm, oracle_qtm_marks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -72,14 +72,29 @@ def mixed_batch(n_each=40, seed=11):
     for it in items:
         pos = (pos + 15) & ~15
         offs.append(pos); pos += len(it[1])
+    # the Quantum units carry marks (MSPACK_HIP_UF_QTM_MARKS, round 6): their tables lie behind all the streams -- another chunk's
+    # part of the arena for most of them
+    marks = {}
+    for i, it in enumerate(items):
+        if it[0] == M.KIND_QUANTUM:
+            pos = (pos + 3) & ~3
+            marks[i] = (pos, np.unique(rng.integers(1, it[2], 40)).astype(np.uint32)); pos += 4 * marks[i][1].size
     arena = np.zeros(pos + 64, dtype=np.uint8)
     for it, o in zip(items, offs):
         arena[o:o + len(it[1])] = np.frombuffer(it[1], dtype=np.uint8)
+    for o, m in marks.values():
+        arena[o:o + 4 * m.size] = m.view(np.uint8)
     kinds = np.array([it[0] for it in items], dtype=np.uint8)
     units, out_bytes = M.make_units(kinds, offs, [len(it[1]) for it in items], [it[2] for it in items],
                                     window_bits=[it[3] for it in items], reset_frames=[it[4] for it in items],
                                     out_slack=32768)
+    for i, (o, m) in marks.items():
+        units["flags"][i] |= M.UF_QTM_MARKS; units["in_chunk"][i] = o // 4; units["ref_len"][i] = m.size
+    ARENA_OF[id(units)] = arena
     return units, arena, out_bytes, items
+
+
+ARENA_OF = {}
 
 
 def check(units, out, res, items):
@@ -87,6 +102,12 @@ def check(units, out, res, items):
         assert res["err"][i] == 0 and res["out_len"][i] == olen, (i, kind, res[i])
         o = int(units["out_off"][i])
         assert np.array_equal(out[o:o + olen], plain), (i, kind)
+        if kind == M.KIND_QUANTUM and units["flags"][i] & M.UF_QTM_MARKS:
+            # the unit's log behind its output (mspack_hip.h) against one oracle decode with the same marks -- read back out of the
+            # arena the units point into
+            m = int(units["ref_len"][i]); lo = o + ((olen + 15) & ~15)
+            e, want = oracle_qtm_marks(stream, olen, wb, ARENA_OF[id(units)][int(units["in_chunk"][i]) * 4:][:4 * m].view(np.uint32))
+            assert e == 0 and out[lo:lo + 4 * m].view(np.uint32).tolist() == want, (i, "marks")
     # the oracle on a sample of every kind
     seen = set()
     for i, (kind, stream, olen, wb, rf, plain) in enumerate(items):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import libmspack_amd as M
-from helpers import oracle_qtm
+from helpers import oracle_qtm, oracle_qtm_marks
 
 pytestmark = pytest.mark.gpu
 
@@ -61,6 +61,63 @@ def test_qtm_partial_truncated_corrupt(built):
         if e == 0:
             got = out[units["out_off"][i]:units["out_off"][i] + r.out_len].tobytes()
             assert got == o[:r.out_len], i
+
+
+def test_qtm_marks_vs_oracle(built):
+    """MSPACK_HIP_UF_QTM_MARKS (round 6): what a request ending at each marked position holds back for the next call (qtmd.c:268-276),
+    0xFFFFFFFF where the reference cannot end a request (inside a match that crosses the window's end, qtmd.c:358-374), 0 where the
+    stream never got to -- against ONE oracle decode with the same marks (the oracle's marks are pinned to the real qtmd's
+    o_end - o_ptr in tests/test_oracle_vs_ref.py): every window from 10 to 21, marks at random places and around every window
+    end, clean, damaged and cut streams, one unit whose marks outnumber its 32 KiB of slack."""
+    rng = np.random.default_rng(77)
+    streams, lens, wbs, marks = [], [], [], []
+    for wb in range(10, 22):
+        n = int(rng.integers(20000, 90000))
+        d = M.gen_plaintext(700 + wb, int(rng.integers(0, 4)), n)
+        s, _ = M.qtm_encode(d, wb)
+        m = sorted(set(int(x) for x in rng.integers(1, n, 300)) |
+                   set((k << wb) + j for k in range(1, (n >> wb) + 1) for j in range(-4, 2) if 0 < (k << wb) + j < n))[:2000]
+        for what in ("clean", "flip", "cut"):
+            b = bytearray(s)
+            if what == "flip":
+                b[int(rng.integers(len(b) // 4, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            if what == "cut":
+                b = b[:len(b) * 2 // 3]
+            streams.append(bytes(b)); lens.append(n); wbs.append(wb); marks.append(m)
+    d = M.gen_plaintext(799, 0, 60000)
+    s, _ = M.qtm_encode(d, 12)
+    streams.append(bytes(s)); lens.append(d.size); wbs.append(12); marks.append(list(range(1, 20001)))      # (80 KB of log)
+    offs, pos = [], 0
+    for st in streams:
+        pos = (pos + 15) & ~15
+        offs.append(pos); pos += len(st)
+    tabs = []
+    for m in marks:
+        pos = (pos + 3) & ~3
+        tabs.append(pos); pos += 4 * len(m)
+    arena = np.zeros(pos + 64, dtype=np.uint8)
+    for st, o in zip(streams, offs):
+        arena[o:o + len(st)] = np.frombuffer(st, dtype=np.uint8)
+    for m, o in zip(marks, tabs):
+        arena[o:o + 4 * len(m)] = np.asarray(m, dtype=np.uint32).view(np.uint8)
+    # (room for the logs: 16 bytes of alignment + 4 bytes per mark behind every unit's output)
+    units, out_bytes = M.make_units(M.KIND_QUANTUM, offs, [len(st) for st in streams], lens, window_bits=wbs, out_slack=16 + 4 * 20000)
+    units["flags"] |= M.UF_QTM_MARKS
+    units["in_chunk"] = np.asarray(tabs) // 4
+    units["ref_len"] = [len(m) for m in marks]
+    out, res = M.decode_batch(units, arena, out_bytes)
+    held = fails = 0
+    for i, st in enumerate(streams):
+        e, want = oracle_qtm_marks(st, lens[i], wbs[i], marks[i])
+        _e, o, r = oracle_qtm(st, lens[i], wbs[i])
+        assert res["err"][i] == e and res["out_len"][i] == r.out_len, (i, wbs[i], res[i], e, r.out_len)
+        lo = int(units["out_off"][i]) + ((lens[i] + 15) & ~15)
+        got = out[lo:lo + 4 * len(marks[i])].view(np.uint32).tolist()
+        assert got == want, (i, wbs[i], [(p, g, w) for p, g, w in zip(marks[i], got, want) if g != w][:5])
+        held += sum(0 < w < M.QTM_MARK_FAILS for w in want); fails += sum(w == M.QTM_MARK_FAILS for w in want)
+        if e == 0:
+            assert out[int(units["out_off"][i]):int(units["out_off"][i]) + lens[i]].tobytes() == o
+    assert held > 1000 and fails > 20, (held, fails)
 
 
 def test_qtm_batch_512_folders(built):

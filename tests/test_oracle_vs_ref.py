@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import libmspack_amd as M
-from helpers import have_ref, oracle_lzx, oracle_mszip, oracle_qtm, ref_lzx, ref_mszip, ref_qtm
+from helpers import have_ref, oracle_lzx, oracle_mszip, oracle_qtm, oracle_qtm_marks, ref_lzx, ref_mszip, ref_qtm, ref_qtm_carry
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (reference sources absent)")
 
@@ -59,6 +59,41 @@ def test_qtm_encoder_and_oracle_vs_reference(built):
         e1, o1, w1 = ref_qtm(bytes(b), d.size, 16)
         e2, o2, r = oracle_qtm(bytes(b), d.size, 16)
         assert (e1, w1) == (e2, r.out_len)
+
+
+def test_qtm_what_a_request_holds_back_oracle_vs_reference(built):
+    """qtmd decodes whole tokens: the match that covers a request's last byte usually runs past it, and the rest waits in the window
+    for the NEXT call, which writes it before it decodes anything (qtmd.c:268-276).  The oracle reports that length (in_next) -- the
+    ground truth of MSPACK_HIP_UF_QTM_MARKS -- and the real qtmd's o_end - o_ptr after the same request must agree: windows smaller
+    and larger than a frame, requests that end at frame and window boundaries, and in damaged streams (both must fail alike)."""
+    rng = np.random.default_rng(5)
+    for kind, wb, n in [(0, 16, 90000), (2, 12, 40000), (4, 21, 70000), (1, 10, 9000)]:
+        d = M.gen_plaintext(60 + kind, kind, n)
+        s, _ = M.qtm_encode(d, wb)
+        ps = sorted(set([1, 2, 32767, 32768, 32769, n - 1, n] + [int(x) for x in rng.integers(1, n, 60)] +
+                        [(k << wb) + j for k in range(1, (n >> wb) + 1) for j in (-3, -2, -1, 0, 1)][:400]))
+        seen = 0
+        ps = [p for p in ps if p <= n]
+        e, log = oracle_qtm_marks(s, n, wb, [p for p in ps if p < n])        # ONE decode, every boundary marked
+        assert e == 0
+        wraps = 0
+        for i, p in enumerate(ps):
+            e1, c1 = ref_qtm_carry(s, p, wb)
+            e2, _o, r = oracle_qtm(s, p, wb)
+            assert e1 == e2 and (e1 != 0 or c1 == r.in_next), (kind, wb, p, e1, c1, e2, r.in_next)
+            # (an undamaged stream: the only requests that fail end inside a match that crosses the window's end, qtmd.c:366-374)
+            assert p == n or log[i] == (c1 if e1 == 0 else 0xFFFFFFFF), (kind, wb, p, log[i], e1, c1)
+            seen += e1 == 0 and c1 != 0
+            wraps += e1 != 0
+        assert wraps or wb >= 16, (kind, wb)
+        assert seen > 5 or kind == 4, (kind, wb, seen)         # (requests do end inside matches; kind 4 has next to none)
+        b = bytearray(s); b[len(b) // 2] ^= 0x20
+        e, log = oracle_qtm_marks(bytes(b), n, wb, [p for p in ps if p < n])
+        for i, p in enumerate(ps):
+            e1, c1 = ref_qtm_carry(bytes(b), p, wb)
+            e2, _o, r = oracle_qtm(bytes(b), p, wb)
+            assert e1 == e2 and (e1 != 0 or c1 == r.in_next), (kind, wb, p, e1, c1, e2, r.in_next)
+            assert p == n or log[i] in ((c1,) if e1 == 0 else (0, 0xFFFFFFFF)), (kind, wb, p, log[i], e1, c1)       # (never reached: 0)
 
 
 def test_mszip_oracle_vs_reference(built):

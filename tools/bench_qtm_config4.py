@@ -1,5 +1,5 @@
 """scratch (GPU box): BASELINE config 4 -- 512 Quantum folders of 32 blocks, window 2^21 -- kernel time of the library named by
-MSPACK_HIP_SO (default: the shipped one), every byte verified.  python tools/bench_qtm_config4.py [folders] [frames]"""
+MSPACK_HIP_SO (default: the shipped one), every byte verified.  python tools/bench_qtm_config4.py [folders] [frames] [marks per folder]"""
 import os, sys, json
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -8,8 +8,9 @@ import libmspack_amd as M
 import bench as B
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 fr = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-r = B.secondary_qtm(M, torch, torch.device("cuda", 0), n=n, frames=fr, cpu=False)
-print(json.dumps({k: r[k] for k in ("kernel_ms", "value", "bit_exact")}), os.environ.get("MSPACK_HIP_SO", "shipped"))
+mk = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+r = B.secondary_qtm(M, torch, torch.device("cuda", 0), n=n, frames=fr, cpu=False, marks=mk)
+print(json.dumps({k: r[k] for k in ("kernel_ms", "value", "bit_exact")}), os.environ.get("MSPACK_HIP_SO", "shipped"), "marks per folder: %d" % mk)
 
 L = M.lib()
 if hasattr(L, "mspack_hip_debug_qtm_timers"):

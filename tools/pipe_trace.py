@@ -24,6 +24,9 @@ if hasattr(L, "mspack_hip_debug_pipe_phases"):
     print("parse tasks, us per frame (%d frames):" % (2 * n))
     for k, nm in enumerate(names):
         print("  %-46s %8.1f" % (nm, ph[k] / 100.0 / (2 * n)))
+    if ph[15]:
+        print("  per pass: %.1f steps of the count walks in %.2f rounds, %.1f steps of the last walk; %.2f passes per frame" %
+              (ph[12] / ph[15], ph[13] / ph[15], ph[14] / ph[15], ph[15] / (2.0 * n)))
     print("resolve half of the tasks, us per UNIT (two frames): front (load, R0-R2, checks) %.1f  push %.1f  resolve %.1f" %
           (ph[16 + 9] / 100.0 / n, ph[16 + 10] / 100.0 / n, ph[16 + 11] / 100.0 / n))
 assert (res["err"] == 0).all() and np.array_equal(out[:n * ub], plain)
