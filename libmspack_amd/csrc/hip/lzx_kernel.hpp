@@ -1758,6 +1758,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
           }
         }
         PHCNT(0, 1u);
+        PHCNT(4, round >= 2u ? 1u : 0u);                   /* (steps of the walks behind the second) */
         LZX_MARK("emit_count_step_begin");
         STAGE_BITS(act ? p : 0u, w0, w1, ALIGNED)
         const EmitTok t = lzx_emit_token<ALIGNED, false>(sh, act, length_empty, mlim, llim, main_fov, len_fov, w0, w1, two_level);
@@ -1774,6 +1775,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
       const u32 ne = lane == 0u ? b0 : pe;
       changed = lane < nl && ne != entry;
       entry = ne;
+      PHCNT(5, round >= 2u ? (u32) __popcll(ballot(changed)) : 0u);      /* (lanes that walk again behind the second walk) */
       if (!ballot(changed) || round >= LZX_LANE_ROUNDS) break;
     }
     // ---- the consistent prefix: lanes < mm ----
@@ -2302,6 +2304,7 @@ __device__ u32 lzx_pipe_parse(const mspack_hip_unit &u, const mspack_hip_unit *u
 #ifdef LZX_PIPE_TRACE
   pha_[6] = d.st_t[6]; pha_[7] = d.st_t[7]; pha_[8] = d.st_t[8];
   pha_[12] = d.st_t[0]; pha_[13] = d.st_t[1]; pha_[14] = d.st_t[2]; pha_[15] = d.st_t[3];
+  pha_[9] = d.st_t[4]; pha_[10] = d.st_t[5];
 #endif
   PHFLUSH();
   return 0u;

@@ -27,6 +27,7 @@ if hasattr(L, "mspack_hip_debug_pipe_phases"):
     if ph[15]:
         print("  per pass: %.1f steps of the count walks in %.2f rounds, %.1f steps of the last walk; %.2f passes per frame" %
               (ph[12] / ph[15], ph[13] / ph[15], ph[14] / ph[15], ph[15] / (2.0 * n)))
+        print("            of the count walks' steps %.1f are the walks behind the second (%.2f of them per pass, %.2f lanes walking in each)" % (ph[9] / ph[15], ph[13] / ph[15] - 2.0, ph[10] / max(1.0, float(ph[13]) - 2.0 * float(ph[15]))))
     print("resolve half of the tasks, us per UNIT (two frames): front (load, R0-R2, checks) %.1f  push %.1f  resolve %.1f" %
           (ph[16 + 9] / 100.0 / n, ph[16 + 10] / 100.0 / n, ph[16 + 11] / 100.0 / n))
 assert (res["err"] == 0).all() and np.array_equal(out[:n * ub], plain)
