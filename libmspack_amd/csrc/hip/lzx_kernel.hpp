@@ -1845,7 +1845,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
           else { gst(&rec->edge_lit[pos], (u8) t.sym); atomicOr(&sh->cnt[pos >> 5], 1u << (pos & 31u)); }
         }
         // (an offset beyond the field -- only garbage decodes to one -- is recorded as 0: never valid, lzx_pipe_commit stops there)
-        if (mt) gst_stream(W.at(j), make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
+        if (mt) gst_record(W.at(j), make_uint2(frame_pos + pos, (t.expl ? ((t.off < (1u << 21) ? t.off : 0u) << 11) : 0u) | (t.olen << 2) |
                                                          (t.expl ? 0u : t.slot + 1u)));
         cross = cross || crs;
         const bool adv = lit || mt;
@@ -1869,7 +1869,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
           if (lim > (frame_size & ~15u)) lim = frame_size & ~15u;
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
           for (u32 row = lit_flushed + 16u * lane; row < lim; row += 16u * WAVE)
-            gst((uint4 *)(fout + row), *(const uint4 *)((const u8 *) sh->litring + (row & (LZX_LIT_RING - 1u))));
+            gst_row((uint4 *)(fout + row), *(const uint4 *)((const u8 *) sh->litring + (row & (LZX_LIT_RING - 1u))));
           if (upto > lit_flushed) lit_flushed = upto;
         }
       }
@@ -1913,7 +1913,7 @@ __device__ __forceinline__ void lzx_parse_emit(LzxDec &d, const bool length_empt
     // the last rows (the frame's end, or where the parse stopped): byte by byte behind the last complete row
     const u32 full = P & ~15u;
     for (u32 row = lit_flushed + 16u * lane; row < full; row += 16u * WAVE)
-      gst((uint4 *)(fout + row), *(const uint4 *)((const u8 *) sh->litring + (row & (LZX_LIT_RING - 1u))));
+      gst_row((uint4 *)(fout + row), *(const uint4 *)((const u8 *) sh->litring + (row & (LZX_LIT_RING - 1u))));
     const u32 b0 = full > lit_flushed ? full : lit_flushed;
     if (b0 + lane < P) gst(fout + b0 + lane, ((const u8 *) sh->litring)[(b0 + lane) & (LZX_LIT_RING - 1u)]);
   }

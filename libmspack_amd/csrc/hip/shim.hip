@@ -587,7 +587,7 @@ static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr; 
 // MSPACK_HIP_FOLD: 0 = a folder's copies always through lzx_pipe_resolve, 1 (default) = through mspack_lzx_fold when the launch is few
 // long units, 2 = whenever the units allow it (tests, A/B runs)
 // MSPACK_HIP_STREAM_RESOLVE=0: resolve tasks never take frames up while they are parsed (A/B runs)
-static const bool g_stream_resolve = !getenv("MSPACK_HIP_STREAM_RESOLVE") || atoi(getenv("MSPACK_HIP_STREAM_RESOLVE")) != 0;
+static const int g_stream_resolve = getenv("MSPACK_HIP_STREAM_RESOLVE") ? atoi(getenv("MSPACK_HIP_STREAM_RESOLVE")) : 1;     // (2: also in launches that run beside others -- A/B runs)
 static const u32 g_fold_policy = getenv("MSPACK_HIP_FOLD") ? (u32) atoi(getenv("MSPACK_HIP_FOLD")) : 1u;
 // persistent waves of mspack_lzx_pipe: as many as the device holds at once (nothing depends on that number being right)
 // (cached per device: mspack_hip_decode_batch_multi runs one host thread per device)
@@ -676,7 +676,7 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
       LK(hipMemsetAsync(L.frame_unit + slot_lo, 0xFF, n_slots * sizeof(u32), st));
       // (resolve tasks that take their frames up while they are parsed: only where every ticket finds a wave at once -- a resolve
       // wave that has started holds its slot until its frame's parse task is through -- and no other launch runs beside this one)
-      const bool stream = alone && g_stream_resolve;      // (and the kernel knows how many tickets the launch has)
+      const bool stream = (alone && g_stream_resolve != 0) || g_stream_resolve >= 2;      // (and the kernel knows how many tickets the launch has)
       LK(hipMemcpyAsync(hdr, stream ? hdr_init_stream : hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st));
       LK(launch(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr));
       const size_t tickets = 2u * n_slots;

@@ -50,6 +50,26 @@ typedef unsigned int gv2u_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 gld(const uint2 *p) { const gv2u_ t = *(const __attribute__((address_space(1))) gv2u_ *) p; return make_uint2(t.x, t.y); }
 __device__ __forceinline__ void gst(uint2 *p, uint2 v) { gv2u_ t; t.x = v.x; t.y = v.y; *(__attribute__((address_space(1))) gv2u_ *) p = t; }
 #endif
+// write-through forms (`sc1`: the bytes go to memory at once and the line is dropped from the XCD's L2) for payload that only
+// another workgroup reads: an agent-scope release (buffer_wbl2) writes back EVERY dirty line of the XCD's L2, so what a wave leaves
+// dirty there is written out -- partially filled -- by whichever of the XCD's 512 waves publishes next (MI355X guide: stores of each
+// flavour; profiles/round6_sc1_stores.txt).  MSPACK_SC1_RECORDS: the parse waves' match records; MSPACK_SC1_ROWS: their literal rows.
+#if defined(MSPACK_SC1_RECORDS) && !defined(MSPACK_WAVE_EMU)
+__device__ __forceinline__ void gst_record(uint2 *p, uint2 v) {
+  __hip_atomic_store((unsigned long long *) p, ((unsigned long long) v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+__device__ __forceinline__ void gst_record(uint2 *p, uint2 v) { gst_stream(p, v); }
+#endif
+#if defined(MSPACK_SC1_ROWS) && !defined(MSPACK_WAVE_EMU)
+typedef unsigned int gv4u_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gst_row(uint4 *p, uint4 v) {
+  gv4u_ t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  asm volatile("flat_store_dwordx4 %0, %1 sc1" :: "v"(p), "v"(t) : "memory");
+}
+#else
+#define gst_row(p_, v_) gst((p_), (v_))
+#endif
 
 __device__ __forceinline__ u32 rfl(u32 v) { return (u32) __builtin_amdgcn_readfirstlane((int) v); }
 __device__ __forceinline__ u32 rdl(u32 v, u32 l) { return (u32) __builtin_amdgcn_readlane((int) v, (int) l); }
