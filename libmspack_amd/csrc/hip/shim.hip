@@ -1018,6 +1018,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       uint64_t tl, th;
       if (unit_side_table(u, tl, th)) {
         if (th > in_bytes) { snprintf(errbuf, errcap, "unit's table outside arena"); return -1; }
+        if (u.kind == MSPACK_HIP_KIND_QUANTUM && (u.out_off & 3u)) { snprintf(errbuf, errcap, "unit %u: a Quantum unit with marks needs out_off %% 4 == 0", idx[i]); return -1; }
         in_lo = std::min(in_lo, tl); in_hi = std::max(in_hi, th);
       }
     }
