@@ -71,6 +71,10 @@ struct folder_p {
   unsigned int n_marks;
   unsigned int *marks;
   const unsigned char *mark_log;
+  /* (decode_cabinet: how many of the cabinet's files lie in this folder and the first of them in list order -- one pass over the
+   * file list for all folders, so that a folder's files are found without walking the whole list per folder) */
+  unsigned int file_count;
+  struct mscabd_file *first_file;
 };
 struct cab_p {
   struct mscabd_cabinet base;
@@ -765,10 +769,12 @@ static void gather_marks(struct mspack_system *sys, struct cab_p *cab, struct ga
   size_t nf = 0, m = 0, i;
   unsigned int *v;
   g->n_marks = 0; g->marks = NULL; g->marks_off = 0;
-  for (f = cab->base.files; f; f = f->next) if ((struct folder_p *) f->folder == g->fol) nf++;
+  (void) cab;
+  nf = g->fol->file_count;                     /* (counted by decode_cabinet in one pass over the list) */
   if (!nf || !(v = (unsigned int *) sys->alloc(sys, 2 * nf * sizeof(unsigned int)))) return;
-  for (f = cab->base.files; f; f = f->next) {
+  for (f = g->fol->first_file, i = 0; f && i < nf; f = f->next) {
     if ((struct folder_p *) f->folder != g->fol) continue;
+    i++;
     if (f->offset > 0 && f->offset < g->total) v[m++] = f->offset;
     if (f->length < g->total && f->offset < g->total - f->length && f->offset + f->length > 0) v[m++] = f->offset + f->length;
   }
@@ -931,7 +937,14 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   size_t n = 0, k, out_bytes = 0, budget = (size_t) self->cache_mb << 20, used = 0, nu;
   int err = MSPACK_ERR_OK, rc, again = 0;
 
-  for (fo = cab->base.folders; fo; fo = fo->next) n++;
+  for (fo = cab->base.folders; fo; fo = fo->next) { n++; ((struct folder_p *) fo)->file_count = 0; ((struct folder_p *) fo)->first_file = NULL; }
+  {
+    struct mscabd_file *fi;
+    for (fi = cab->base.files; fi; fi = fi->next) {
+      struct folder_p *fp = (struct folder_p *) fi->folder;
+      if (fp && !fp->file_count++) fp->first_file = fi;
+    }
+  }
   gs = (struct gathered *) sys->alloc(sys, n * sizeof(*gs));
   units = NULL; res = NULL;                              /* (sized once the gather knows how many checksum units ride along) */
   /* (first guess for the arena: the cabinet's stated length, within reason -- it grows when that was wrong or the folders

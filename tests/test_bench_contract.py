@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the line the final build printed on the GPU box (profiles/round5_final_bench.json,
+"""The bench line's contract, checked on the line the final build printed on the GPU box (profiles/round6_final_bench.json,
 copied there from the gpurun session): the keys the driver reads, the roofline and cpu_baseline objects, internal
 consistency of the numbers.  bench.py itself needs a GPU; what it prints must not drift from what is documented."""
 import json
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def line():
-    return json.loads(open(os.path.join(ROOT, "profiles", "round5_final_bench.json")).read().strip().splitlines()[-1])
+    return json.loads(open(os.path.join(ROOT, "profiles", "round6_final_bench.json")).read().strip().splitlines()[-1])
 
 
 def test_driver_keys_and_types():
@@ -44,7 +44,12 @@ def test_host_inclusive_and_secondary_configs():
     assert h["MBps"] < d["value"] and h["to_host_MBps"] < h["MBps"]            # copies cost something; back to the host costs more
     assert "same_calls_from_this_process" in h
     sec = d["secondary"]
-    assert len(sec) == 4 and all(s["bit_exact"] is True and s["roofline"]["frac"] < 1.0 for s in sec)
+    assert len(sec) == 7 and all(s["bit_exact"] is True and s["roofline"]["frac"] < 1.0 for s in sec)
+    # round 6: what real containers look like -- blocks that span frames, ONE long folder per codec with the
+    # reference on one core beside it
+    assert any("SPAN frames" in s["config"] and s["units_on_frame_parallel_path"] == 1.0 for s in sec)
+    one = [s for s in sec if s["config"].startswith("ONE cabinet folder")]
+    assert len(one) == 2 and all(s["cpu_baseline"]["cores"] == 1 and s["value"] > s["cpu_baseline"]["value"] for s in one)
     assert any("config 2" in s["config"] for s in sec) and any("config 3" in s["config"] for s in sec)
     assert any("config 4" in s["config"] for s in sec) and any("config 5" in s["config"] for s in sec)
     for s in sec:
@@ -70,7 +75,7 @@ def test_through_api_and_socket_estimate():
 
 def test_traffic_file_is_this_rounds():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert t["round"] == "round 5" and os.path.exists(os.path.join(ROOT, t["source"]))
+    assert t["round"] == "round 6" and os.path.exists(os.path.join(ROOT, t["source"]))
     src = json.load(open(os.path.join(ROOT, t["source"])))
     assert src["fetch_kib_per_launch"] == t["fetch_kib_per_launch"] and src["write_kib_per_launch"] == t["write_kib_per_launch"]
     d = line()
