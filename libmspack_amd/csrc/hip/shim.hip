@@ -1500,9 +1500,10 @@ void mspack_hip_stage_free(void *p)
 {
   if (!p) return;
   // what stays page-locked while nobody uses it is bounded too (a process that once opened a large cabinet kept
-  // hundreds of MiB locked for good): MSPACK_HIP_PINNED_IDLE_MB, default 512 -- the arenas of a cabinet of 128 MiB come back at
-  // once for the next one; beyond that the largest idle blocks go back to the system
-  static const size_t idle_limit = (size_t) env_int("MSPACK_HIP_PINNED_IDLE_MB", 512, 0, 1 << 20) << 20;
+  // hundreds of MiB locked for good): MSPACK_HIP_PINNED_IDLE_MB, default 768 -- the arenas of the largest single cabinet among
+  // BASELINE's configs (config 4: 190 MB in + 528 MB out) come back at once for the next one (with 512 its output arena was locked anew
+  // on every open-and-extract: 175 ms of a 620 ms run, tools/sessions/gpu_r6_v.sh); beyond that the largest idle blocks go back to the system
+  static const size_t idle_limit = (size_t) env_int("MSPACK_HIP_PINNED_IDLE_MB", 768, 0, 1 << 20) << 20;
   std::lock_guard<std::mutex> lock(g_stage_mu);
   for (StageBlock &b : g_stage) if (b.p == p) { b.busy = false; break; }
   for (;;) {
