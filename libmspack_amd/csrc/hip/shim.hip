@@ -328,7 +328,7 @@ __device__ unsigned long long g_pipe_trace[4 << 16];
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LZX_PIPE_WAVES_PER_EU)))
 void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units, u32 slot_lo, u32 n_slots,
                      const u8 *in_arena, u8 *out_arena, mspack_hip_result *results, int32_t *frame_meta,
-                     const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks, u32 pool_chunks, u32 fold_policy)
+                     const u32 *frame_unit, u32 *ctl, lzxn::LzxFrameRec *recs, uint2 *toks, u32 pool_chunks, u32 fold_policy, u32 order_mode)
 {
   __shared__ LzxPipeLds sh;
   const u32 lane = threadIdx.x;
@@ -348,6 +348,15 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
   const u32 F = (Fmax != 0u && Fmax == Fmin && !fold) ? Fmax : 0u;
   const u32 T = F ? 2u * n_units * F : n_slots;
   const u32 stream = (stream_ok != 0u && F != 0u && T <= gridDim.x) ? 1u : 0u;      // (every ticket finds a wave at once)
+  // Ticket order of a uniform launch (round 6; measured: profiles/round6_ticket_order.txt).  Every order is correct -- a task only
+  // ever waits for earlier tickets --; what differs is who runs beside whom.  Level order (P(f0) | P(f1) | R(f0) | R(f1), §4.1c) is
+  // right when the launch has about as many units as the chip has waves: nobody waits.  When every ticket finds a wave at once
+  // (T <= gridDim.x: 1024 intervals) the order only says which tasks share a CU, and level order gives a CU sixteen tasks of ONE
+  // kind -- unit-major (a unit's tasks in a row) mixes them: 1.53 -> 1.40 ms.  With many more units than waves, sections that
+  // alternate P(f_k) and R(f_k-1) keep parse and resolve waves side by side through the launch: 8192 intervals 5.34 -> 5.24 ms.
+  // order_mode: 0 level, 1 mixed sections, 2 unit-major; 3 (the default) = by the launch's shape.
+  u32 mode = order_mode;
+  if (mode >= 3u) mode = T <= gridDim.x ? 2u : (2u * n_units >= 3u * gridDim.x ? 1u : 0u);
   for (;;) {
     u32 t = 0;
     if (lane == 0) t = atomicAdd(&ctl[2], 1u);
@@ -356,9 +365,33 @@ void mspack_lzx_pipe(const mspack_hip_unit *units, const u32 *order, u32 n_units
     u32 ui = 0xFFFFFFFFu, f = 0;
     bool do_parse = true, do_resolve = !fold;
     if (F) {
-      const u32 sct = t / n_units;
-      ui = rfl(order ? order[t % n_units] : t % n_units);
-      if (sct < F) { f = sct; do_resolve = false; } else { f = sct - F; do_parse = false; }
+      u32 ix;
+      if (mode == 1u) {
+        // P(f0) | P(f1) and R(f0) alternating | ... | R(f_last): parse and resolve tasks side by side on every CU
+        if (t < n_units) { ix = t; f = 0u; do_resolve = false; }
+        else {
+          const u32 t1 = t - n_units, k = t1 / (2u * n_units) + 1u;
+          if (k >= F) { ix = t1 - 2u * n_units * (F - 1u); f = F - 1u; do_parse = false; }
+          else {
+            const u32 w = t1 % (2u * n_units);
+            ix = w >> 1;
+            if (w & 1u) { f = k - 1u; do_parse = false; } else { f = k; do_resolve = false; }
+          }
+        }
+      }
+      else if (mode == 2u) {
+        // a unit's tasks in a row: P(f0) .. P(f_last), R(f0) .. R(f_last) (a launch whose tickets all run at once: the order only
+        // says which tasks share a CU)
+        ix = t / (2u * F);
+        const u32 w = t % (2u * F);
+        if (w < F) { f = w; do_resolve = false; } else { f = w - F; do_parse = false; }
+      }
+      else {
+        const u32 sct = t / n_units;
+        ix = t % n_units;
+        if (sct < F) { f = sct; do_resolve = false; } else { f = sct - F; do_parse = false; }
+      }
+      ui = rfl(order ? order[ix] : ix);
     }
     else {
       const u32 slot = slot_lo + t;
@@ -589,6 +622,9 @@ static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr; 
 // MSPACK_HIP_STREAM_RESOLVE=0: resolve tasks never take frames up while they are parsed (A/B runs)
 static const int g_stream_resolve = getenv("MSPACK_HIP_STREAM_RESOLVE") ? atoi(getenv("MSPACK_HIP_STREAM_RESOLVE")) : 1;     // (2: also in launches that run beside others -- A/B runs)
 static const u32 g_fold_policy = getenv("MSPACK_HIP_FOLD") ? (u32) atoi(getenv("MSPACK_HIP_FOLD")) : 1u;
+// MSPACK_HIP_TICKET_ORDER (A/B runs, tests): 0 level order, 1 mixed sections, 2 unit-major; 3 (default): by the launch's shape --
+// unit-major when every ticket finds a wave at once, mixed sections from 1.5 x as many units as waves on, level order in between
+static const u32 g_ticket_order = getenv("MSPACK_HIP_TICKET_ORDER") ? (u32) atoi(getenv("MSPACK_HIP_TICKET_ORDER")) : 3u;
 // persistent waves of mspack_lzx_pipe: as many as the device holds at once (nothing depends on that number being right)
 // (cached per device: mspack_hip_decode_batch_multi runs one host thread per device)
 static unsigned lzx_pipe_waves()
@@ -682,7 +718,7 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
       const size_t tickets = 2u * n_slots;
       const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
       LK(launch(mspack_lzx_pipe, dim3(waves), block, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots, in, out, d_results,
-                L.meta, L.frame_unit, hdr, L.recs, pool, pool_chunks, g_fold_policy));
+                L.meta, L.frame_unit, hdr, L.recs, pool, pool_chunks, g_fold_policy, g_ticket_order));
       // few long units: the frames' copies as fold tasks, one wave per CU (the kernel decides from what the map kernel counted and
       // leaves at once otherwise; a launch of more units than the rule allows is not even asked)
       if (g_fold_policy >= 2u || (g_fold_policy == 1u && n <= LZX_FOLD_MAX_UNITS && n_slots >= LZX_FOLD_MIN_FRAMES))

@@ -99,7 +99,6 @@ def test_some_gpu_parity_tests_on_the_emulator(built):
            "tests/test_gpu_lzx_frames.py::test_wrong_tables_cost_time_not_correctness",
            "tests/test_gpu_lzx_frames.py::test_frames_other_plaintexts",
            "tests/test_gpu_lzx_log.py",            # (the reset log of units whose blocks outlive their frames: serial and with tables)
-           "tests/test_gpu_hostpath.py::test_copies_are_cut_at_pin_boundaries",     # (round 5: copies cut at the boundaries of locked ranges)
            "tests/test_gpu_hostpath.py::test_xorsum_units_vs_oracle",               # (round 5: the CFDATA checksum kernel)
            "tests/test_gpu_lzx_frames.py::test_real_cabinet_blocks_of_megabytes"]   # (round 5: frames inside multi-frame blocks)
     env = dict(os.environ, MSPACK_HIP_SO=SO, MSPACK_EMU_PUBLISH_DELAY_US="500")

@@ -397,9 +397,9 @@ def test_copies_are_cut_at_pin_boundaries(built):
     """The deterministic form of the same fault: a caller page-locks PART of its input arena and of its output buffer
     (mspack_hip_pin) -- every copy the entry points make then starts inside a locked range and ends behind it, or the other
     way round.  The runtime refuses such a copy (hipErrorInvalidValue); the entry points cut theirs at the boundaries.
-    Runs on the hardware (256 units) and, smaller, on the wavefront emulator in the CPU suite (tests/test_emu_kernels.py); the same
-    scenario at the hardware's size runs under real ASan / TSan against a model of the runtime's page-lock rules in
-    tests/test_hostcheck.py.  History: in round 5 this test aborted the process ONCE in five whole-suite runs on the hardware and was
+    Runs on the hardware (256 units); the same scenario at the hardware's size runs in the CPU suite under real ASan / TSan against a
+    model of the runtime's page-lock rules (tests/test_hostcheck.py) -- which replaced the emulator run of rounds 5 / 6 there (the
+    emulator still takes it, smaller, when asked: MSPACK_HIP_SO=tests/_build/libmspack_emu.so).  History: in round 5 this test aborted the process ONCE in five whole-suite runs on the hardware and was
     moved off it; round 6 put it back (what was found, what was not; tests/conftest.py now keeps the native
     backtrace and the runtime's last words of anything that aborts)."""
     n, ub = (24 if "emu" in os.path.basename(M.HIP_SO) else 256), 65536     # (the emulator decodes ~1 MB/s: the cuts are what is tested, not the kernels)

@@ -160,13 +160,16 @@ def test_frames_other_plaintexts(built, fam):
         assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
 
 
-@pytest.mark.parametrize("env", [{}, {"MSPACK_HIP_STREAM_RESOLVE": "0"}, {"MSPACK_HIP_NO_FRAME_PARSE": "1"}], ids=["pipe", "pipe_no_stream", "serial"])
+@pytest.mark.parametrize("env", [{}, {"MSPACK_HIP_STREAM_RESOLVE": "0"}, {"MSPACK_HIP_TICKET_ORDER": "0"}, {"MSPACK_HIP_TICKET_ORDER": "1"},
+                                 {"MSPACK_HIP_TICKET_ORDER": "2"}, {"MSPACK_HIP_NO_FRAME_PARSE": "1"}],
+                         ids=["pipe", "pipe_no_stream", "level_order", "mixed_sections", "unit_major", "serial"])
 def test_launch_paths_same_bytes(built, env):
     """shim.hip launch_kind: the shipped default (mspack_lzx_pipe: one dependency-driven launch) and the serial kernel alone
     (MSPACK_HIP_NO_FRAME_PARSE; round 2's header / parse / unit kernels in a row were removed in round 4) --
     same results, on launches smaller than, about and larger than the chip, and on units of three frames; launches with a wave for
     every ticket (300 units of three frames, 1024 of two) take their frames up while they are parsed (lzx_pipe_resolve_stream, round 6) --
-    MSPACK_HIP_STREAM_RESOLVE=0 is the same launches without.  Every unit
+    MSPACK_HIP_STREAM_RESOLVE=0 is the same launches without; MSPACK_HIP_TICKET_ORDER forces one ticket order on every launch (the
+    shipped rule picks by the launch's shape: every order is correct, a task only waits for earlier tickets).  Every unit
     carries its table; with the pipe every unit must have had all its frames' records adopted.  (Own process: the
     switches are read when the library loads.)"""
     import os, subprocess, sys
@@ -187,7 +190,7 @@ def go(n, ub):
     return float(((res['flags'] & ADOPTED) != 0).mean())
 print(go(300, 3 * 32768), go(1024, 65536), go(3600, 32768), go(3600, 3 * 32768), go(6144, 32768))
 """
-    e2 = dict(os.environ); e2.pop("MSPACK_HIP_NO_FRAME_PARSE", None); e2.pop("MSPACK_HIP_STREAM_RESOLVE", None); e2.update(env)
+    e2 = dict(os.environ); e2.pop("MSPACK_HIP_NO_FRAME_PARSE", None); e2.pop("MSPACK_HIP_STREAM_RESOLVE", None); e2.pop("MSPACK_HIP_TICKET_ORDER", None); e2.update(env)
     r = subprocess.run([sys.executable, "-c", code], env=e2, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stderr[-2000:]
     adopted = [float(x) for x in r.stdout.split()[-5:]]
