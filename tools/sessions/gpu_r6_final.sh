@@ -2,7 +2,7 @@
 # round 6, final session (GPU box): smoke, the whole -m gpu suite, the default bench line, rocprofv3 kernel stats of the bench command,
 # the traffic passes, SQ counters, the trace build's phases -- what profiles/round6_final_* is made of
 set -u
-R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r6final; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/${OUTDIR:-r6final}; mkdir -p $O
 cd $R
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" ) > $O/smoke.txt 2>&1; echo "smoke rc=$?" | tee -a $O/summary.txt
 timeout 2400 python -m pytest tests -m gpu -x -q -p no:cacheprovider --durations=12 > $O/pytest_gpu.txt 2>&1; echo "pytest gpu rc=$?" | tee -a $O/summary.txt; tail -n 3 $O/pytest_gpu.txt >> $O/summary.txt
