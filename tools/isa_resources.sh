@@ -5,10 +5,10 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I $R/include --cuda-device-only -S $R/libmspack_amd/csrc/hip/shim.hip -o $T/shim.s 2>/dev/null
-python3 - $T/shim.s <<'P'
+python3 - $T/shim.s $R <<'P'
 import re, sys
 s = open(sys.argv[1]).read()
-print("# hipcc --offload-arch=gfx950 -O3 (ROCm 7.2), libmspack_amd/csrc/hip/shim.hip @ %s" % __import__("subprocess").run(["git", "-C", sys.argv[1].rsplit("/", 1)[0], "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip())
+print("# hipcc --offload-arch=gfx950 -O3 (ROCm 7.2), libmspack_amd/csrc/hip/shim.hip @ %s" % __import__("subprocess").run(["git", "-C", sys.argv[2], "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip())
 print("%-26s %6s %6s %8s %9s %11s %11s" % ("kernel", "VGPRs", "SGPRs", "LDS B", "scratch B", "sgpr spills", "vgpr spills"))
 for m in re.finditer(r"\.group_segment_fixed_size:\s*(\d+).*?\.name:\s*(\S+).*?\.private_segment_fixed_size:\s*(\d+).*?\.sgpr_count:\s*(\d+).*?\.sgpr_spill_count:\s*(\d+).*?\.vgpr_count:\s*(\d+).*?\.vgpr_spill_count:\s*(\d+)", s, re.S):
     lds, name, scr, sg, sgs, vg, vgs = m.groups()
