@@ -1505,7 +1505,8 @@ void mspack_hip_unpin(const void *p)
 // hipHostMalloc'ed memory that are KEPT when they are handed back and reused by the next batch -- the cost of locking is paid
 // once per process, not once per call.  Bounded: MSPACK_HIP_PINNED_MB (default 1024) MiB in all; a request that does not fit
 // returns NULL and the caller takes the sys->alloc + mspack_hip_pin way.  mspack_hip_release() gives the idle blocks back.
-struct StageBlock { void *p; size_t cap; bool busy; };
+struct StageBlock { void *p; size_t cap; bool busy; unsigned long long used; };      // used: when it was last handed out or back (g_stage_clock)
+static unsigned long long g_stage_clock = 0;
 static std::mutex g_stage_mu;
 static std::vector<StageBlock> g_stage;
 static size_t g_stage_total = 0;
@@ -1517,7 +1518,7 @@ void *mspack_hip_stage_alloc(size_t bytes)
   StageBlock *best = nullptr;
   for (StageBlock &b : g_stage)
     if (!b.busy && b.cap >= bytes && b.cap <= bytes + bytes / 2 + (1u << 20) && (!best || b.cap < best->cap)) best = &b;
-  if (best) { best->busy = true; return best->p; }
+  if (best) { best->busy = true; best->used = ++g_stage_clock; return best->p; }
   // room?  idle blocks that fit nothing are given back first
   if (g_stage_total + bytes > limit) {
     for (size_t i = 0; i < g_stage.size() && g_stage_total + bytes > limit; )
@@ -1528,7 +1529,7 @@ void *mspack_hip_stage_alloc(size_t bytes)
   void *p = nullptr;
   const size_t cap = (bytes + ((size_t) 2 << 20) - 1) & ~(((size_t) 2 << 20) - 1);
   if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess || !p) { (void) hipGetLastError(); return nullptr; }
-  g_stage.push_back(StageBlock{ p, cap, true });
+  g_stage.push_back(StageBlock{ p, cap, true, ++g_stage_clock });
   g_stage_total += cap;
   return p;
 }
@@ -1538,14 +1539,16 @@ void mspack_hip_stage_free(void *p)
   // what stays page-locked while nobody uses it is bounded too (a process that once opened a large cabinet kept
   // hundreds of MiB locked for good): MSPACK_HIP_PINNED_IDLE_MB, default 768 -- the arenas of the largest single cabinet among
   // BASELINE's configs (config 4: 190 MB in + 528 MB out) come back at once for the next one (with 512 its output arena was locked anew
-  // on every open-and-extract: 175 ms of a 620 ms run, tools/sessions/gpu_r6_v.sh); beyond that the largest idle blocks go back to the system
+  // on every open-and-extract: 175 ms of a 620 ms run, tools/sessions/gpu_r6_v.sh); beyond that the idle blocks that have been idle
+  // LONGEST go back to the system (the largest first, as it was, gave config 4's output arena back whenever a process had opened
+  // other cabinets before: the blocks just handed back are the ones the next cabinet of that size will ask for)
   static const size_t idle_limit = (size_t) env_int("MSPACK_HIP_PINNED_IDLE_MB", 768, 0, 1 << 20) << 20;
   std::lock_guard<std::mutex> lock(g_stage_mu);
-  for (StageBlock &b : g_stage) if (b.p == p) { b.busy = false; break; }
+  for (StageBlock &b : g_stage) if (b.p == p) { b.busy = false; b.used = ++g_stage_clock; break; }
   for (;;) {
     size_t idle = 0, big = (size_t) -1;
     for (size_t i = 0; i < g_stage.size(); i++)
-      if (!g_stage[i].busy) { idle += g_stage[i].cap; if (big == (size_t) -1 || g_stage[i].cap > g_stage[big].cap) big = i; }
+      if (!g_stage[i].busy) { idle += g_stage[i].cap; if (big == (size_t) -1 || g_stage[i].used < g_stage[big].used) big = i; }
     if (idle <= idle_limit || big == (size_t) -1) break;
     if (hipHostFree(g_stage[big].p) != hipSuccess) (void) hipGetLastError();
     g_stage_total -= g_stage[big].cap;
