@@ -202,6 +202,25 @@ size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total);
 int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
                             void *out, size_t out_bytes, mspack_hip_result *results);
 
+/* ---- jobs: mspack_hip_decode_batch, handed over chunk by chunk while it runs -------------------------------
+ * The reference's API is one extract() per file (cabd.c:1075-1214, chmd.c:906-1041); a driver that decodes a whole container in
+ * one batch made the FIRST extract() wait for all of it and the caller's sys->write of file 1 begin only then.  A job is the same
+ * batch on a thread of the library's own: _begin() returns at once, _wait_unit(job, i) returns as soon as the chunk that holds
+ * unit i is through -- units[i]'s bytes are in `out`, results[i] is written (so are those of every unit of that chunk and of the
+ * chunks before it: chunks finish in arena order) -- while the later chunks are still decoded and copied back; _end() waits for
+ * the rest, frees the job and returns what mspack_hip_decode_batch would have returned.  `units`, `in`, `out` and `results` are
+ * the job's until _end(): nothing of them may be written or freed before, and of `out` / `results` only what a successful
+ * _wait_unit has covered may be read.  _wait_unit returns 0, or the batch's error code once the batch has failed before the
+ * unit's chunk came through (mspack_hip_last_error() says what).  A batch that is not cut into chunks (interleaved outputs, a
+ * small batch) is handed over whole: _wait_unit then returns with _end's answer.  _begin returns NULL when no job could be
+ * started (no thread, MSPACK_HIP_JOBS=0): the caller then makes the synchronous call.  One device (the calling thread's current
+ * one); calls for the same device -- jobs or not -- are serialised: a second batch waits until the job's batch has returned. */
+typedef struct mspack_hip_job mspack_hip_job;
+mspack_hip_job *mspack_hip_decode_batch_begin(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
+                                              void *out, size_t out_bytes, mspack_hip_result *results);
+int mspack_hip_job_wait_unit(mspack_hip_job *job, size_t i);
+int mspack_hip_job_end(mspack_hip_job *job);
+
 /* Host input, DEVICE output: as above, but the decoded bytes stay in the caller's device buffer `d_out` on
  * the current device (unit out_off relative to it; LZX DELTA reference data must already be there). */
 int mspack_hip_decode_batch_to_device(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,

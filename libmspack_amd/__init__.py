@@ -58,6 +58,10 @@ def lib():
         L.mspack_hip_decode_batch.argtypes = [vp, sz, vp, sz, vp, sz, vp]
         L.mspack_hip_decode_batch_multi.argtypes = [vp, sz, vp, sz, vp, sz, vp, C.c_int]
         L.mspack_hip_decode_batch_to_device.argtypes = [vp, sz, vp, sz, vp, sz, vp]
+        L.mspack_hip_decode_batch_begin.restype = vp
+        L.mspack_hip_decode_batch_begin.argtypes = [vp, sz, vp, sz, vp, sz, vp]
+        L.mspack_hip_job_wait_unit.argtypes = [vp, sz]
+        L.mspack_hip_job_end.argtypes = [vp]
         L.mspack_hip_release.restype = None
         _lib = L
     return _lib
@@ -70,6 +74,7 @@ EXPORTED_SYMBOLS = [
     "mspack_hip_decode_batch_to_device", "mspack_hip_release",
     "mspack_hip_set_default_devices", "mspack_hip_default_devices", "mspack_hip_set_cache_mb", "mspack_hip_cache_mb",
     "mspack_hip_host_path_stats", "mspack_hip_pin", "mspack_hip_unpin", "mspack_hip_stage_alloc", "mspack_hip_stage_free",
+    "mspack_hip_decode_batch_begin", "mspack_hip_job_wait_unit", "mspack_hip_job_end",
 ]
 
 

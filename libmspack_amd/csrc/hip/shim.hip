@@ -604,6 +604,7 @@ void mspack_xorsum(const mspack_hip_unit *units, const u32 *order, u32 n_units, 
 // Host side of the C ABI.
 // ---------------------------------------------------------------------------------------------------
 #include <mutex>
+#include <condition_variable>
 #include <atomic>
 #define MSPK_MAX_DEV_CACHE 64
 static thread_local char g_err[256] = "";
@@ -886,7 +887,7 @@ struct DevCtx {
   bool ready = false;
   int ns = 0;
   hipStream_t st[MSPK_MAX_STREAMS];      // [0] copy-in (and everything of a one-chunk call), [1] copy-out, [2] [3] compute
-  hipEvent_t ev_in[MSPK_MAX_CHUNKS], ev_done[MSPK_MAX_CHUNKS];
+  hipEvent_t ev_in[MSPK_MAX_CHUNKS], ev_done[MSPK_MAX_CHUNKS], ev_back[MSPK_MAX_CHUNKS];      // chunk c: input there / launches through / output back
   int max_chunks = 1, n_compute = 2;
   DevBuf d_in, d_out, d_units, d_order, d_res, d_fm;
   DevBuf h_stage;                       // pinned: results + (optionally) the output on its way to pageable memory
@@ -911,6 +912,15 @@ static hipError_t grow(DevBuf &b, size_t need, bool pinned) {
 }
 
 static void host_path_account(double plan_ms, double issue_ms, double drain_ms);
+// What a job (mspack_hip_decode_batch_begin) lets its caller see of a batch that is still running: which chunk a unit went into, and
+// how many chunks are through -- their bytes in the caller's output buffer, their units' results written.  Chunks finish in order.
+struct JobProgress {
+  std::mutex mu; std::condition_variable cv;
+  bool planned = false;                 // chunk_of is filled in
+  std::vector<uint32_t> chunk_of;       // the caller's unit index -> chunk
+  size_t done = 0;                      // chunks complete
+  bool finished = false; int rc = 0;    // the call has returned (rc); nothing is promised about chunks >= done when rc != 0
+};
 struct Chunk {
   size_t a, b;                          // local unit range [a, b)
   uint64_t in_lo, in_hi, out_lo, out_hi;
@@ -1007,7 +1017,7 @@ static hipError_t copy_cut(void *dst, const void *src, size_t n, hipMemcpyKind k
 static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uint32_t *sel, size_t n_sel,
                                       const void *in, size_t in_bytes, void *host_out, void *dev_out,
                                       size_t out_bytes, mspack_hip_result *results, char *errbuf, size_t errcap,
-                                      bool per_unit_back = false)
+                                      bool per_unit_back = false, JobProgress *pg = nullptr)
 {
   if (n_sel == 0) return 0;
   if (dev < 0 || dev >= MSPK_MAX_DEV) { snprintf(errbuf, errcap, "device index %d out of range", dev); return -1; }
@@ -1095,6 +1105,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     for (int i = 0; i < MSPK_MAX_CHUNKS; i++) {
       TRY(hipEventCreateWithFlags(&cx.ev_in[i], hipEventDisableTiming));
       TRY(hipEventCreateWithFlags(&cx.ev_done[i], hipEventDisableTiming));
+      TRY(hipEventCreateWithFlags(&cx.ev_back[i], hipEventDisableTiming));
     }
     cx.ready = true;
   }
@@ -1167,6 +1178,12 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
         std::stable_sort(order.begin() + c.order_off[k], order.begin() + op, [&](uint32_t x, uint32_t y) {
           return local[x].in_len + (local[x].out_len >> 2) > local[y].in_len + (local[y].out_len >> 2); });
       }
+    }
+    if (pg) {
+      std::lock_guard<std::mutex> lk(pg->mu);
+      for (size_t ci = 0; ci < chunks.size(); ci++) for (size_t i = chunks[ci].a; i < chunks[ci].b; i++) pg->chunk_of[idx[i]] = (uint32_t) ci;
+      pg->planned = true;
+      pg->cv.notify_all();
     }
     for (size_t i = 0; i < n_sel; i++) {
       { uint64_t tl, th; if (unit_side_table(local[i], tl, th)) local[i].in_chunk -= (uint32_t)(in_lo >> 2); }      // in_lo is a multiple of 16
@@ -1254,8 +1271,12 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       ~Pins() { if (n) { hipDeviceSynchronize(); release(); } }      // (an error path: nothing may still be writing them)
     } pins, pins_in;
     struct Staged { void *host; size_t off, n; };
-    std::vector<Staged> staged;                            // (written by the thread that issues the copies back, read after it)
-    staged.reserve(STAGE_SLOTS);
+    // (written by the thread that issues the copies back; read behind it: chunk ci's pieces are staged[.. staged_upto[ci]), final once
+    // back_issued says the chunk's copies are on the stream)
+    Staged staged[4u * MSPK_MAX_CHUNKS];
+    size_t n_staged = 0, staged_upto[MSPK_MAX_CHUNKS] = { 0 };
+    std::atomic<size_t> back_issued{0};                    // chunks whose copies back are on st_out, ev_back recorded behind them
+    std::atomic<bool> back_ended{false};
     // one span of the output, device -> caller's memory on st_out: cut at the boundaries of every registration this library
     // knows; pieces outside all of them that are small go through the pinned staging buffer (no pageable copy in the way)
     auto copy_out = [&](uintptr_t lo, uintptr_t hi, const u8 *d_src) -> hipError_t {
@@ -1268,10 +1289,10 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
         bool locked = false;
         for (int k = 0; k < pins.n && !locked; k++) locked = at >= pins.r[k].ra && to <= pins.r[k].rb;
         hipError_t ce;
-        if (!locked && pins.n && to - at <= STAGE_PIECE && staged.size() < STAGE_SLOTS) {
-          const size_t off = stage_res + STAGE_PIECE * staged.size();
+        if (!locked && pins.n && to - at <= STAGE_PIECE && n_staged < STAGE_SLOTS) {
+          const size_t off = stage_res + STAGE_PIECE * n_staged;
           ce = hipMemcpyAsync((char *) cx.h_stage.p + off, d_src + (at - lo), to - at, hipMemcpyDeviceToHost, st_out);
-          staged.push_back(Staged{ (void *) at, off, (size_t)(to - at) });
+          staged[n_staged++] = Staged{ (void *) at, off, (size_t)(to - at) };
         }
         else ce = hipMemcpyAsync((void *) at, d_src + (at - lo), to - at, hipMemcpyDeviceToHost, st_out);
         if (ce != hipSuccess) return ce;
@@ -1312,8 +1333,11 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
           while (issued.load(std::memory_order_acquire) <= ci) { if (stop.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
           be = hipStreamWaitEvent(st_out, cx.ev_done[ci], 0);
           if (be == hipSuccess) be = copy_out(base + c.out_lo, base + c.out_hi, d_out + (c.out_lo - out_lo));
+          if (be == hipSuccess && pg) be = hipEventRecord(cx.ev_back[ci], st_out);
+          if (be == hipSuccess) { staged_upto[ci] = n_staged; back_issued.store(ci + 1, std::memory_order_release); }
         }
         back_err = be;
+        back_ended.store(true, std::memory_order_release);
       });
       back_started = true;
     } catch (...) { back_started = false; }      // (no helper thread: the copies back are issued below, in this thread)
@@ -1323,11 +1347,20 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       uintptr_t ra, rb;
       if (inner_pages((const char *) in + in_lo, in_span, ra, rb)) pins_in.lock(ra, rb);
     }
+    // (what the copies so far have brought: ONE interval -- the chunks' input ranges ascend and may overlap: a CHM's intervals all
+    // read "to the end of the file", chmd.c:1146-1149, so its first chunk's range is the whole arena and the later chunks' ranges
+    // lie inside it; the copies run one after the other on st_in, and a chunk's launches wait for the event behind ITS copy)
+    uint64_t cov_lo = 0, cov_hi = 0;
     for (size_t ci = 0; ci < chunks.size(); ci++) {
       const Chunk &c = chunks[ci];
       hipStream_t st = one ? cx.st[0] : cx.st[2 + ci % n_comp];
-      TRY(copy_cut(d_in + (c.in_lo - in_lo), (const char *) in + c.in_lo, (size_t)(c.in_hi - c.in_lo), hipMemcpyHostToDevice, st_in,
-                   pins_in.r.data(), pins_in.n));
+      {
+        uint64_t lo = c.in_lo, hi = c.in_hi;
+        if (cov_hi > cov_lo && lo >= cov_lo && lo <= cov_hi) { lo = std::min(hi, cov_hi); cov_hi = std::max(cov_hi, hi); }
+        else { cov_lo = lo; cov_hi = hi; }
+        TRY(copy_cut(d_in + (lo - in_lo), (const char *) in + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st_in,
+                     pins_in.r.data(), pins_in.n));
+      }
       if (host_out)
         for (size_t i = c.a; i < c.b; i++)               // LZX DELTA reference data sits below the unit's output
           if (local[i].ref_len && local[i].kind == MSPACK_HIP_KIND_LZX_DELTA)
@@ -1362,17 +1395,35 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
         TRY(copy_out((uintptr_t) host_out + c.out_lo, (uintptr_t) host_out + c.out_hi, d_out + (c.out_lo - out_lo)));
       }
     }
+    auto hand_over = [&](size_t a, size_t b) {             // the results of local units [a, b) into the caller's array
+      for (size_t i = a; i < b; i++) {
+        results[idx[i]] = h_res[i];
+        if (local[i].kind == 0) { memset(&results[idx[i]], 0, sizeof(mspack_hip_result)); results[idx[i]].err = ERR_ARGS; }
+      }
+    };
+    size_t handed = 0, staged_done = 0;                    // units / staged pieces already in the caller's memory
+    if (pg && back_started) {
+      // a job: chunk by chunk as the copies back end -- the caller (mspack_hip_job_wait_unit) takes a chunk's bytes while the later
+      // chunks are still being decoded and copied
+      for (size_t ci = 0; ci < chunks.size(); ci++) {
+        while (back_issued.load(std::memory_order_acquire) <= ci && !back_ended.load(std::memory_order_acquire)) std::this_thread::yield();
+        if (back_issued.load(std::memory_order_acquire) <= ci) break;          // (the thread gave up: its error is reported below)
+        TRY(hipEventSynchronize(cx.ev_back[ci]));            // chunk ci's launches, its results' copy and its bytes' copies are through
+        for (; staged_done < staged_upto[ci]; staged_done++) memcpy(staged[staged_done].host, (const char *) cx.h_stage.p + staged[staged_done].off, staged[staged_done].n);
+        hand_over(chunks[ci].a, chunks[ci].b);
+        handed = chunks[ci].b;
+        { std::lock_guard<std::mutex> lk(pg->mu); pg->done = ci + 1; }
+        pg->cv.notify_all();
+      }
+    }
     if (back.joinable()) {
       back.join();
       if (back_err != hipSuccess) TRY(back_err);
     }
     for (int i = 0; i < cx.ns; i++) TRY(hipStreamSynchronize(cx.st[i]));
-    for (const Staged &sg : staged) memcpy(sg.host, (const char *) cx.h_stage.p + sg.off, sg.n);
+    for (; staged_done < n_staged; staged_done++) memcpy(staged[staged_done].host, (const char *) cx.h_stage.p + staged[staged_done].off, staged[staged_done].n);
     { auto r0 = tnow(); pins.release(); pins_in.release(); unpin_ms = tms(r0, tnow()); }
-    for (size_t i = 0; i < n_sel; i++) {
-      results[idx[i]] = h_res[i];
-      if (local[i].kind == 0) { memset(&results[idx[i]], 0, sizeof(mspack_hip_result)); results[idx[i]].err = ERR_ARGS; }
-    }
+    hand_over(handed, n_sel);
     t3 = tnow();
     host_path_account(tms(t0, t1), tms(t1, t2), tms(t2, t3));
     if (trace)
@@ -1409,6 +1460,58 @@ int mspack_hip_decode_batch_to_device(mspack_hip_unit *units, size_t n_units, co
 {
   return pipeline_on_current_device(current_device(), units, nullptr, n_units, in, in_bytes, nullptr, d_out, out_bytes,
                                     results, g_err, sizeof(g_err));
+}
+
+// ---- jobs: the same batch, handed over chunk by chunk while it runs (include/mspack_hip.h) ----
+struct mspack_hip_job {
+  std::thread th;
+  JobProgress pg;
+  char err[256];
+};
+
+mspack_hip_job *mspack_hip_decode_batch_begin(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
+                                              void *out, size_t out_bytes, mspack_hip_result *results)
+{
+  static const bool off = env_int("MSPACK_HIP_JOBS", 1, 0, 1) == 0;          // (A/B runs: every caller takes its synchronous way)
+  if (off || !units || !results || !out) return nullptr;
+  mspack_hip_job *job = nullptr;
+  try {
+    job = new mspack_hip_job();
+    job->err[0] = 0;
+    job->pg.chunk_of.assign(n_units, 0u);
+    const int dev = current_device();
+    job->th = std::thread([=]() {
+      int rc;
+      if (hipSetDevice(dev) != hipSuccess) { (void) hipGetLastError(); snprintf(job->err, sizeof(job->err), "hipSetDevice(%d) failed", dev); rc = -1; }
+      else rc = pipeline_on_current_device(dev, units, nullptr, n_units, in, in_bytes, out, nullptr, out_bytes, results,
+                                           job->err, sizeof(job->err), false, &job->pg);
+      { std::lock_guard<std::mutex> lk(job->pg.mu); job->pg.rc = rc; job->pg.finished = true; }
+      job->pg.cv.notify_all();
+    });
+  } catch (...) { delete job; return nullptr; }            // (no thread, no memory: the caller takes the synchronous call)
+  return job;
+}
+
+int mspack_hip_job_wait_unit(mspack_hip_job *job, size_t i)
+{
+  if (!job) return -1;
+  JobProgress &pg = job->pg;
+  std::unique_lock<std::mutex> lk(pg.mu);
+  if (i >= pg.chunk_of.size()) return -1;
+  pg.cv.wait(lk, [&]() { return pg.finished || (pg.planned && pg.done > pg.chunk_of[i]); });
+  if (pg.planned && pg.done > pg.chunk_of[i]) return 0;    // (its chunk came through, whatever became of the later ones)
+  if (pg.rc) { snprintf(g_err, sizeof(g_err), "%s", job->err); return pg.rc; }
+  return 0;                                                // finished without an error: everything is there
+}
+
+int mspack_hip_job_end(mspack_hip_job *job)
+{
+  if (!job) return -1;
+  if (job->th.joinable()) job->th.join();
+  const int rc = job->pg.rc;
+  if (rc) snprintf(g_err, sizeof(g_err), "%s", job->err);
+  delete job;
+  return rc;
 }
 
 int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const void *in,
@@ -1585,7 +1688,7 @@ void mspack_hip_release(void)
     if (cx.h_stage.p) { hipHostFree(cx.h_stage.p); cx.h_stage.p = nullptr; cx.h_stage.cap = 0; }
     if (cx.ready) {
       for (int i = 0; i < cx.ns; i++) hipStreamDestroy(cx.st[i]);
-      for (int i = 0; i < MSPK_MAX_CHUNKS; i++) { hipEventDestroy(cx.ev_in[i]); hipEventDestroy(cx.ev_done[i]); }
+      for (int i = 0; i < MSPK_MAX_CHUNKS; i++) { hipEventDestroy(cx.ev_in[i]); hipEventDestroy(cx.ev_done[i]); hipEventDestroy(cx.ev_back[i]); }
     }
     cx.ready = false;
   }

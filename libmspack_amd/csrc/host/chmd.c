@@ -31,6 +31,11 @@ struct chm_chunk {                /* a run of reset intervals decoded in one GPU
   unsigned char *buf;             /* decoded bytes (E8 origin 0), or NULL when evicted               */
   unsigned long stamp;            /* LRU clock                                                      */
   int res_valid;                  /* ires[] of these intervals is filled in                         */
+  /* the chunk's batch while it is still running (mspack_hip.h: jobs): interval first + i is unit i; of buf and ires[] only what
+   * chunk_wait() has covered may be read, and neither may be freed before chunk_settle() */
+  mspack_hip_job *job;
+  mspack_hip_unit *job_units;
+  unsigned int job_waited;        /* units [0, job_waited) have come through                        */
 };
 struct chm_p {
   struct mschmd_header base;
@@ -519,7 +524,7 @@ static int hip_batch(mspack_hip_unit *units, size_t n, const void *in, size_t in
 
 /* decode intervals [first, first+count) stand-alone; interval i's E8 origin is i*interval - e8_origin */
 static int decode_intervals(struct chmd_p *self, struct chm_p *c, unsigned int first, unsigned int count,
-                            off_t e8_origin, unsigned char *out, mspack_hip_result *res)
+                            off_t e8_origin, unsigned char *out, mspack_hip_result *res, struct chm_chunk *as_job)
 {
   struct mspack_system *sys = self->system;
   mspack_hip_unit *units = (mspack_hip_unit *) sys->alloc(sys, (size_t) count * sizeof(*units));
@@ -550,15 +555,34 @@ static int decode_intervals(struct chmd_p *self, struct chm_p *c, unsigned int f
       units[k].in_chunk = (uint32_t)((c->ftab_off + (size_t)(first + k) * c->fper * 4) / 4);
     }
   }
+  /* a chunk's batch runs as a job when it can: extract() of the first file returns when the file's intervals are through,
+   * and the caller writes it while the rest is decoded and copied back (one device: a sharded batch is synchronous) */
+  if (as_job && count > 1 && mspack_hip_default_devices() <= 1 &&
+      (as_job->job = mspack_hip_decode_batch_begin(units, count, c->arena, c->arena_room, out, (size_t) count * (size_t) c->interval_bytes + 64, res))) {
+    as_job->job_units = units; as_job->job_waited = 0;
+    return MSPACK_ERR_OK;
+  }
   rc = hip_batch(units, count, c->arena, c->arena_room, out, (size_t) count * (size_t) c->interval_bytes + 64, res);
   sys->free(units);
   if (rc) { sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error()); return MSPACK_ERR_DECRUNCH; }
   return MSPACK_ERR_OK;
 }
 
+/* the chunk's batch, if it is still running, to its end: buf and ires[] are the driver's again (0, or the batch's failure) */
+static int chunk_settle(struct mspack_system *sys, struct chm_chunk *ch)
+{
+  int rc = 0;
+  if (ch->job) {
+    rc = mspack_hip_job_end(ch->job);
+    ch->job = NULL;
+    sys->free(ch->job_units); ch->job_units = NULL;
+  }
+  return rc;
+}
+
 static void free_sec1(struct mspack_system *sys, struct chm_p *c) {
   unsigned int i;
-  if (c->chunks) for (i = 0; i < c->n_chunks; i++) mspack_arena_free(sys, c->chunks[i].buf);
+  if (c->chunks) for (i = 0; i < c->n_chunks; i++) { (void) chunk_settle(sys, &c->chunks[i]); mspack_arena_free(sys, c->chunks[i].buf); }
   if (c->arena_pinned) { mspack_hip_unpin(c->arena); c->arena_pinned = 0; }
   sys->free(c->chunks); mspack_arena_free(sys, c->arena); sys->free(c->ioff); sys->free(c->ires); mspack_arena_free(sys, c->s_buf);
   c->chunks = NULL; c->arena = NULL; c->ioff = NULL; c->ires = NULL; c->s_buf = NULL; c->sec1_state = 0;
@@ -709,14 +733,42 @@ static int setup_sec1(struct chmd_p *self, struct chm_p *c, struct mspack_file *
     c->chunk_int = (unsigned int)(CHM_CHUNK_BYTES / c->interval_bytes); if (!c->chunk_int) c->chunk_int = 1;
     c->n_chunks = (c->n_fast + c->chunk_int - 1) / c->chunk_int;
     if (!(c->chunks = (struct chm_chunk *) sys->alloc(sys, (size_t) c->n_chunks * sizeof(*c->chunks)))) return MSPACK_ERR_NOMEMORY;
-    for (i = 0; i < c->n_chunks; i++) { c->chunks[i].buf = NULL; c->chunks[i].stamp = 0; c->chunks[i].res_valid = 0; }
+    for (i = 0; i < c->n_chunks; i++) {
+      c->chunks[i].buf = NULL; c->chunks[i].stamp = 0; c->chunks[i].res_valid = 0;
+      c->chunks[i].job = NULL; c->chunks[i].job_units = NULL; c->chunks[i].job_waited = 0;
+    }
     if (!(c->ires = (mspack_hip_result *) sys->alloc(sys, (size_t) c->n_fast * sizeof(mspack_hip_result)))) return MSPACK_ERR_NOMEMORY;
   }
   return MSPACK_ERR_OK;
 }
 
-/* fast results (and, if `need_buf`, the decoded bytes) of the chunk that holds interval k */
-static int ensure_chunk(struct chmd_p *self, struct chm_p *c, unsigned int k, int need_buf, struct chm_chunk **out)
+/* a chunk whose batch is still running: wait until intervals up to k_to (of this chunk) have come through */
+static int chunk_wait(struct chmd_p *self, struct chm_chunk *ch, unsigned int first, unsigned int count, unsigned int k_to)
+{
+  struct mspack_system *sys = self->system;
+  unsigned int upto = k_to - first + 1;
+  if (!ch->job) return MSPACK_ERR_OK;
+  if (upto > count) upto = count;
+  while (ch->job_waited < upto) {
+    if (mspack_hip_job_wait_unit(ch->job, ch->job_waited)) {
+      /* the batch failed: what decode_intervals says of a failed call -- nothing of the chunk is kept */
+      (void) chunk_settle(sys, ch);
+      sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error());
+      mspack_arena_free(sys, ch->buf); ch->buf = NULL; ch->res_valid = 0;
+      return MSPACK_ERR_DECRUNCH;
+    }
+    ch->job_waited++;
+  }
+  if (ch->job_waited >= count && chunk_settle(sys, ch)) {
+    sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error());
+    mspack_arena_free(sys, ch->buf); ch->buf = NULL; ch->res_valid = 0;
+    return MSPACK_ERR_DECRUNCH;
+  }
+  return MSPACK_ERR_OK;
+}
+
+/* fast results (and, if `need_buf`, the decoded bytes) of the chunk that holds interval k -- of its intervals up to k_to */
+static int ensure_chunk_to(struct chmd_p *self, struct chm_p *c, unsigned int k, unsigned int k_to, int need_buf, struct chm_chunk **out)
 {
   struct mspack_system *sys = self->system;
   unsigned int ci = k / c->chunk_int, first = ci * c->chunk_int, i;
@@ -725,7 +777,7 @@ static int ensure_chunk(struct chmd_p *self, struct chm_p *c, unsigned int k, in
   int err;
   if (out) *out = ch;
   ch->stamp = ++c->stamp;
-  if (ch->buf || (ch->res_valid && !need_buf)) return MSPACK_ERR_OK;
+  if (ch->buf || (ch->res_valid && !need_buf)) return chunk_wait(self, ch, first, count, k_to);
   /* stay inside the cache budget: drop the least recently used buffers */
   {
     size_t budget = (size_t) mspack_hip_cache_mb() << 20, each = (size_t) c->chunk_int * (size_t) c->interval_bytes;
@@ -734,15 +786,24 @@ static int ensure_chunk(struct chmd_p *self, struct chm_p *c, unsigned int k, in
       for (i = 0; i < c->n_chunks; i++)
         if (c->chunks[i].buf) { used += each; if (&c->chunks[i] != ch && (!lru || c->chunks[i].stamp < lru->stamp)) lru = &c->chunks[i]; }
       if (used + each <= budget || !lru) break;
+      if (chunk_settle(sys, lru)) lru->res_valid = 0;      /* (a batch that failed behind what was asked of it: decoded again when needed) */
       mspack_arena_free(sys, lru->buf); lru->buf = NULL;
     }
   }
   if (!(ch->buf = (unsigned char *) mspack_arena_alloc(sys, (size_t) count * (size_t) c->interval_bytes + 128))) return MSPACK_ERR_NOMEMORY;
-  err = decode_intervals(self, c, first, count, 0, ch->buf, &c->ires[first]);
-  if (err) { mspack_arena_free(sys, ch->buf); ch->buf = NULL; return err; }
-  ch->res_valid = 1;
-  if (!need_buf && count * (size_t) c->interval_bytes > ((size_t) mspack_hip_cache_mb() << 20)) { mspack_arena_free(sys, ch->buf); ch->buf = NULL; }
-  return MSPACK_ERR_OK;
+  /* (a chunk whose bytes will not be kept -- beyond the cache budget -- is decoded synchronously: its buffer goes at once) */
+  {
+    const int keep = need_buf || count * (size_t) c->interval_bytes <= ((size_t) mspack_hip_cache_mb() << 20);
+    err = decode_intervals(self, c, first, count, 0, ch->buf, &c->ires[first], keep ? ch : NULL);
+    if (err) { mspack_arena_free(sys, ch->buf); ch->buf = NULL; return err; }
+    ch->res_valid = 1;
+    if (!keep) { mspack_arena_free(sys, ch->buf); ch->buf = NULL; }
+  }
+  return chunk_wait(self, ch, first, count, k_to);
+}
+static int ensure_chunk(struct chmd_p *self, struct chm_p *c, unsigned int k, int need_buf, struct chm_chunk **out)
+{
+  return ensure_chunk_to(self, c, k, k, need_buf, out);
 }
 
 static int interval_clean(const mspack_hip_result *r) {
@@ -903,7 +964,7 @@ static int vdec_emit(struct chmd_p *self, struct chm_p *c, struct mspack_file *f
     unsigned int k1 = (unsigned int)((stop - 1) / c->interval_bytes), i;
     struct chm_chunk *ch;
     int err, shifted = 0;
-    if ((err = ensure_chunk(self, c, k, 1, &ch))) return err;
+    if ((err = ensure_chunk_to(self, c, k, k1, 1, &ch))) return err;
     /* E8: fast results have origin 0; the reference's origin is where its decoder was created (lzxd.c:712) */
     if (v->init != 0)
       for (i = k; i <= k1; i++) if (c->ires[i].flags & MSPACK_HIP_F_E8_APPLIED) shifted = 1;
@@ -911,7 +972,7 @@ static int vdec_emit(struct chmd_p *self, struct chm_p *c, struct mspack_file *f
       unsigned int cnt = k1 - k + 1;
       mspack_hip_result *r2 = (mspack_hip_result *) sys->alloc(sys, cnt * sizeof(*r2));
       unsigned char *tmp = (unsigned char *) mspack_arena_alloc(sys, (size_t) cnt * (size_t) c->interval_bytes + 128);
-      err = (!r2 || !tmp) ? MSPACK_ERR_NOMEMORY : decode_intervals(self, c, k, cnt, v->init, tmp, r2);
+      err = (!r2 || !tmp) ? MSPACK_ERR_NOMEMORY : decode_intervals(self, c, k, cnt, v->init, tmp, r2, NULL);
       if (!err) err = write_slice(sys, fh, tmp + (from - (off_t) k * c->interval_bytes), (size_t)(stop - from));
       sys->free(r2); mspack_arena_free(sys, tmp);
       if (err) return err;

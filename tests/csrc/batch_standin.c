@@ -138,6 +138,47 @@ int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n_units, const 
   return mspack_hip_decode_batch(units, n_units, in, in_bytes, out, out_bytes, results);
 }
 
+/* jobs (mspack_hip.h): the stand-in's job is LAZY and hostile on purpose -- _begin() decodes nothing and fills the results with
+ * 0xEE; _wait_unit(i) decodes unit i and the units before it (chunks finish in arena order: the real library promises no more);
+ * _end() decodes the rest.  A driver that reads a result or a byte it has not waited for sees garbage here, in the CPU suite. */
+static unsigned long g_jobs_begun, g_job_waits;
+unsigned long mspack_standin_jobs_begun(void) { return g_jobs_begun; }
+unsigned long mspack_standin_job_waits(void) { return g_job_waits; }
+struct mspack_hip_job {
+  mspack_hip_unit *units; size_t n, upto; const void *in; size_t in_bytes; void *out; size_t out_bytes; mspack_hip_result *res; int rc;
+};
+mspack_hip_job *mspack_hip_decode_batch_begin(mspack_hip_unit *units, size_t n_units, const void *in, size_t in_bytes,
+                                              void *out, size_t out_bytes, mspack_hip_result *results)
+{
+  struct mspack_hip_job *j;
+  const char *e = getenv("MSPACK_HIP_JOBS");
+  if (e && atoi(e) == 0) return NULL;
+  if (!(j = (struct mspack_hip_job *) malloc(sizeof(*j)))) return NULL;
+  j->units = units; j->n = n_units; j->upto = 0; j->in = in; j->in_bytes = in_bytes; j->out = out; j->out_bytes = out_bytes;
+  j->res = results; j->rc = 0;
+  memset(results, 0xEE, n_units * sizeof(*results));
+  g_jobs_begun++;
+  return j;
+}
+static int job_advance(struct mspack_hip_job *j, size_t upto)
+{
+  while (!j->rc && j->upto < upto) {
+    uint32_t one = (uint32_t) j->upto;
+    j->rc = mspack_standin_decode_units(j->units, &one, 1, j->in, j->in_bytes, j->out, j->out_bytes, j->res);
+    j->upto++;
+  }
+  return j->rc;
+}
+int mspack_hip_job_wait_unit(mspack_hip_job *job, size_t i) { g_job_waits++; return (!job || i >= job->n) ? -1 : job_advance(job, i + 1); }
+int mspack_hip_job_end(mspack_hip_job *job)
+{
+  int rc;
+  if (!job) return -1;
+  rc = job_advance(job, job->n);
+  free(job);
+  return rc;
+}
+
 void mspack_hip_host_path_stats(double *ms4, int reset)
 {
   (void) reset;

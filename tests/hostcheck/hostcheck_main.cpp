@@ -271,6 +271,58 @@ static void scn_lifetimes(int reps)
   remove(f_chm.c_str()); remove(f_cab.c_str()); remove(f_out.c_str());
 }
 
+// jobs (mspack_hip.h: mspack_hip_decode_batch_begin): the caller reads a unit's bytes and result the moment _wait_unit has covered it,
+// while the library's threads still decode and copy the later chunks -- what TSan is here for; a job ended without a wait; a
+// synchronous call of the same thread and one of another thread beside a running job (serialised inside); units waited out of order
+static void scn_jobs(int reps)
+{
+  Batch B = lzx_batch(0x3131, 320, 65536, true);
+  Batch C = lzx_batch(0x3232, 100, 65536, false);
+  const size_t n = B.units.size(), ub = 65536;
+  for (int rep = 0; rep < reps; rep++) {
+    const bool staged = rep & 1;                             // (page-locked arenas out of the library's pool / pageable ones)
+    std::vector<uint8_t> outv(B.out_bytes + 64 + 4096);
+    uint8_t *in = staged ? (uint8_t *) mspack_hip_stage_alloc(B.comp.size()) : B.comp.data();
+    uint8_t *out = staged ? (uint8_t *) mspack_hip_stage_alloc(B.out_bytes + 64) : outv.data() + 100 * rep;
+    CHECK(in && out);
+    if (staged) memcpy(in, B.comp.data(), B.comp.size());
+    std::vector<mspack_hip_result> res(n);
+    std::vector<mspack_hip_unit> u = B.units;
+    mspack_hip_job *job = mspack_hip_decode_batch_begin(u.data(), n, in, B.comp.size(), out, B.out_bytes + 64, res.data());
+    CHECK(job);
+    std::thread other;
+    std::vector<uint8_t> out2(C.out_bytes + 64);
+    if (rep % 3 == 1) other = std::thread([&]() { decode_and_compare(C, C.comp.data(), C.comp.size(), out2.data(), out2.size(), 0); });
+    if (rep % 3 == 2) {
+      // out of order: the last unit first (everything is there then), then the rest
+      CHECK(mspack_hip_job_wait_unit(job, n - 1) == 0);
+      CHECK(memcmp(out, B.plain.data(), B.out_bytes) == 0);
+    }
+    for (size_t i = 0; i < n; i++) {
+      CHECK(mspack_hip_job_wait_unit(job, i) == 0);
+      CHECK(res[i].err == 0 && res[i].out_len == ub);
+      CHECK(memcmp(out + i * ub, B.plain.data() + i * ub, ub) == 0);
+      if (rep % 3 == 0 && i == n / 2) decode_and_compare(C, C.comp.data(), C.comp.size(), out2.data(), out2.size(), 0);   // (waits for the job's batch)
+    }
+    CHECK(mspack_hip_job_wait_unit(job, n) != 0);            // (no such unit)
+    CHECK(mspack_hip_job_end(job) == 0);
+    if (other.joinable()) other.join();
+    // ended without a wait: everything is there afterwards
+    memset(out, 0, B.out_bytes);
+    u = B.units;
+    job = mspack_hip_decode_batch_begin(u.data(), n, in, B.comp.size(), out, B.out_bytes + 64, res.data());
+    CHECK(job && mspack_hip_job_end(job) == 0);
+    CHECK(memcmp(out, B.plain.data(), B.out_bytes) == 0);
+    // a batch that fails as a whole (a unit outside the arena): the waiters hear of it, _end returns the code
+    u = B.units; u[n - 1].in_off = B.comp.size() + 5;
+    job = mspack_hip_decode_batch_begin(u.data(), n, in, B.comp.size(), out, B.out_bytes + 64, res.data());
+    CHECK(job);
+    CHECK(mspack_hip_job_wait_unit(job, 0) != 0);
+    CHECK(mspack_hip_job_end(job) != 0);
+    if (staged) { mspack_hip_stage_free(in); mspack_hip_stage_free(out); }
+  }
+}
+
 int main(int argc, char **argv)
 {
   const std::string s = argc > 1 ? argv[1] : "";
@@ -278,6 +330,7 @@ int main(int argc, char **argv)
   else if (s == "ownership") scn_ownership();
   else if (s == "shards_threads") scn_shards_and_threads();
   else if (s == "lifetimes") scn_lifetimes(argc > 2 ? atoi(argv[2]) : 4);
+  else if (s == "jobs") scn_jobs(argc > 2 ? atoi(argv[2]) : 6);
   else { fprintf(stderr, "usage: hostcheck partial_pins|ownership|shards_threads|lifetimes [reps]\n"); return 2; }
   mspack_hip_release();
   if (hostcheck_violations()) { fprintf(stderr, "hostcheck: %d violation(s) of the runtime's modelled rules\n", hostcheck_violations()); return 4; }

@@ -75,3 +75,38 @@ def test_chm_big_reset_interval_small_table(built, hostlogic):
                 err, data = c.extract(i)
                 if want is not None:
                     assert err == want[i][0] and (err or data == want[i][1]), (frames, i, err, want[i][0])
+
+
+def test_chm_chunks_run_as_jobs(built, hostlogic):
+    """A chunk's batch runs as a job (include/mspack_hip.h: mspack_hip_decode_batch_begin): extract() of file i waits for the
+    intervals file i needs, not for the chunk.  The stand-in's job is lazy and hostile (tests/csrc/batch_standin.c: results
+    poisoned at _begin, a unit decoded only when it is waited for), so a driver that read a result or a byte it had not waited
+    for would fail the goldens above; here: the jobs ARE taken (every multi-interval golden went through one), and the
+    synchronous way (MSPACK_HIP_JOBS=0, read per call by the stand-in) gives the same bytes file by file, in several orders."""
+    import ctypes
+    hostlogic.mspack_standin_jobs_begun.restype = ctypes.c_ulong
+    hostlogic.mspack_standin_job_waits.restype = ctypes.c_ulong
+    v = next(x for x in VECS if x["tag"].startswith("config3") or len(x["case"].get("files", [])) >= 8)
+    chm, _d, files = R.build(v["case"])
+    orders = [list(range(len(files))), list(reversed(range(len(files)))), [len(files) // 2, 0, len(files) - 1, 1]]
+    got = {}
+    for jobs in ("1", "0"):
+        os.environ["MSPACK_HIP_JOBS"] = jobs
+        try:
+            b0, w0 = hostlogic.mspack_standin_jobs_begun(), hostlogic.mspack_standin_job_waits()
+            for oi, order in enumerate(orders):
+                with api.Chm(chm, mem=True, L=hostlogic) as c:
+                    assert not c.open_error
+                    for i in order:
+                        err, data = c.extract(i)
+                        got.setdefault((oi, i), []).append((err, hashlib.md5(data).hexdigest(), len(data)))
+            b1, w1 = hostlogic.mspack_standin_jobs_begun(), hostlogic.mspack_standin_job_waits()
+            if jobs == "1":
+                assert b1 > b0 and w1 > w0, "the CHM driver did not take the job path"
+            else:
+                assert b1 == b0, "MSPACK_HIP_JOBS=0 still began a job"
+        finally:
+            os.environ.pop("MSPACK_HIP_JOBS", None)
+    for key, pair in got.items():
+        assert pair[0] == pair[1], (key, pair)
+        assert pair[0][0] == 0

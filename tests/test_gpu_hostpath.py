@@ -489,3 +489,62 @@ def test_staging_pool(built):
     L.mspack_hip_stage_free(again)
     assert not L.mspack_hip_stage_alloc(1 << 44)                   # beyond any budget
     M.lib().mspack_hip_release()
+
+
+JOB_WORKER = r"""
+import sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import libmspack_amd as M
+import test_gpu_hostpath as T
+L = M.lib()
+units, arena, out_bytes, items = T.mixed_batch(n_each=int(sys.argv[1]), seed=11)
+n = len(units)
+# the units in ARENA order are what the chunks are cut from: wait for them in that order, reading each one's bytes and result the
+# moment its wait returns -- the later chunks are still being decoded and copied back then
+by_arena = np.argsort(units["in_off"], kind="stable")
+for rep in range(3):
+    out = np.full(out_bytes + 64, 0xAB, dtype=np.uint8)
+    res = np.zeros(n, dtype=M.RESULT_DTYPE); res["err"] = 77
+    u = units.copy(); T.ARENA_OF[id(u)] = arena
+    job = L.mspack_hip_decode_batch_begin(u.ctypes.data, n, arena.ctypes.data, arena.size, out.ctypes.data, out_bytes + 64, res.ctypes.data)
+    assert job, "no job"
+    early = 0
+    for k, i in enumerate(by_arena if rep != 1 else by_arena[::-1]):
+        i = int(i)
+        assert L.mspack_hip_job_wait_unit(job, i) == 0, L.mspack_hip_last_error()
+        kind, stream, olen, wb, rf, plain = items[i]
+        assert res["err"][i] == 0 and res["out_len"][i] == olen, (rep, i, res[i])
+        o = int(u["out_off"][i])
+        assert np.array_equal(out[o:o + olen], plain), (rep, i)
+        if rep == 0 and k < n // 4 and (res["err"][by_arena[-1]] == 77):
+            early += 1                                    # (the last unit's result had not been written yet: a hand-over ahead of the end)
+    assert L.mspack_hip_job_wait_unit(job, n) != 0
+    assert L.mspack_hip_job_end(job) == 0
+    T.check(u, out, res, items)
+    print("rep", rep, "units handed over before the batch had ended:", early)
+# a job that is ended without a wait; a synchronous call right behind a begin (waits for the job's batch)
+out = np.zeros(out_bytes + 64, dtype=np.uint8); res = np.zeros(n, dtype=M.RESULT_DTYPE); u = units.copy(); T.ARENA_OF[id(u)] = arena
+job = L.mspack_hip_decode_batch_begin(u.ctypes.data, n, arena.ctypes.data, arena.size, out.ctypes.data, out_bytes + 64, res.ctypes.data)
+out2, res2 = M.decode_batch(units, arena, out_bytes)
+assert job and L.mspack_hip_job_end(job) == 0
+T.check(u, out, res, items); T.check(units, out2, res2, items)
+# a batch that fails as a whole
+u = units.copy(); u["in_off"][0] = arena.size + 9
+job = L.mspack_hip_decode_batch_begin(u.ctypes.data, n, arena.ctypes.data, arena.size, out.ctypes.data, out_bytes + 64, res.ctypes.data)
+assert job and L.mspack_hip_job_wait_unit(job, 1) != 0 and L.mspack_hip_job_end(job) != 0
+print("JOBS_OK")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nchunks", [1, 4, 8])
+def test_jobs_hand_over_chunk_by_chunk(built, nchunks, tmp_path):
+    """mspack_hip_decode_batch_begin / _job_wait_unit / _job_end (include/mspack_hip.h): a mixed batch cut into 1, 4 and 8 chunks; every
+    unit's bytes and result are read the moment its wait returns, in arena order and against it; same bytes as the synchronous call"""
+    script = tmp_path / "j.py"
+    script.write_text(JOB_WORKER % (ROOT, ROOT))
+    env = dict(os.environ, MSPACK_HIP_NCHUNKS=str(nchunks), MSPACK_HIP_CHUNK_BYTES="4096", MSPACK_HIP_CHUNK_UNITS="4", MSPACK_HIP_TRACE="1")
+    p = subprocess.run([sys.executable, str(script), "24"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert p.returncode == 0 and b"JOBS_OK" in p.stdout, p.stdout.decode()[-3000:]
+    assert (b"in %d chunks" % nchunks) in p.stdout, p.stdout.decode()[-3000:]

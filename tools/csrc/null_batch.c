@@ -33,6 +33,12 @@ int mspack_hip_decode_batch(mspack_hip_unit *units, size_t n, const void *in, si
 int mspack_hip_decode_batch_multi(mspack_hip_unit *units, size_t n, const void *in, size_t in_bytes, void *out, size_t out_bytes,
                                   mspack_hip_result *res, int devices)
 { (void) devices; return mspack_hip_decode_batch(units, n, in, in_bytes, out, out_bytes, res); }
+/* (no jobs: the drivers take the synchronous call) */
+mspack_hip_job *mspack_hip_decode_batch_begin(mspack_hip_unit *units, size_t n, const void *in, size_t in_bytes, void *out, size_t out_bytes,
+                                              mspack_hip_result *res)
+{ (void) units; (void) n; (void) in; (void) in_bytes; (void) out; (void) out_bytes; (void) res; return 0; }
+int mspack_hip_job_wait_unit(mspack_hip_job *job, size_t i) { (void) job; (void) i; return -1; }
+int mspack_hip_job_end(mspack_hip_job *job) { (void) job; return -1; }
 void mspack_hip_host_path_stats(double *ms4, int reset) { (void) reset; if (ms4) { ms4[0] = ms4[1] = ms4[3] = 0; ms4[2] = g_ms; } if (reset) g_ms = 0; }
 int mspack_hip_pin(const void *p, size_t bytes) { (void) p; (void) bytes; return 1; }      /* (nothing to lock without a device) */
 void mspack_hip_unpin(const void *p) { (void) p; }
