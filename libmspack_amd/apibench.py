@@ -82,7 +82,7 @@ def summary(d, reps_note=""):
                          "sys->write": round(d["write_s"] * 1e3, 2),
                          "drivers' own work (block checksums, arenas, slicing)": round(other * 1e3, 2),
                          "minus what ran side by side (a job's batch beside sys->write)": -round(overlapped * 1e3, 2)},
-            "batch_calls": d["lib_calls"],
+            "batch_calls": d["lib_calls"], "first_extract_ms": round(d["first_extract_s"] * 1e3, 2),
             "what": "mspack_create_*_decompressor() -> open() -> extract() of every file, C in-memory mspack_system "
                     "(libmspack_amd/csrc/bench/api_bench.c)" + reps_note}
 

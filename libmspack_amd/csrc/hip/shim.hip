@@ -1138,10 +1138,23 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
         w[k] = shape == 1 ? (k >= 2 ? (uint64_t) 2 << (k - 1) : 2) : (shape == 2 && k == 0 && want >= 3 ? 1 : 2);
         wsum += w[k];
       }
+      // (a unit weighs what it reads that the NEXT unit does not start inside: a CHM's intervals are all given "to the end of the
+      // file" as input, chmd.c:1146-1149 -- by in_len alone config 3's four chunks held 77, 174, 227 and 546 of its 1024 intervals)
+      auto weight = [&](size_t i) -> uint64_t {
+        uint64_t wgt = local[i].in_len;
+        for (size_t j = i + 1; j < n_sel; j++) {
+          if (local[j].kind == MSPACK_HIP_KIND_XORSUM) continue;
+          if (local[j].in_off > local[i].in_off && local[j].in_off - local[i].in_off < wgt) wgt = local[j].in_off - local[i].in_off;
+          break;
+        }
+        return wgt;
+      };
+      uint64_t w_sum = 0;
+      for (size_t i = 0; i < n_sel; i++) if (local[i].kind != MSPACK_HIP_KIND_XORSUM) w_sum += weight(i);
       size_t a = 0; uint64_t acc = 0, upto = 0;
       for (size_t i = 0; i < n_sel; i++) {
-        if (local[i].kind != MSPACK_HIP_KIND_XORSUM) acc += local[i].in_len;     // (in_sum leaves the checksum units out too)
-        const uint64_t goal = (uint64_t)((double) in_sum * (double)(upto + w[chunks.size()]) / (double) wsum);
+        if (local[i].kind != MSPACK_HIP_KIND_XORSUM) acc += weight(i);           // (the checksum units ride along)
+        const uint64_t goal = (uint64_t)((double) w_sum * (double)(upto + w[chunks.size()]) / (double) wsum);
         if (i + 1 == n_sel || (acc >= goal && chunks.size() + 1 < want)) {
           Chunk c; c.a = a; c.b = i + 1; upto += w[chunks.size()]; chunks.push_back(c); a = i + 1;
         }
@@ -1218,7 +1231,12 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     // (A Quantum unit is one long serial chain: a launch of them takes as long as its slowest folder however few there are.
     // Chunks that hold some must not queue behind each other on one compute stream: all streams then, also to the host --
     // with 16 384 checksum units beside 512 folders config 4 was cut into four chunks on two streams: 794 ms instead of 416)
-    const size_t n_comp = (host_out && !has_qtm) ? std::min<size_t>(2, (size_t) cx.n_compute) : (size_t) cx.n_compute;
+    // (... unless the whole batch is small beside the chip -- config 3's 1024 intervals are 4096 tickets for 4096 waves: its four
+    // chunks' launches then fit side by side, and on two streams the second pair only waited: to the host 4.2 -> 3.3 ms,
+    // tools/sessions/gpu_r6_ab.sh; the headline batch on four streams: slower, as it was)
+    static const int ncomp_host = env_int("MSPACK_HIP_NCOMP_HOST", 0, 0, MSPK_MAX_STREAMS - 2);
+    const size_t few = (ncomp_host > 0) ? (size_t) ncomp_host : (n_frames <= 6144u ? (size_t) cx.n_compute : 2u);
+    const size_t n_comp = (host_out && !has_qtm) ? std::min<size_t>(few, (size_t) cx.n_compute) : (size_t) cx.n_compute;
     hipStream_t st_in = cx.st[0], st_out = one ? cx.st[0] : cx.st[1];
     TRY(hipMemcpyAsync(d_units, local.data(), n_sel * sizeof(mspack_hip_unit), hipMemcpyHostToDevice, st_in));
     TRY(hipMemcpyAsync(d_order, order.data(), n_sel * sizeof(uint32_t), hipMemcpyHostToDevice, st_in));
@@ -1412,6 +1430,8 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
         for (; staged_done < staged_upto[ci]; staged_done++) memcpy(staged[staged_done].host, (const char *) cx.h_stage.p + staged[staged_done].off, staged[staged_done].n);
         hand_over(chunks[ci].a, chunks[ci].b);
         handed = chunks[ci].b;
+        if (trace) fprintf(stderr, "mspack_hip[dev %d]: chunk %zu of %zu (%zu units, %.1f MB out) handed over %.2f ms after the call began\n", dev, ci, chunks.size(),
+                           chunks[ci].b - chunks[ci].a, (chunks[ci].out_hi - chunks[ci].out_lo) / 1e6, tms(t0, tnow()));
         { std::lock_guard<std::mutex> lk(pg->mu); pg->done = ci + 1; }
         pg->cv.notify_all();
       }

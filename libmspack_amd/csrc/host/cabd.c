@@ -75,6 +75,10 @@ struct folder_p {
    * file list for all folders, so that a folder's files are found without walking the whole list per folder) */
   unsigned int file_count;
   struct mscabd_file *first_file;
+  /* the folder's batch while it is still running (mspack_hip.h: jobs): unit job_k of it -- not decoded yet, and not to be gathered
+   * again; folder_settle() waits for the unit and takes its result over */
+  struct cab_batch *job;
+  size_t job_k;
 };
 struct cab_p {
   struct mscabd_cabinet base;
@@ -168,7 +172,9 @@ static char *read_cstring(struct mspack_system *sys, struct mspack_file *fh, int
   return str;
 }
 
+static void batch_abandon(struct mspack_system *sys, struct cab_batch *B);
 static void free_folder_cache(struct mspack_system *sys, struct folder_p *f) {
+  if (f->job) batch_abandon(sys, f->job);                 /* (its batch is still running: to its end, nothing of it kept) */
   if (f->store && --f->store->refs == 0) { mspack_arena_free(sys, f->store->base); sys->free(f->store); }
   f->store = NULL; f->dec = NULL; f->decoded = 0;
   sys->free(f->rep); f->rep = NULL; f->rep_n = 0;
@@ -923,6 +929,62 @@ static int gather_folder(struct cabd_p *self, struct gathered *g, struct in_aren
   return err;
 }
 
+/* one batch of a cabinet's folders: what it reads (units, the input arena with the block parts' checksums noted in it), what it
+ * writes (results, the output arena = the folders' decoded bytes afterwards) and, while it runs as a job, the job */
+struct cab_batch {
+  struct mspack_system *sys;
+  struct gathered *gs; mspack_hip_unit *units; mspack_hip_result *res; struct ck_list ck; struct in_arena A;
+  unsigned char *out_arena; struct out_store *store;
+  size_t n, nu, left;                  /* folders, units (folders + checksum parts), folders that have not settled yet */
+  int pinned;
+  mspack_hip_job *job;
+};
+
+/* folder k of the batch is through: its result and its place in the output arena become the folder's decoded state */
+static void batch_take_folder(struct cab_batch *B, size_t k)
+{
+  struct mspack_system *sys = B->sys;
+  struct gathered *gs = B->gs;
+  const mspack_hip_unit *units = B->units;
+  const mspack_hip_result *res = B->res;
+  unsigned char *const out_arena = B->out_arena;
+  struct folder_p *fp = gs[k].fol;
+  int method = fp->base.comp_type & 0x0F;
+  fp->total = gs[k].total; fp->read_err = gs[k].read_err; fp->hard_eof = gs[k].hard_eof;
+  fp->store = B->store; B->store->refs++;
+  fp->dec = out_arena + units[k].out_off;
+  if (method >= 1 && method <= 3) {
+    unsigned int g = res[k].good_len > gs[k].total ? gs[k].total : res[k].good_len;
+    fp->good_len = g; fp->dec_err = res[k].err; fp->res_flags = res[k].flags;
+    fp->written = res[k].out_len > gs[k].total ? gs[k].total : res[k].out_len;
+    if (method == MSCAB_COMP_MSZIP && res[k].err == MSPACK_ERR_OK && !(units[k].flags & MSPACK_HIP_UF_MSZIP_REPAIR) &&
+        res[k].in_next && res[k].in_next <= CAB_BLOCKMAX && res[k].out_len == gs[k].total) {
+      /* mszipd never reads a CFDATA header's uncompressed size: a block is as long as its deflate stream (mszipd.c:377-460), and
+       * what the folder's last block inflated to beyond the headers' sum is there for the files that ask for it (the unit's
+       * slack holds those bytes, in_next says how many: DESIGN.md section 8g) */
+      fp->total += res[k].in_next; fp->good_len = fp->total; fp->written = fp->total;
+    }
+    sys->free(fp->marks); fp->marks = NULL; fp->n_marks = 0; fp->mark_log = NULL;
+    if (units[k].flags & MSPACK_HIP_UF_QTM_MARKS) {
+      fp->marks = gs[k].marks; fp->n_marks = gs[k].n_marks; gs[k].marks = NULL;
+      fp->mark_log = out_arena + units[k].out_off + (((size_t) gs[k].total + 15) & ~(size_t) 15);
+    }
+    if (units[k].flags & MSPACK_HIP_UF_MSZIP_LOG) {
+      const unsigned char *lg = out_arena + units[k].out_off + (((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15);
+      unsigned int cnt = rd_le32(lg), i;
+      if (cnt > (unsigned int) units[k].e8_base) cnt = (unsigned int) units[k].e8_base;
+      sys->free(fp->rep); fp->rep = NULL; fp->rep_n = 0;
+      if (cnt && (fp->rep = (unsigned int *) sys->alloc(sys, (size_t) cnt * 2 * sizeof(unsigned int)))) {
+        for (i = 0; i < 2 * cnt; i++) fp->rep[i] = rd_le32(lg + 4 + 4 * (size_t) i);
+        fp->rep_n = cnt;
+      }
+    }
+  }
+  else { fp->good_len = 0; fp->written = 0; fp->dec_err = MSPACK_ERR_DATAFORMAT; fp->res_flags = 0; }   /* cabd.c:1254 */
+  fp->n_frames_good = fp->good_len / CAB_BLOCKMAX;
+  fp->decoded = 1;
+}
+
 /* decode every not-yet-decoded folder of `cab` (budget permitting, `want` always) in ONE batch */
 static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_p *want)
 {
@@ -933,6 +995,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   mspack_hip_result *res;
   struct in_arena A = { NULL, 0, 0 };
   struct ck_list ck = { NULL, 0, 0, 0 };
+  struct cab_batch B;
   unsigned char *out_arena = NULL;
   size_t n = 0, k, out_bytes = 0, budget = (size_t) self->cache_mb << 20, used = 0, nu;
   int err = MSPACK_ERR_OK, rc, again = 0;
@@ -962,7 +1025,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   for (fo = cab->base.folders; fo; fo = fo->next) {
     struct folder_p *fp = (struct folder_p *) fo;
     size_t est = (size_t) fo->num_blocks * CAB_BLOCKMAX;
-    if (fp->decoded) continue;
+    if (fp->decoded || fp->job) continue;
     if ((fo->comp_type & 0x0F) == MSCAB_COMP_NONE || fp->merge_prev) continue;   /* streamed / not extractable */
     if (fp != want && used + est > budget) continue;
     gs[n].fol = fp;
@@ -1025,9 +1088,28 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     size_t nhip = 0;
     for (k = 0; k < n; k++) if (units[k].kind != 0) nhip++;
     memset(res, 0, nu * sizeof(*res));
+    B.sys = sys; B.gs = gs; B.units = units; B.res = res; B.ck = ck; B.A = A; B.out_arena = out_arena; B.n = n; B.nu = nu;
+    B.store = NULL; B.job = NULL; B.left = 0; B.pinned = 0;
     if (nhip || ck.n) {                  /* (checksum units alone are a batch too: stored folders' parts -- ADVICE round 5) */
       /* the arena was written a moment ago: page-locked, its copy to the device is plain DMA (mspack_hip.h; advice only) */
       const int pinned = A.len >= ((size_t) 4 << 20) && !mspack_arena_is_locked(A.p) && mspack_hip_pin(A.p, mspack_arena_room(A.len + 64)) == 0;
+      /* Several folders on one device: the batch runs as a job (mspack_hip.h) -- this extract() returns when ITS folder is through,
+       * the caller writes the file while the other folders are decoded and copied back, and every later extract() waits for its
+       * own folder only (folder_settle).  Everything the batch reads and writes belongs to it until then: struct cab_batch. */
+      struct cab_batch *J = NULL;
+      if (n >= 2 && self->devices <= 1 && (J = (struct cab_batch *) sys->alloc(sys, sizeof(*J)))) {
+        *J = B; J->pinned = pinned;
+        if ((J->store = (struct out_store *) sys->alloc(sys, sizeof(*J->store)))) {
+          J->store->base = out_arena; J->store->refs = 1;             /* (the batch's own hold on the arena) */
+          J->job = mspack_hip_decode_batch_begin(units, nu, A.p, A.len + 64, out_arena, out_bytes + 64, res);
+        }
+        if (!J->job) { sys->free(J->store); sys->free(J); J = NULL; }
+      }
+      if (J) {
+        for (k = 0; k < n; k++) { gs[k].fol->job = J; gs[k].fol->job_k = k; }
+        J->left = n;
+        return MSPACK_ERR_OK;                                          /* (folder_settle takes it from here) */
+      }
       /* kinds other than 1..3 are answered with MSPACK_ERR_ARGS by the kernels; fix them up below */
       rc = (self->devices > 1)
         ? mspack_hip_decode_batch_multi(units, nu, A.p, A.len + 64, out_arena, out_bytes + 64, res, self->devices)
@@ -1046,59 +1128,70 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
   }
   if (!err && n) {
     /* the output arena stays: every folder's decoded bytes are where the batch put them (no copy per folder) */
-    struct out_store *store = (struct out_store *) sys->alloc(sys, sizeof(*store));
-    if (!store) err = MSPACK_ERR_NOMEMORY;
-    else { store->base = out_arena; store->refs = 0; }
+    if (!(B.store = (struct out_store *) sys->alloc(sys, sizeof(*B.store)))) err = MSPACK_ERR_NOMEMORY;
+    else { B.store->base = out_arena; B.store->refs = 0; }
     for (k = 0; k < n && !err; k++) {
       struct folder_p *fp = gs[k].fol;
-      int method = fp->base.comp_type & 0x0F;
       if (fp->cksum_on_host && ck.n) {                     /* (flagged just now?  It was decoded past a bad block: not kept) */
         size_t j; int mine = 0;
         for (j = 0; j < ck.n && !mine; j++) mine = ck.p[j].owner == (unsigned int) k;
         if (mine) continue;
       }
-      fp->total = gs[k].total; fp->read_err = gs[k].read_err; fp->hard_eof = gs[k].hard_eof;
-      fp->store = store; store->refs++;
-      fp->dec = out_arena + units[k].out_off;
-      if (method >= 1 && method <= 3) {
-        unsigned int g = res[k].good_len > gs[k].total ? gs[k].total : res[k].good_len;
-        fp->good_len = g; fp->dec_err = res[k].err; fp->res_flags = res[k].flags;
-        fp->written = res[k].out_len > gs[k].total ? gs[k].total : res[k].out_len;
-        if (method == MSCAB_COMP_MSZIP && res[k].err == MSPACK_ERR_OK && !(units[k].flags & MSPACK_HIP_UF_MSZIP_REPAIR) &&
-            res[k].in_next && res[k].in_next <= CAB_BLOCKMAX && res[k].out_len == gs[k].total) {
-          /* mszipd never reads a CFDATA header's uncompressed size: a block is as long as its deflate stream (mszipd.c:377-460), and
-           * what the folder's last block inflated to beyond the headers' sum is there for the files that ask for it (the unit's
-           * slack holds those bytes, in_next says how many: DESIGN.md section 8g) */
-          fp->total += res[k].in_next; fp->good_len = fp->total; fp->written = fp->total;
-        }
-        sys->free(fp->marks); fp->marks = NULL; fp->n_marks = 0; fp->mark_log = NULL;
-        if (units[k].flags & MSPACK_HIP_UF_QTM_MARKS) {
-          fp->marks = gs[k].marks; fp->n_marks = gs[k].n_marks; gs[k].marks = NULL;
-          fp->mark_log = out_arena + units[k].out_off + (((size_t) gs[k].total + 15) & ~(size_t) 15);
-        }
-        if (units[k].flags & MSPACK_HIP_UF_MSZIP_LOG) {
-          const unsigned char *lg = out_arena + units[k].out_off + (((size_t) gs[k].total + 32768 + 15) & ~(size_t) 15);
-          unsigned int cnt = rd_le32(lg), i;
-          if (cnt > (unsigned int) units[k].e8_base) cnt = (unsigned int) units[k].e8_base;
-          sys->free(fp->rep); fp->rep = NULL; fp->rep_n = 0;
-          if (cnt && (fp->rep = (unsigned int *) sys->alloc(sys, (size_t) cnt * 2 * sizeof(unsigned int)))) {
-            for (i = 0; i < 2 * cnt; i++) fp->rep[i] = rd_le32(lg + 4 + 4 * (size_t) i);
-            fp->rep_n = cnt;
-          }
-        }
-      }
-      else { fp->good_len = 0; fp->written = 0; fp->dec_err = MSPACK_ERR_DATAFORMAT; fp->res_flags = 0; }   /* cabd.c:1254 */
-      fp->n_frames_good = fp->good_len / CAB_BLOCKMAX;
-      fp->decoded = 1;
+      batch_take_folder(&B, k);
     }
-    if (store && store->refs) out_arena = NULL;            /* the folders own it now */
-    else if (store) sys->free(store);
+    if (B.store && B.store->refs) out_arena = NULL;        /* the folders own it now */
+    else if (B.store) sys->free(B.store);
   }
   for (k = 0; k < n; k++) { sys->free(gs[k].boff); sys->free(gs[k].marks); }
   sys->free(gs); sys->free(units); sys->free(res); sys->free(ck.p); mspack_arena_free(sys, A.p); mspack_arena_free(sys, out_arena);
   /* (the folders flagged above defer nothing the second time: one more round at most) */
   if (!err && again) return decode_cabinet(self, cab, want);
   return err;
+}
+
+/* ---- a cabinet's batch as a job ---- */
+/* the batch to its end and everything it held given back; the folders that have not taken their results stay undecoded */
+static void batch_release(struct mspack_system *sys, struct cab_batch *B)
+{
+  size_t k;
+  if (B->job) { (void) mspack_hip_job_end(B->job); B->job = NULL; }
+  if (B->pinned) mspack_hip_unpin(B->A.p);
+  for (k = 0; k < B->n; k++) {
+    if (B->gs[k].fol) { B->gs[k].fol->job = NULL; B->gs[k].fol = NULL; }
+    sys->free(B->gs[k].boff); sys->free(B->gs[k].marks);
+  }
+  sys->free(B->gs); sys->free(B->units); sys->free(B->res); sys->free(B->ck.p); mspack_arena_free(sys, B->A.p);
+  if (B->store && --B->store->refs == 0) { mspack_arena_free(sys, B->store->base); sys->free(B->store); }
+  sys->free(B);
+}
+static void batch_abandon(struct mspack_system *sys, struct cab_batch *B) { batch_release(sys, B); }
+
+/* a folder whose batch is still running: wait for its unit (and its blocks' checksum units), take the result over.  Returns 0 with
+ * the folder decoded -- or flagged and NOT decoded (a block failed its checksum on the device: the caller has it gathered again,
+ * the reference's way) --, or the error of a batch that failed as a whole */
+static int folder_settle(struct cabd_p *self, struct folder_p *fp)
+{
+  struct mspack_system *sys = self->system;
+  struct cab_batch *B = fp->job;
+  const size_t k = fp->job_k;
+  size_t j;
+  int rc = mspack_hip_job_wait_unit(B->job, k), bad = 0;
+  for (j = 0; j < B->ck.n && !rc; j++)
+    if (B->ck.p[j].owner == (unsigned int) k) {
+      rc = mspack_hip_job_wait_unit(B->job, B->n + j);
+      if (!rc && (B->res[B->n + j].err != MSPACK_ERR_OK || B->res[B->n + j].in_next != B->ck.p[j].want)) bad = 1;
+    }
+  if (rc) {
+    /* the batch failed as a whole: what decode_cabinet says of a failed call -- none of its folders is decoded */
+    batch_release(sys, B);
+    sys->message(NULL, "GPU batch decode failed: %s", mspack_hip_last_error());
+    return MSPACK_ERR_DECRUNCH;
+  }
+  if (bad) fp->cksum_on_host = 1;                          /* (decoded past a bad block: not kept) */
+  else batch_take_folder(B, k);
+  fp->job = NULL; B->gs[k].fol = NULL;
+  if (--B->left == 0) batch_release(sys, B);
+  return MSPACK_ERR_OK;
 }
 
 /* Quantum: what the codec holds back when a request ends at `pos` -- the batch's answer for the folder's marks (0: nothing, or not
@@ -1210,9 +1303,14 @@ static int cabd_extract(struct mscab_decompressor *base, struct mscabd_file *fil
   self->last_folder = fol;
   if ((fol->base.comp_type & 0x0F) == MSCAB_COMP_NONE) { self->live_folder = NULL; self->msg_folder = NULL; return stored_extract(self, fol, file, filelen, filename); }
 
-  if (!fol->decoded) {
-    int err = decode_cabinet(self, (struct cab_p *) fol->data.cab, fol);
-    if (err) return self->error = err;
+  /* (a folder whose batch is still running waits for its own unit; one that comes out of that flagged -- a block failed its
+   * checksum on the device -- is gathered again, which may start the next batch) */
+  {
+    int tries;
+    for (tries = 0; !fol->decoded && tries < 4; tries++) {
+      int err = fol->job ? folder_settle(self, fol) : decode_cabinet(self, (struct cab_p *) fol->data.cab, fol);
+      if (err) return self->error = err;
+    }
   }
   self->read_error = fol->read_err;
   if (self->live_folder != fol || self->live_offset > file->offset) {    /* cabd.c:1136: another folder, or an earlier offset */

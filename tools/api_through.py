@@ -22,4 +22,4 @@ for c in which:
         img, plain, _sl = A.build_config3_chm(M); s = measure("chm", img, plain)
     else:
         img, plain = A.build_config4_cab(M); s = measure("cab", img, plain)
-    print("config %d hugepages=%s: %.1f MB/s  %s" % (c, os.environ.get("MSPACK_ARENA_HUGEPAGES", "1"), s["MBps"], json.dumps(s["split_ms"])))
+    print("config %d hugepages=%s: %.1f MB/s (first extract() %.2f ms of %.2f)  %s" % (c, os.environ.get("MSPACK_ARENA_HUGEPAGES", "1"), s["MBps"], s["first_extract_ms"], s["seconds"] * 1e3, json.dumps(s["split_ms"])))
