@@ -936,6 +936,8 @@ struct cab_batch {
   struct gathered *gs; mspack_hip_unit *units; mspack_hip_result *res; struct ck_list ck; struct in_arena A;
   unsigned char *out_arena; struct out_store *store;
   size_t n, nu, left;                  /* folders, units (folders + checksum parts), folders that have not settled yet */
+  size_t *ck_lo;                       /* n + 1 entries: folder k's checksum parts are ck.p[ck_lo[k] .. ck_lo[k + 1]) -- the gather notes
+                                          them folder by folder; NULL: not in that order (or no memory), every part is looked at */
   int pinned;
   mspack_hip_job *job;
 };
@@ -1089,7 +1091,7 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
     for (k = 0; k < n; k++) if (units[k].kind != 0) nhip++;
     memset(res, 0, nu * sizeof(*res));
     B.sys = sys; B.gs = gs; B.units = units; B.res = res; B.ck = ck; B.A = A; B.out_arena = out_arena; B.n = n; B.nu = nu;
-    B.store = NULL; B.job = NULL; B.left = 0; B.pinned = 0;
+    B.store = NULL; B.job = NULL; B.left = 0; B.pinned = 0; B.ck_lo = NULL;
     if (nhip || ck.n) {                  /* (checksum units alone are a batch too: stored folders' parts -- ADVICE round 5) */
       /* the arena was written a moment ago: page-locked, its copy to the device is plain DMA (mspack_hip.h; advice only) */
       const int pinned = A.len >= ((size_t) 4 << 20) && !mspack_arena_is_locked(A.p) && mspack_hip_pin(A.p, mspack_arena_room(A.len + 64)) == 0;
@@ -1104,6 +1106,17 @@ static int decode_cabinet(struct cabd_p *self, struct cab_p *cab, struct folder_
           J->job = mspack_hip_decode_batch_begin(units, nu, A.p, A.len + 64, out_arena, out_bytes + 64, res);
         }
         if (!J->job) { sys->free(J->store); sys->free(J); J = NULL; }
+      }
+      if (J && ck.n && (J->ck_lo = (size_t *) sys->alloc(sys, (n + 1) * sizeof(size_t)))) {
+        /* (a folder's parts by index: looking at all parts for every folder was 4096 x 4096 steps for config 2 -- 7 ms of 24) */
+        size_t j = 0, f;
+        int sorted = 1;
+        for (f = 0; f <= n; f++) {
+          J->ck_lo[f] = j;
+          while (j < ck.n && ck.p[j].owner == (unsigned int) f) j++;
+        }
+        if (j != ck.n) sorted = 0;
+        if (!sorted) { sys->free(J->ck_lo); J->ck_lo = NULL; }
       }
       if (J) {
         for (k = 0; k < n; k++) { gs[k].fol->job = J; gs[k].fol->job_k = k; }
@@ -1160,7 +1173,7 @@ static void batch_release(struct mspack_system *sys, struct cab_batch *B)
     if (B->gs[k].fol) { B->gs[k].fol->job = NULL; B->gs[k].fol = NULL; }
     sys->free(B->gs[k].boff); sys->free(B->gs[k].marks);
   }
-  sys->free(B->gs); sys->free(B->units); sys->free(B->res); sys->free(B->ck.p); mspack_arena_free(sys, B->A.p);
+  sys->free(B->gs); sys->free(B->units); sys->free(B->res); sys->free(B->ck.p); sys->free(B->ck_lo); mspack_arena_free(sys, B->A.p);
   if (B->store && --B->store->refs == 0) { mspack_arena_free(sys, B->store->base); sys->free(B->store); }
   sys->free(B);
 }
@@ -1176,7 +1189,8 @@ static int folder_settle(struct cabd_p *self, struct folder_p *fp)
   const size_t k = fp->job_k;
   size_t j;
   int rc = mspack_hip_job_wait_unit(B->job, k), bad = 0;
-  for (j = 0; j < B->ck.n && !rc; j++)
+  const size_t j_lo = B->ck_lo ? B->ck_lo[k] : 0, j_hi = B->ck_lo ? B->ck_lo[k + 1] : B->ck.n;
+  for (j = j_lo; j < j_hi && !rc; j++)
     if (B->ck.p[j].owner == (unsigned int) k) {
       rc = mspack_hip_job_wait_unit(B->job, B->n + j);
       if (!rc && (B->res[B->n + j].err != MSPACK_ERR_OK || B->res[B->n + j].in_next != B->ck.p[j].want)) bad = 1;
