@@ -1131,11 +1131,12 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       // shares of the input bytes.  MSPACK_HIP_CHUNK_SHAPE: 0 equal (to the device: the default); 1 = 1 : 1 : 2 : 4 ... (measured
       // at the headline: to the device 4.55 ms against 4.74, to the host 8.06 against 7.62); 2 = a first chunk of half a
       // share (to the host: the default -- the copy-back, the longest leg, starts as soon as the first chunk is through)
-      static const int shape_env = getenv("MSPACK_HIP_CHUNK_SHAPE") ? env_int("MSPACK_HIP_CHUNK_SHAPE", 0, 0, 2) : -1;
+      static const int shape_env = getenv("MSPACK_HIP_CHUNK_SHAPE") ? env_int("MSPACK_HIP_CHUNK_SHAPE", 0, 0, 3) : -1;
       const int shape = shape_env >= 0 ? shape_env : (host_out ? 2 : 0);
       uint64_t wsum = 0, w[MSPK_MAX_CHUNKS];
       for (size_t k = 0; k < want; k++) {
-        w[k] = shape == 1 ? (k >= 2 ? (uint64_t) 2 << (k - 1) : 2) : (shape == 2 && k == 0 && want >= 3 ? 1 : 2);
+        static const uint64_t ramp[MSPK_MAX_CHUNKS] = { 4, 6, 9, 13, 20, 30, 45, 67 };          // (3: every chunk half as large again)
+        w[k] = shape == 3 ? ramp[k] : shape == 1 ? (k >= 2 ? (uint64_t) 2 << (k - 1) : 2) : (shape == 2 && k == 0 && want >= 3 ? 1 : 2);
         wsum += w[k];
       }
       // (a unit weighs what it reads that the NEXT unit does not start inside: a CHM's intervals are all given "to the end of the
@@ -1351,7 +1352,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
           while (issued.load(std::memory_order_acquire) <= ci) { if (stop.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
           be = hipStreamWaitEvent(st_out, cx.ev_done[ci], 0);
           if (be == hipSuccess) be = copy_out(base + c.out_lo, base + c.out_hi, d_out + (c.out_lo - out_lo));
-          if (be == hipSuccess && pg) be = hipEventRecord(cx.ev_back[ci], st_out);
+          if (be == hipSuccess && (pg || trace)) be = hipEventRecord(cx.ev_back[ci], st_out);
           if (be == hipSuccess) { staged_upto[ci] = n_staged; back_issued.store(ci + 1, std::memory_order_release); }
         }
         back_err = be;
@@ -1420,7 +1421,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       }
     };
     size_t handed = 0, staged_done = 0;                    // units / staged pieces already in the caller's memory
-    if (pg && back_started) {
+    if ((pg || trace) && back_started) {
       // a job: chunk by chunk as the copies back end -- the caller (mspack_hip_job_wait_unit) takes a chunk's bytes while the later
       // chunks are still being decoded and copied
       for (size_t ci = 0; ci < chunks.size(); ci++) {
@@ -1432,8 +1433,10 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
         handed = chunks[ci].b;
         if (trace) fprintf(stderr, "mspack_hip[dev %d]: chunk %zu of %zu (%zu units, %.1f MB out) handed over %.2f ms after the call began\n", dev, ci, chunks.size(),
                            chunks[ci].b - chunks[ci].a, (chunks[ci].out_hi - chunks[ci].out_lo) / 1e6, tms(t0, tnow()));
-        { std::lock_guard<std::mutex> lk(pg->mu); pg->done = ci + 1; }
-        pg->cv.notify_all();
+        if (pg) {
+          { std::lock_guard<std::mutex> lk(pg->mu); pg->done = ci + 1; }
+          pg->cv.notify_all();
+        }
       }
     }
     if (back.joinable()) {

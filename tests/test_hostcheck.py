@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BUILD = os.path.join(ROOT, "tests", "hostcheck", "build_hostcheck.sh")
 FOUR_CHUNKS = {"MSPACK_HIP_CHUNK_BYTES": "65536", "MSPACK_HIP_CHUNK_UNITS": "16"}     # (the copy-back thread only runs for several chunks)
 SCENARIOS = [("partial_pins", ["2"], {}), ("partial_pins", ["2"], FOUR_CHUNKS), ("ownership", [], {}), ("ownership", [], FOUR_CHUNKS),
-             ("shards_threads", [], FOUR_CHUNKS), ("lifetimes", ["3"], {}), ("lifetimes", ["2"], FOUR_CHUNKS),
-             ("jobs", ["6"], FOUR_CHUNKS), ("jobs", ["3"], {})]
+             ("shards_threads", [], FOUR_CHUNKS), ("lifetimes", ["3"], {}), ("lifetimes", ["1"], FOUR_CHUNKS),
+             ("jobs", ["3"], FOUR_CHUNKS), ("jobs", ["1"], {})]
 
 
 @pytest.fixture(scope="module")
