@@ -1131,12 +1131,13 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       // shares of the input bytes.  MSPACK_HIP_CHUNK_SHAPE: 0 equal (to the device: the default); 1 = 1 : 1 : 2 : 4 ... (measured
       // at the headline: to the device 4.55 ms against 4.74, to the host 8.06 against 7.62); 2 = a first chunk of half a
       // share (to the host: the default -- the copy-back, the longest leg, starts as soon as the first chunk is through)
-      static const int shape_env = getenv("MSPACK_HIP_CHUNK_SHAPE") ? env_int("MSPACK_HIP_CHUNK_SHAPE", 0, 0, 3) : -1;
+      static const int shape_env = getenv("MSPACK_HIP_CHUNK_SHAPE") ? env_int("MSPACK_HIP_CHUNK_SHAPE", 0, 0, 4) : -1;
       const int shape = shape_env >= 0 ? shape_env : (host_out ? 2 : 0);
       uint64_t wsum = 0, w[MSPK_MAX_CHUNKS];
       for (size_t k = 0; k < want; k++) {
         static const uint64_t ramp[MSPK_MAX_CHUNKS] = { 4, 6, 9, 13, 20, 30, 45, 67 };          // (3: every chunk half as large again)
-        w[k] = shape == 3 ? ramp[k] : shape == 1 ? (k >= 2 ? (uint64_t) 2 << (k - 1) : 2) : (shape == 2 && k == 0 && want >= 3 ? 1 : 2);
+        static const uint64_t fall[MSPK_MAX_CHUNKS] = { 8, 6, 4, 3, 2, 2, 1, 1 };               // (4: the last chunks -- whose launches end the call -- small)
+        w[k] = shape == 4 ? fall[k] : shape == 3 ? ramp[k] : shape == 1 ? (k >= 2 ? (uint64_t) 2 << (k - 1) : 2) : (shape == 2 && k == 0 && want >= 3 ? 1 : 2);
         wsum += w[k];
       }
       // (a unit weighs what it reads that the NEXT unit does not start inside: a CHM's intervals are all given "to the end of the
@@ -1234,7 +1235,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     // with 16 384 checksum units beside 512 folders config 4 was cut into four chunks on two streams: 794 ms instead of 416)
     // (... unless the whole batch is small beside the chip -- config 3's 1024 intervals are 4096 tickets for 4096 waves: its four
     // chunks' launches then fit side by side, and on two streams the second pair only waited: to the host 4.2 -> 3.3 ms,
-    // tools/sessions/gpu_r6_ab.sh; the headline batch on four streams: slower, as it was)
+    // tools/sessions/round6_sessions.md: session AB; the headline batch on four streams: slower, as it was)
     static const int ncomp_host = env_int("MSPACK_HIP_NCOMP_HOST", 0, 0, MSPK_MAX_STREAMS - 2);
     const size_t few = (ncomp_host > 0) ? (size_t) ncomp_host : (n_frames <= 6144u ? (size_t) cx.n_compute : 2u);
     const size_t n_comp = (host_out && !has_qtm) ? std::min<size_t>(few, (size_t) cx.n_compute) : (size_t) cx.n_compute;
@@ -1665,7 +1666,7 @@ void mspack_hip_stage_free(void *p)
   // what stays page-locked while nobody uses it is bounded too (a process that once opened a large cabinet kept
   // hundreds of MiB locked for good): MSPACK_HIP_PINNED_IDLE_MB, default 768 -- the arenas of the largest single cabinet among
   // BASELINE's configs (config 4: 190 MB in + 528 MB out) come back at once for the next one (with 512 its output arena was locked anew
-  // on every open-and-extract: 175 ms of a 620 ms run, tools/sessions/gpu_r6_v.sh); beyond that the idle blocks that have been idle
+  // on every open-and-extract: 175 ms of a 620 ms run, tools/sessions/round6_sessions.md: session V); beyond that the idle blocks that have been idle
   // LONGEST go back to the system (the largest first, as it was, gave config 4's output arena back whenever a process had opened
   // other cabinets before: the blocks just handed back are the ones the next cabinet of that size will ask for)
   static const size_t idle_limit = (size_t) env_int("MSPACK_HIP_PINNED_IDLE_MB", 768, 0, 1 << 20) << 20;
