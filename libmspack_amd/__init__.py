@@ -147,6 +147,19 @@ def decode_batch(units, in_arena, out_bytes, n_devices=1, refs=None):
     if n_devices > 1:
         rc = L.mspack_hip_decode_batch_multi(units.ctypes.data, len(units), in_arena.ctypes.data, in_arena.size,
                                              out.ctypes.data, out.size, res.ctypes.data, n_devices)
+    elif os.environ.get("MSPACK_PY_VIA_JOBS") and len(units):
+        # (parity sweeps of the job entry points: the same batch through _begin / _wait_unit / _end, a third of the units waited for
+        # one by one -- their results are looked at the moment the wait returns)
+        job = L.mspack_hip_decode_batch_begin(units.ctypes.data, len(units), in_arena.ctypes.data, in_arena.size,
+                                              out.ctypes.data, out.size, res.ctypes.data)
+        if not job:
+            raise MspackHipError("mspack_hip_decode_batch_begin returned no job")
+        res["err"] = 0x7777
+        for i in np.argsort(units["in_off"], kind="stable")[::3]:
+            if L.mspack_hip_job_wait_unit(job, int(i)) == 0 and int(res["err"][int(i)]) == 0x7777:
+                L.mspack_hip_job_end(job)
+                raise MspackHipError("unit %d: the wait returned before the unit's result was written" % int(i))
+        rc = L.mspack_hip_job_end(job)
     else:
         rc = L.mspack_hip_decode_batch(units.ctypes.data, len(units), in_arena.ctypes.data, in_arena.size,
                                        out.ctypes.data, out.size, res.ctypes.data)

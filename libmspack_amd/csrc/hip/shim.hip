@@ -1128,16 +1128,24 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     }
     std::vector<Chunk> chunks;
     {
-      // shares of the input bytes.  MSPACK_HIP_CHUNK_SHAPE: 0 equal (to the device: the default); 1 = 1 : 1 : 2 : 4 ... (measured
-      // at the headline: to the device 4.55 ms against 4.74, to the host 8.06 against 7.62); 2 = a first chunk of half a
-      // share (to the host: the default -- the copy-back, the longest leg, starts as soon as the first chunk is through)
+      // shares of the input bytes.  MSPACK_HIP_CHUNK_SHAPE: 0 equal; 1 = 1 : 1 : 2 : 4 ... (to the device: the default -- the small
+      // chunks get the launches going while most of the input is still on its way, and the LAST chunk, whose launches end the call,
+      // is the large one that fills the chip: headline 4.64-4.84 -> 4.05-4.15 ms, every growing shape within 0.1 ms of it, falling
+      // ones and more than four chunks slower; 1024 and 16 384 units: no difference -- profiles/round6_jobs.txt; round 3 had it at
+      // 4.55 against 4.74 and kept the equal shares); 2 = a first chunk of half a share (to the host: the default -- the copy-back,
+      // the longest leg, starts as soon as the first chunk is through; 1 there: 8.2 against 7.6 ms); 3, 4: a x1.5 ramp, falling shares
+      // (sweeps)
       static const int shape_env = getenv("MSPACK_HIP_CHUNK_SHAPE") ? env_int("MSPACK_HIP_CHUNK_SHAPE", 0, 0, 4) : -1;
-      const int shape = shape_env >= 0 ? shape_env : (host_out ? 2 : 0);
+      const int shape = shape_env >= 0 ? shape_env : (host_out ? 2 : 1);
       uint64_t wsum = 0, w[MSPK_MAX_CHUNKS];
+      // (MSPACK_HIP_CHUNK_WEIGHTS="1,1,2,4": the shares spelled out -- sweeps)
+      static const char *const w_env = getenv("MSPACK_HIP_CHUNK_WEIGHTS");
+      uint64_t w_given[MSPK_MAX_CHUNKS]; size_t n_given = 0;
+      if (w_env) for (const char *q = w_env; *q && n_given < MSPK_MAX_CHUNKS; ) { const long v = strtol(q, (char **) &q, 10); w_given[n_given++] = v > 0 ? (uint64_t) v : 1u; while (*q == ',' || *q == ' ') q++; }
       for (size_t k = 0; k < want; k++) {
         static const uint64_t ramp[MSPK_MAX_CHUNKS] = { 4, 6, 9, 13, 20, 30, 45, 67 };          // (3: every chunk half as large again)
         static const uint64_t fall[MSPK_MAX_CHUNKS] = { 8, 6, 4, 3, 2, 2, 1, 1 };               // (4: the last chunks -- whose launches end the call -- small)
-        w[k] = shape == 4 ? fall[k] : shape == 3 ? ramp[k] : shape == 1 ? (k >= 2 ? (uint64_t) 2 << (k - 1) : 2) : (shape == 2 && k == 0 && want >= 3 ? 1 : 2);
+        w[k] = (k < n_given) ? w_given[k] : shape == 4 ? fall[k] : shape == 3 ? ramp[k] : shape == 1 ? (k >= 2 ? (uint64_t) 2 << (k - 1) : 2) : (shape == 2 && k == 0 && want >= 3 ? 1 : 2);
         wsum += w[k];
       }
       // (a unit weighs what it reads that the NEXT unit does not start inside: a CHM's intervals are all given "to the end of the
