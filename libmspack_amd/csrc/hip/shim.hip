@@ -1303,6 +1303,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
     // back_issued says the chunk's copies are on the stream)
     Staged staged[4u * MSPK_MAX_CHUNKS];
     size_t n_staged = 0, staged_upto[MSPK_MAX_CHUNKS] = { 0 };
+    double tr_locked[MSPK_MAX_CHUNKS] = { 0 }, tr_h2d[MSPK_MAX_CHUNKS] = { 0 };      // (trace: ms after the call began)
     std::atomic<size_t> back_issued{0};                    // chunks whose copies back are on st_out, ev_back recorded behind them
     std::atomic<bool> back_ended{false};
     // one span of the output, device -> caller's memory on st_out: cut at the boundaries of every registration this library
@@ -1358,6 +1359,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
           auto r0 = tnow();
           if (pin_out && any) pins.lock(ra, rb);
           pin_ms += tms(r0, tnow());
+          tr_locked[ci] = tms(t0, tnow());
           while (issued.load(std::memory_order_acquire) <= ci) { if (stop.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
           be = hipStreamWaitEvent(st_out, cx.ev_done[ci], 0);
           if (be == hipSuccess) be = copy_out(base + c.out_lo, base + c.out_hi, d_out + (c.out_lo - out_lo));
@@ -1395,6 +1397,7 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
             TRY(copy_cut(d_out + local[i].out_off - local[i].ref_len,
                          (const char *) host_out + out_lo + local[i].out_off - local[i].ref_len, local[i].ref_len,
                          hipMemcpyHostToDevice, st_in));
+      tr_h2d[ci] = tms(t0, tnow());
       if (!one) { TRY(hipEventRecord(cx.ev_in[ci], st_in)); TRY(hipStreamWaitEvent(st, cx.ev_in[ci], 0)); }
       for (unsigned k = 1; k <= MSPACK_HIP_KIND_XORSUM; k++)
         TRY(launch_kind(k, d_units, d_order + c.order_off[k], c.order_n[k], d_in, d_out, d_res, cx.d_fm.p, n_frames, c.fm_lo, c.fm_n, st,
@@ -1436,12 +1439,15 @@ static int pipeline_on_current_device(int dev, mspack_hip_unit *units, const uin
       for (size_t ci = 0; ci < chunks.size(); ci++) {
         while (back_issued.load(std::memory_order_acquire) <= ci && !back_ended.load(std::memory_order_acquire)) std::this_thread::yield();
         if (back_issued.load(std::memory_order_acquire) <= ci) break;          // (the thread gave up: its error is reported below)
+        double tr_done = 0.0;
+        if (trace) { TRY(hipEventSynchronize(cx.ev_done[ci])); tr_done = tms(t0, tnow()); }
         TRY(hipEventSynchronize(cx.ev_back[ci]));            // chunk ci's launches, its results' copy and its bytes' copies are through
         for (; staged_done < staged_upto[ci]; staged_done++) memcpy(staged[staged_done].host, (const char *) cx.h_stage.p + staged[staged_done].off, staged[staged_done].n);
         hand_over(chunks[ci].a, chunks[ci].b);
         handed = chunks[ci].b;
-        if (trace) fprintf(stderr, "mspack_hip[dev %d]: chunk %zu of %zu (%zu units, %.1f MB out) handed over %.2f ms after the call began\n", dev, ci, chunks.size(),
-                           chunks[ci].b - chunks[ci].a, (chunks[ci].out_hi - chunks[ci].out_lo) / 1e6, tms(t0, tnow()));
+        if (trace) fprintf(stderr, "mspack_hip[dev %d]: chunk %zu of %zu (%zu units, %.1f MB out): input copied %.2f, output pages seen to %.2f, launches through %.2f, "
+                           "handed over %.2f ms after the call began\n", dev, ci, chunks.size(),
+                           chunks[ci].b - chunks[ci].a, (chunks[ci].out_hi - chunks[ci].out_lo) / 1e6, tr_h2d[ci], tr_locked[ci], tr_done, tms(t0, tnow()));
         if (pg) {
           { std::lock_guard<std::mutex> lk(pg->mu); pg->done = ci + 1; }
           pg->cv.notify_all();
