@@ -617,6 +617,7 @@ static int fail(hipError_t e, const char *what) {
 // one launch per codec over a COMPACT list of that codec's units (order[0..n) = unit indices).  LZX units
 // that carry a frame table get their frames parsed by one wave each first (slots [slot_lo, slot_lo + n_slots)
 // of the work scratch belong to this launch).
+static int env_int(const char *name, int dflt, int lo, int hi);
 static const bool g_no_frames = getenv("MSPACK_HIP_NO_FRAME_PARSE") != nullptr;     // experiments: serial path only
 // MSPACK_HIP_FOLD: 0 = a folder's copies always through lzx_pipe_resolve, 1 (default) = through mspack_lzx_fold when the launch is few
 // long units, 2 = whenever the units allow it (tests, A/B runs)
@@ -717,7 +718,9 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
       LK(hipMemcpyAsync(hdr, stream ? hdr_init_stream : hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st));
       LK(launch(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr));
       const size_t tickets = 2u * n_slots;
-      const unsigned waves = (unsigned) std::min<size_t>(tickets, lzx_pipe_waves());
+      // (MSPACK_HIP_CHUNK_WAVE_DIV=d: a launch that runs beside other chunks' launches asks for tickets / d waves -- sweeps)
+      static const size_t wave_div = (size_t) env_int("MSPACK_HIP_CHUNK_WAVE_DIV", 1, 1, 16);
+      const unsigned waves = (unsigned) std::min<size_t>(alone ? tickets : std::max<size_t>(64, tickets / wave_div), lzx_pipe_waves());
       LK(launch(mspack_lzx_pipe, dim3(waves), block, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots, in, out, d_results,
                 L.meta, L.frame_unit, hdr, L.recs, pool, pool_chunks, g_fold_policy, g_ticket_order));
       // few long units: the frames' copies as fold tasks, one wave per CU (the kernel decides from what the map kernel counted and
