@@ -718,8 +718,12 @@ static hipError_t launch_kind(unsigned kind, const mspack_hip_unit *d_units, con
       LK(hipMemcpyAsync(hdr, stream ? hdr_init_stream : hdr_init, sizeof(hdr_init), hipMemcpyHostToDevice, st));
       LK(launch(mspack_lzx_pipe_map, dim3((unsigned)((n + 63) / 64)), block, st, d_units, d_order, (u32) n, L.frame_unit, L.recs, hdr));
       const size_t tickets = 2u * n_slots;
-      // (MSPACK_HIP_CHUNK_WAVE_DIV=d: a launch that runs beside other chunks' launches asks for tickets / d waves -- sweeps)
-      static const size_t wave_div = (size_t) env_int("MSPACK_HIP_CHUNK_WAVE_DIV", 1, 1, 16);
+      // A launch that runs beside other chunks' launches asks for a third as many waves as it has tickets (MSPACK_HIP_CHUNK_WAVE_DIV): with
+      // a wave for every ticket it ran unit-major, its resolve waves waiting on their slots for the parse waves -- slots the next chunk's
+      // launch could use (the first chunk's 586 intervals were through after 1.9 ms instead of the 1.25 they take alone).  Headline batch
+      // to the host 7.56-7.75 -> 7.38-7.48 ms, 1024 intervals to the device / host 2.16-2.24 / 3.38-3.47 -> 2.10-2.17 / 3.30-3.36 ms; 2 and 4
+      // within 0.05 ms of 3 (profiles/round6_jobs.txt)
+      static const size_t wave_div = (size_t) env_int("MSPACK_HIP_CHUNK_WAVE_DIV", 3, 1, 16);
       const unsigned waves = (unsigned) std::min<size_t>(alone ? tickets : std::max<size_t>(64, tickets / wave_div), lzx_pipe_waves());
       LK(launch(mspack_lzx_pipe, dim3(waves), block, st, d_units, d_order, (u32) n, (u32) slot_lo, (u32) n_slots, in, out, d_results,
                 L.meta, L.frame_unit, hdr, L.recs, pool, pool_chunks, g_fold_policy, g_ticket_order));
