@@ -189,7 +189,9 @@ size_t mspack_hip_frame_scratch_bytes(size_t n_frames_total);
 /* ---- host-buffer entry points (what the C drivers in mspack.h use) -------------------------------------
  * Same semantics with HOST pointers.  Each device keeps a persistent context (device arenas, pinned staging,
  * its streams and their events, grown or created on demand, never freed per call).  The batch is cut into up to
- * MSPACK_HIP_NCHUNKS (default 4) chunks of arena-contiguous units (each >= 8 MiB of input and >= 256 units); chunk c's
+ * MSPACK_HIP_NCHUNKS (default 4) chunks of arena-contiguous units (each >= 8 MiB of input and >= 256 units; to the device the
+ * chunks grow 1 : 1 : 2 : 4 -- the small ones get the launches going while the input is on its way, the last one fills the chip --,
+ * to the host the first chunk is half a share so that the copy back, the long leg, begins early); chunk c's
  * input is copied on the copy-in stream, its launches (one per codec over a compact list of that codec's units) run on
  * a compute stream (four of them when the output stays on the device, two when it goes back to the host), its decoded
  * span goes back on the copy-out stream -- so copies overlap decode in both directions; the three roles' streams have
