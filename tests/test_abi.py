@@ -103,6 +103,39 @@ def test_no_gpu_means_loud_failure_not_fallback(built):
         M.decode_batch(units, np.zeros(64, dtype=np.uint8), out_bytes)
 
 
+def test_no_gpu_job_fails_loudly_too(built):
+    """The job entry points (include/mspack_hip.h) on a machine without a GPU: the batch fails on its thread, every wait and the end
+    say so (negative hip error, mspack_hip_last_error set on the caller's thread), nothing is decoded -- and through the object API a
+    cabinet's extract() answers MSPACK_ERR_DECRUNCH with the driver's "GPU batch decode failed" line, as the synchronous call does."""
+    import zlib
+    import numpy as np
+    L = M.lib()
+    if L.mspack_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    units, out_bytes = M.make_units(M.KIND_LZX, [0, 32], [16, 16], [32768, 32768], window_bits=15)
+    arena = np.zeros(128, dtype=np.uint8); out = np.full(out_bytes + 64, 0x5A, dtype=np.uint8)
+    res = np.zeros(2, dtype=M.RESULT_DTYPE)
+    job = L.mspack_hip_decode_batch_begin(units.ctypes.data, 2, arena.ctypes.data, arena.size, out.ctypes.data, out.size, res.ctypes.data)
+    assert job
+    assert L.mspack_hip_job_wait_unit(job, 0) != 0 and L.mspack_hip_last_error()
+    assert L.mspack_hip_job_wait_unit(job, 1) != 0
+    assert L.mspack_hip_job_end(job) < 0
+    assert (out == 0x5A).all()
+    from libmspack_amd import api
+    plain = M.gen_plaintext(3, 0, 2 * 32768)
+    folders, files = [], []
+    for i in range(2):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        folders.append((1, [b"CK" + co.compress(plain[i * 32768:(i + 1) * 32768].tobytes()) + co.flush()], [32768]))
+        files.append((b"n%d.bin" % i, 32768, 0, i))
+    with api.Cab(M.cab_write(folders, files), mem=True) as c:
+        assert c.open_error == 0
+        for i in (0, 1, 0):
+            err, data = c.extract(i)
+            assert err == 11 and len(data) == 0, (i, err, len(data))          # MSPACK_ERR_DECRUNCH
+        assert any(b"GPU batch decode failed" in (m if isinstance(m, bytes) else str(m).encode()) for m in c.mem.messages), c.mem.messages
+
+
 def test_open_of_missing_files_is_an_error_not_a_crash(built):
     """open() of a file that does not exist returns NULL with MSPACK_ERR_OPEN for every decompressor kind, also when
     malloc hands out dirty memory (MALLOC_PERTURB_: kwaj_open once freed two uninitialised pointers there)."""
