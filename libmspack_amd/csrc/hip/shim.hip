@@ -882,6 +882,10 @@ double mspack_hip_time_batch_device(const mspack_hip_unit *d_units, const uint32
 //                       launch -- on the other stream -- fills the slots they free: no tail between chunks)
 //     copy-out stream:  wait for chunk c's launches -> D2H chunk c          (PCIe is full duplex)
 // so the copy of chunk c+1 overlaps the decode of chunk c and the copy-back of chunk c the decode of chunk c+1.
+// Round 6's end (profiles/round6_jobs.txt): the chunks' shares GROW to the device (1 : 1 : 2 : 4: the last chunk's launches end the call
+// and should fill the chip) and begin with half a share to the host (the copy back is the long leg); a batch that is small beside the
+// chip uses all compute streams either way; an LZX launch beside other chunks' launches asks for a third of its tickets' waves; and the
+// whole pipeline can run on a thread of its own and hand its chunks over as they come back (JobProgress, mspack_hip_decode_batch_begin).
 // (Four streams = four hardware queues: with more, two streams share a queue and a copy waits behind another
 // chunk's kernel -- what profiles/round2_hostpath_streams.txt shows for its third chunk.)
 // ---------------------------------------------------------------------------------------------------
