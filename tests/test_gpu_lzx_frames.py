@@ -160,10 +160,13 @@ def test_frames_other_plaintexts(built, fam):
         assert np.array_equal(out[units["out_off"][i]:units["out_off"][i] + data.size], data), i
 
 
+_LAUNCH_PATHS_CACHE = None
+
+
 @pytest.mark.parametrize("env", [{}, {"MSPACK_HIP_STREAM_RESOLVE": "0"}, {"MSPACK_HIP_TICKET_ORDER": "0"}, {"MSPACK_HIP_TICKET_ORDER": "1"},
                                  {"MSPACK_HIP_TICKET_ORDER": "2"}, {"MSPACK_HIP_NO_FRAME_PARSE": "1"}],
                          ids=["pipe", "pipe_no_stream", "level_order", "mixed_sections", "unit_major", "serial"])
-def test_launch_paths_same_bytes(built, env):
+def test_launch_paths_same_bytes(built, env, tmp_path_factory):
     """shim.hip launch_kind: the shipped default (mspack_lzx_pipe: one dependency-driven launch) and the serial kernel alone
     (MSPACK_HIP_NO_FRAME_PARSE; round 2's header / parse / unit kernels in a row were removed in round 4) --
     same results, on launches smaller than, about and larger than the chip, and on units of three frames; launches with a wave for
@@ -180,7 +183,15 @@ import libmspack_amd as M
 from helpers import oracle_lzx
 ADOPTED = M.F_FRAMES_ADOPTED
 def go(n, ub):
-    plain, comp, off, ln, tab = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21, frame_tables=True)
+    # (the six runs of this test decode the same five corpora: the first one generates them -- ~30 s of the box's CPU -- and leaves them
+    # in the session's temporary directory for the others)
+    import os
+    cache = os.path.join(os.environ["LAUNCH_PATHS_CACHE"], "c_%d_%d.npz" % (n, ub))
+    if os.path.exists(cache):
+        z = np.load(cache); plain, comp, off, ln, tab = z["plain"], z["comp"], z["off"], z["ln"], z["tab"]
+    else:
+        plain, comp, off, ln, tab = M.corpus_lzx_units(0xBA5E11, 0, n, ub, 21, frame_tables=True)
+        np.savez(cache + ".tmp.npz", plain=plain, comp=comp, off=off, ln=ln, tab=tab); os.replace(cache + ".tmp.npz", cache)
     units, out_bytes = M.make_units(M.KIND_LZX, off, ln + 4, np.full(n, ub), window_bits=21, reset_frames=ub // 32768, frame_tabs=tab)
     out, res = M.decode_batch(units, comp, out_bytes)
     assert (res['err'] == 0).all() and (res['out_len'] == ub).all() and np.array_equal(out[:n * ub], plain)
@@ -190,7 +201,10 @@ def go(n, ub):
     return float(((res['flags'] & ADOPTED) != 0).mean())
 print(go(300, 3 * 32768), go(1024, 65536), go(3600, 32768), go(3600, 3 * 32768), go(6144, 32768))
 """
-    e2 = dict(os.environ); e2.pop("MSPACK_HIP_NO_FRAME_PARSE", None); e2.pop("MSPACK_HIP_STREAM_RESOLVE", None); e2.pop("MSPACK_HIP_TICKET_ORDER", None); e2.update(env)
+    global _LAUNCH_PATHS_CACHE
+    if _LAUNCH_PATHS_CACHE is None:
+        _LAUNCH_PATHS_CACHE = str(tmp_path_factory.mktemp("launch_paths"))
+    e2 = dict(os.environ, LAUNCH_PATHS_CACHE=_LAUNCH_PATHS_CACHE); e2.pop("MSPACK_HIP_NO_FRAME_PARSE", None); e2.pop("MSPACK_HIP_STREAM_RESOLVE", None); e2.pop("MSPACK_HIP_TICKET_ORDER", None); e2.update(env)
     r = subprocess.run([sys.executable, "-c", code], env=e2, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     assert r.returncode == 0, r.stderr[-2000:]
     adopted = [float(x) for x in r.stdout.split()[-5:]]
